@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by EXECUTING the upstream reference in this container.
+
+Run:  python tools/gen_golden.py            (needs /root/reference; never runs on the GPU box)
+Writes small .npz fixtures (inputs + the reference's outputs) to tests/golden/.
+The fixtures are data only; no reference source text is stored.
+
+Reference entry points exercised (file:line in /root/reference):
+  G1  avlmaps/utils/mapping_utils.py:18-26 cvt_pose_vec2tf, :226-251 depth2pc, :305-315 transform_pc,
+      :345-349 base_pos2grid_id_3d, :591-596 get_sim_cam_mat, :599-605 project_point
+  G2  avlmaps/map/vlmap_builder.py:54-185 VLMapBuilder.create_mobile_base_map (the real loop;
+      only disk/model I/O is replaced by in-memory fakes), avlmaps/map/map.py:54-68 _setup_transforms
+  G3  avlmaps/utils/clip_utils.py:196-242 get_lseg_score, avlmaps/map/vlmap.py:92-125
+      VLMap.init_categories / index_map
+  G4  avlmaps/utils/visualize_utils.py:29-49 get_heatmap_from_mask_3d
+"""
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE))
+from ref_import import import_reference  # noqa: E402
+
+OUT = HERE.parent / "tests" / "golden"
+
+
+class Cfg(dict):
+    """attr+item access config, stands in for omegaconf.DictConfig"""
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+        return v
+
+
+def make_map_config(gs, cs, cam_h, calib, rate):
+    return Cfg(
+        map_type="vlmap",
+        pose_info=Cfg(
+            pose_type="mobile_base", camera_height=cam_h,
+            base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1],
+            base_forward_axis=[0, 0, -1], base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0],
+        ),
+        cam_calib_mat=list(map(float, calib)), grid_size=gs, cell_size=cs, depth_sample_rate=rate,
+    )
+
+
+# --------------------------------------------------------------------------------------
+def gen_g1(m, rng):
+    mu = m["mapping_utils"]
+    out = {}
+    # poses
+    quats = rng.standard_normal((16, 4))
+    quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+    pos = rng.uniform(-3, 3, (16, 3))
+    posevecs = np.concatenate([pos, quats], axis=1)
+    out["posevecs"] = posevecs
+    out["pose_tfs"] = np.stack([mu.cvt_pose_vec2tf(p) for p in posevecs])
+
+    # voxel ids incl. edge cases
+    gs, cs = 1000, 0.05
+    pts = rng.uniform(-30, 30, (1500, 3))
+    pts[:, 2] = rng.uniform(-0.3, 1.8, 1500)
+    k = rng.integers(-520, 520, (300, 3)).astype(np.float64)
+    edge = k * cs                               # exactly-integral multiples of the cell size
+    edge2 = np.nextafter(edge, np.inf)
+    edge3 = np.nextafter(edge, -np.inf)
+    neg = rng.uniform(-cs, 0, (100, 3))          # (-cs,0) truncates toward zero -> index 0
+    allp = np.concatenate([pts, edge, edge2, edge3, neg,
+                           np.array([[0.0, 0.0, 0.0], [-0.0, 25.0, 1.5], [24.999999, -25.0, 1.4999999]])])
+    ids = np.array([mu.base_pos2grid_id_3d(gs, cs, p[0], p[1], p[2]) for p in allp], dtype=np.int64)
+    out["vox_gs"] = gs
+    out["vox_cs"] = cs
+    out["vox_pts"] = allp
+    out["vox_ids"] = ids
+
+    # project_point with the two camera matrices the builder uses
+    calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0]).reshape(3, 3)
+    simcam = mu.get_sim_cam_mat(347, 520)
+    out["simcam_347_520"] = simcam
+    pl = rng.uniform(-4, 4, (1200, 3))
+    pl[:, 2] = rng.uniform(0.1, 6, 1200)
+    # reproduce the builder's access pattern: p is a row of pc.T
+    pc = np.ascontiguousarray(pl.T)
+    pr = np.array([mu.project_point(calib, p) for p in pc.T])
+    ps = np.array([mu.project_point(simcam, p) for p in pc.T])
+    out["proj_pts"] = pl
+    out["proj_calib"] = calib
+    out["proj_calib_xyz"] = pr
+    out["proj_sim_xyz"] = ps
+
+    # depth2pc on a small image + transform_pc
+    H, W = 20, 28
+    depth = rng.uniform(0.0, 7.0, (H, W)).astype(np.float32)
+    depth[0, 0] = 0.1
+    depth[0, 1] = 6.0
+    depth[0, 2] = np.float32(0.1) + np.float32(1e-6)
+    K = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0]).reshape(3, 3)
+    pc, mask = mu.depth2pc(depth, intr_mat=K, min_depth=0.1, max_depth=6)
+    out["d2p_depth"] = depth
+    out["d2p_K"] = K
+    out["d2p_pc"] = pc
+    out["d2p_mask"] = mask
+    T = out["pose_tfs"][3]
+    out["tpc_T"] = T
+    out["tpc_out"] = mu.transform_pc(pc, T)
+    np.savez_compressed(OUT / "g1_geometry.npz", **out)
+    print("G1 written", {k: np.asarray(v).shape for k, v in out.items()})
+
+
+# --------------------------------------------------------------------------------------
+def run_reference_builder(m, cfg, poses, rgbs, depths, feats, seed):
+    """Run the REAL VLMapBuilder.create_mobile_base_map with in-memory I/O fakes.
+    Returns dict with the final map arrays + the per-frame sampled pixel lists."""
+    vb = m["vlmap_builder"]
+    Map = m["map"].Map
+    tmp = Path(tempfile.mkdtemp(prefix="avl_golden_"))
+    pose_path = tmp / "poses.txt"
+    np.savetxt(pose_path, poses)           # same text round-trip a real dataset has
+    poses_rt = np.loadtxt(pose_path)
+    nfr = len(rgbs)
+    rgb_paths = [tmp / f"{i:06d}.png" for i in range(nfr)]
+    depth_paths = [tmp / f"{i:06d}.npy" for i in range(nfr)]
+
+    mp = Map(cfg)  # real _setup_transforms
+    builder = vb.VLMapBuilder(tmp, cfg, pose_path, rgb_paths, depth_paths, mp.base2cam_tf, mp.base_transform)
+
+    D = feats[0].shape[1]
+    captured = {}
+    samples = []
+
+    def fake_imread(p):
+        i = int(Path(p).stem)
+        return rgbs[i][:, :, ::-1].copy()          # "bgr"
+
+    def fake_cvt(bgr, code):
+        return bgr[:, :, ::-1].copy()
+
+    def fake_depth(p):
+        return depths[int(Path(p).stem)]
+
+    frame_counter = {"i": 0}
+
+    def fake_lseg(*a, **k):
+        f = feats[frame_counter["i"]]
+        frame_counter["i"] += 1
+        return f
+
+    def fake_init_lseg(self):
+        self.device = "cpu"
+        self.clip_feat_dim = D
+        return None, None, 480, 520, [0.5] * 3, [0.5] * 3
+
+    def fake_save(self, grid_feat, grid_pos, weight, grid_rgb, occupied_ids, mapped_iter_set, max_id):
+        captured.update(
+            grid_feat=np.array(grid_feat[:max_id]), grid_pos=np.array(grid_pos[:max_id]),
+            weight=np.array(weight[:max_id]), grid_rgb=np.array(grid_rgb[:max_id]),
+            occupied_ids=np.array(occupied_ids), mapped_iter_list=np.array(sorted(mapped_iter_set), dtype=np.int32),
+            max_id=max_id,
+        )
+
+    orig_shuffle = np.random.shuffle
+    rate = cfg.depth_sample_rate
+
+    def rec_shuffle(x):
+        orig_shuffle(x)
+        samples.append(np.array(x[::rate], dtype=np.int32))
+
+    vb.cv2.imread = fake_imread
+    vb.cv2.cvtColor = fake_cvt
+    vb.load_depth_npy = fake_depth
+    vb.get_lseg_feat = fake_lseg
+    vb.VLMapBuilder._init_lseg = fake_init_lseg
+    vb.VLMapBuilder._save_3d_map = fake_save
+    vb.tqdm = lambda it, **k: _NoBar(it)
+    np.random.seed(seed)
+    np.random.shuffle = rec_shuffle
+    try:
+        builder.create_mobile_base_map()
+    finally:
+        np.random.shuffle = orig_shuffle
+    captured["samples"] = samples
+    captured["poses_rt"] = poses_rt
+    captured["base2cam_tf"] = mp.base2cam_tf
+    captured["base_transform"] = mp.base_transform
+    return captured
+
+
+class _NoBar:
+    def __init__(self, it):
+        self.it = it
+
+    def __iter__(self):
+        return iter(self.it)
+
+    def set_description(self, *a, **k):
+        pass
+
+
+def synth_sequence(rng, nfr, H, W, Hf, Wf, D, feat_scale=14.2857, dbase=2.5, damp=1.5):
+    """smooth-ish depth scene, random rgb, smooth trajectory, random unit features * LSeg logit scale"""
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    depths, rgbs, feats, poses = [], [], [], []
+    for i in range(nfr):
+        d = dbase + damp * np.sin(2.0 * xx + 0.3 * i) * np.cos(1.5 * yy) + 0.3 * damp * yy
+        d = d + rng.normal(0, 0.02, d.shape)
+        d[rng.random(d.shape) < 0.03] = 0.0           # holes
+        d[rng.random(d.shape) < 0.02] = 8.0           # beyond max_depth
+        depths.append(d.astype(np.float32))
+        rgbs.append(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+        f = rng.standard_normal((1, D, Hf, Wf)).astype(np.float32)
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        # LSeg emits logit_scale * unit vector computed in fp16 then cast (lseg_net.py:318-324)
+        f = (f * feat_scale).astype(np.float16).astype(np.float32)
+        feats.append(f)
+        yaw = 0.15 * i
+        # habitat pose: y up; rotate about y, translate in x/z
+        q = np.array([0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)])
+        p = np.array([0.2 * i, 0.05, -0.1 * i])
+        poses.append(np.concatenate([p, q]))
+    return depths, rgbs, feats, np.array(poses)
+
+
+def gen_g2(m, rng):
+    # (a) regular small scene
+    H, W, Hf, Wf, D, nfr = 48, 64, 23, 31, 16, 6
+    calib = [W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1]
+    cfg = make_map_config(gs=200, cs=0.05, cam_h=1.5, calib=calib, rate=7)
+    depths, rgbs, feats, poses = synth_sequence(rng, nfr, H, W, Hf, Wf, D)
+    res = run_reference_builder(m, cfg, poses, rgbs, depths, feats, seed=1234)
+    save_builder_fixture("g2a_builder_small.npz", cfg, depths, rgbs, feats, poses, res)
+    # (b) coarse grid so that the reference's capacity doubling (_reserve_map_space) triggers:
+    #     initial capacity = gs*gs = 400 rows < number of voxels
+    cfg = make_map_config(gs=20, cs=0.1, cam_h=1.7, calib=calib, rate=3)
+    depths, rgbs, feats, poses = synth_sequence(np.random.default_rng(5), 16, H, W, Hf, Wf, 8, dbase=0.7, damp=0.3)
+    res = run_reference_builder(m, cfg, poses, rgbs, depths, feats, seed=99)
+    save_builder_fixture("g2b_builder_growth.npz", cfg, depths, rgbs, feats, poses, res)
+
+
+def save_builder_fixture(name, cfg, depths, rgbs, feats, poses, res):
+    occ = res["occupied_ids"]
+    nz = np.argwhere(occ != -1).astype(np.int32)
+    out = dict(
+        gs=cfg.grid_size, cs=cfg.cell_size, camera_height=cfg.pose_info.camera_height,
+        rate=cfg.depth_sample_rate, calib=np.array(cfg.cam_calib_mat, dtype=np.float64),
+        base2cam_rot=np.array(cfg.pose_info.base2cam_rot, dtype=np.float64),
+        base_axes=np.array([cfg.pose_info.base_forward_axis, cfg.pose_info.base_left_axis,
+                            cfg.pose_info.base_up_axis], dtype=np.float64),
+        depths=np.stack(depths), rgbs=np.stack(rgbs), feats=np.concatenate(feats, 0),
+        poses=poses, poses_rt=res["poses_rt"],
+        base2cam_tf=res["base2cam_tf"], base_transform=res["base_transform"],
+        samples=np.stack(res["samples"]),
+        grid_feat=res["grid_feat"], grid_pos=res["grid_pos"], weight=res["weight"],
+        grid_rgb=res["grid_rgb"], occ_shape=np.array(occ.shape), occ_nz=nz,
+        occ_nz_vals=occ[nz[:, 0], nz[:, 1], nz[:, 2]].astype(np.int32),
+        mapped_iter_list=res["mapped_iter_list"], max_id=res["max_id"],
+        numpy_version=np.__version__,
+    )
+    np.savez_compressed(OUT / name, **out)
+    print(name, "voxels", res["max_id"], "weight dtype", res["weight"].dtype, "rgb dtype", res["grid_rgb"].dtype,
+          "pts/frame", [len(s) for s in res["samples"]])
+
+
+# --------------------------------------------------------------------------------------
+def gen_g3(m, rng):
+    cu = m["clip_utils"]
+    VLMap = m["vlmap"].VLMap
+    ntmpl = len(cu.multiple_templates)
+    out = {"n_templates": ntmpl}
+    N, D = 1024, 512
+    feat = rng.standard_normal((N, D)).astype(np.float32)
+    feat *= (rng.uniform(0.2, 14.2857, (N, 1)) / np.linalg.norm(feat, axis=1, keepdims=True)).astype(np.float32)
+    feat[100] = feat[7]                  # duplicate rows
+    feat[200] = 0.0                      # all-zero row -> all scores tie at 0 -> argmax 0
+    out["feat"] = feat
+
+    table = {}
+
+    def fake_text_feats(in_text, clip_model, clip_feat_dim, batch_size=64):
+        r = np.zeros((len(in_text), clip_feat_dim), dtype=np.float32)
+        for i, t in enumerate(in_text):
+            r[i] = table[t]
+        return r
+
+    cu.get_text_feats = fake_text_feats
+    m["vlmap"].get_lseg_score = cu.get_lseg_score
+
+    def register(landmarks):
+        for lm in landmarks + ["other"]:
+            for t in cu.multiple_templates:
+                s = t.format(lm)
+                if s not in table:
+                    v = rng.standard_normal(D).astype(np.float32)
+                    table[s] = v / np.linalg.norm(v)
+            if lm not in table:
+                v = rng.standard_normal(D).astype(np.float32)
+                table[lm] = v / np.linalg.norm(v)
+
+    cases = {
+        "q1": ["sofa"],
+        "q2": ["chair", "table"],
+        "q64": [f"thing{i}" for i in range(64)],
+        "q40_other_last": [f"cat{i}" for i in range(39)] + ["other"],
+    }
+    for name, lms in cases.items():
+        register(lms)
+        sc = cu.get_lseg_score(None, list(lms), feat, D, use_multiple_templates=True, add_other=True)
+        lm_other = lms if lms[-1] == "other" else lms + ["other"]
+        tf = np.stack([np.stack([table[t.format(lm)] for t in cu.multiple_templates]) for lm in lm_other])
+        if len(lm_other) <= 3:
+            out[f"{name}_template_feats"] = tf.astype(np.float32)      # (Q, 63, D): pins the template mean
+        # what the reference reduces the templates to (clip_utils.py:223-225: reshape + np.mean(axis=1))
+        out[f"{name}_mean_feats"] = np.mean(tf.astype(np.float32), axis=1)
+        out[f"{name}_scores"] = sc
+        out[f"{name}_argmax"] = np.argmax(sc, axis=1).astype(np.int32)
+        # single-template path
+        sc1 = cu.get_lseg_score(None, list(lms), feat, D, use_multiple_templates=False, add_other=True)
+        out[f"{name}_single_feats"] = np.stack([table[lm] for lm in lm_other]).astype(np.float32)
+        out[f"{name}_single_scores"] = sc1
+    # exact-tie case: two identical query columns -> first index must win
+    register(["dup"])
+    tf = np.stack([table[t.format("dup")] for t in cu.multiple_templates]).mean(0)
+    q = np.stack([tf, tf, -tf]).astype(np.float32)
+    sc = feat @ q.T
+    out["tie_queries"] = q
+    out["tie_scores"] = sc
+    out["tie_argmax"] = np.argmax(sc, axis=1).astype(np.int32)
+
+    # VLMap.index_map (real class) without preloaded categories
+    cfg = make_map_config(1000, 0.05, 1.5, [540, 0, 540, 0, 540, 360, 0, 0, 1], 100)
+    vm = VLMap(cfg)
+    vm.grid_feat = feat
+    vm.clip_model = None
+    vm.clip_feat_dim = D
+    out["index_map_sofa_mask"] = vm.index_map("sofa", with_init_cat=False)
+    sm = vm.init_categories(list(cases["q40_other_last"]))
+    out["init_categories_scores"] = sm
+    np.savez_compressed(OUT / "g3_similarity.npz", **out)
+    print("G3 written; Q64 scores", out["q64_scores"].shape, out["q64_scores"].dtype)
+
+
+# --------------------------------------------------------------------------------------
+def gen_g4(m, rng):
+    vu = m["visualize_utils"]
+    vu.tqdm = lambda it, **k: it
+    N = 2000
+    pos = np.stack([rng.integers(400, 470, N), rng.integers(400, 470, N), rng.integers(0, 30, N)], 1).astype(np.int32)
+    pos = np.unique(pos, axis=0)
+    rng.shuffle(pos)
+    mask = rng.random(len(pos)) < 0.04
+    out = {"grid_pos": pos, "mask": mask}
+    for decay in (0.01, 0.1):
+        out[f"heat_{decay}"] = vu.get_heatmap_from_mask_3d(pos, mask, cell_size=0.05, decay_rate=decay)
+    np.savez_compressed(OUT / "g4_heatmap.npz", **out)
+    print("G4 written", len(pos), mask.sum())
+
+
+def main():
+    OUT.mkdir(parents=True, exist_ok=True)
+    m = import_reference()
+    gen_g1(m, np.random.default_rng(11))
+    gen_g2(m, np.random.default_rng(22))
+    gen_g3(m, np.random.default_rng(33))
+    gen_g4(m, np.random.default_rng(44))
+    os.system(f"ls -la {OUT}")
+
+
+if __name__ == "__main__":
+    main()
