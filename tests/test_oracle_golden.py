@@ -1,0 +1,113 @@
+"""Pins the CPU oracle (oracle/) to golden vectors produced by executing the upstream reference
+(tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import avl_oracle as O
+
+
+def test_cvt_pose_vec2tf(golden):
+    g = golden("g1_geometry.npz")
+    for v, tf in zip(g["posevecs"], g["pose_tfs"]):
+        assert np.array_equal(O.cvt_pose_vec2tf(v), tf)
+
+
+def test_base_pos2grid_id_3d_bit_exact(golden):
+    g = golden("g1_geometry.npz")
+    gs, cs = int(g["vox_gs"]), float(g["vox_cs"])
+    got = np.array([O.base_pos2grid_id_3d(gs, cs, *p) for p in g["vox_pts"]])
+    assert np.array_equal(got, g["vox_ids"])
+
+
+def test_project_point_bit_exact(golden):
+    g = golden("g1_geometry.npz")
+    for K, ref in ((g["proj_calib"], g["proj_calib_xyz"]), (g["simcam_347_520"], g["proj_sim_xyz"])):
+        got = np.array([O.project_point(K, p) for p in g["proj_pts"]])
+        assert np.array_equal(got[:, :2], ref[:, :2])
+        assert np.array_equal(got[:, 2], ref[:, 2])
+    assert np.array_equal(O.get_sim_cam_mat(347, 520), g["simcam_347_520"])
+
+
+def test_depth2pc_and_transform_bit_exact(golden):
+    g = golden("g1_geometry.npz")
+    depth, K = g["d2p_depth"], g["d2p_K"]
+    pix = np.arange(depth.size)
+    pc, mask = O.depth2pc_pixels(depth, np.linalg.inv(K), pix, 0.1, 6)
+    assert np.array_equal(mask, g["d2p_mask"])
+    assert np.array_equal(pc.T, g["d2p_pc"])
+    assert np.array_equal(O.transform_points(g["tpc_T"], pc).T, g["tpc_out"])
+
+
+def _run_oracle_builder(g):
+    b2c, bt = O.setup_transforms(g["base2cam_rot"], float(g["camera_height"]), *g["base_axes"])
+    assert np.array_equal(b2c, g["base2cam_tf"]) and np.array_equal(bt, g["base_transform"])
+    Ts = O.pc_transforms(g["poses_rt"], bt, b2c)
+    D = g["feats"].shape[1]
+    m = O.OracleMap(int(g["gs"]), float(g["cs"]), float(g["camera_height"]), D)
+    for i in range(len(g["depths"])):
+        m.integrate(g["depths"][i], g["calib"], Ts[i], g["samples"][i], g["feats"][i], g["rgbs"][i])
+    return m.export()
+
+
+@pytest.mark.parametrize("name", ["g2a_builder_small.npz", "g2b_builder_growth.npz"])
+def test_sequential_builder_matches_reference(golden, name):
+    g = golden(name)
+    out = _run_oracle_builder(g)
+    assert len(out["grid_pos"]) == int(g["max_id"])
+    assert np.array_equal(out["grid_pos"], g["grid_pos"])                    # voxel ids + id order: bit exact
+    occ = out["occupied_ids"]
+    assert tuple(occ.shape) == tuple(g["occ_shape"])
+    nz = np.argwhere(occ != -1)
+    assert np.array_equal(nz, g["occ_nz"])
+    assert np.array_equal(occ[nz[:, 0], nz[:, 1], nz[:, 2]], g["occ_nz_vals"])
+    assert out["weight"].dtype == g["weight"].dtype and out["grid_rgb"].dtype == g["grid_rgb"].dtype
+    # same rounding sequence as the reference; exp() may differ by an ulp between libms
+    np.testing.assert_allclose(out["weight"], g["weight"], rtol=2e-7, atol=0)
+    np.testing.assert_allclose(out["grid_feat"], g["grid_feat"], rtol=1e-6, atol=1e-6)
+    if g["grid_rgb"].dtype == np.uint8:
+        assert np.abs(out["grid_rgb"].astype(int) - g["grid_rgb"].astype(int)).max() <= 1
+    else:
+        np.testing.assert_allclose(out["grid_rgb"], g["grid_rgb"], rtol=1e-5, atol=1e-4)
+    frac_exact = np.mean(out["grid_feat"] == g["grid_feat"])
+    assert frac_exact > 0.99, frac_exact
+
+
+def test_growth_fixture_really_grew(golden):
+    g = golden("g2b_builder_growth.npz")
+    assert g["weight"].dtype == np.float64 and g["grid_rgb"].dtype == np.float32
+    assert int(g["max_id"]) > int(g["gs"]) ** 2
+
+
+def test_similarity_matches_reference(golden):
+    g = golden("g3_similarity.npz")
+    feat = g["feat"]
+    for name in ("q1", "q2"):
+        tm = O.template_mean(g[f"{name}_template_feats"])
+        assert np.array_equal(tm, g[f"{name}_mean_feats"])
+    for name in ("q1", "q2", "q64", "q40_other_last"):
+        sc = O.sim_scores(feat, g[f"{name}_mean_feats"])
+        assert sc.dtype == np.float32 and sc.shape == g[f"{name}_scores"].shape
+        np.testing.assert_allclose(sc, g[f"{name}_scores"], rtol=0, atol=1e-5)
+        assert np.array_equal(np.argmax(sc, axis=1), g[f"{name}_argmax"])
+        sc1 = O.sim_scores(feat, g[f"{name}_single_feats"])
+        np.testing.assert_allclose(sc1, g[f"{name}_single_scores"], rtol=0, atol=1e-5)
+        # scalar float64-accumulating port agrees within float32 round-off of the BLAS result
+        sc2, _ = O.sim_scores_scalar(feat, g[f"{name}_mean_feats"])
+        np.testing.assert_allclose(sc2, g[f"{name}_scores"], rtol=0, atol=2e-5)
+    assert g["q1_scores"].shape[1] == 2 and g["q64_scores"].shape[1] == 65 and g["q40_other_last_scores"].shape[1] == 40
+    mask, _ = O.argmax_mask(O.sim_scores(feat, g["q1_mean_feats"]), 0)
+    assert np.array_equal(mask, g["index_map_sofa_mask"])
+    # exact ties: first maximum wins
+    sc = O.sim_scores(feat, g["tie_queries"])
+    assert np.array_equal(np.argmax(sc, axis=1), g["tie_argmax"])
+    _, am = O.sim_scores_scalar(feat, g["tie_queries"])
+    assert np.array_equal(am, g["tie_argmax"])
+    assert g["tie_argmax"][200] == 0
+
+
+def test_heatmap_matches_reference(golden):
+    g = golden("g4_heatmap.npz")
+    for decay in (0.01, 0.1):
+        h = O.heatmap_from_mask(g["grid_pos"], g["mask"], 0.05, decay)
+        np.testing.assert_allclose(h, g[f"heat_{decay}"], rtol=0, atol=1e-6)
+        assert np.array_equal(h == 1.0, g[f"heat_{decay}"] == 1.0)
