@@ -1,0 +1,96 @@
+"""ctypes binding of libavlmaps_hip.so (include/avlmaps_hip.h).  Fails loudly when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("AVLMAPS_HIP_LIB", _PKG / "lib" / "libavlmaps_hip.so"))
+
+AVL_OK = 0
+SIM_AUTO, SIM_EXACT, SIM_SPLIT_F16 = 0, 1, 2
+
+
+class AvlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i32, _i64, _f64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
+_SIGS = {
+    "avl_last_error": (C.c_char_p, []),
+    "avl_version": (C.c_int, []),
+    "avl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "avl_set_device": (C.c_int, [C.c_int]),
+    "avl_device_name": (C.c_int, [C.c_int, C.c_char_p, _sz]),
+    "avl_device_sync": (C.c_int, []),
+    "avl_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "avl_stream_destroy": (C.c_int, [_vp]),
+    "avl_stream_sync": (C.c_int, [_vp]),
+    "avl_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
+    "avl_free": (C.c_int, [_vp]),
+    "avl_memset": (C.c_int, [_vp, C.c_int, _sz, _vp]),
+    "avl_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "avl_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "avl_memcpy_d2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "avl_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "avl_event_destroy": (C.c_int, [_vp]),
+    "avl_event_record": (C.c_int, [_vp, _vp]),
+    "avl_event_sync": (C.c_int, [_vp]),
+    "avl_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "avl_sim_scores": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp]),
+    "avl_sim_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(_sz)]),
+    "avl_sim_scores_ws": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
+    "avl_sim_scores_host": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),
+    "avl_mask_from_argmax": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "avl_argmax_f32": (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(C.c_float), _vp]),
+    "avl_builder_create": (C.c_int, [C.POINTER(_vp), C.c_int, _f64, C.c_int, C.c_int, _i64]),
+    "avl_builder_destroy": (C.c_int, [_vp]),
+    "avl_builder_reset": (C.c_int, [_vp, _vp]),
+    "avl_builder_integrate_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int,
+                                              C.c_int, _vp, _i64, _f64, _f64, _f64, _vp]),
+    "avl_builder_num_voxels": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
+    "avl_builder_num_points": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
+    "avl_builder_finalize": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_builder_export_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "avl_builder_merge_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "avl_heatmap_from_mask": (C.c_int, [_vp, _vp, _i64, _f64, _f64, _vp, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def load():
+    """dlopen the HIP library and declare signatures.  Raises AvlError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise AvlError(
+                f"{LIB_PATH} not found: build it with `python -m avlmaps_amd.build` (needs hipcc, gfx950). "
+                "There is no CPU fallback for the avlmaps_amd compute path.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != AVL_OK:
+        msg = load().avl_last_error().decode(errors="replace")
+        raise AvlError(f"{what or 'libavlmaps_hip'} failed (status {rc}): {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load().avl_device_count(C.byref(n))
+    return n.value if rc == AVL_OK else 0
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise AvlError("no HIP device visible: avlmaps_amd has no CPU fallback (the reference CPU path lives upstream)")

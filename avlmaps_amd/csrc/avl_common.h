@@ -1,0 +1,39 @@
+// Internal helpers shared by the HIP translation units of libavlmaps_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/avlmaps_hip.h"
+
+namespace avl {
+
+void set_error(const char* fmt, ...);
+
+#define AVL_HIP_CHECK(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            avl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AVL_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define AVL_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            avl::set_error(__VA_ARGS__);  \
+            return AVL_ERR_INVALID;       \
+        }                                 \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// number of CUs of the current device (cached)
+int num_cus();
+
+constexpr int kWave = 64;
+
+}  // namespace avl

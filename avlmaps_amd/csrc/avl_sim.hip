@@ -1,0 +1,577 @@
+// Voxel x query similarity (+ fused row argmax) for gfx950.
+//
+// Replaces (upstream reference, path:line):
+//   avlmaps/utils/clip_utils.py:227-229   scores_list = map_feats @ text_feats.T      (raw dot product)
+//   avlmaps/map/vlmap.py:123-124          max_ids = np.argmax(scores_mat, axis=1)     (first max wins)
+//
+// HBM layout: grid_feat (N, D) float32 row-major (row stride ld), streamed exactly once per 64-query
+// chunk; queries are tiny and live in LDS.  Two kernels:
+//
+//   sim_exact_kernel      float32 FMA on the vector ALU.  One wave per voxel row, lanes span D with
+//                         16-byte loads (a row is one or two fully coalesced 1 KiB requests), up to 8
+//                         query rows in LDS, wave-level shuffle reduction.  HBM-bound for Q <= 8.
+//   sim_split_f16_kernel  for larger Q the fp32 vector/matrix rate (157 TF) is below what the HBM stream
+//                         demands (AI = Q/2 flop/B), so the contraction runs on the fp16 matrix cores with
+//                         an error-free hi/lo split:  a = ah + al, q = qh + ql (fp16 each, q pre-scaled by
+//                         a power of two), a.q ~= ah.qh + ah.ql + al.qh  with fp32 accumulation
+//                         (v_mfma_f32_32x32x16_f16 x3).  Dropped term and split residuals are ~2^-22
+//                         relative, i.e. float32-class accuracy, at 1/5 of the fp32-MFMA time.
+//                         MFMA "A" operand = 32 queries (from LDS), "B" operand = 32 voxels (straight
+//                         from HBM into registers: lane (voxel j, half kg) owns one whole 128-byte line of
+//                         its row per 64-wide k step, so every fetched line is consumed by the 8 loads of
+//                         one lane).  The accumulator then holds, per lane, 16 queries of ONE voxel:
+//                         the row argmax is an in-register scan plus one cross-half exchange.
+#include <cfloat>
+#include <climits>
+
+#include "avl_common.h"
+
+namespace avl {
+
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2 = __attribute__((ext_vector_type(2))) _Float16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ------------------------------------------------------------------------------------------------
+// exact float32 path
+// ------------------------------------------------------------------------------------------------
+constexpr int kExactQB = 8;  // query rows resident in LDS per pass
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void sim_exact_kernel(const float* __restrict__ feat, int64_t N, int D, int64_t ld,
+                                                        const float* __restrict__ q, int Q, int64_t ldq, int q0,
+                                                        float* __restrict__ scores, int32_t* __restrict__ argmax,
+                                                        float* __restrict__ best, int first_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [kExactQB][Dp]
+    const int Dp = (D + 3) & ~3;
+    const int qn = min(kExactQB, Q - q0);
+    for (int i = threadIdx.x; i < kExactQB * Dp; i += blockDim.x) {
+        int j = i / Dp, d = i - j * Dp;
+        qs[i] = (j < qn && d < D) ? q[(int64_t)(q0 + j) * ldq + d] : 0.f;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+
+    for (int64_t row = wave; row < N; row += nwaves) {
+        const float* rp = feat + row * ld;
+        float acc[kExactQB];
+#pragma unroll
+        for (int j = 0; j < kExactQB; ++j) acc[j] = 0.f;
+        if constexpr (VEC4) {
+            const int nchunk = D >> 2;
+            for (int c = lane; c < nchunk; c += 64) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rp + 4 * c);
+#pragma unroll
+                for (int j = 0; j < kExactQB; ++j) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(qs + j * Dp + 4 * c);
+                    acc[j] = fmaf(a.x, b.x, acc[j]);
+                    acc[j] = fmaf(a.y, b.y, acc[j]);
+                    acc[j] = fmaf(a.z, b.z, acc[j]);
+                    acc[j] = fmaf(a.w, b.w, acc[j]);
+                }
+            }
+        } else {
+            for (int d = lane; d < D; d += 64) {
+                const float a = rp[d];
+#pragma unroll
+                for (int j = 0; j < kExactQB; ++j) acc[j] = fmaf(a, qs[j * Dp + d], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kExactQB; ++j) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
+        }
+        if (lane == 0) {
+            float bv = -INFINITY;
+            int bi = q0;
+            if (!first_chunk) {
+                if (best) bv = best[row];
+                if (argmax) bi = argmax[row];
+            }
+            bool have = !first_chunk;
+#pragma unroll
+            for (int j = 0; j < kExactQB; ++j) {
+                if (j < qn) {
+                    if (scores) scores[row * (int64_t)Q + q0 + j] = acc[j];
+                    if (!have || acc[j] > bv) {
+                        bv = acc[j];
+                        bi = q0 + j;
+                        have = true;
+                    }
+                }
+            }
+            if (argmax) argmax[row] = bi;
+            if (best) best[row] = bv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-fp16 MFMA path
+// ------------------------------------------------------------------------------------------------
+// workspace header (device memory): [0] = query scale 2^S, [1] = 2^-S
+constexpr int kHdrBytes = 64;
+constexpr int kRowPadHalves = 8;  // +16 B per query row: consecutive rows shift one 16-byte LDS slot
+constexpr int kSplitThreads = 512;
+constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup iteration
+
+__global__ void sim_query_scale_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq, float* __restrict__ hdr) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)Q * D; i += blockDim.x) {
+        int r = (int)(i / D), d = (int)(i - (int64_t)r * D);
+        m = fmaxf(m, fabsf(q[r * ldq + d]));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float mx = red[0];
+        int S = 0;
+        if (mx > 0.f && isfinite(mx)) S = 9 - ilogbf(mx);  // max|q| * 2^S in [512, 1024)
+        S = max(-40, min(40, S));
+        hdr[0] = ldexpf(1.f, S);
+        hdr[1] = ldexpf(1.f, -S);
+    }
+}
+
+// image layout: [nqc][nkc][2 (hi, lo)][Qc][KC + pad] fp16
+__global__ void sim_prep_queries_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq,
+                                        const float* __restrict__ hdr, _Float16* __restrict__ img, int Qc, int KC,
+                                        int nqc, int nkc) {
+    const int rowlen = KC + kRowPadHalves;
+    const int64_t total = (int64_t)nqc * nkc * Qc * rowlen;
+    const float scale = hdr[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int kk = (int)(i % rowlen);
+        int64_t t = i / rowlen;
+        int qi = (int)(t % Qc);
+        t /= Qc;
+        int kc = (int)(t % nkc);
+        int qc = (int)(t / nkc);
+        int qg = qc * Qc + qi, k = kc * KC + kk;
+        float v = 0.f;
+        if (kk < KC && qg < Q && k < D) v = q[(int64_t)qg * ldq + k] * scale;
+        half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
+        float r = v - (float)h[0];
+        _Float16 lo = (_Float16)r;
+        const int64_t base = ((int64_t)(qc * nkc + kc) * 2) * Qc * rowlen;
+        img[base + (int64_t)qi * rowlen + kk] = h[0];
+        img[base + (int64_t)Qc * rowlen + (int64_t)qi * rowlen + kk] = lo;
+    }
+}
+
+__device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi, half8& lo) {
+    // error-free split of 8 floats into fp16 hi (round-toward-zero) + fp16 lo (residual, exact in fp32)
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
+        float r0 = x[2 * p] - (float)h[0];
+        float r1 = x[2 * p + 1] - (float)h[1];
+        half2 l = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        hi[2 * p] = h[0];
+        hi[2 * p + 1] = h[1];
+        lo[2 * p] = l[0];
+        lo[2 * p + 1] = l[1];
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
+    const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
+    const float* __restrict__ hdr, int KC, int nkc, int q_base, int Q, float* __restrict__ scores,
+    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Qc = QT * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
+    const int img_b = Qc * row_b;                // bytes per hi (or lo) image
+    const int chunk_b = 2 * img_b;
+    const float inv_scale = hdr[1];
+
+    auto fill_lds = [&](int kc) {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + (int64_t)kc * chunk_b);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < chunk_b / 16; i += kSplitThreads) dst[i] = src[i];
+    };
+    if (nkc == 1) {
+        fill_lds(0);
+        __syncthreads();
+    }
+
+    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    const char* a_hi_base = smem + j * row_b + kg * 64;  // this lane's query row, its k half (32 halves = 64 B)
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * kTileRows + wave * 32 + j;
+        const int64_t rowc = row < N ? row : N - 1;
+        const float* rp = feat + rowc * ld + 32 * kg;
+
+        f32x16 acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            if (nkc > 1) {
+                __syncthreads();
+                fill_lds(kc);
+                __syncthreads();
+            }
+            const int klen = min(KC, D - kc * KC);
+            const int nsteps = klen >> 6;
+            const float* p = rp + kc * KC;
+
+            f32x4 buf0[8], buf1[8];
+            auto load = [&](f32x4(&b)[8], int s) {
+                const f32x4* g = reinterpret_cast<const f32x4*>(p + 64 * s);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[t] = g[t];
+            };
+            auto compute = [&](const f32x4(&b)[8], int s) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    half8 bh, bl;
+                    split8(b[2 * m], b[2 * m + 1], bh, bl);
+                    const char* ap = a_hi_base + (s * 64 + 8 * m) * 2;
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const half8 ah = *reinterpret_cast<const half8*>(ap + t * 32 * row_b);
+                        const half8 al = *reinterpret_cast<const half8*>(ap + t * 32 * row_b + img_b);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                    }
+                }
+            };
+            load(buf0, 0);
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 1 < nsteps) load(buf1, s + 1);
+                compute(buf0, s);
+                if (s + 1 < nsteps) {
+                    if (s + 2 < nsteps) load(buf0, s + 2);
+                    compute(buf1, s + 1);
+                }
+            }
+        }
+
+        // ---- epilogue: this lane holds voxel `row`, queries q_base + t*32 + 8g + 4kg + e (g<4, e<4) in acc[t][4g+e]
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qg = q_base + t * 32 + 8 * g + 4 * kg;
+                f32x4 v;
+                v.x = acc[t][4 * g + 0] * inv_scale;
+                v.y = acc[t][4 * g + 1] * inv_scale;
+                v.z = acc[t][4 * g + 2] * inv_scale;
+                v.w = acc[t][4 * g + 3] * inv_scale;
+                if (scores && row < N) {
+                    float* sp = scores + row * (int64_t)Q + qg;
+                    if (qg + 3 < Q && (Q & 3) == 0) {
+                        *reinterpret_cast<f32x4*>(sp) = v;
+                    } else {
+                        if (qg + 0 < Q) sp[0] = v.x;
+                        if (qg + 1 < Q) sp[1] = v.y;
+                        if (qg + 2 < Q) sp[2] = v.z;
+                        if (qg + 3 < Q) sp[3] = v.w;
+                    }
+                }
+                if (qg + 0 < Q && v.x > bv) { bv = v.x; bi = qg + 0; }
+                if (qg + 1 < Q && v.y > bv) { bv = v.y; bi = qg + 1; }
+                if (qg + 2 < Q && v.z > bv) { bv = v.z; bi = qg + 2; }
+                if (qg + 3 < Q && v.w > bv) { bv = v.w; bi = qg + 3; }
+            }
+        }
+        if (argmax || best) {
+            const float ov = __shfl_xor(bv, 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+            if (kg == 0 && row < N) {
+                if (bi == INT_MAX) bi = q_base;
+                if (!first_chunk) {  // earlier chunks hold smaller indices: they win ties
+                    const float pv = best[row];
+                    if (!(bv > pv)) {
+                        bv = pv;
+                        bi = argmax ? argmax[row] : bi;
+                    }
+                }
+                if (argmax) argmax[row] = bi;
+                if (best) best[row] = bv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void mask_from_argmax_kernel(const int32_t* __restrict__ am, int64_t N, int32_t cat, uint8_t* __restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = am[i] == cat;
+}
+
+// first-maximum argmax over a float vector: per-block partials, then one block finishes
+__global__ void argmax_partial_kernel(const float* __restrict__ v, int64_t N, float* __restrict__ pv, int64_t* __restrict__ pi) {
+    float bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        float x = v[i];
+        if (x > bv) { bv = x; bi = i; }   // ascending i per thread: first max kept
+    }
+    __shared__ float sv[256];
+    __shared__ int64_t si[256];
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            float ov = sv[threadIdx.x + s];
+            int64_t oi = si[threadIdx.x + s];
+            if (ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x])) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        pv[blockIdx.x] = sv[0];
+        pi[blockIdx.x] = si[0];
+    }
+}
+
+struct SplitPlan {
+    int Qc, QT, KC, nqc, nkc;
+    size_t lds_bytes, ws_bytes;
+};
+
+static bool make_split_plan(int D, int Q, SplitPlan& p) {
+    if (D % 64 != 0 || D <= 0 || Q <= 0) return false;
+    p.QT = Q > 32 ? 2 : 1;
+    p.Qc = p.QT * 32;
+    p.nqc = (Q + p.Qc - 1) / p.Qc;
+    const size_t lds_budget = 156 * 1024;
+    // bytes = 2 images * Qc rows * (KC + pad) halves * 2 B
+    int kcmax = (int)(lds_budget / (4 * (size_t)p.Qc)) - kRowPadHalves;
+    kcmax = (kcmax / 64) * 64;
+    if (kcmax < 64) return false;
+    p.nkc = (D + kcmax - 1) / kcmax;
+    int kc = (D + p.nkc - 1) / p.nkc;
+    p.KC = ((kc + 63) / 64) * 64;
+    p.nkc = (D + p.KC - 1) / p.KC;
+    p.lds_bytes = (size_t)4 * p.Qc * (p.KC + kRowPadHalves);
+    p.ws_bytes = kHdrBytes + (size_t)p.nqc * p.nkc * p.lds_bytes;
+    return true;
+}
+
+static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
+                     float* d_scores, int32_t* d_argmax, float* d_best, hipStream_t st) {
+    const int Dp = (D + 3) & ~3;
+    const size_t lds = (size_t)kExactQB * Dp * sizeof(float);
+    AVL_REQUIRE(lds <= 160 * 1024, "avl_sim_scores: D=%d too large for the exact path", D);
+    const bool vec4 = (D % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0);
+    const int waves_per_block = 4;
+    int64_t blocks = (N + waves_per_block - 1) / waves_per_block;
+    const int64_t maxb = (int64_t)num_cus() * 8;
+    if (blocks > maxb) blocks = maxb;
+    if (blocks < 1) blocks = 1;
+    auto kern = vec4 ? sim_exact_kernel<true> : sim_exact_kernel<false>;
+    if (lds > 64 * 1024)
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // a scratch best buffer is needed to chain chunks when the caller did not ask for one
+    for (int q0 = 0, first = 1; q0 < Q; q0 += kExactQB, first = 0) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, d_feat, N, D, ld, d_q, Q, ldq, q0, d_scores,
+                           d_argmax, d_best, first);
+    }
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
+                     float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
+    float* hdr = reinterpret_cast<float*>(d_ws);
+    _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + kHdrBytes);
+    hipLaunchKernelGGL(sim_query_scale_kernel, dim3(1), dim3(256), 0, st, d_q, Q, D, ldq, hdr);
+    {
+        int64_t total = (int64_t)p.nqc * p.nkc * p.Qc * (p.KC + kRowPadHalves);
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(blocks), dim3(256), 0, st, d_q, Q, D, ldq, hdr, img, p.Qc, p.KC,
+                           p.nqc, p.nkc);
+    }
+    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    int64_t blocks = ntiles < num_cus() ? ntiles : num_cus();
+    if (blocks < 1) blocks = 1;
+    auto kern = p.QT == 2 ? sim_split_f16_kernel<2> : sim_split_f16_kernel<1>;
+    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)p.lds_bytes));
+    const size_t chunk_halves = p.lds_bytes / 2;
+    for (int qc = 0; qc < p.nqc; ++qc) {
+        const _Float16* img_qc = img + (size_t)qc * p.nkc * chunk_halves;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), p.lds_bytes, st, d_feat, N, D, ld, img_qc,
+                           hdr, p.KC, p.nkc, qc * p.Qc, Q, d_scores, d_argmax, d_best, qc == 0 ? 1 : 0);
+    }
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+}  // namespace avl
+
+using namespace avl;
+
+extern "C" {
+
+int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes) {
+    AVL_REQUIRE(h_bytes, "avl_sim_workspace_bytes: null output");
+    SplitPlan p;
+    *h_bytes = make_split_plan(D, Q, p) ? p.ws_bytes : (size_t)kHdrBytes;
+    return AVL_OK;
+}
+
+int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
+                      int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
+                      void* d_workspace, size_t workspace_bytes, void* stream) {
+    AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores: bad shape N=%lld D=%d Q=%d", (long long)N, D, Q);
+    AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
+    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_SPLIT_F16, "avl_sim_scores: bad precision %d", precision);
+    if (N == 0) return AVL_OK;
+    AVL_REQUIRE(d_feat && d_queries, "avl_sim_scores: null input");
+    hipStream_t st = as_stream(stream);
+
+    SplitPlan p;
+    const bool aligned = (ld_feat % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0) &&
+                         (!d_scores || (reinterpret_cast<uintptr_t>(d_scores) & 15) == 0);
+    const bool can_split = make_split_plan(D, Q, p) && aligned;
+    bool use_split;
+    if (precision == AVL_SIM_EXACT) use_split = false;
+    else if (precision == AVL_SIM_SPLIT_F16) {
+        AVL_REQUIRE(can_split, "avl_sim_scores: SPLIT_F16 needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D,
+                    (long long)ld_feat);
+        use_split = true;
+    } else use_split = can_split && Q > kExactQB;
+
+    // chaining query chunks needs a best-score buffer even if the caller does not want it
+    float* best = d_best;
+    float* tmp_best = nullptr;
+    const int nchunks = use_split ? p.nqc : (Q + kExactQB - 1) / kExactQB;
+    if (!best && d_argmax && nchunks > 1) {
+        AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_best), (size_t)N * sizeof(float), st));
+        best = tmp_best;
+    }
+    int rc;
+    if (use_split) {
+        void* ws = d_workspace;
+        void* tmp_ws = nullptr;
+        if (!ws || workspace_bytes < p.ws_bytes) {
+            AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, p.ws_bytes, st));
+            ws = tmp_ws;
+        }
+        rc = run_split(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st);
+        if (tmp_ws) (void)hipFreeAsync(tmp_ws, st);
+    } else {
+        rc = run_exact(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, st);
+    }
+    if (tmp_best) (void)hipFreeAsync(tmp_best, st);
+    return rc;
+}
+
+int avl_sim_scores(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q, int64_t ld_q,
+                   float* d_scores, int32_t* d_argmax, float* d_best, int precision, void* stream) {
+    return avl_sim_scores_ws(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, d_best, precision, nullptr, 0,
+                             stream);
+}
+
+int avl_sim_scores_host(const float* h_feat, int64_t N, int D, const float* h_queries, int Q, float* h_scores,
+                        int32_t* h_argmax, float* h_best, int precision) {
+    AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores_host: bad shape");
+    if (N == 0) return AVL_OK;
+    float *d_feat = nullptr, *d_q = nullptr, *d_sc = nullptr, *d_best = nullptr;
+    int32_t* d_am = nullptr;
+    int rc = AVL_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_feat); (void)hipFree(d_q); (void)hipFree(d_sc); (void)hipFree(d_best); (void)hipFree(d_am);
+    };
+#define AVL_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                       \
+            cleanup();                                                                      \
+            return AVL_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+    AVL_TRY(hipMalloc(reinterpret_cast<void**>(&d_feat), (size_t)N * D * 4));
+    AVL_TRY(hipMalloc(reinterpret_cast<void**>(&d_q), (size_t)Q * D * 4));
+    AVL_TRY(hipMemcpy(d_feat, h_feat, (size_t)N * D * 4, hipMemcpyHostToDevice));
+    AVL_TRY(hipMemcpy(d_q, h_queries, (size_t)Q * D * 4, hipMemcpyHostToDevice));
+    if (h_scores) AVL_TRY(hipMalloc(reinterpret_cast<void**>(&d_sc), (size_t)N * Q * 4));
+    if (h_argmax) AVL_TRY(hipMalloc(reinterpret_cast<void**>(&d_am), (size_t)N * 4));
+    if (h_best) AVL_TRY(hipMalloc(reinterpret_cast<void**>(&d_best), (size_t)N * 4));
+    rc = avl_sim_scores(d_feat, N, D, D, d_q, Q, D, d_sc, d_am, d_best, precision, nullptr);
+    if (rc == AVL_OK) {
+        AVL_TRY(hipDeviceSynchronize());
+        if (h_scores) AVL_TRY(hipMemcpy(h_scores, d_sc, (size_t)N * Q * 4, hipMemcpyDeviceToHost));
+        if (h_argmax) AVL_TRY(hipMemcpy(h_argmax, d_am, (size_t)N * 4, hipMemcpyDeviceToHost));
+        if (h_best) AVL_TRY(hipMemcpy(h_best, d_best, (size_t)N * 4, hipMemcpyDeviceToHost));
+    }
+#undef AVL_TRY
+    cleanup();
+    return rc;
+}
+
+int avl_mask_from_argmax(const int32_t* d_argmax, int64_t N, int32_t cat_id, uint8_t* d_mask, void* stream) {
+    AVL_REQUIRE(N >= 0, "avl_mask_from_argmax: bad N");
+    if (N == 0) return AVL_OK;
+    AVL_REQUIRE(d_argmax && d_mask, "avl_mask_from_argmax: null pointer");
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mask_from_argmax_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_argmax, N, cat_id,
+                       d_mask);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_argmax_f32(const float* d_vals, int64_t N, int64_t* h_index, float* h_value, void* stream) {
+    AVL_REQUIRE(N > 0 && d_vals, "avl_argmax_f32: empty input");
+    hipStream_t st = as_stream(stream);
+    const int nb = 256;
+    float* d_pv = nullptr;
+    int64_t* d_pi = nullptr;
+    AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_pv), (nb + 1) * sizeof(float), st));
+    AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_pi), (nb + 1) * sizeof(int64_t), st));
+    hipLaunchKernelGGL(argmax_partial_kernel, dim3(nb), dim3(256), 0, st, d_vals, N, d_pv, d_pi);
+    float hv[nb];
+    int64_t hi[nb];
+    AVL_HIP_CHECK(hipMemcpyAsync(hv, d_pv, nb * sizeof(float), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipMemcpyAsync(hi, d_pi, nb * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFreeAsync(d_pv, st);
+    (void)hipFreeAsync(d_pi, st);
+    float bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int b = 0; b < nb; ++b)
+        if (hv[b] > bv || (hv[b] == bv && hi[b] < bi)) { bv = hv[b]; bi = hi[b]; }
+    if (bi == INT64_MAX) bi = 0;
+    if (h_index) *h_index = bi;
+    if (h_value) *h_value = bv;
+    return AVL_OK;
+}
+
+}  // extern "C"

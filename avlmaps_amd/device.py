@@ -1,0 +1,94 @@
+"""Device-buffer plumbing for the ctypes layer.
+
+Accepts three kinds of array arguments and always hands a raw device pointer to the C ABI:
+  * numpy arrays        -> staged through a library-allocated device buffer (avl_malloc + H2D)
+  * torch CUDA tensors  -> zero-copy (data_ptr)
+  * DeviceArray         -> this module's own minimal device array (no torch needed)
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    """Minimal owning device array (shape + dtype + pointer) backed by avl_malloc."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _lib.check(_lib.load().avl_malloc(C.byref(p), self.nbytes), "avl_malloc")
+        self.ptr = p.value or 0
+
+    @classmethod
+    def from_numpy(cls, a, stream=None):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        if a.nbytes:
+            _lib.check(_lib.load().avl_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes, stream), "avl_memcpy_h2d")
+            _lib.check(_lib.load().avl_stream_sync(stream), "avl_stream_sync")   # source may be a temporary
+        return d
+
+    def zero_(self, stream=None):
+        _lib.check(_lib.load().avl_memset(self.ptr, 0, self.nbytes, stream), "avl_memset")
+        return self
+
+    def numpy(self, stream=None):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            _lib.check(_lib.load().avl_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, stream), "avl_memcpy_d2h")
+        return out
+
+    def free(self):
+        if getattr(self, "ptr", 0):
+            _lib.load().avl_free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def as_device(x, dtype, stream=None):
+    """-> (ptr, shape, keepalive).  Raises if a torch tensor is not a contiguous CUDA tensor of `dtype`."""
+    dtype = np.dtype(dtype)
+    if isinstance(x, DeviceArray):
+        if x.dtype != dtype:
+            raise TypeError(f"expected {dtype}, got {x.dtype}")
+        return x.ptr, x.shape, x
+    if _is_torch(x):
+        import torch
+        want = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
+                np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64}[dtype]
+        if not x.is_cuda:
+            raise TypeError("torch tensors passed to avlmaps_amd must live on the GPU")
+        if x.dtype != want:
+            raise TypeError(f"expected torch dtype {want}, got {x.dtype}")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        return x.data_ptr(), tuple(x.shape), x
+    a = np.ascontiguousarray(x, dtype=dtype)
+    d = DeviceArray.from_numpy(a, stream)
+    return d.ptr, d.shape, d
+
+
+def torch_stream_ptr():
+    """raw hipStream_t of torch's current stream, or None when torch/GPU is unavailable"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream or None
+    except Exception:
+        pass
+    return None

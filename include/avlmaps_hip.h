@@ -1,0 +1,185 @@
+/*
+ * avlmaps_hip.h -- C ABI of libavlmaps_hip.so: the MI355X (gfx950) implementation of the AVLMaps
+ * map-creation / landmark-indexing hot path.
+ *
+ * The upstream reference is pure Python and has no FFI layer; each entry point below replaces a
+ * span of reference Python (cited as path:line relative to the upstream repo root) and is what a
+ * ctypes binding inside the reference would call.
+ *
+ * Conventions
+ *   - every function returns an int status (AVL_OK == 0); avl_last_error() returns a thread-local
+ *     human-readable message for the last failure on the calling thread.
+ *   - pointers named d_* are DEVICE pointers (HIP), pointers named h_* are HOST pointers.
+ *     Small fixed-size parameter blocks (3x3 / 4x4 float64 matrices) are always host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous with respect to the host unless stated otherwise.
+ *   - caller-owned buffers in, library-owned state only behind opaque handles, nothing allocated
+ *     by the library crosses the boundary.
+ *   - one handle is used by one host thread at a time; one process (or thread) per GPU.
+ */
+#ifndef AVLMAPS_HIP_H
+#define AVLMAPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVL_API __attribute__((visibility("default")))
+
+enum {
+    AVL_OK = 0,
+    AVL_ERR_INVALID = 1,   /* bad argument                                   */
+    AVL_ERR_HIP = 2,       /* a HIP runtime call failed                      */
+    AVL_ERR_CAPACITY = 3,  /* voxel capacity exhausted (builder)             */
+    AVL_ERR_NO_DEVICE = 4, /* no usable gfx950 device                        */
+    AVL_ERR_STATE = 5      /* call not valid in the handle's current state   */
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * library / device plumbing
+ * ------------------------------------------------------------------------------------------------ */
+AVL_API const char* avl_last_error(void);
+AVL_API int avl_version(void);                       /* major*10000 + minor*100 + patch */
+AVL_API int avl_device_count(int* h_count);
+AVL_API int avl_set_device(int device);
+AVL_API int avl_device_name(int device, char* h_buf, size_t buf_len);
+AVL_API int avl_device_sync(void);
+AVL_API int avl_stream_create(void** h_stream_out);
+AVL_API int avl_stream_destroy(void* stream);
+AVL_API int avl_stream_sync(void* stream);
+/* device memory helpers so that hosts without a GPU array library can drive the ABI */
+AVL_API int avl_malloc(void** h_ptr_out, size_t bytes);
+AVL_API int avl_free(void* d_ptr);
+AVL_API int avl_memset(void* d_ptr, int value, size_t bytes, void* stream);
+AVL_API int avl_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
+AVL_API int avl_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
+AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
+/* HIP-event timing on `stream` (bench.py measures kernels on the stream they are launched on) */
+AVL_API int avl_event_create(void** h_event_out);
+AVL_API int avl_event_destroy(void* event);
+AVL_API int avl_event_record(void* event, void* stream);
+AVL_API int avl_event_sync(void* event);
+AVL_API int avl_event_elapsed_ms(void* start, void* stop, float* h_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) voxel x query similarity + row argmax
+ *     replaces  avlmaps/utils/clip_utils.py:227-229   scores_list = map_feats @ text_feats.T
+ *               avlmaps/map/vlmap.py:123-124          max_ids = np.argmax(scores_mat, axis=1)
+ *               avlmaps/utils/index_utils.py:153-161  (same pair, obstacle classes)
+ *     The score is the reference's RAW dot product (no normalisation).  Ties in the argmax resolve
+ *     to the lowest query index, like np.argmax.
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+    AVL_SIM_AUTO = 0,   /* pick per shape: EXACT for small Q, SPLIT_F16 otherwise                       */
+    AVL_SIM_EXACT = 1,  /* float32 FMA on the vector ALU (any N, D, Q, strides)                          */
+    AVL_SIM_SPLIT_F16 = 2 /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q| */
+};
+
+/*
+ * d_feat     (N, D) float32 row-major with row stride ld_feat (elements)  -- VLMap.grid_feat
+ * d_queries  (Q, D) float32 row-major with row stride ld_q                -- text_feats
+ * d_scores   (N, Q) float32 row-major, or NULL to skip materialising scores_mat
+ * d_argmax   (N,) int32, or NULL
+ * d_best     (N,) float32 score of the argmax column, or NULL
+ * precision  one of AVL_SIM_*
+ */
+AVL_API int avl_sim_scores(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
+                           int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
+                           void* stream);
+
+/* Scratch the SPLIT_F16 path needs for the prepared query image; pass the same buffer to
+ * avl_sim_scores_ws to avoid the internal allocation (used by the benchmark / graph capture). */
+AVL_API int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes);
+AVL_API int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
+                              int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
+                              void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Host-buffer convenience wrapper (synchronous): copies in, runs, copies out. */
+AVL_API int avl_sim_scores_host(const float* h_feat, int64_t N, int D, const float* h_queries, int Q,
+                                float* h_scores, int32_t* h_argmax, float* h_best, int precision);
+
+/* mask[i] = (argmax[i] == cat_id) as uint8 -- avlmaps/map/vlmap.py:124 */
+AVL_API int avl_mask_from_argmax(const int32_t* d_argmax, int64_t N, int32_t cat_id, uint8_t* d_mask, void* stream);
+
+/* index and value of the maximum of a float32 vector, first maximum wins -- the navigator's
+ * heatmap argmax, avlmaps/robot/habitat_lang_robot.py:427-430.  Synchronous (returns host scalars). */
+AVL_API int avl_argmax_f32(const float* d_vals, int64_t N, int64_t* h_index, float* h_value, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) map builder: depth back-projection + voxelisation + weighted feature fusion
+ *     replaces  avlmaps/map/vlmap_builder.py:129-178 (per-frame body of create_mobile_base_map)
+ *               avlmaps/utils/mapping_utils.py:226-251 depth2pc, :305-315 transform_pc,
+ *               :345-349 base_pos2grid_id_3d, :599-605 project_point
+ *     State lives on the device behind the handle; avl_builder_finalize reproduces the reference's
+ *     arrays (grid_feat, grid_pos, weight, grid_rgb, occupied_ids) in the reference's voxel-id order.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct avl_builder avl_builder;
+
+/* gs, cs, vh: grid size, cell size (m), cells in height (= int(camera_height / cs), vlmap_builder.py:201)
+ * D: feature dimension; capacity: maximum number of occupied voxels the handle can hold. */
+AVL_API int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, int64_t capacity);
+AVL_API int avl_builder_destroy(avl_builder* b);
+AVL_API int avl_builder_reset(avl_builder* b, void* stream);
+
+/*
+ * Fuse one RGB-D frame.
+ *   d_depth        (H, W) float32 metres
+ *   h_calib        3x3 float64 row-major camera matrix  (map_config.cam_calib_mat)
+ *   h_calib_inv    3x3 float64 = numpy.linalg.inv(calib) as the reference computes it (mapping_utils.py:237)
+ *   h_pc_transform 4x4 float64 row-major camera->map transform (vlmap_builder.py:133)
+ *   d_sample_idx   (P,) int32 flattened pixel indices in the reference's sampling order
+ *                  (shuffle_mask[::depth_sample_rate], vlmap_builder.py:275-277), BEFORE depth masking
+ *   d_feat         (Hf, Wf, D) float32 CHANNELS-LAST pixel features (the reference holds (1, D, Hf, Wf))
+ *   d_rgb          (H, W, 3) uint8
+ *   frame_idx      position of the frame in the sequence (defines first-touch order across frames)
+ *   min_depth/max_depth  strict bounds on camera-frame z (0.1, 6: vlmap_builder.py:129)
+ *   sigma_sq       0.6 (vlmap_builder.py:157)
+ */
+AVL_API int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int W, const double* h_calib,
+                                        const double* h_calib_inv, const double* h_pc_transform,
+                                        const int32_t* d_sample_idx, int P, const float* d_feat, int Hf, int Wf,
+                                        const uint8_t* d_rgb, int64_t frame_idx, double min_depth,
+                                        double max_depth, double sigma_sq, void* stream);
+
+/* number of occupied voxels so far (synchronises the stream) */
+AVL_API int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream);
+/* number of sampled points that updated a voxel so far (synchronises the stream) */
+AVL_API int avl_builder_num_points(avl_builder* b, int64_t* h_n, void* stream);
+
+/*
+ * Produce the reference's arrays, rows ordered by first touch (== the reference's max_id order):
+ *   d_grid_feat (n, D) f32, d_grid_pos (n, 3) i32, d_weight (n,) f32, d_grid_rgb (n, 3) u8,
+ *   d_occupied_ids (gs, gs, vh) i32 (-1 = empty) -- any of them may be NULL.
+ * n must equal avl_builder_num_voxels().  Synchronous.
+ */
+AVL_API int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
+                                 uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream);
+
+/*
+ * Multi-GPU merge support (frames sharded over ranks; the collectives run in the host layer over RCCL).
+ * Export the raw per-voxel accumulators in slot order:
+ *   d_cell (n,) int32 linear cell index (row*gs + col)*vh + h;  d_first_key (n,) uint64 first-touch key
+ *   d_acc  (n, D+5) int64 fixed-point sums  [sum(alpha*f) (D), sum(alpha), sum(alpha*rgb) (3), spare]
+ *   d_first (n, D+1) float32 [first-touch feature (D), first-touch alpha]
+ * and import/merge a peer's export into this handle (sums add, the smaller first-touch key wins).
+ */
+AVL_API int avl_builder_export_raw(avl_builder* b, int64_t n, int32_t* d_cell, uint64_t* d_first_key, int64_t* d_acc,
+                                   float* d_first, void* stream);
+AVL_API int avl_builder_merge_raw(avl_builder* b, int64_t n, const int32_t* d_cell, const uint64_t* d_first_key,
+                                  const int64_t* d_acc, const float* d_first, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) nearest-target distance-decay heatmap
+ *     replaces  avlmaps/utils/visualize_utils.py:29-49 get_heatmap_from_mask_3d
+ *     heat[i] = 1 for mask[i] != 0, else clip(1 - min_t ||pos_t - pos_i|| / cell_size * decay, 0, 1)
+ * ------------------------------------------------------------------------------------------------ */
+AVL_API int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d_mask, int64_t N, double cell_size,
+                                  double decay_rate, float* d_heat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVLMAPS_HIP_H */

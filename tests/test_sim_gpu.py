@@ -1,0 +1,119 @@
+"""GPU parity of the similarity kernels (through the C ABI) against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from avlmaps_amd import _lib, ops
+    _lib.load()
+    _lib.require_gpu()
+    return ops
+
+
+def _check(sc, am, best, ref, atol):
+    np.testing.assert_allclose(sc, ref, rtol=0, atol=atol)
+    # the winner must be (numerically) a maximum of the reference row, and exact ties go to the lowest index
+    rows = np.arange(len(ref))
+    assert np.all(ref[rows, am] >= ref.max(axis=1) - 2 * atol)
+    if best is not None:
+        np.testing.assert_allclose(best, ref.max(axis=1), rtol=0, atol=atol)
+
+
+@pytest.mark.parametrize("precision", ["exact", "split_f16", "auto"])
+@pytest.mark.parametrize("case", ["q1", "q2", "q64", "q40_other_last"])
+def test_golden_scores(ops, golden, case, precision):
+    g = golden("g3_similarity.npz")
+    sc, am, best = ops.sim_scores(g["feat"], g[f"{case}_mean_feats"], want_best=True, precision=precision)
+    # north_star tolerance: scores within 1e-4 (fp32) of the reference
+    _check(sc, am, best, g[f"{case}_scores"], 1e-4)
+    # measured accuracy is far better than the contract; keep a tighter regression bound
+    assert np.abs(sc - g[f"{case}_scores"]).max() < 2e-5
+    agree = np.mean(am == g[f"{case}_argmax"])
+    assert agree == 1.0, agree
+
+
+@pytest.mark.parametrize("precision", ["exact", "split_f16"])
+def test_exact_ties_first_index_wins(ops, golden, precision):
+    g = golden("g3_similarity.npz")
+    sc, am, _ = ops.sim_scores(g["feat"], g["tie_queries"], precision=precision)
+    assert np.array_equal(sc[:, 0], sc[:, 1])
+    assert np.array_equal(am, g["tie_argmax"])
+    assert am[200] == 0          # all-zero voxel row: every score ties at 0
+
+
+def test_mask_matches_reference_index_map(ops, golden):
+    g = golden("g3_similarity.npz")
+    _, am, _ = ops.sim_scores(g["feat"], g["q1_mean_feats"], want_scores=False)
+    mask = ops.mask_from_argmax(am, 0)
+    assert np.array_equal(mask, g["index_map_sofa_mask"])
+
+
+@pytest.mark.parametrize("N,D,Q", [(1, 512, 1), (33, 512, 3), (257, 512, 9), (1000, 512, 33), (777, 512, 65),
+                                   (300, 768, 40), (129, 1024, 64), (260, 1536, 128), (50, 100, 5), (64, 64, 70),
+                                   (513, 192, 96)])
+def test_shapes_vs_oracle(ops, N, D, Q):
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(N * 7 + D + Q)
+    feat = rng.standard_normal((N, D)).astype(np.float32)
+    feat *= (rng.uniform(0.1, 14.3, (N, 1)) / np.linalg.norm(feat, axis=1, keepdims=True)).astype(np.float32)
+    q = rng.standard_normal((Q, D)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(1, 3, (Q, 1)).astype(np.float32)
+    ref = (feat.astype(np.float64) @ q.astype(np.float64).T)
+    assert np.abs(O.sim_scores(feat, q) - ref).max() < 1e-4
+    for precision in ("exact", "auto") + (("split_f16",) if D % 64 == 0 else ()):
+        sc, am, best = ops.sim_scores(feat, q, want_best=True, precision=precision)
+        _check(sc, am, best, ref, 1e-4)
+        sc2, am2, _ = ops.sim_scores(feat, q, want_scores=False, precision=precision)
+        assert sc2 is None and np.array_equal(am2, am)
+
+
+def test_empty_and_errors(ops):
+    from avlmaps_amd._lib import AvlError
+    sc, am, _ = ops.sim_scores(np.zeros((0, 512), np.float32), np.ones((3, 512), np.float32))
+    assert sc.shape == (0, 3) and am.shape == (0,)
+    with pytest.raises(ValueError):
+        ops.sim_scores(np.zeros((4, 512), np.float32), np.ones((3, 256), np.float32))
+    with pytest.raises(AvlError):
+        ops.sim_scores(np.zeros((4, 100), np.float32), np.ones((3, 100), np.float32), precision="split_f16")
+
+
+def test_large_magnitude_and_tiny_values(ops):
+    """split path keeps float32-class accuracy over a wide dynamic range (queries are rescaled by 2^S)."""
+    rng = np.random.default_rng(5)
+    feat = (rng.standard_normal((512, 512)) * np.exp(rng.uniform(-8, 3, (512, 512)))).astype(np.float32)
+    q = (rng.standard_normal((64, 512)) * 1e-3).astype(np.float32)
+    ref = feat.astype(np.float64) @ q.astype(np.float64).T
+    sc, _, _ = ops.sim_scores(feat, q, precision="split_f16")
+    bound = 3e-6 * (np.abs(feat).astype(np.float64) @ np.abs(q).astype(np.float64).T)
+    assert np.all(np.abs(sc - ref) <= bound + 1e-9)
+
+
+def test_full_size_properties(ops):
+    """config-2 size (2M x 512, 64 queries): linearity and checksum properties, no CPU reference needed."""
+    import torch
+    N, D, Q = 2_000_000, 512, 64
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    feat = torch.randn((N, D), device="cuda", generator=gen)
+    feat *= (14.2857 * torch.rand((N, 1), device="cuda", generator=gen)) / feat.norm(dim=1, keepdim=True)
+    q = torch.randn((Q, D), device="cuda", generator=gen)
+    q /= q.norm(dim=1, keepdim=True)
+    sc, am, best = ops.sim_scores(feat, q, want_best=True)
+    torch.cuda.synchronize()
+    # (1) argmax/best consistent with the materialised scores
+    assert torch.equal(sc.max(dim=1).values, best)
+    assert torch.equal(sc.gather(1, am.long()[:, None])[:, 0], best)
+    # (2) checksum of checksums: sum_n scores[n, :] == (sum_n feat[n]) @ q.T   (float64 on the device)
+    lhs = sc.double().sum(0)
+    rhs = feat.double().sum(0) @ q.double().T
+    assert torch.allclose(lhs, rhs, rtol=0, atol=2e-2), (lhs - rhs).abs().max()
+    # (3) a random 4096-row sample against float64
+    idx = torch.randint(0, N, (4096,), device="cuda", generator=gen)
+    ref = feat[idx].double() @ q.double().T
+    assert (sc[idx].double() - ref).abs().max() < 1e-4
+    # (4) linearity in the queries: scores(q1 + q2) == scores(q1) + scores(q2)
+    sub = feat[:200_000]
+    s12, _, _ = ops.sim_scores(sub, q[:32] + q[32:], want_argmax=False)
+    assert (s12 - (sc[:200_000, :32] + sc[:200_000, 32:])).abs().max() < 1e-4
