@@ -54,8 +54,8 @@ _SIGS = {
     "avl_builder_num_voxels": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_num_points": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_finalize": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "avl_builder_export_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "avl_builder_merge_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "avl_builder_export_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_finalize_raw": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_heatmap_from_mask": (C.c_int, [_vp, _vp, _i64, _f64, _f64, _vp, _vp]),
 }
 
@@ -66,6 +66,13 @@ def load():
     """dlopen the HIP library and declare signatures.  Raises AvlError if it has not been built."""
     global _lib
     if _lib is None:
+        # torch bundles its own HIP runtime; it must be the first one loaded into the process so that this
+        # library binds to the same runtime instance (device pointers and streams are shared with torch).
+        if os.environ.get("AVLMAPS_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         if not LIB_PATH.exists():
             raise AvlError(
                 f"{LIB_PATH} not found: build it with `python -m avlmaps_amd.build` (needs hipcc, gfx950). "

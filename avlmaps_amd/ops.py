@@ -79,3 +79,130 @@ def argmax_f32(vals, stream=None):
     idx, val = C.c_int64(), C.c_float()
     _lib.check(lib.avl_argmax_f32(vp, int(np.prod(vshape)), C.byref(idx), C.byref(val), stream), "avl_argmax_f32")
     return idx.value, val.value
+
+
+class VoxelAccumulator:
+    """Device-resident map under construction (handle over avl_builder_*).
+
+    One instance = the state the reference keeps in grid_feat / grid_pos / weight / grid_rgb / occupied_ids
+    inside VLMapBuilder.create_mobile_base_map (vlmap_builder.py:86-95), living in HBM.
+    """
+
+    def __init__(self, gs, cs, vh, D, capacity=None):
+        lib = _lib.load()
+        _lib.require_gpu()
+        self.gs, self.cs, self.vh, self.D = int(gs), float(cs), int(vh), int(D)
+        self.capacity = int(capacity) if capacity else min(self.gs * self.gs, self.gs * self.gs * self.vh)
+        h = C.c_void_p()
+        _lib.check(lib.avl_builder_create(C.byref(h), self.gs, self.cs, self.vh, self.D, self.capacity), "avl_builder_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().avl_builder_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self, stream=None):
+        _lib.check(_lib.load().avl_builder_reset(self._h, stream), "avl_builder_reset")
+
+    def integrate_frame(self, depth, calib, pc_transform, sample_idx, feat_hwc, rgb, frame_idx, calib_inv=None,
+                        min_depth=0.1, max_depth=6.0, sigma_sq=0.6, stream=None):
+        """Fuse one frame.  depth (H,W) f32, feat_hwc (Hf,Wf,D) f32 channels-last, rgb (H,W,3) u8,
+        sample_idx (P,) i32 in sampling order; calib 3x3 and pc_transform 4x4 are host float64."""
+        lib = _lib.load()
+        dp, dshape, k1 = as_device(depth, np.float32, stream)
+        fp_, fshape, k2 = as_device(feat_hwc, np.float32, stream)
+        rp, rshape, k3 = as_device(rgb, np.uint8, stream)
+        sp, sshape, k4 = as_device(sample_idx, np.int32, stream)
+        if len(dshape) != 2 or len(fshape) != 3 or fshape[2] != self.D or tuple(rshape) != (dshape[0], dshape[1], 3):
+            raise ValueError(f"bad frame shapes depth {dshape} feat {fshape} rgb {rshape}")
+        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
+        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
+        T = np.ascontiguousarray(np.asarray(pc_transform, dtype=np.float64).reshape(4, 4))
+        rc = lib.avl_builder_integrate_frame(self._h, dp, dshape[0], dshape[1], K.ctypes.data, Kinv.ctypes.data, T.ctypes.data,
+                                             sp, int(np.prod(sshape)), fp_, fshape[0], fshape[1], rp, int(frame_idx),
+                                             float(min_depth), float(max_depth), float(sigma_sq), stream)
+        _lib.check(rc, "avl_builder_integrate_frame")
+        self._keep = (k1, k2, k3, k4)   # inputs must outlive the asynchronous launches
+        return self
+
+    def num_voxels(self, stream=None):
+        n = C.c_int64()
+        _lib.check(_lib.load().avl_builder_num_voxels(self._h, C.byref(n), stream), "avl_builder_num_voxels")
+        return n.value
+
+    def num_points(self, stream=None):
+        n = C.c_int64()
+        _lib.check(_lib.load().avl_builder_num_points(self._h, C.byref(n), stream), "avl_builder_num_points")
+        return n.value
+
+    def finalize(self, stream=None, want_occupied=True, as_numpy=True):
+        """-> dict(grid_feat, grid_pos, weight, grid_rgb, occupied_ids) in the reference's voxel-id order."""
+        lib = _lib.load()
+        n = self.num_voxels(stream)
+        gf = DeviceArray((n, self.D), np.float32)
+        gp = DeviceArray((n, 3), np.int32)
+        w = DeviceArray((n,), np.float32)
+        rgb = DeviceArray((n, 3), np.uint8)
+        occ = DeviceArray((self.gs, self.gs, self.vh), np.int32) if want_occupied else None
+        _lib.check(lib.avl_builder_finalize(self._h, n, gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr if occ else None, stream),
+                   "avl_builder_finalize")
+        out = dict(grid_feat=gf, grid_pos=gp, weight=w, grid_rgb=rgb, occupied_ids=occ)
+        if as_numpy:
+            out = {k: (v.numpy(stream) if v is not None else None) for k, v in out.items()}
+        return out
+
+    def export_raw(self, stream=None, as_numpy=True):
+        """raw accumulators of all voxels (see avl_builder_export_raw) for the multi-GPU merge"""
+        lib = _lib.load()
+        n = self.num_voxels(stream)
+        arrs = dict(cell=DeviceArray((n,), np.int32), first_key=DeviceArray((n,), np.uint64),
+                    sum_feat=DeviceArray((n, self.D), np.float64), sum_w4=DeviceArray((n, 4), np.float64),
+                    first_feat=DeviceArray((n, self.D), np.float32), first_alpha=DeviceArray((n,), np.float64))
+        _lib.check(lib.avl_builder_export_raw(self._h, n, *(a.ptr for a in arrs.values()), stream), "avl_builder_export_raw")
+        _lib.check(lib.avl_stream_sync(stream))
+        return {k: v.numpy(stream) for k, v in arrs.items()} if as_numpy else arrs
+
+
+def finalize_raw(raw, D, gs, vh, stream=None):
+    """Stateless finalisation of (merged) raw accumulators -> the reference's arrays (numpy in, numpy out)."""
+    lib = _lib.load()
+    n = len(raw["cell"])
+    dev = {k: as_device(raw[k], dt, stream) for k, dt in (("cell", np.int32), ("sum_feat", np.float64), ("sum_w4", np.float64),
+                                                          ("first_feat", np.float32), ("first_alpha", np.float64))}
+    gf, gp = DeviceArray((n, D), np.float32), DeviceArray((n, 3), np.int32)
+    w, rgb = DeviceArray((n,), np.float32), DeviceArray((n, 3), np.uint8)
+    occ = DeviceArray((gs, gs, vh), np.int32)
+    _lib.check(lib.avl_memset(occ.ptr, 0xFF, occ.nbytes, stream))
+    rc = lib.avl_finalize_raw(n, D, gs, vh, dev["cell"][0], dev["sum_feat"][0], dev["sum_w4"][0], dev["first_feat"][0],
+                              dev["first_alpha"][0], gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr, stream)
+    _lib.check(rc, "avl_finalize_raw")
+    return dict(grid_feat=gf.numpy(stream), grid_pos=gp.numpy(stream), weight=w.numpy(stream), grid_rgb=rgb.numpy(stream),
+                occupied_ids=occ.numpy(stream))
+
+
+def heatmap_from_mask(grid_pos, mask, cell_size=0.05, decay_rate=0.01, stream=None):
+    """visualize_utils.py:29-49 on the GPU.  grid_pos (N,3) int32, mask (N,) bool/uint8 -> (N,) float32."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    if _is_torch(mask):
+        import torch
+        if mask.dtype == torch.bool:
+            mask = mask.to(torch.uint8)
+    elif isinstance(mask, np.ndarray):
+        mask = mask.astype(np.uint8)
+    pp, pshape, k1 = as_device(grid_pos, np.int32, stream)
+    mp, mshape, k2 = as_device(mask, np.uint8, stream)
+    N = pshape[0]
+    if _is_torch(grid_pos):
+        import torch
+        heat = torch.empty((N,), dtype=torch.float32, device=grid_pos.device)
+        _lib.check(lib.avl_heatmap_from_mask(pp, mp, N, float(cell_size), float(decay_rate), heat.data_ptr(), stream),
+                   "avl_heatmap_from_mask")
+        return heat
+    heat = DeviceArray((N,), np.float32)
+    _lib.check(lib.avl_heatmap_from_mask(pp, mp, N, float(cell_size), float(decay_rate), heat.ptr, stream),
+               "avl_heatmap_from_mask")
+    return heat.numpy(stream) if isinstance(grid_pos, np.ndarray) else heat

@@ -150,7 +150,8 @@ AVL_API int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream);
 AVL_API int avl_builder_num_points(avl_builder* b, int64_t* h_n, void* stream);
 
 /*
- * Produce the reference's arrays, rows ordered by first touch (== the reference's max_id order):
+ * Produce the reference's arrays.  Slot ids are assigned in first-touch order (a deterministic prefix
+ * scan over each frame's sample list), so row r of every output IS the reference's voxel id r:
  *   d_grid_feat (n, D) f32, d_grid_pos (n, 3) i32, d_weight (n,) f32, d_grid_rgb (n, 3) u8,
  *   d_occupied_ids (gs, gs, vh) i32 (-1 = empty) -- any of them may be NULL.
  * n must equal avl_builder_num_voxels().  Synchronous.
@@ -159,17 +160,32 @@ AVL_API int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, 
                                  uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream);
 
 /*
- * Multi-GPU merge support (frames sharded over ranks; the collectives run in the host layer over RCCL).
- * Export the raw per-voxel accumulators in slot order:
- *   d_cell (n,) int32 linear cell index (row*gs + col)*vh + h;  d_first_key (n,) uint64 first-touch key
- *   d_acc  (n, D+5) int64 fixed-point sums  [sum(alpha*f) (D), sum(alpha), sum(alpha*rgb) (3), spare]
- *   d_first (n, D+1) float32 [first-touch feature (D), first-touch alpha]
- * and import/merge a peer's export into this handle (sums add, the smaller first-touch key wins).
+ * Multi-GPU merge support (frames sharded over ranks; the exchange itself runs in the host layer over
+ * RCCL, see avlmaps_amd/parallel.py).  Export the raw per-voxel accumulators of the first n slots:
+ *   d_cell        (n,)   int32   linear cell index (row*gs + col)*vh + h
+ *   d_first_key   (n,)   uint64  first-touch key (frame_idx << 32 | position in the frame's sample list)
+ *   d_sum_feat    (n, D) float64 sum_i alpha_i * f_i
+ *   d_sum_w4      (n, 4) float64 [sum alpha, sum alpha*r, sum alpha*g, sum alpha*b]
+ *   d_first_feat  (n, D) float32 feature of the first-touch point
+ *   d_first_alpha (n,)   float64 alpha of the first-touch point
+ * Any output may be NULL.
  */
-AVL_API int avl_builder_export_raw(avl_builder* b, int64_t n, int32_t* d_cell, uint64_t* d_first_key, int64_t* d_acc,
-                                   float* d_first, void* stream);
-AVL_API int avl_builder_merge_raw(avl_builder* b, int64_t n, const int32_t* d_cell, const uint64_t* d_first_key,
-                                  const int64_t* d_acc, const float* d_first, void* stream);
+AVL_API int avl_builder_export_raw(avl_builder* b, int64_t n, int32_t* d_cell, uint64_t* d_first_key,
+                                   double* d_sum_feat, double* d_sum_w4, float* d_first_feat,
+                                   double* d_first_alpha, void* stream);
+
+/*
+ * Stateless finalisation of raw accumulators (the arrays of avl_builder_export_raw, possibly merged
+ * across ranks and re-ordered by first-touch key): applies the reference's first-touch weighting
+ *   grid_feat = (sum_feat - a1*(1-a1)*first_feat) / sum_alpha      (vlmap_builder.py:166-174 closed form)
+ * and writes grid_feat (n,D) f32, grid_pos (n,3) i32, weight (n,) f32, grid_rgb (n,3) u8 in the given row
+ * order, and occupied_ids[cell] = row index (d_occupied_ids (gs,gs,vh) must be pre-filled with -1).
+ * Any output may be NULL.
+ */
+AVL_API int avl_finalize_raw(int64_t n, int D, int gs, int vh, const int32_t* d_cell, const double* d_sum_feat,
+                             const double* d_sum_w4, const float* d_first_feat, const double* d_first_alpha,
+                             float* d_grid_feat, int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb,
+                             int32_t* d_occupied_ids, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (3) nearest-target distance-decay heatmap

@@ -1,0 +1,157 @@
+"""GPU parity of the map-builder kernels (through the C ABI) against golden vectors and the sequential oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FEAT_RTOL = 2e-5     # closed-form fp64 accumulation vs the reference's float32 running mean
+RGB_LSB = 3          # the reference truncates to uint8 at every update; we truncate the exact weighted mean
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from avlmaps_amd import _lib, ops
+    _lib.load()
+    _lib.require_gpu()
+    return ops
+
+
+def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samples, capacity=None, frame_offset=0):
+    D = feats_chw.shape[1]
+    vh = int(cam_h / cs)
+    acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=capacity)
+    for i in range(len(depths)):
+        feat_hwc = np.ascontiguousarray(np.transpose(feats_chw[i], (1, 2, 0)))
+        acc.integrate_frame(depths[i], calib, Ts[i], samples[i], feat_hwc, rgbs[i], frame_idx=frame_offset + i)
+    return acc
+
+
+def compare_maps(out, ref, feat_scale):
+    assert np.array_equal(out["grid_pos"], ref["grid_pos"])                 # bit-exact voxel indices + id order
+    assert np.array_equal(out["occupied_ids"], ref["occupied_ids"])
+    np.testing.assert_allclose(out["weight"], ref["weight"].astype(np.float32), rtol=3e-6, atol=1e-30)
+    np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=FEAT_RTOL, atol=FEAT_RTOL * feat_scale)
+    d = np.abs(out["grid_rgb"].astype(int) - np.asarray(ref["grid_rgb"]).astype(int))
+    assert d.max() <= RGB_LSB, d.max()
+
+
+@pytest.mark.parametrize("name", ["g2a_builder_small.npz", "g2b_builder_growth.npz"])
+def test_builder_matches_reference_golden(ops, golden, name):
+    from oracle import avl_oracle as O
+    g = golden(name)
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    acc = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"],
+                          g["rgbs"], g["feats"], g["samples"], capacity=2000)
+    assert acc.num_voxels() == int(g["max_id"])
+    out = acc.finalize()
+    occ = -np.ones(tuple(g["occ_shape"]), dtype=np.int32)
+    nz = g["occ_nz"]
+    occ[nz[:, 0], nz[:, 1], nz[:, 2]] = g["occ_nz_vals"]
+    ref = dict(grid_pos=g["grid_pos"], occupied_ids=occ, weight=g["weight"], grid_feat=g["grid_feat"],
+               grid_rgb=np.floor(g["grid_rgb"]) if g["grid_rgb"].dtype != np.uint8 else g["grid_rgb"])
+    compare_maps(out, ref, 14.3)
+
+
+def synth_scene(rng, nfr, H, W, Hf, Wf, D):
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    depths, rgbs, feats, poses = [], [], [], []
+    for i in range(nfr):
+        d = 2.2 + 1.2 * np.sin(2.0 * xx + 0.2 * i) * np.cos(1.5 * yy) + 0.6 * yy + rng.normal(0, 0.02, xx.shape)
+        d[rng.random(d.shape) < 0.03] = 0.0
+        d[rng.random(d.shape) < 0.02] = 9.0
+        depths.append(d.astype(np.float32))
+        rgbs.append(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+        f = rng.standard_normal((D, Hf, Wf)).astype(np.float32)
+        f = (f / np.linalg.norm(f, axis=0, keepdims=True) * 14.2857).astype(np.float16).astype(np.float32)
+        feats.append(f)
+        yaw = 0.07 * i
+        poses.append([0.08 * i, 0.0, -0.05 * i, 0.0, np.sin(yaw / 2), 0.0, np.cos(yaw / 2)])
+    return np.stack(depths), np.stack(rgbs), np.stack(feats), np.array(poses)
+
+
+def test_builder_vs_sequential_oracle_medium(ops):
+    """24 frames 120x160, D=64, default grid: same sample lists through the GPU path and the sequential oracle."""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(7)
+    H, W, Hf, Wf, D, nfr, rate = 120, 160, 58, 77, 64, 24, 5
+    gs, cs, cam_h = 1000, 0.05, 1.5
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(3)
+    samples = [O.sample_indices(rs, H * W, rate) for _ in range(nfr)]
+    om = O.OracleMap(gs, cs, cam_h, D)
+    for i in range(nfr):
+        om.integrate(depths[i], calib, Ts[i], samples[i], feats[i], rgbs[i])
+    ref = om.export()
+    acc = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000)
+    assert acc.num_voxels() == len(ref["grid_pos"])
+    assert acc.num_points() == sum(1 for _ in range(0)) or acc.num_points() > 0
+    out = acc.finalize()
+    compare_maps(out, ref, 14.3)
+    # determinism: a second run gives identical indices and (to fp64 round-off) identical features
+    acc2 = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000)
+    out2 = acc2.finalize()
+    assert np.array_equal(out2["grid_pos"], out["grid_pos"])
+    assert np.mean(out2["grid_feat"] == out["grid_feat"]) > 0.9999
+
+
+def test_edge_cases(ops):
+    from avlmaps_amd._lib import AvlError
+    H, W, Hf, Wf, D = 16, 20, 8, 10, 8
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    T = np.eye(4)
+    feat = np.ones((Hf, Wf, D), np.float32)
+    rgb = np.zeros((H, W, 3), np.uint8)
+    acc = ops.VoxelAccumulator(100, 0.05, 30, D, capacity=64)
+    # every depth invalid (0, NaN, inf, beyond max): no voxel, no crash
+    depth = np.zeros((H, W), np.float32)
+    depth[0, :] = np.nan
+    depth[1, :] = np.inf
+    depth[2, :] = 7.0
+    acc.integrate_frame(depth, calib, T, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
+    assert acc.num_voxels() == 0
+    out = acc.finalize()
+    assert out["grid_feat"].shape == (0, D) and np.all(out["occupied_ids"] == -1)
+    # empty sample list
+    acc.integrate_frame(depth, calib, T, np.zeros((0,), np.int32), feat, rgb, 1)
+    assert acc.num_voxels() == 0
+    # capacity overflow is reported, not silently dropped
+    depth = np.full((H, W), 1.0, np.float32)
+    small = ops.VoxelAccumulator(100, 0.01, 150, D, capacity=4)
+    T2 = np.eye(4)
+    T2[:3, :3] = [[0, 0, 1], [-1, 0, 0], [0, -1, 0]]   # camera z -> map x (forward), so points land in range
+    T2[2, 3] = 0.5
+    small.integrate_frame(depth, calib, T2, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
+    with pytest.raises(AvlError, match="capacity"):
+        small.num_voxels()
+
+
+def test_heatmap_matches_reference(ops, golden):
+    g = golden("g4_heatmap.npz")
+    for decay in (0.01, 0.1):
+        h = ops.heatmap_from_mask(g["grid_pos"], g["mask"], 0.05, decay)
+        assert np.array_equal(h, g[f"heat_{decay}"]), np.abs(h - g[f"heat_{decay}"]).max()
+    # brute-force path (tiny decay -> huge window) agrees with the oracle bit for bit
+    from oracle import avl_oracle as O
+    for decay in (1e-4, 0.003):
+        h = ops.heatmap_from_mask(g["grid_pos"], g["mask"], 0.05, decay)
+        assert np.array_equal(h, O.heatmap_from_mask(g["grid_pos"], g["mask"], 0.05, decay))
+    # navigator argmax: first maximum wins
+    idx, val = ops.argmax_f32(g["heat_0.01"])
+    assert idx == int(np.argmax(g["heat_0.01"])) and val == 1.0
+
+
+def test_export_raw_and_finalize_raw_roundtrip(ops, golden):
+    from oracle import avl_oracle as O
+    g = golden("g2a_builder_small.npz")
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    acc = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"],
+                          g["rgbs"], g["feats"], g["samples"], capacity=2000)
+    out = acc.finalize()
+    raw = acc.export_raw()
+    assert np.all(np.diff(raw["first_key"].astype(np.int64)) > 0)      # slots are already in first-touch order
+    out2 = ops.finalize_raw(raw, acc.D, acc.gs, acc.vh)
+    for k in ("grid_feat", "grid_pos", "weight", "grid_rgb", "occupied_ids"):
+        assert np.array_equal(out[k], out2[k]), k
