@@ -5,7 +5,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 FEAT_RTOL = 2e-5     # closed-form fp64 accumulation vs the reference's float32 running mean
-RGB_LSB = 3          # the reference truncates to uint8 at every update; we truncate the exact weighted mean
+# grid_rgb: the reference stores its running mean into a uint8 array, truncating at EVERY update, which biases it
+# downwards by up to ~1 LSB per update; the GPU path truncates the exact weighted mean once.  Not part of the
+# parity contract (indices + scores); bounded here, documented in DESIGN.md.
+RGB_LSB = 3          # few updates per voxel
 
 
 @pytest.fixture(scope="module")
@@ -26,13 +29,14 @@ def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samp
     return acc
 
 
-def compare_maps(out, ref, feat_scale):
+def compare_maps(out, ref, feat_scale, rgb_lsb=RGB_LSB):
     assert np.array_equal(out["grid_pos"], ref["grid_pos"])                 # bit-exact voxel indices + id order
     assert np.array_equal(out["occupied_ids"], ref["occupied_ids"])
     np.testing.assert_allclose(out["weight"], ref["weight"].astype(np.float32), rtol=3e-6, atol=1e-30)
     np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=FEAT_RTOL, atol=FEAT_RTOL * feat_scale)
     d = np.abs(out["grid_rgb"].astype(int) - np.asarray(ref["grid_rgb"]).astype(int))
-    assert d.max() <= RGB_LSB, d.max()
+    assert d.max() <= rgb_lsb, d.max()
+    assert d.mean() < 1.5, d.mean()
 
 
 @pytest.mark.parametrize("name", ["g2a_builder_small.npz", "g2b_builder_growth.npz"])
@@ -49,7 +53,8 @@ def test_builder_matches_reference_golden(ops, golden, name):
     occ[nz[:, 0], nz[:, 1], nz[:, 2]] = g["occ_nz_vals"]
     ref = dict(grid_pos=g["grid_pos"], occupied_ids=occ, weight=g["weight"], grid_feat=g["grid_feat"],
                grid_rgb=np.floor(g["grid_rgb"]) if g["grid_rgb"].dtype != np.uint8 else g["grid_rgb"])
-    compare_maps(out, ref, 14.3)
+    # the growth fixture funnels ~16k points into 463 coarse voxels: many truncating updates per voxel upstream
+    compare_maps(out, ref, 14.3, rgb_lsb=16 if "growth" in name else RGB_LSB)
 
 
 def synth_scene(rng, nfr, H, W, Hf, Wf, D):
@@ -82,12 +87,13 @@ def test_builder_vs_sequential_oracle_medium(ops):
     rs = np.random.RandomState(3)
     samples = [O.sample_indices(rs, H * W, rate) for _ in range(nfr)]
     om = O.OracleMap(gs, cs, cam_h, D)
+    om_points = 0
     for i in range(nfr):
-        om.integrate(depths[i], calib, Ts[i], samples[i], feats[i], rgbs[i])
+        om_points += om.integrate(depths[i], calib, Ts[i], samples[i], feats[i], rgbs[i])
     ref = om.export()
     acc = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000)
     assert acc.num_voxels() == len(ref["grid_pos"])
-    assert acc.num_points() == sum(1 for _ in range(0)) or acc.num_points() > 0
+    assert acc.num_points() == om_points
     out = acc.finalize()
     compare_maps(out, ref, 14.3)
     # determinism: a second run gives identical indices and (to fp64 round-off) identical features
@@ -119,7 +125,7 @@ def test_edge_cases(ops):
     assert acc.num_voxels() == 0
     # capacity overflow is reported, not silently dropped
     depth = np.full((H, W), 1.0, np.float32)
-    small = ops.VoxelAccumulator(100, 0.01, 150, D, capacity=4)
+    small = ops.VoxelAccumulator(100, 0.05, 30, D, capacity=4)
     T2 = np.eye(4)
     T2[:3, :3] = [[0, 0, 1], [-1, 0, 0], [0, -1, 0]]   # camera z -> map x (forward), so points land in range
     T2[2, 3] = 0.5
