@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 8;
 
-__global__ __launch_bounds__(kScanThreads) void assign_slots_kernel(int P, unsigned long long frame_idx, int64_t capacity,
+__global__ __launch_bounds__(kScanThreads) void assign_slots_kernel(int P, unsigned long long frame_idx,
+                                                                    unsigned long long key_bias, int64_t capacity,
                                                                     int32_t* __restrict__ cell_slot, PointRec* __restrict__ recs,
                                                                     int32_t* __restrict__ slot_cell,
                                                                     unsigned long long* __restrict__ slot_key,
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kScanThreads) void assign_slots_kernel(int P, unsig
                 } else {
                     cell_slot[cells[i]] = (int32_t)slot;
                     slot_cell[slot] = cells[i];
-                    slot_key[slot] = (frame_idx << 32) | (unsigned)idx;
+                    slot_key[slot] = key_bias | (frame_idx << 32) | (unsigned)idx;
                     first_alpha[slot] = recs[idx].alpha;
                     recs[idx].first = 1;
                 }
@@ -309,6 +310,40 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
     }
 }
 
+// wave per imported voxel row: rebuild accumulators from a finalised map (resume, vlmap_builder.py:212-222)
+__global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int gs, int vh, const float* __restrict__ grid_feat,
+                                                         const int32_t* __restrict__ grid_pos, const float* __restrict__ weight,
+                                                         const uint8_t* __restrict__ grid_rgb, int32_t* __restrict__ cell_slot,
+                                                         int32_t* __restrict__ slot_cell, unsigned long long* __restrict__ slot_key,
+                                                         double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                                         float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                                         int* __restrict__ err_flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave0; r < n; r += nwaves) {
+        const double w = (double)weight[r];
+        for (int c = lane; c < D; c += 64) {
+            sum_feat[r * D + c] = (double)grid_feat[r * D + c] * w;   // first-touch weighting is already baked in
+            first_feat[r * D + c] = 0.f;
+        }
+        if (lane == 0) {
+            const int row = grid_pos[r * 3], col = grid_pos[r * 3 + 1], h = grid_pos[r * 3 + 2];
+            if (row < 0 || row >= gs || col < 0 || col >= gs || h < 0 || h >= vh) {
+                atomicOr(err_flags, 4);
+            } else {
+                const int32_t cell = (row * gs + col) * vh + h;
+                cell_slot[cell] = (int32_t)r;
+                slot_cell[r] = cell;
+            }
+            slot_key[r] = (unsigned long long)r;
+            first_alpha[r] = 1.0;                                       // a1*(1-a1) == 0: no further correction
+            sum_w4[r * 4] = w;
+            for (int c = 0; c < 3; ++c) sum_w4[r * 4 + 1 + c] = (grid_rgb ? (double)grid_rgb[r * 3 + c] : 0.0) * w;
+        }
+    }
+}
+
 }  // namespace avl
 
 using namespace avl;
@@ -329,6 +364,7 @@ struct avl_builder {
     int* err_flags = nullptr;
     PointRec* recs = nullptr;
     int recs_cap = 0;
+    unsigned long long key_bias = 0;  // set after import_map so that imported voxels order before new ones
 };
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
@@ -360,6 +396,7 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_key, 0xFF, (size_t)b->capacity * sizeof(unsigned long long), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->counters, 0, 2 * sizeof(long long), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->err_flags, 0, sizeof(int), st));
+    b->key_bias = 0;
     return AVL_OK;
 }
 
@@ -445,7 +482,7 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
 
     hipLaunchKernelGGL(bp_voxelize_kernel, dim3((P + 255) / 256), dim3(256), 0, st, fp, d_depth, d_sample_idx, d_rgb,
                        b->cell_slot, b->recs, b->err_flags);
-    hipLaunchKernelGGL(assign_slots_kernel, dim3(1), dim3(kScanThreads), 0, st, P, fp.frame_idx, b->capacity, b->cell_slot,
+    hipLaunchKernelGGL(assign_slots_kernel, dim3(1), dim3(kScanThreads), 0, st, P, fp.frame_idx, b->key_bias, b->capacity, b->cell_slot,
                        b->recs, b->slot_cell, b->slot_key, b->first_alpha, b->counters, b->err_flags);
     hipLaunchKernelGGL(accumulate_kernel, dim3((P + 3) / 4), dim3(256), 0, st, P, b->D, b->recs, b->cell_slot, d_feat,
                        b->sum_feat, b->sum_w4, b->first_feat);
@@ -503,6 +540,40 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
                           d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, nullptr, stream);
     if (rc != AVL_OK) return rc;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
+    return AVL_OK;
+}
+
+int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, const int32_t* d_grid_pos,
+                           const float* d_weight, const uint8_t* d_grid_rgb, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_import_map: null handle");
+    AVL_REQUIRE(n >= 0 && n <= b->capacity, "avl_builder_import_map: %lld voxels exceed the capacity %lld", (long long)n,
+                (long long)b->capacity);
+    hipStream_t st = as_stream(stream);
+    int64_t have = 0;
+    int rc = avl_builder_num_voxels(b, &have, stream);
+    if (rc != AVL_OK) return rc;
+    if (have != 0) {
+        set_error("avl_builder_import_map: the map already holds %lld voxels (import into an empty builder)", (long long)have);
+        return AVL_ERR_STATE;
+    }
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_grid_feat && d_grid_pos && d_weight, "avl_builder_import_map: null input");
+    int64_t blocks = (n + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(import_map_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, b->D, b->gs, b->vh, d_grid_feat, d_grid_pos,
+                       d_weight, d_grid_rgb, b->cell_slot, b->slot_cell, b->slot_key, b->sum_feat, b->sum_w4, b->first_feat,
+                       b->first_alpha, b->err_flags);
+    const long long nn = n;
+    AVL_HIP_CHECK(hipMemcpyAsync(b->counters, &nn, sizeof(long long), hipMemcpyHostToDevice, st));
+    int flags = 0;
+    AVL_HIP_CHECK(hipMemcpyAsync(&flags, b->err_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    if (flags & 4) {
+        set_error("avl_builder_import_map: a grid_pos row lies outside the (gs, gs, vh) grid");
+        return AVL_ERR_INVALID;
+    }
+    b->key_bias = 1ull << 62;
     return AVL_OK;
 }
 

@@ -1,0 +1,101 @@
+"""VLMap with the reference's interface (avlmaps/map/vlmap.py:27-187), indexing on the MI355X.
+
+grid_feat stays a host NumPy attribute (the navigator reads it) and is mirrored ONCE into HBM; every
+index_map / init_categories call then streams the device copy through the similarity kernel."""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Union
+
+import numpy as np
+
+from ..utils.clip_utils import get_lseg_score, landmark_text_feats
+from ..utils.mapping_utils import load_3d_map, map_file_exists
+from .map import Map, cfg_get
+
+CLIP_FEAT_DIM = {"RN50": 1024, "RN101": 512, "RN50x4": 640, "RN50x16": 768, "RN50x64": 1024, "ViT-B/32": 512,
+                 "ViT-B/16": 512, "ViT-L/14": 768}
+
+
+class VLMap(Map):
+    def __init__(self, map_config, data_dir: str = ""):
+        super().__init__(map_config, data_dir=data_dir)
+        self.scores_mat = None
+        self.categories = None
+        self._dev_feat = None
+        self._dev_feat_src = None
+
+    # ------------------------------------------------------------------ build / load
+    def create_map(self, data_dir: Union[Path, str], feat_extractor=None) -> None:
+        """Reference: vlmap.py:33-48."""
+        from .vlmap_builder import VLMapBuilder
+        print("Creating map for scene at: ", data_dir)
+        self._setup_paths(data_dir)
+        self.map_builder = VLMapBuilder(self.data_dir, self.map_config, self.pose_path, self.rgb_paths, self.depth_paths,
+                                        self.base2cam_tf, self.base_transform, feat_extractor=feat_extractor)
+        pose_type = cfg_get(cfg_get(self.map_config, "pose_info"), "pose_type")
+        if pose_type == "mobile_base":
+            self.map_builder.create_mobile_base_map()
+        elif pose_type == "camera":
+            self.map_builder.create_camera_map()
+
+    def load_map(self, data_dir: str) -> bool:
+        """Reference: vlmap.py:50-65 (prints and returns False when the file is missing)."""
+        self._setup_paths(data_dir)
+        self.map_save_path = Path(data_dir) / "vlmap" / "vlmaps.h5df"
+        if not map_file_exists(self.map_save_path):
+            print("Loading VLMap failed because the file doesn't exist.")
+            return False
+        (self.mapped_iter_list, self.grid_feat, self.grid_pos, self.weight, self.occupied_ids,
+         self.grid_rgb) = load_3d_map(self.map_save_path)[:6]
+        self._dev_feat = None
+        return True
+
+    def _init_clip(self, clip_version="ViT-B/32"):
+        """Reference: vlmap.py:67-90."""
+        if hasattr(self, "clip_model"):
+            print("clip model is already initialized")
+            return
+        import torch
+        import clip
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.clip_version = clip_version
+        self.clip_feat_dim = CLIP_FEAT_DIM[self.clip_version]
+        print("Loading CLIP model...")
+        self.clip_model, self.preprocess = clip.load(self.clip_version)
+        self.clip_model.to(self.device).eval()
+
+    # ------------------------------------------------------------------ index
+    def _device_feat(self):
+        """grid_feat mirrored into HBM once (re-uploaded only if the host array object changes)"""
+        from ..device import DeviceArray
+        if self._dev_feat is None or self._dev_feat_src is not self.grid_feat:
+            self._dev_feat = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_feat, dtype=np.float32))
+            self._dev_feat_src = self.grid_feat
+        return self._dev_feat
+
+    def init_categories(self, categories: List[str]) -> np.ndarray:
+        """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
+        self.categories = categories
+        self.scores_mat = get_lseg_score(self.clip_model, self.categories, self._device_feat(), self.clip_feat_dim,
+                                         use_multiple_templates=True, add_other=True)
+        return self.scores_mat
+
+    def index_map(self, language_desc: str, with_init_cat: bool = True):
+        """bool mask (N,): argmax over the query columns == category.  Reference: vlmap.py:104-125."""
+        from .. import ops
+        if with_init_cat and self.scores_mat is not None and self.categories is not None:
+            from ..utils.index_utils import find_similar_category_id
+            cat_id = find_similar_category_id(language_desc, self.categories)
+            return np.argmax(self.scores_mat, axis=1) == cat_id
+        if with_init_cat:
+            raise Exception(
+                "Categories are not preloaded. Call init_categories(categories: List[str]) to initialize categories.")
+        # fused path: scores never leave the GPU, only the (N,) argmax comes back
+        q, _ = landmark_text_feats(self.clip_model, [language_desc], self.clip_feat_dim, use_multiple_templates=True,
+                                   add_other=True)
+        _, am, _ = ops.sim_scores(self._device_feat(), q, want_scores=False, want_argmax=True)
+        return am.numpy() == 0
+
+    def get_pos(self, name: str):
+        raise NotImplementedError("contour extraction (vlmap.py:158-187) is navigator-side and not on the accelerated path")

@@ -1,0 +1,181 @@
+"""VLMapBuilder with the reference's interface (avlmaps/map/vlmap_builder.py:35-327), fusing frames on the MI355X.
+
+Per frame the reference runs LSeg, back-projects ~7.8 k sampled pixels and updates the map in a Python loop
+(vlmap_builder.py:102-183).  Here the per-point loop is three HIP launches (avl_builder_integrate_frame); the host
+keeps only what is inherently sequential and tiny: the float64 pose chain (one 4x4 per frame) and the reference's
+sampling order (np.random.shuffle on the GLOBAL NumPy state, so a seeded run samples the same pixels upstream and here).
+
+Feature extraction stays on PyTorch-ROCm: `feat_extractor(rgb_uint8_hwc) -> (Hf, Wf, D) float32 CUDA tensor`
+(channels-last, stays on the device).  A reference-style (1, D, Hf, Wf) array is accepted and transposed.
+With torch.distributed initialised (one process per GPU) frames are sharded contiguously over ranks and merged with one
+sparse RCCL reduce (avlmaps_amd.parallel.merge_raw); rank 0 writes the map file.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from .. import ops, parallel
+from ..utils.mapping_utils import (cvt_pose_vec2tf, load_3d_map, load_depth_npy, load_rgb_png, map_file_exists,
+                                   save_3d_map)
+from .map import cfg_get
+
+
+class VLMapBuilder:
+    def __init__(self, data_dir: Path, map_config, pose_path: Path, rgb_paths: List[Path], depth_paths: List[Path],
+                 base2cam_tf: np.ndarray, base_transform: np.ndarray, feat_extractor: Optional[Callable] = None):
+        self.data_dir = Path(data_dir)
+        self.pose_path = pose_path
+        self.rgb_paths = rgb_paths
+        self.depth_paths = depth_paths
+        self.map_config = map_config
+        self.base2cam_tf = base2cam_tf
+        self.base_transform = base_transform
+        self.feat_extractor = feat_extractor
+        self.save_every = 100                      # vlmap_builder.py:181
+        self.capacity = None                       # voxels; default below
+        self.min_depth, self.max_depth = 0.1, 6    # vlmap_builder.py:129
+        self.sigma_sq = 0.6                        # vlmap_builder.py:157
+
+    # ------------------------------------------------------------------ pose chain (host, float64)
+    def frame_transforms(self, base_poses: np.ndarray) -> List[np.ndarray]:
+        """pc_transform per frame.  Reference: vlmap_builder.py:64-76, :106-108, :133 (same matmul order)."""
+        self.init_base_tf = self.base_transform @ cvt_pose_vec2tf(base_poses[0]) @ np.linalg.inv(self.base_transform)
+        self.inv_init_base_tf = np.linalg.inv(self.init_base_tf)
+        self.init_cam_tf = self.init_base_tf @ self.base2cam_tf
+        self.inv_init_cam_tf = np.linalg.inv(self.init_cam_tf)
+        out = []
+        for posevec in base_poses:
+            habitat_base_pose = cvt_pose_vec2tf(posevec)
+            base_pose = self.base_transform @ habitat_base_pose @ np.linalg.inv(self.base_transform)
+            tf = self.inv_init_base_tf @ base_pose
+            out.append(tf @ self.base_transform @ self.base2cam_tf)
+        return out
+
+    @staticmethod
+    def sample_pixels(n_pix: int, depth_sample_rate: int) -> np.ndarray:
+        """shuffle_mask[::rate] on the global NumPy RNG.  Reference: vlmap_builder.py:275-277."""
+        shuffle_mask = np.arange(n_pix)
+        np.random.shuffle(shuffle_mask)
+        return shuffle_mask[::depth_sample_rate].astype(np.int32)
+
+    # ------------------------------------------------------------------ frame sources (overridable for in-memory data)
+    def load_frame(self, frame_i: int):
+        rgb = load_rgb_png(self.rgb_paths[frame_i])
+        depth = load_depth_npy(self.depth_paths[frame_i])
+        return rgb, depth
+
+    def _init_lseg(self):
+        """Reference: vlmap_builder.py:226-264 builds LSegEncNet from demo_e200.ckpt.  The model is not part of this
+        package: pass feat_extractor=..., or have the upstream `avlmaps` package (and its checkpoint) importable."""
+        if self.feat_extractor is not None:
+            return self.feat_extractor
+        try:
+            from ..lseg_adapter import load_upstream_lseg
+        except Exception as e:  # pragma: no cover
+            raise RuntimeError("no feat_extractor given and the upstream LSeg model is not importable") from e
+        self.feat_extractor = load_upstream_lseg()
+        return self.feat_extractor
+
+    def _features_hwc(self, rgb):
+        f = self.feat_extractor(rgb)
+        if isinstance(f, np.ndarray):
+            if f.ndim == 4:                          # reference layout (1, D, Hf, Wf)
+                f = np.transpose(f[0], (1, 2, 0))
+            return np.ascontiguousarray(f, dtype=np.float32)
+        if f.dim() == 4:
+            f = f[0].permute(1, 2, 0)
+        return f.float().contiguous()
+
+    # ------------------------------------------------------------------ the build
+    def create_mobile_base_map(self):
+        """Build the 3-D map centred at the first base frame.  Reference: vlmap_builder.py:54-185."""
+        pose_info = cfg_get(self.map_config, "pose_info")
+        camera_height = cfg_get(pose_info, "camera_height")
+        cs = cfg_get(self.map_config, "cell_size")
+        gs = cfg_get(self.map_config, "grid_size")
+        depth_sample_rate = cfg_get(self.map_config, "depth_sample_rate")
+        calib_mat = np.array(list(cfg_get(self.map_config, "cam_calib_mat")), dtype=np.float64).reshape((3, 3))
+        calib_inv = np.linalg.inv(calib_mat)        # mapping_utils.py:237
+
+        self.base_poses = np.loadtxt(self.pose_path).reshape((-1, 7))
+        transforms = self.frame_transforms(self.base_poses)
+
+        self.map_save_dir = self.data_dir / "vlmap"
+        os.makedirs(self.map_save_dir, exist_ok=True)
+        self.map_save_path = self.map_save_dir / "vlmaps.h5df"
+
+        self._init_lseg()
+        rank, ws = _dist_rank_ws()
+        n_frames = min(len(self.rgb_paths), len(self.depth_paths), len(self.base_poses))
+        lo, hi = parallel.shard_frames(n_frames, rank, ws)
+
+        vh = int(camera_height / cs)                 # vlmap_builder.py:201
+        acc = None
+        mapped_iter_set = set()
+        for frame_i in range(lo, hi):
+            rgb, depth = self.load_frame(frame_i)
+            feat = self._features_hwc(rgb)
+            if acc is None:
+                D = int(feat.shape[2])
+                self.clip_feat_dim = D
+                cap = self.capacity or max(gs * gs, 1 << 16)   # the reference starts at gs*gs rows and doubles
+                acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=cap)
+                mapped_iter_set = self._resume(acc, ws)
+            samples = self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
+            acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
+                                calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,
+                                sigma_sq=self.sigma_sq)
+            mapped_iter_set.add(frame_i)
+            if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
+                print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
+                self._save_3d_map(acc.finalize(), mapped_iter_set)
+        if acc is None:
+            raise RuntimeError("no frames to map")
+        self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
+
+    def create_camera_map(self):
+        """Upstream returns (does not raise) NotImplementedError.  Reference: vlmap_builder.py:187-193."""
+        return NotImplementedError
+
+    # ------------------------------------------------------------------ helpers
+    def _resume(self, acc, ws):
+        """Continue from an existing map file.  Reference: vlmap_builder.py:212-222 (note: upstream restores
+        mapped_iter_set but never skips frames, so a resumed run re-fuses every frame; kept as is)."""
+        if ws > 1 or not map_file_exists(self.map_save_path):
+            return set()
+        mapped_iter_list, grid_feat, grid_pos, weight, _occ, grid_rgb = load_3d_map(self.map_save_path)[:6]
+        acc.import_map(grid_feat, grid_pos, weight, grid_rgb)
+        return set(mapped_iter_list)
+
+    def _finish(self, acc, mapped_iter_set, rank, ws, gs, vh):
+        if ws == 1:
+            self._save_3d_map(acc.finalize(), mapped_iter_set)
+            return
+        import torch.distributed as dist
+        merged = parallel.merge_raw(ops.export_raw_torch(acc), dst=0)
+        sets = [None] * ws
+        dist.all_gather_object(sets, sorted(mapped_iter_set))
+        if rank == 0:
+            fin = ops.finalize_raw(merged, acc.D, gs, vh)
+            self._save_3d_map(fin, set(i for s in sets for i in s))
+        dist.barrier()
+
+    def _save_3d_map(self, arrays, mapped_iter_set) -> None:
+        """Reference: vlmap_builder.py:313-327 -> mapping_utils.save_3d_map."""
+        self.last_map = arrays
+        save_3d_map(self.map_save_path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"],
+                    list(mapped_iter_set), arrays["grid_rgb"])
+
+
+def _dist_rank_ws():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:
+        pass
+    return 0, 1

@@ -128,6 +128,20 @@ class VoxelAccumulator:
         self._keep = (k1, k2, k3, k4)   # inputs must outlive the asynchronous launches
         return self
 
+    def import_map(self, grid_feat, grid_pos, weight, grid_rgb=None, stream=None):
+        """seed an empty accumulator from a finished map (resume, vlmap_builder.py:212-222)"""
+        lib = _lib.load()
+        fp_, fshape, k1 = as_device(np.asarray(grid_feat, dtype=np.float32) if isinstance(grid_feat, np.ndarray) else grid_feat,
+                                    np.float32, stream)
+        pp, _, k2 = as_device(np.asarray(grid_pos, dtype=np.int32) if isinstance(grid_pos, np.ndarray) else grid_pos, np.int32, stream)
+        wp, _, k3 = as_device(np.asarray(weight, dtype=np.float32) if isinstance(weight, np.ndarray) else weight, np.float32, stream)
+        rp = None
+        if grid_rgb is not None:
+            rgb8 = np.clip(np.asarray(grid_rgb), 0, 255).astype(np.uint8) if isinstance(grid_rgb, np.ndarray) else grid_rgb
+            rp, _, k4 = as_device(rgb8, np.uint8, stream)
+        _lib.check(lib.avl_builder_import_map(self._h, fshape[0], fp_, pp, wp, rp, stream), "avl_builder_import_map")
+        return self
+
     def num_voxels(self, stream=None):
         n = C.c_int64()
         _lib.check(_lib.load().avl_builder_num_voxels(self._h, C.byref(n), stream), "avl_builder_num_voxels")
@@ -206,3 +220,20 @@ def heatmap_from_mask(grid_pos, mask, cell_size=0.05, decay_rate=0.01, stream=No
     _lib.check(lib.avl_heatmap_from_mask(pp, mp, N, float(cell_size), float(decay_rate), heat.ptr, stream),
                "avl_heatmap_from_mask")
     return heat.numpy(stream) if isinstance(grid_pos, np.ndarray) else heat
+
+
+def export_raw_torch(acc: "VoxelAccumulator", device=None, stream=None):
+    """VoxelAccumulator.export_raw into torch tensors on the GPU (input of parallel.merge_raw)."""
+    import torch
+    lib = _lib.load()
+    n = acc.num_voxels(stream)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    t = dict(cell=torch.empty((n,), dtype=torch.int32, device=device),
+             first_key=torch.empty((n,), dtype=torch.int64, device=device),
+             sum_feat=torch.empty((n, acc.D), dtype=torch.float64, device=device),
+             sum_w4=torch.empty((n, 4), dtype=torch.float64, device=device),
+             first_feat=torch.empty((n, acc.D), dtype=torch.float32, device=device),
+             first_alpha=torch.empty((n,), dtype=torch.float64, device=device))
+    _lib.check(lib.avl_builder_export_raw(acc._h, n, *(v.data_ptr() for v in t.values()), stream), "avl_builder_export_raw")
+    _lib.check(lib.avl_stream_sync(stream))
+    return t

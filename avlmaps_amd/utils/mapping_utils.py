@@ -1,0 +1,104 @@
+"""Host-side geometry + map I/O with the names and argument meaning of the reference's
+avlmaps/utils/mapping_utils.py (cited per function, path:line in the upstream repo).
+
+Everything here is tiny float64 host math (one 4x4 per frame) or file I/O; per-point work runs in the
+HIP builder kernels.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Optional, Sequence
+
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+try:  # optional: the reference's on-disk format is HDF5
+    import h5py  # type: ignore
+except Exception:  # pragma: no cover - absent in the build container
+    h5py = None
+
+MAP_DATASETS = ("mapped_iter_list", "grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")
+
+
+def cvt_pose_vec2tf(pos_quat_vec: np.ndarray) -> np.ndarray:
+    """(px, py, pz, qx, qy, qz, qw) -> 4x4 float64.  Reference: mapping_utils.py:18-26."""
+    v = np.asarray(pos_quat_vec, dtype=np.float64).flatten()
+    tf = np.eye(4)
+    tf[:3, 3] = v[:3]
+    tf[:3, :3] = R.from_quat(v[3:]).as_matrix()
+    return tf
+
+
+def get_sim_cam_mat(h: int, w: int) -> np.ndarray:
+    """90-degree-FOV pinhole matrix of an (h, w) image.  Reference: mapping_utils.py:591-596."""
+    m = np.eye(3)
+    m[0, 0] = m[1, 1] = w / 2.0
+    m[0, 2] = w / 2.0
+    m[1, 2] = h / 2.0
+    return m
+
+
+def base_pos2grid_id_3d(gs: int, cs: float, x_base: float, y_base: float, z_base: float) -> List[int]:
+    """Scalar host version for callers such as the Habitat dataloader.  Reference: mapping_utils.py:345-349."""
+    return [int(gs / 2 - int(x_base / cs)), int(gs / 2 - int(y_base / cs)), int(z_base / cs)]
+
+
+def grid_id2base_pos_3d(row: int, col: int, height: int, cs: float, gs: int):
+    """Inverse of base_pos2grid_id_3d (cell origin).  Reference: mapping_utils.py (grid_id2base_pos_3d)."""
+    return (gs / 2 - row) * cs, (gs / 2 - col) * cs, height * cs
+
+
+def load_depth_npy(depth_filepath) -> np.ndarray:
+    """depth/*.npy holds float32 metres (H, W).  Reference: dataset/README.md:76-93."""
+    with open(depth_filepath, "rb") as f:
+        return np.load(f)
+
+
+def load_rgb_png(rgb_filepath) -> np.ndarray:
+    """RGB uint8 (H, W, 3).  The reference does cv2.imread + BGR2RGB (vlmap_builder.py:118-119)."""
+    from PIL import Image
+    with Image.open(rgb_filepath) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
+def _npz_path(path) -> Path:
+    p = Path(path)
+    return p.with_name(p.name + ".npz")
+
+
+def save_3d_map(save_path, grid_feat, grid_pos, weight, occupied_ids, mapped_iter_list, grid_rgb=None,
+                init_height_id=None) -> None:
+    """Write the six datasets of the reference's map file.  Reference: mapping_utils.py:469-505.
+    HDF5 (vlmaps.h5df) when h5py is importable, otherwise the same arrays in `<save_path>.npz`."""
+    data = dict(mapped_iter_list=np.array(sorted(mapped_iter_list), dtype=np.int32), grid_feat=np.asarray(grid_feat),
+                grid_pos=np.asarray(grid_pos), weight=np.asarray(weight), occupied_ids=np.asarray(occupied_ids))
+    if init_height_id is not None:
+        data["init_height_id"] = np.array(init_height_id, dtype=np.int32)
+    if grid_rgb is not None:
+        data["grid_rgb"] = np.asarray(grid_rgb)
+    if h5py is not None:
+        with h5py.File(save_path, "w") as f:
+            for k, v in data.items():
+                f.create_dataset(k, data=v)
+    else:
+        np.savez(_npz_path(save_path), **data)
+
+
+def map_file_exists(map_path) -> bool:
+    return Path(map_path).exists() or _npz_path(map_path).exists()
+
+
+def load_3d_map(map_path):
+    """-> (mapped_iter_list, grid_feat, grid_pos, weight, occupied_ids, grid_rgb).  Reference: mapping_utils.py:508-541."""
+    if Path(map_path).exists():
+        if h5py is None:
+            raise RuntimeError(f"{map_path} is an HDF5 map but h5py is not installed")
+        with h5py.File(map_path, "r") as f:
+            d = {k: f[k][:] for k in f.keys()}
+    else:
+        with np.load(_npz_path(map_path)) as z:
+            d = {k: z[k] for k in z.files}
+    out = (d["mapped_iter_list"].tolist(), d["grid_feat"], d["grid_pos"], d["weight"], d["occupied_ids"], d.get("grid_rgb"))
+    if "init_height_id" in d:
+        return out + (d["init_height_id"],)
+    return out

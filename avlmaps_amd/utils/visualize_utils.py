@@ -1,0 +1,22 @@
+"""Reference interface of avlmaps/utils/visualize_utils.py for the pieces on the hot path."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def get_heatmap_from_mask_3d(pc: np.ndarray, mask: np.ndarray, cell_size: float = 0.05, decay_rate: float = 0.01) -> np.ndarray:
+    """Nearest-target distance-decay heat per voxel, (N,) float32.  Reference: visualize_utils.py:29-49
+    (an O(N_other * N_target) Python loop upstream; here the windowed / brute-force HIP kernels)."""
+    from .. import ops
+    mask = np.asarray(mask)
+    if mask.sum() == 0:
+        raise ValueError("attempt to get argmin of an empty sequence")   # what np.argmin raises upstream
+    return ops.heatmap_from_mask(np.ascontiguousarray(pc, dtype=np.int32), mask.astype(np.uint8), cell_size, decay_rate)
+
+
+def pool_3d_label_to_2d(mask_3d: np.ndarray, grid_pos: np.ndarray, gs: int) -> np.ndarray:
+    """Top-down OR-pooling of a per-voxel mask.  Reference: visualize_utils.py:77-83 (Python loop upstream)."""
+    mask_2d = np.zeros((gs, gs), dtype=bool)
+    sel = np.asarray(mask_3d, dtype=bool)
+    mask_2d[grid_pos[sel, 0], grid_pos[sel, 1]] = True
+    return mask_2d

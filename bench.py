@@ -1,0 +1,362 @@
+#!/usr/bin/env python3
+"""Benchmark of the AVLMaps hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload index|build]
+
+Default workload = BASELINE.json configs[1]: landmark indexing of a 2M-voxel x 512-D map with 64 text
+queries on one GPU (voxel rows shard across GPUs for N > 1, no data-path collective -> weak scaling).
+One step = one pass of the index hot path: scores = feat @ queries.T fused with the row argmax
+(VLMap.index_map, vlmap.py:104-125); the feature map is resident in HBM when the timed region starts.
+`--workload build` times map creation instead (configs[2]/[3]): one step = fusing one 720x1080 RGB-D
+frame (7 776 sampled pixels, 512-D channels-last features) into the voxel map; frames shard across GPUs
+and one sparse RCCL merge runs at the end (reported separately).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def event_timer(lib):
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.avl_event_create(C.byref(e0))
+    lib.avl_event_create(C.byref(e1))
+
+    def elapsed_ms(fn, stream=None):
+        lib.avl_event_record(e0, stream)
+        fn()
+        lib.avl_event_record(e1, stream)
+        lib.avl_event_sync(e1)
+        ms = C.c_float()
+        lib.avl_event_elapsed_ms(e0, e1, C.byref(ms))
+        return ms.value
+
+    return elapsed_ms
+
+
+def barrier_sync(torch, dist, ws):
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(torch, dist, ws, x):
+    if ws == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(torch, dist, ws, x):
+    if ws == 1:
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------- index workload
+def make_index_inputs(torch, N, D, Q, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    feat = torch.randn((N, D), device="cuda", generator=g)
+    # LSeg rows: weighted means of logit_scale * unit vectors -> norms <= 14.29 (lseg_net.py:268,321)
+    feat *= (14.2857 * (0.05 + 0.95 * torch.rand((N, 1), device="cuda", generator=g))) / feat.norm(dim=1, keepdim=True)
+    # queries: mean of 63 unit template embeddings each, not re-normalised (clip_utils.py:218-225)
+    base = torch.randn((Q, 1, D), device="cuda", generator=g)
+    t = base + 0.7 * torch.randn((Q, 63, D), device="cuda", generator=g)
+    t /= t.norm(dim=2, keepdim=True)
+    return feat, t.mean(dim=1).contiguous()
+
+
+def cpu_index_baseline(feat_h, q_h, repeats=3):
+    """the reference's own op on the host cores: map_feats @ text_feats.T then argmax(axis=1)"""
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    best = float("inf")
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        sc = feat_h @ q_h.T
+        am = np.argmax(sc, axis=1)
+        best = min(best, time.perf_counter() - t0)
+    return best, threads, am
+
+
+def run_index(args, torch, dist, lib, rank, ws):
+    from avlmaps_amd import _lib
+    N, D, Q = args.voxels, 512, args.queries
+    feat, q = make_index_inputs(torch, N, D, Q, seed=1234 + rank)
+    am = torch.empty((N,), dtype=torch.int32, device="cuda")
+    best = torch.empty((N,), dtype=torch.float32, device="cuda")
+    wsb = C.c_size_t()
+    lib.avl_sim_workspace_bytes(D, Q, C.byref(wsb))
+    wsbuf = torch.empty((max(wsb.value, 64),), dtype=torch.uint8, device="cuda")
+
+    def step(scores_ptr=None):
+        rc = lib.avl_sim_scores_ws(feat.data_ptr(), N, D, D, q.data_ptr(), Q, D, scores_ptr, am.data_ptr(), best.data_ptr(),
+                                   _lib.SIM_AUTO, wsbuf.data_ptr(), wsb.value, None)
+        _lib.check(rc, "avl_sim_scores_ws")
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(torch, dist, ws)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(torch, dist, ws, dt)
+    if ws > 1:
+        dist.barrier()
+
+    # per-launch duration of the dominant kernel with HIP events on the launch stream
+    timer = event_timer(lib)
+    ev = [timer(step) for _ in range(max(5, min(args.steps, 20)))]
+    ev_ms = float(np.mean(ev))
+    alg_bytes = N * D * 4 + Q * D * 4 + N * 8            # feature stream + queries + argmax/best out
+    achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
+
+    out = dict(
+        metric="voxel_query_similarities_per_sec", value=ws * N * Q * args.steps / dt, unit="similarities/s",
+        n_gpus=ws, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+        scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload=f"index_map: {N} voxels x {D}-D float32 map per GPU, {Q} text queries, "
+                             "scores fused with row argmax (no scores_mat write)",
+                    voxels_per_gpu=N, feat_dim=D, queries=Q, parallelism=f"voxel-row shards x{ws}, no collective",
+                    kernel="sim_split_f16_kernel<2> (fp16 hi/lo split MFMA, fp32 accumulate)" if Q > 8 else "sim_exact_kernel"),
+    )
+    out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                           traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes)
+    if rank == 0:
+        # variant: also materialise scores_mat (VLMap.init_categories, vlmap.py:92-102)
+        sc = torch.empty((N, Q), dtype=torch.float32, device="cuda")
+        for _ in range(2):
+            step(sc.data_ptr())
+        ms_sc = float(np.mean([timer(lambda: step(sc.data_ptr())) for _ in range(5)]))
+        # parity spot check against float64 on the device (north_star tolerance 1e-4)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        idx = torch.randint(0, N, (8192,), device="cuda", generator=g)
+        ref = feat[idx].double() @ q.double().T
+        err = float((sc[idx].double() - ref).abs().max())
+        am_ok = float((ref.argmax(dim=1) == am[idx].long()).double().mean())
+        out["extra"] = dict(
+            scores_mat_variant=dict(ms=ms_sc, similarities_per_s=N * Q / (ms_sc * 1e-3),
+                                    gbs=(alg_bytes + N * Q * 4) / (ms_sc * 1e-3) / 1e9),
+            parity_sample=dict(rows=8192, max_abs_err_vs_fp64=err, argmax_agreement=am_ok, tolerance=1e-4))
+        if ws == 1 and not args.no_cpu:
+            feat_h, q_h = feat.cpu().numpy(), q.cpu().numpy()
+            t_cpu, threads, am_cpu = cpu_index_baseline(feat_h, q_h)
+            agree = float(np.mean(am_cpu == am.cpu().numpy()))
+            out["cpu_baseline"] = dict(value=N * Q / t_cpu, unit="similarities/s", cores=threads, kind="port",
+                                       sample=f"full workload ({N}x{D} @ {D}x{Q} numpy/OpenBLAS sgemm + np.argmax, best of 3, "
+                                              f"{t_cpu * 1e3:.0f} ms; the op at clip_utils.py:229 + vlmap.py:123)",
+                                       argmax_agreement_with_gpu=agree)
+            out["extra"]["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            del feat_h
+            if not args.no_build_extra:
+                del sc
+                torch.cuda.empty_cache()
+                out["extra"]["map_build"] = run_build_core(args, torch, dist, lib, 0, 1, frames=args.build_frames, quiet=True)
+    return out
+
+
+# ---------------------------------------------------------------------------------------- build workload
+def make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H, device="cuda"), torch.linspace(-1, 1, W, device="cuda"), indexing="ij")
+    depths, rgbs, feats = [], [], []
+    for i in range(nbuf):
+        d = 2.6 + 1.6 * torch.sin(2.0 * xx + 0.37 * i) * torch.cos(1.5 * yy) + 0.7 * yy
+        d = d + 0.02 * torch.randn((H, W), device="cuda", generator=g)
+        depths.append(d.float().contiguous())
+        rgbs.append(torch.randint(0, 256, (H, W, 3), device="cuda", generator=g, dtype=torch.uint8))
+        f = torch.randn((Hf, Wf, D), device="cuda", generator=g)
+        f = (f / f.norm(dim=2, keepdim=True) * 14.2857).half().float().contiguous()      # LSeg: fp16 then cast
+        feats.append(f)
+    return depths, rgbs, feats
+
+
+def trajectory(n):
+    from scipy.spatial.transform import Rotation as R
+    i = np.arange(n)
+    yaw = 0.012 * i
+    q = R.from_euler("y", yaw).as_quat()
+    p = np.stack([3.0 * np.sin(0.004 * i), np.zeros(n), -3.0 * (1 - np.cos(0.004 * i))], 1)
+    return np.concatenate([p, q], 1)
+
+
+def pc_transforms(poses):
+    """host-side pose chain exactly as the product does it (avlmaps_amd.map.vlmap_builder)"""
+    from avlmaps_amd.utils.mapping_utils import cvt_pose_vec2tf
+    b2c = np.eye(4)
+    b2c[:3, :3] = np.array([1, 0, 0, 0, -1, 0, 0, 0, -1.0]).reshape(3, 3)
+    b2c[1, 3] = 1.5
+    bt = np.eye(4)
+    bt[0, :3], bt[1, :3], bt[2, :3] = [0, 0, -1], [-1, 0, 0], [0, 1, 0]
+    inv_bt = np.linalg.inv(bt)
+    init = bt @ cvt_pose_vec2tf(poses[0]) @ inv_bt
+    inv_init = np.linalg.inv(init)
+    return [inv_init @ (bt @ cvt_pose_vec2tf(p) @ inv_bt) @ bt @ b2c for p in poses]
+
+
+def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
+    from avlmaps_amd import ops, parallel
+    H, W, Hf, Wf, D, rate = 720, 1080, 347, 520, 512, 100
+    nbuf = 4
+    depths, rgbs, feats = make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=99 + rank)
+    total = frames * ws
+    lo, hi = parallel.shard_frames(total, rank, ws)
+    Ts = pc_transforms(trajectory(total))
+    calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
+    rs = np.random.RandomState(5 + rank)
+    samples = []
+    for _ in range(nbuf):
+        m = np.arange(H * W)
+        rs.shuffle(m)
+        samples.append(torch.from_numpy(m[::rate].astype(np.int32)).cuda())
+    P = int(samples[0].numel())
+    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=args.capacity)
+
+    def fuse(i):
+        b = i % nbuf
+        acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
+
+    nwarm = min(args.warmup, hi - lo)
+    for i in range(lo, lo + nwarm):
+        fuse(i)
+    barrier_sync(torch, dist, ws)
+    t0 = time.perf_counter()
+    for i in range(lo + nwarm, hi):
+        fuse(i)
+    torch.cuda.synchronize()
+    dt = max_over_ranks(torch, dist, ws, time.perf_counter() - t0)
+    timed = hi - lo - nwarm
+    nvox = acc.num_voxels()
+    npts = acc.num_points()
+    # merge (one sparse RCCL reduce) + finalize on rank 0
+    barrier_sync(torch, dist, ws)
+    t1 = time.perf_counter()
+    raw = ops.export_raw_torch(acc)
+    merged = parallel.merge_raw(raw, dst=0)
+    n_merged = None
+    if merged is not None:
+        fin = ops.finalize_raw({k: merged[k] for k in ("cell", "sum_feat", "sum_w4", "first_feat", "first_alpha")}, D, 1000, 30)
+        n_merged = int(fin["grid_pos"].shape[0])
+    torch.cuda.synchronize()
+    t_merge = max_over_ranks(torch, dist, ws, time.perf_counter() - t1)
+    timed_all = sum_over_ranks(torch, dist, ws, timed)
+    # algorithmic bytes per frame: per active point 4 B depth + 3 B rgb + D*4 gather + 2*D*8 fp64 RMW + ~40 B records
+    pts_per_frame = npts / max(1, hi - lo)
+    alg_frame = pts_per_frame * (4 + 3 + D * 4 + 2 * D * 8 + 40) + P * (4 + 4 + 24)
+    res = dict(frames_per_s=timed_all / dt, ms_per_frame=dt / max(1, timed) * 1e3, frames_timed_per_gpu=timed,
+               sampled_px_per_frame=P, active_points_per_frame=pts_per_frame, voxels_local=nvox, voxels_merged=n_merged,
+               merge_finalize_s=t_merge, algorithmic_bytes_per_frame=alg_frame,
+               achieved_gbs=alg_frame * timed / dt / 1e9 if dt > 0 else None)
+    acc.close()
+    return res
+
+
+def run_build(args, torch, dist, lib, rank, ws):
+    r = run_build_core(args, torch, dist, lib, rank, ws, frames=args.steps + args.warmup)
+    out = dict(metric="map_build_frames_per_sec", value=r["frames_per_s"], unit="frames/s", n_gpus=ws, steps=args.steps,
+               warmup=args.warmup, ms_per_step=r["ms_per_frame"], higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f64", data="synthetic",
+               config=dict(workload="create_map kernels: 720x1080 RGB-D frame -> 7776 sampled px -> back-project + voxelise "
+                                    "+ fp64 feature fusion, 512-D channels-last features resident in HBM (LSeg not included)",
+                           parallelism=f"contiguous frame shards x{ws}, one sparse RCCL reduce at the end"))
+    out["roofline"] = dict(bound="hbm", achieved=r["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                           frac=(r["achieved_gbs"] or 0) / HBM_PEAK_GBS, traffic=load_pmc_traffic("build"))
+    out["extra"] = r
+    if rank == 0 and ws == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_build_baseline()
+    return out
+
+
+def cpu_build_baseline(frames=12):
+    """sequential C port of the reference loop (oracle) on one core; the reference itself is a Python loop (~5 frames/s)"""
+    from oracle import avl_oracle as O
+    H, W, Hf, Wf, D, rate = 720, 1080, 347, 520, 512, 100
+    rng = np.random.default_rng(0)
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    depth = (2.6 + 1.6 * np.sin(2 * xx) * np.cos(1.5 * yy) + 0.7 * yy).astype(np.float32)
+    rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    feat = rng.standard_normal((D, Hf, Wf), dtype=np.float32)
+    Ts = pc_transforms(trajectory(frames))
+    calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
+    rs = np.random.RandomState(1)
+    samples = [O.sample_indices(rs, H * W, rate) for _ in range(frames)]
+    m = O.OracleMap(1000, 0.05, 1.5, D)
+    t0 = time.perf_counter()
+    for i in range(frames):
+        m.integrate(depth, calib, Ts[i], samples[i], feat, rgb)
+    dt = time.perf_counter() - t0
+    return dict(value=frames / dt, unit="frames/s", cores=1, kind="port",
+                sample=f"{frames} frames 720x1080, 7776 sampled px each, sequential C restatement of vlmap_builder.py:129-178 "
+                       "(the reference's own Python loop measured ~5.2 frames/s, SURVEY.md section 6)")
+
+
+def load_pmc_traffic(which):
+    p = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        return json.loads(p.read_text()).get(which)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["index", "build"], default="index")
+    ap.add_argument("--voxels", type=int, default=2_000_000)
+    ap.add_argument("--queries", type=int, default=64)
+    ap.add_argument("--capacity", type=int, default=1_500_000)
+    ap.add_argument("--build-frames", type=int, default=300)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-build-extra", action="store_true")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 50 if args.workload == "index" else 500
+    if args.warmup is None:
+        args.warmup = 5 if args.workload == "index" else 20
+
+    import torch
+    import torch.distributed as dist
+    from avlmaps_amd import _lib, parallel
+    rank, ws, local = parallel.init_distributed()
+    if ws != args.gpus and rank == 0:
+        print(f"[bench] note: WORLD_SIZE={ws} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    lib = _lib.load()
+    _lib.require_gpu()
+    _lib.check(lib.avl_set_device(local), "avl_set_device")
+
+    out = run_index(args, torch, dist, lib, rank, ws) if args.workload == "index" else run_build(args, torch, dist, lib, rank, ws)
+    if rank == 0:
+        print(json.dumps(out))
+    if ws > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

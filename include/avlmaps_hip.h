@@ -144,6 +144,12 @@ AVL_API int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, in
                                         const uint8_t* d_rgb, int64_t frame_idx, double min_depth,
                                         double max_depth, double sigma_sq, void* stream);
 
+/* Seed an EMPTY builder from a finished map so that more frames can be fused on top (the reference's resume path,
+ * vlmap_builder.py:212-222): d_grid_feat (n,D) f32, d_grid_pos (n,3) i32, d_weight (n,) f32, d_grid_rgb (n,3) u8 or NULL.
+ * Voxel ids 0..n-1 are kept; new voxels are appended after them.  Synchronous. */
+AVL_API int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, const int32_t* d_grid_pos,
+                                   const float* d_weight, const uint8_t* d_grid_rgb, void* stream);
+
 /* number of occupied voxels so far (synchronises the stream) */
 AVL_API int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream);
 /* number of sampled points that updated a voxel so far (synchronises the stream) */

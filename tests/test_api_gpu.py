@@ -1,0 +1,138 @@
+"""End-to-end GPU tests through the reference-shaped Python API (VLMapBuilder / VLMap / AVLMap)."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from test_host_mirror import Cfg, make_cfg  # noqa: E402
+
+
+class MemoryBuilder:
+    """VLMapBuilder fed from arrays instead of rgb/*.png + depth/*.npy"""
+
+    @staticmethod
+    def make(g, tmp_path, feats_as="numpy_chw"):
+        from avlmaps_amd.map.map import Map
+        from avlmaps_amd.map.vlmap_builder import VLMapBuilder
+        cfg = make_cfg(g)
+        m = Map(cfg)
+        nfr = len(g["depths"])
+        pose_path = tmp_path / "poses.txt"
+        np.savetxt(pose_path, g["poses"])
+        counter = {"i": 0}
+
+        def extractor(rgb):
+            f = g["feats"][counter["i"]][None]           # reference layout (1, D, Hf, Wf)
+            counter["i"] += 1
+            if feats_as == "torch_hwc":
+                import torch
+                return torch.from_numpy(np.ascontiguousarray(np.transpose(f[0], (1, 2, 0)))).cuda()
+            return f
+
+        b = VLMapBuilder(tmp_path, cfg, pose_path, [None] * nfr, [None] * nfr, m.base2cam_tf, m.base_transform,
+                         feat_extractor=extractor)
+        b.load_frame = lambda i: (g["rgbs"][i], g["depths"][i])
+        b.capacity = 4000
+        return b
+
+
+@pytest.mark.parametrize("feats_as", ["numpy_chw", "torch_hwc"])
+def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as):
+    from avlmaps_amd.utils.mapping_utils import load_3d_map
+    g = golden("g2a_builder_small.npz")
+    b = MemoryBuilder.make(g, tmp_path, feats_as)
+    np.random.seed(1234)                     # same global-RNG state the reference run had
+    b.create_mobile_base_map()
+    it, gf, gp, w, occ, rgb = load_3d_map(tmp_path / "vlmap" / "vlmaps.h5df")
+    assert it == list(range(len(g["depths"])))
+    assert np.array_equal(gp, g["grid_pos"]) and gp.dtype == np.int32
+    nz = np.argwhere(occ != -1)
+    assert np.array_equal(nz, g["occ_nz"]) and np.array_equal(occ[nz[:, 0], nz[:, 1], nz[:, 2]], g["occ_nz_vals"])
+    np.testing.assert_allclose(gf, g["grid_feat"], rtol=2e-5, atol=3e-4)
+    np.testing.assert_allclose(w, g["weight"], rtol=3e-6)
+    assert gf.dtype == np.float32 and w.dtype == np.float32 and rgb.dtype == np.uint8 and occ.dtype == np.int32
+
+
+def test_resume_appends_on_top_of_saved_map(golden, tmp_path):
+    """second run finds the map file, imports it and fuses all frames again (upstream resume semantics)"""
+    from avlmaps_amd.utils.mapping_utils import load_3d_map
+    g = golden("g2a_builder_small.npz")
+    np.random.seed(1234)
+    MemoryBuilder.make(g, tmp_path).create_mobile_base_map()
+    first = load_3d_map(tmp_path / "vlmap" / "vlmaps.h5df")
+    np.random.seed(1234)
+    MemoryBuilder.make(g, tmp_path).create_mobile_base_map()
+    second = load_3d_map(tmp_path / "vlmap" / "vlmaps.h5df")
+    assert np.array_equal(second[2], first[2])                       # same voxels, same ids
+    np.testing.assert_allclose(second[3], 2 * first[3], rtol=1e-5)   # every weight doubled
+    # second pass: no voxel is new, so the result is the plain weighted mean of (old map, all points)
+    assert np.abs(second[1] - first[1]).max() < 0.51 * np.abs(first[1]).max()
+
+
+class FakeClip:
+    """OpenAI-CLIP shaped stub: tokenize() -> ids, encode_text(ids) -> rows of a fixed table"""
+
+    def __init__(self, D, seed=0):
+        self.D, self.rng, self.vocab, self.rows = D, np.random.default_rng(seed), {}, []
+
+    def tokenize(self, texts):
+        import torch
+        ids = []
+        for t in texts:
+            if t not in self.vocab:
+                self.vocab[t] = len(self.rows)
+                self.rows.append(self.rng.standard_normal(self.D).astype(np.float32))
+            ids.append(self.vocab[t])
+        return torch.tensor(ids, dtype=torch.int64)
+
+    def encode_text(self, ids):
+        import torch
+        return torch.from_numpy(np.stack([self.rows[i] for i in ids.cpu().tolist()])).to(ids.device)
+
+
+def test_vlmap_index_and_avlmap_index_object(golden):
+    from avlmaps_amd.map import AVLMap, VLMap
+    from avlmaps_amd.utils.clip_utils import get_lseg_score, get_text_feats, multiple_templates
+    from oracle import avl_oracle as O
+    g3, g4 = golden("g3_similarity.npz"), golden("g4_heatmap.npz")
+    cfg = Cfg(map_config=Cfg(map_type="vlmap", grid_size=1000, cell_size=0.05,
+                             pose_info=Cfg(pose_type="mobile_base", camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1],
+                                           base_forward_axis=[0, 0, -1], base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0])),
+              params=Cfg(cs=0.05))
+    av = AVLMap(cfg)
+    vm = av.vlmap
+    n = len(g4["grid_pos"])
+    vm.grid_feat = g3["feat"][:n] if len(g3["feat"]) >= n else np.resize(g3["feat"], (n, 512))
+    vm.grid_pos = g4["grid_pos"]
+    vm.clip_model = FakeClip(512)
+    vm.clip_feat_dim = 512
+    # expected through the oracle on the same text features
+    prompts = [t.format(lm) for lm in ["sofa", "other"] for t in multiple_templates]
+    tf = get_text_feats(prompts, vm.clip_model, 512)
+    assert np.allclose(np.linalg.norm(tf, axis=1), 1, atol=1e-6)
+    q = O.template_mean(tf.reshape(2, 63, 512))
+    ref = O.sim_scores(vm.grid_feat, q)
+    mask = vm.index_map("sofa", with_init_cat=False)
+    margin = np.abs(ref[:, 0] - ref[:, 1]) > 1e-4
+    assert mask.dtype == bool and np.array_equal(mask[margin], (np.argmax(ref, 1) == 0)[margin])
+    sc = get_lseg_score(vm.clip_model, ["sofa"], vm.grid_feat, 512, use_multiple_templates=True, add_other=True)
+    assert sc.shape == (n, 2) and sc.dtype == np.float32 and np.abs(sc - ref).max() < 1e-4
+    # avg_mode=1: average of per-template scores
+    sc1 = get_lseg_score(vm.clip_model, ["sofa"], vm.grid_feat, 512, use_multiple_templates=True, avg_mode=1)
+    assert np.abs(sc1 - (vm.grid_feat @ tf.T).reshape(n, 2, 63).mean(2)).max() < 1e-4
+    # init_categories caches (N, Q) scores; "other" is appended only when missing
+    sm = vm.init_categories(["chair", "table", "other"])
+    assert sm.shape == (n, 3) and vm.scores_mat is sm
+    assert np.array_equal(vm.index_map("table"), np.argmax(sm, 1) == 1)
+    with pytest.raises(KeyError):
+        vm.index_map("zebra")
+    # AVLMap.index_object = mask -> nearest-target decay heat
+    heat = av.index_object("sofa", decay_rate=0.01)
+    assert heat.shape == (n,) and heat.dtype == np.float32
+    assert np.array_equal(heat, O.heatmap_from_mask(vm.grid_pos, mask, 0.05, 0.01))
+    for fn in (av.index_sound, av.index_area, av.index_image):
+        with pytest.raises(NotImplementedError):
+            fn("x")

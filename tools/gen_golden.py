@@ -367,7 +367,20 @@ def main():
     gen_g2(m, np.random.default_rng(22))
     gen_g3(m, np.random.default_rng(33))
     gen_g4(m, np.random.default_rng(44))
+    gen_templates_hash(m)
     os.system(f"ls -la {OUT}")
+
+
+
+
+def gen_templates_hash(m):
+    """hash (not text) of the reference's prompt templates, clip_utils.py:10-74"""
+    import hashlib
+    import json
+    ref = m["clip_utils"].multiple_templates
+    h = hashlib.sha256("\n".join(ref).encode()).hexdigest()
+    json.dump({"n_templates": len(ref), "sha256_of_newline_joined": h,
+               "source": "avlmaps/utils/clip_utils.py:10-74 (hash only)"}, open(OUT / "templates.json", "w"), indent=1)
 
 
 if __name__ == "__main__":
