@@ -114,58 +114,51 @@ __global__ __launch_bounds__(256) void sim_exact_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // split-fp16 MFMA path
 // ------------------------------------------------------------------------------------------------
-// workspace header (device memory): [0] = query scale 2^S, [1] = 2^-S
-constexpr int kHdrBytes = 64;
+// workspace layout (device memory): [inv_scale: nqc*Qc floats, padded to kHdrAlign][fp16 images]
+constexpr int kHdrAlign = 256;
 constexpr int kRowPadHalves = 8;  // +16 B per query row: consecutive rows shift one 16-byte LDS slot
 constexpr int kSplitThreads = 512;
 constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup iteration
 
-__global__ void sim_query_scale_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq, float* __restrict__ hdr) {
-    __shared__ float red[256];
+// One workgroup per (padded) query row: row max -> power-of-two scale 2^S with max|q|*2^S in [512, 1024)
+// (keeps the fp16 lo parts out of the subnormal range), then the fp16 hi/lo images of the scaled row.
+// image layout: [nkc][2 (hi, lo)][Qtot][KC + pad] fp16, Qtot = Q rounded up to 32
+__global__ __launch_bounds__(256) void sim_prep_queries_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq,
+                                                               float* __restrict__ inv_scale, _Float16* __restrict__ img,
+                                                               int Qtot, int KC, int nkc) {
+    __shared__ float red[4];
+    __shared__ float scale_s;
+    const int qg = blockIdx.x;
+    const bool live = qg < Q;
+    const float* row = q + (int64_t)qg * ldq;
     float m = 0.f;
-    for (int64_t i = threadIdx.x; i < (int64_t)Q * D; i += blockDim.x) {
-        int r = (int)(i / D), d = (int)(i - (int64_t)r * D);
-        m = fmaxf(m, fabsf(q[r * ldq + d]));
-    }
-    red[threadIdx.x] = m;
+    if (live)
+        for (int d = threadIdx.x; d < D; d += blockDim.x) m = fmaxf(m, fabsf(row[d]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
-        float mx = red[0];
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         int S = 0;
-        if (mx > 0.f && isfinite(mx)) S = 9 - ilogbf(mx);  // max|q| * 2^S in [512, 1024)
-        S = max(-40, min(40, S));
-        hdr[0] = ldexpf(1.f, S);
-        hdr[1] = ldexpf(1.f, -S);
+        if (mx > 0.f && isfinite(mx)) S = 9 - ilogbf(mx);
+        S = max(-60, min(60, S));
+        scale_s = ldexpf(1.f, S);
+        inv_scale[qg] = ldexpf(1.f, -S);
     }
-}
-
-// image layout: [nqc][nkc][2 (hi, lo)][Qc][KC + pad] fp16
-__global__ void sim_prep_queries_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq,
-                                        const float* __restrict__ hdr, _Float16* __restrict__ img, int Qc, int KC,
-                                        int nqc, int nkc) {
+    __syncthreads();
+    const float scale = scale_s;
     const int rowlen = KC + kRowPadHalves;
-    const int64_t total = (int64_t)nqc * nkc * Qc * rowlen;
-    const float scale = hdr[0];
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int kk = (int)(i % rowlen);
-        int64_t t = i / rowlen;
-        int qi = (int)(t % Qc);
-        t /= Qc;
-        int kc = (int)(t % nkc);
-        int qc = (int)(t / nkc);
-        int qg = qc * Qc + qi, k = kc * KC + kk;
-        float v = 0.f;
-        if (kk < KC && qg < Q && k < D) v = q[(int64_t)qg * ldq + k] * scale;
-        half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
-        float r = v - (float)h[0];
-        _Float16 lo = (_Float16)r;
-        const int64_t base = ((int64_t)(qc * nkc + kc) * 2) * Qc * rowlen;
-        img[base + (int64_t)qi * rowlen + kk] = h[0];
-        img[base + (int64_t)Qc * rowlen + (int64_t)qi * rowlen + kk] = lo;
+    for (int kc = 0; kc < nkc; ++kc) {
+        _Float16* hi = img + ((int64_t)(kc * 2) * Qtot + qg) * rowlen;
+        _Float16* lo = hi + (int64_t)Qtot * rowlen;
+        for (int kk = threadIdx.x; kk < rowlen; kk += blockDim.x) {
+            const int k = kc * KC + kk;
+            float v = 0.f;
+            if (live && kk < KC && k < D) v = row[k] * scale;
+            const half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
+            hi[kk] = h[0];
+            lo[kk] = (_Float16)(v - (float)h[0]);
+        }
     }
 }
 
@@ -185,32 +178,40 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi
     }
 }
 
+// QT = number of 32-query MFMA tiles of this chunk (1..3); `rows` = valid query rows of the chunk (<= 32*QT):
+// only those rows are resident in LDS (lanes of a partial tile re-read the last valid row; their results are masked).
 template <int QT>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
-    const float* __restrict__ hdr, int KC, int nkc, int q_base, int Q, float* __restrict__ scores,
-    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
+    const float* __restrict__ inv_scale, int Qtot, int KC, int nkc, int q_base, int rows, int Q,
+    float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int Qc = QT * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kg = lane >> 5;
     const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
-    const int img_b = Qc * row_b;                // bytes per hi (or lo) image
-    const int chunk_b = 2 * img_b;
-    const float inv_scale = hdr[1];
+    const int img_b = rows * row_b;              // bytes of the hi (or lo) image resident in LDS
+    float* isc = reinterpret_cast<float*>(smem + 2 * img_b);  // per-query 2^-S of this chunk
+    if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
 
     auto fill_lds = [&](int kc) {
-        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + (int64_t)kc * chunk_b);
-        uint4* dst = reinterpret_cast<uint4*>(smem);
-        for (int i = threadIdx.x; i < chunk_b / 16; i += kSplitThreads) dst[i] = src[i];
+        const char* hi = reinterpret_cast<const char*>(img) + ((int64_t)(kc * 2) * Qtot + q_base) * row_b;
+        const char* lo = hi + (int64_t)Qtot * row_b;
+        const uint4* s0 = reinterpret_cast<const uint4*>(hi);
+        const uint4* s1 = reinterpret_cast<const uint4*>(lo);
+        uint4* d0 = reinterpret_cast<uint4*>(smem);
+        uint4* d1 = reinterpret_cast<uint4*>(smem + img_b);
+        for (int i = threadIdx.x; i < img_b / 16; i += kSplitThreads) {
+            d0[i] = s0[i];
+            d1[i] = s1[i];
+        }
     };
-    if (nkc == 1) {
-        fill_lds(0);
-        __syncthreads();
-    }
+    if (nkc == 1) fill_lds(0);
+    __syncthreads();
 
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
-    const char* a_hi_base = smem + j * row_b + kg * 64;  // this lane's query row, its k half (32 halves = 64 B)
+    const char* a_base[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) a_base[t] = smem + min(t * 32 + j, rows - 1) * row_b + kg * 64;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row = tile * kTileRows + wave * 32 + j;
@@ -244,11 +245,11 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                 for (int m = 0; m < 4; ++m) {
                     half8 bh, bl;
                     split8(b[2 * m], b[2 * m + 1], bh, bl);
-                    const char* ap = a_hi_base + (s * 64 + 8 * m) * 2;
+                    const int off = (s * 64 + 8 * m) * 2;
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        const half8 ah = *reinterpret_cast<const half8*>(ap + t * 32 * row_b);
-                        const half8 al = *reinterpret_cast<const half8*>(ap + t * 32 * row_b + img_b);
+                        const half8 ah = *reinterpret_cast<const half8*>(a_base[t] + off);
+                        const half8 al = *reinterpret_cast<const half8*>(a_base[t] + off + img_b);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
@@ -267,33 +268,36 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         }
 
         // ---- epilogue: this lane holds voxel `row`, queries q_base + t*32 + 8g + 4kg + e (g<4, e<4) in acc[t][4g+e]
+        const int qend = q_base + rows;  // first query index NOT in this chunk
         float bv = -INFINITY;
         int bi = INT_MAX;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int qg = q_base + t * 32 + 8 * g + 4 * kg;
+                const int ql = t * 32 + 8 * g + 4 * kg;
+                const int qg = q_base + ql;
+                const f32x4 is4 = *reinterpret_cast<const f32x4*>(isc + ql);
                 f32x4 v;
-                v.x = acc[t][4 * g + 0] * inv_scale;
-                v.y = acc[t][4 * g + 1] * inv_scale;
-                v.z = acc[t][4 * g + 2] * inv_scale;
-                v.w = acc[t][4 * g + 3] * inv_scale;
+                v.x = acc[t][4 * g + 0] * is4.x;
+                v.y = acc[t][4 * g + 1] * is4.y;
+                v.z = acc[t][4 * g + 2] * is4.z;
+                v.w = acc[t][4 * g + 3] * is4.w;
                 if (scores && row < N) {
                     float* sp = scores + row * (int64_t)Q + qg;
-                    if (qg + 3 < Q && (Q & 3) == 0) {
+                    if (qg + 3 < qend && (Q & 3) == 0) {
                         *reinterpret_cast<f32x4*>(sp) = v;
                     } else {
-                        if (qg + 0 < Q) sp[0] = v.x;
-                        if (qg + 1 < Q) sp[1] = v.y;
-                        if (qg + 2 < Q) sp[2] = v.z;
-                        if (qg + 3 < Q) sp[3] = v.w;
+                        if (qg + 0 < qend) sp[0] = v.x;
+                        if (qg + 1 < qend) sp[1] = v.y;
+                        if (qg + 2 < qend) sp[2] = v.z;
+                        if (qg + 3 < qend) sp[3] = v.w;
                     }
                 }
-                if (qg + 0 < Q && v.x > bv) { bv = v.x; bi = qg + 0; }
-                if (qg + 1 < Q && v.y > bv) { bv = v.y; bi = qg + 1; }
-                if (qg + 2 < Q && v.z > bv) { bv = v.z; bi = qg + 2; }
-                if (qg + 3 < Q && v.w > bv) { bv = v.w; bi = qg + 3; }
+                if (qg + 0 < qend && v.x > bv) { bv = v.x; bi = qg + 0; }
+                if (qg + 1 < qend && v.y > bv) { bv = v.y; bi = qg + 1; }
+                if (qg + 2 < qend && v.z > bv) { bv = v.z; bi = qg + 2; }
+                if (qg + 3 < qend && v.w > bv) { bv = v.w; bi = qg + 3; }
             }
         }
         if (argmax || best) {
@@ -357,27 +361,47 @@ __global__ void argmax_partial_kernel(const float* __restrict__ v, int64_t N, fl
     }
 }
 
-struct SplitPlan {
-    int Qc, QT, KC, nqc, nkc;
-    size_t lds_bytes, ws_bytes;
+struct SplitChunk {
+    int q_base, rows, QT;
 };
+
+struct SplitPlan {
+    int Qtot, KC, nkc, nchunks, max_rows;
+    SplitChunk chunks[64];
+    size_t hdr_bytes, ws_bytes;
+    size_t lds_bytes(const SplitChunk& c) const { return (size_t)4 * c.rows * (KC + kRowPadHalves) + (size_t)c.QT * 32 * sizeof(float); }
+};
+
+constexpr size_t kLdsBudget = 163840 - 512;  // 160 KiB per workgroup minus slack
 
 static bool make_split_plan(int D, int Q, SplitPlan& p) {
     if (D % 64 != 0 || D <= 0 || Q <= 0) return false;
-    p.QT = Q > 32 ? 2 : 1;
-    p.Qc = p.QT * 32;
-    p.nqc = (Q + p.Qc - 1) / p.Qc;
-    const size_t lds_budget = 156 * 1024;
-    // bytes = 2 images * Qc rows * (KC + pad) halves * 2 B
-    int kcmax = (int)(lds_budget / (4 * (size_t)p.Qc)) - kRowPadHalves;
+    p.Qtot = (Q + 31) / 32 * 32;
+    // rows that fit next to a <=512-wide K chunk: up to 3 MFMA tiles (96 rows) in one pass, e.g. the reference's
+    // "64 categories + other" (Q = 65) runs as ONE pass with 65 resident rows instead of 64 + 1
+    const int kc0 = D < 512 ? D : 512;
+    int r3 = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)(kc0 + kRowPadHalves)));
+    if (r3 > 96) r3 = 96;
+    // fewest passes over the feature map, balanced: npass = ceil(Q / r3) chunks of ceil(Q / npass) rows
+    const int npass = (Q + r3 - 1) / r3;
+    if (npass > 64) return false;
+    const int per = (Q + npass - 1) / npass;
+    p.nchunks = 0;
+    p.max_rows = 0;
+    for (int base = 0; base < Q; base += per) {
+        const int take = Q - base < per ? Q - base : per;
+        p.chunks[p.nchunks++] = SplitChunk{base, take, (take + 31) / 32};
+        if (take > p.max_rows) p.max_rows = take;
+    }
+    int kcmax = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)p.max_rows)) - kRowPadHalves;
     kcmax = (kcmax / 64) * 64;
     if (kcmax < 64) return false;
     p.nkc = (D + kcmax - 1) / kcmax;
-    int kc = (D + p.nkc - 1) / p.nkc;
+    const int kc = (D + p.nkc - 1) / p.nkc;
     p.KC = ((kc + 63) / 64) * 64;
     p.nkc = (D + p.KC - 1) / p.KC;
-    p.lds_bytes = (size_t)4 * p.Qc * (p.KC + kRowPadHalves);
-    p.ws_bytes = kHdrBytes + (size_t)p.nqc * p.nkc * p.lds_bytes;
+    p.hdr_bytes = (((size_t)p.Qtot * sizeof(float)) + kHdrAlign - 1) / kHdrAlign * kHdrAlign;
+    p.ws_bytes = p.hdr_bytes + (size_t)p.nkc * 2 * p.Qtot * (p.KC + kRowPadHalves) * sizeof(_Float16);
     return true;
 }
 
@@ -406,27 +430,20 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
 
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
-    float* hdr = reinterpret_cast<float*>(d_ws);
-    _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + kHdrBytes);
-    hipLaunchKernelGGL(sim_query_scale_kernel, dim3(1), dim3(256), 0, st, d_q, Q, D, ldq, hdr);
-    {
-        int64_t total = (int64_t)p.nqc * p.nkc * p.Qc * (p.KC + kRowPadHalves);
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(blocks), dim3(256), 0, st, d_q, Q, D, ldq, hdr, img, p.Qc, p.KC,
-                           p.nqc, p.nkc);
-    }
+    float* inv_scale = reinterpret_cast<float*>(d_ws);
+    _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
+    hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Q, D, ldq, inv_scale, img, p.Qtot, p.KC,
+                       p.nkc);
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
     int64_t blocks = ntiles < num_cus() ? ntiles : num_cus();
     if (blocks < 1) blocks = 1;
-    auto kern = p.QT == 2 ? sim_split_f16_kernel<2> : sim_split_f16_kernel<1>;
-    AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)p.lds_bytes));
-    const size_t chunk_halves = p.lds_bytes / 2;
-    for (int qc = 0; qc < p.nqc; ++qc) {
-        const _Float16* img_qc = img + (size_t)qc * p.nkc * chunk_halves;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), p.lds_bytes, st, d_feat, N, D, ld, img_qc,
-                           hdr, p.KC, p.nkc, qc * p.Qc, Q, d_scores, d_argmax, d_best, qc == 0 ? 1 : 0);
+    for (int ci = 0; ci < p.nchunks; ++ci) {
+        const SplitChunk& c = p.chunks[ci];
+        auto kern = c.QT == 3 ? sim_split_f16_kernel<3> : (c.QT == 2 ? sim_split_f16_kernel<2> : sim_split_f16_kernel<1>);
+        const size_t lds = p.lds_bytes(c);
+        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, d_feat, N, D, ld, img, inv_scale, p.Qtot, p.KC,
+                           p.nkc, c.q_base, c.rows, Q, d_scores, d_argmax, d_best, ci == 0 ? 1 : 0);
     }
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
@@ -441,7 +458,7 @@ extern "C" {
 int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes) {
     AVL_REQUIRE(h_bytes, "avl_sim_workspace_bytes: null output");
     SplitPlan p;
-    *h_bytes = make_split_plan(D, Q, p) ? p.ws_bytes : (size_t)kHdrBytes;
+    *h_bytes = make_split_plan(D, Q, p) ? p.ws_bytes : (size_t)kHdrAlign;
     return AVL_OK;
 }
 
@@ -470,7 +487,7 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     // chaining query chunks needs a best-score buffer even if the caller does not want it
     float* best = d_best;
     float* tmp_best = nullptr;
-    const int nchunks = use_split ? p.nqc : (Q + kExactQB - 1) / kExactQB;
+    const int nchunks = use_split ? p.nchunks : (Q + kExactQB - 1) / kExactQB;
     if (!best && d_argmax && nchunks > 1) {
         AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_best), (size_t)N * sizeof(float), st));
         best = tmp_best;
