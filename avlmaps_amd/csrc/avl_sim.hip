@@ -117,7 +117,13 @@ __global__ __launch_bounds__(256) void sim_exact_kernel(const float* __restrict_
 // workspace layout (device memory): [inv_scale: nqc*Qc floats, padded to kHdrAlign][fp16 images]
 constexpr int kHdrAlign = 256;
 constexpr int kRowPadHalves = 8;  // +16 B per query row: consecutive rows shift one 16-byte LDS slot
-constexpr int kSplitThreads = 512;
+#ifndef AVL_SPLIT_THREADS
+#define AVL_SPLIT_THREADS 512
+#endif
+#ifndef AVL_SPLIT_PREFETCH
+#define AVL_SPLIT_PREFETCH 1
+#endif
+constexpr int kSplitThreads = AVL_SPLIT_THREADS;
 constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup iteration
 
 // One workgroup per (padded) query row: row max -> power-of-two scale 2^S with max|q|*2^S in [512, 1024)
@@ -162,8 +168,14 @@ __global__ __launch_bounds__(256) void sim_prep_queries_kernel(const float* __re
     }
 }
 
+// error-free split of 8 floats into fp16 hi (round-toward-zero) + fp16 lo (the residual x - hi is exact in fp32).
+// NOTE: an inline-asm v_fma_mix{lo,hi}_f16 version (1.5 instead of 3 VALU ops per element) was measured: no gain
+// (the kernel is not VALU-bound) and it is unsafe -- hipcc does not pad the MFMA-source WAR hazard for asm writes.
 __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi, half8& lo) {
-    // error-free split of 8 floats into fp16 hi (round-toward-zero) + fp16 lo (residual, exact in fp32)
+#ifdef AVL_ABL_NOSPLIT
+    hi = __builtin_bit_cast(half8, v0);
+    lo = __builtin_bit_cast(half8, v1);
+#else
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -176,11 +188,12 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi
         lo[2 * p] = l[0];
         lo[2 * p + 1] = l[1];
     }
+#endif
 }
 
 // QT = number of 32-query MFMA tiles of this chunk (1..3); `rows` = valid query rows of the chunk (<= 32*QT):
 // only those rows are resident in LDS (lanes of a partial tile re-read the last valid row; their results are masked).
-template <int QT>
+template <int QT, int NSTEPS>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int KC, int nkc, int q_base, int rows, int Q,
@@ -248,21 +261,45 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                     const int off = (s * 64 + 8 * m) * 2;
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
+#ifdef AVL_ABL_NOLDS
+                        half8 ah, al;
+                        for (int e = 0; e < 8; ++e) { ah[e] = (_Float16)1; al[e] = (_Float16)2; }
+                        asm volatile("" : "+v"(ah), "+v"(al));
+#else
                         const half8 ah = *reinterpret_cast<const half8*>(a_base[t] + off);
                         const half8 al = *reinterpret_cast<const half8*>(a_base[t] + off + img_b);
+#endif
+#ifdef AVL_ABL_NOMFMA
+                        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+#else
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+#endif
                     }
                 }
             };
-            load(buf0, 0);
-            for (int s = 0; s < nsteps; s += 2) {
-                if (s + 1 < nsteps) load(buf1, s + 1);
-                compute(buf0, s);
-                if (s + 1 < nsteps) {
-                    if (s + 2 < nsteps) load(buf0, s + 2);
-                    compute(buf1, s + 1);
+            if constexpr (NSTEPS > 0) {
+                // compile-time trip count, ring of 3 register buffers: the loads of steps s+1 and s+2 are in flight
+                // while step s is computed (24 KB per wave, 192 KB per CU), all waits are counted vmcnt
+                f32x4 ring[3][8];
+                load(ring[0], 0);
+                if (NSTEPS > 1) load(ring[1], 1);
+#pragma unroll
+                for (int s = 0; s < NSTEPS; ++s) {
+                    if (s + 2 < NSTEPS) load(ring[(s + 2) % 3], s + 2);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch block ahead of the compute block
+                    compute(ring[s % 3], s);
+                }
+            } else {
+                load(buf0, 0);
+                for (int s = 0; s < nsteps; s += 2) {
+                    if (s + 1 < nsteps) load(buf1, s + 1);
+                    compute(buf0, s);
+                    if (s + 1 < nsteps) {
+                        if (s + 2 < nsteps) load(buf0, s + 2);
+                        compute(buf1, s + 1);
+                    }
                 }
             }
         }
@@ -439,7 +476,9 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     if (blocks < 1) blocks = 1;
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
-        auto kern = c.QT == 3 ? sim_split_f16_kernel<3> : (c.QT == 2 ? sim_split_f16_kernel<2> : sim_split_f16_kernel<1>);
+        const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
+        auto kern = s8 ? (c.QT == 3 ? sim_split_f16_kernel<3, 8> : (c.QT == 2 ? sim_split_f16_kernel<2, 8> : sim_split_f16_kernel<1, 8>))
+                       : (c.QT == 3 ? sim_split_f16_kernel<3, 0> : (c.QT == 2 ? sim_split_f16_kernel<2, 0> : sim_split_f16_kernel<1, 0>));
         const size_t lds = p.lds_bytes(c);
         AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, d_feat, N, D, ld, img, inv_scale, p.Qtot, p.KC,
