@@ -54,6 +54,7 @@ _SIGS = {
     "avl_builder_import_map": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_num_voxels": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_num_points": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
+    "avl_builder_num_groups": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_finalize": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_export_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_finalize_raw": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

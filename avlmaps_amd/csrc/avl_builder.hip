@@ -11,24 +11,35 @@
 // explicit fma() calls that mirror the reference's BLAS dgemm / dgemv summation (see oracle/avl_oracle.c).
 //
 // Device state (all in HBM, sized for a 288 GB part -- dense tables instead of a probing hash):
-//   cell_slot  int32 [gs*gs*vh]   cell -> voxel id (-1 empty).  IS the reference's occupied_ids.
-//   slot_cell  int32 [cap]        voxel id -> linear cell
-//   slot_key   uint64[cap]        first-touch key (frame << 32 | position in the frame's sample list)
-//   sum_feat   f64   [cap, D]     sum_i alpha_i * f_i           (hardware fp64 atomics)
+//   cell_slot  int32 [gs*gs*vh]   cell -> slot (-1 empty)
+//   slot_cell  int32 [cap]        slot -> linear cell
+//   slot_key   uint64[cap]        first-touch key (frame << 32 | position in the frame's sample list), ~0 until known
+//   sum_feat   f64   [cap, D]     sum_i alpha_i * f_i
 //   sum_w4     f64   [cap, 4]     sum alpha, sum alpha*(r,g,b)
 //   first_feat f32   [cap, D]     feature of the first-touch point, first_alpha f64 [cap]
+//   head       int32 [cap]        per-frame list head of the samples that hit the voxel (-1 between frames)
 // The reference's order-dependent result has the closed form
 //   grid_feat = (sum_feat - a1*(1-a1)*first_feat) / sum_alpha,  weight = sum_alpha
-// so the accumulation itself is commutative.  Voxel ids follow first touch: per frame, the earliest
-// sample that hits an empty cell claims it (atomicMin on the claim word) and a prefix scan over the
-// sample list hands out ids in that order -- slot r == the reference's voxel id r, no sort needed.
+// so the accumulation itself is commutative; only the first-touch point (smallest key) is special.
 //
-// Per frame three launches on the caller's stream:
-//   K1 bp_voxelize   thread per sampled pixel : fp64 geometry, claims
-//   K2 assign_slots  one 1024-thread workgroup: creator flags -> exclusive scan -> voxel ids + slot metadata
-//   K3 accumulate    wave per sampled pixel   : channels-last feature gather (2 KB contiguous per point at
-//                                               D=512) and fp64 atomic accumulation into the voxel row
+// Per frame three launches on the caller's stream, none of them serial:
+//   K1 bp_voxelize  thread per sampled pixel: fp64 geometry; an empty cell is created by the CAS winner
+//                   (slot = atomicAdd on the voxel counter)
+//   K2 link         thread per sampled pixel: push the sample on its voxel's list (atomicExch on head);
+//                   the first pusher becomes the voxel's owner for this frame
+//   K3 fuse         wave per sampled pixel, owners only: walk the list, gather each member's channels-last
+//                   feature row (2 KB contiguous at D=512), accumulate alpha*f in fp64 REGISTERS, then ONE plain
+//                   read-modify-write of the voxel row (store-only for a voxel born this frame).  No floating-point
+//                   atomics: an earlier version used 512 fp64 atomics per point and was bound by the L2 atomic rate
+//                   (36 us/frame, 47 MB of write traffic for 11 MB of algorithmic RMW).  The owner also finds the
+//                   voxel's first-touch sample (smallest position) when the voxel is new.
+// Slots are handed out in arrival order, so finalisation sorts the first-touch keys (rocPRIM radix sort) to emit
+// rows in the reference's voxel-id order; the sort is a once-per-save cost.
+#include <algorithm>
 #include <climits>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "avl_common.h"
 
@@ -39,21 +50,25 @@ struct FrameParams {
     double k[9];      // calib                 (vlmap_builder.py:98)
     double kf[9];     // get_sim_cam_mat(Hf,Wf)(mapping_utils.py:591-596)
     double t[16];     // pc_transform          (vlmap_builder.py:133)
-    double min_depth, max_depth, inv_two_sigma_sq_den;  // den = 2*sigma_sq
+    double min_depth, max_depth, two_sigma_sq;
     double cs, half_gs;
     int H, W, Hf, Wf, gs, vh, P;
-    unsigned long long frame_idx;
+    long long capacity;
 };
 
-struct PointRec {
-    double alpha;
-    int32_t cell;   // -1 = inactive
-    int32_t fpix;   // py*Wf + px into the (Hf, Wf, D) feature map
-    uint32_t rgb;   // r | g<<8 | b<<16
-    uint32_t first; // 1 if this point created its voxel
+// per-frame sample records (structure of arrays, sized for the largest P seen)
+struct Recs {
+    double* alpha;
+    int32_t* cell;    // -1 = inactive
+    int32_t* slot;
+    int32_t* fpix;    // py*Wf + px into the (Hf, Wf, D) feature map
+    uint32_t* rgb;    // r | g<<8 | b<<16
+    int32_t* next;    // next sample of the same voxel in this frame, -1 = end
+    uint8_t* owner;   // 1 = this sample's wave fuses the voxel's list
 };
 
-constexpr int kClaimBase = INT_MIN;  // claim word = kClaimBase + sample position  (< -1 == empty)
+constexpr int kEmpty = -1, kPending = -2;
+constexpr unsigned long long kNoKey = ~0ull;
 
 __device__ __forceinline__ long long py_int(double v) {
     // Python int(): truncate toward zero.  Saturate far-out values (they are out of range anyway).
@@ -69,15 +84,13 @@ __device__ __forceinline__ double gemv3(const double* a, double x0, double x1, d
 __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const float* __restrict__ depth,
                                                           const int32_t* __restrict__ sample_idx,
                                                           const uint8_t* __restrict__ rgb, int32_t* __restrict__ cell_slot,
-                                                          PointRec* __restrict__ recs, int* __restrict__ err_flags) {
+                                                          int32_t* __restrict__ slot_cell, Recs recs,
+                                                          unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= fp.P) return;
-    PointRec r;
-    r.alpha = 0.0;
-    r.cell = -1;
-    r.fpix = 0;
-    r.rgb = 0;
-    r.first = 0;
+    double alpha = 0.0;
+    int32_t cell = -1, fpix = 0;
+    uint32_t rgbv = 0;
 
     const int pix = sample_idx[s];
     bool ok = pix >= 0 && pix < fp.H * fp.W;
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
             ok = false;
         } else {
             const uint8_t* c = rgb + ((size_t)py * fp.W + px) * 3;
-            r.rgb = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+            rgbv = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
         }
         // project_point(get_sim_cam_mat(Hf, Wf), p_local) -> feature pixel, bounds-checked (vlmap_builder.py:161)
         q0 = gemv3(fp.kf + 0, pl0, pl1, pl2);
@@ -122,159 +135,199 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
         px = py_int(q0 / q2 - 0.5);
         py = py_int(q1 / q2 - 0.5);
         if (px < 0 || py < 0 || px >= fp.Wf || py >= fp.Hf) ok = false;
-        r.fpix = (int32_t)(py * fp.Wf + px);
+        fpix = (int32_t)(py * fp.Wf + px);
     }
     if (ok) {
         const double radial = (pl0 * pl0 + pl1 * pl1) + pl2 * pl2;  // np.sum(np.square(p_local))
-        r.alpha = exp(-radial / fp.inv_two_sigma_sq_den);
-        const int32_t cell = (int32_t)((row * fp.gs + col) * fp.vh + h);
-        r.cell = cell;
-        // claim an empty cell: the EARLIEST sample position wins (deterministic first touch)
-        if (cell_slot[cell] < 0) atomicMin(&cell_slot[cell], kClaimBase + s);
+        alpha = exp(-radial / fp.two_sigma_sq);
+        cell = (int32_t)((row * fp.gs + col) * fp.vh + h);
     }
-    recs[s] = r;
-}
-
-constexpr int kScanThreads = 1024;
-constexpr int kScanItems = 8;
-
-__global__ __launch_bounds__(kScanThreads) void assign_slots_kernel(int P, unsigned long long frame_idx,
-                                                                    unsigned long long key_bias, int64_t capacity,
-                                                                    int32_t* __restrict__ cell_slot, PointRec* __restrict__ recs,
-                                                                    int32_t* __restrict__ slot_cell,
-                                                                    unsigned long long* __restrict__ slot_key,
-                                                                    double* __restrict__ first_alpha,
-                                                                    long long* __restrict__ counters /* [0]=n_slots [1]=n_points */,
-                                                                    int* __restrict__ err_flags) {
-    __shared__ int wave_sums[kScanThreads / 64];
-    __shared__ int chunk_total;
-    __shared__ long long base_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base_s = counters[0];
-    __syncthreads();
-    long long active_total = 0;
-
-    for (int c0 = 0; c0 < P; c0 += kScanThreads * kScanItems) {
-        int cells[kScanItems];
-        int flags[kScanItems];
-        int local = 0, nact = 0;
-#pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
-            const int idx = c0 + tid * kScanItems + i;
-            cells[i] = idx < P ? recs[idx].cell : -1;
-        }
-#pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
-            const int idx = c0 + tid * kScanItems + i;
-            flags[i] = (cells[i] >= 0 && cell_slot[cells[i]] == kClaimBase + idx) ? 1 : 0;
-            local += flags[i];
-            nact += cells[i] >= 0;
-        }
-        active_total += nact;
-        // block-wide exclusive scan of `local`
-        int incl = local;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wave_sums[wave] = incl;
-        __syncthreads();
-        if (wave == 0) {
-            int v = lane < kScanThreads / 64 ? wave_sums[lane] : 0;
-            int inc2 = v;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                int u = __shfl_up(inc2, off, 64);
-                if (lane >= off) inc2 += u;
-            }
-            if (lane < kScanThreads / 64) wave_sums[lane] = inc2 - v;  // exclusive
-            if (lane == kScanThreads / 64 - 1) chunk_total = inc2;
-        }
-        __syncthreads();
-        const long long base = base_s;
-        long long slot = base + wave_sums[wave] + (incl - local);
-        const bool overflow = base + chunk_total > capacity;
-#pragma unroll
-        for (int i = 0; i < kScanItems; ++i) {
-            if (flags[i]) {
-                const int idx = c0 + tid * kScanItems + i;
-                if (overflow) {
-                    cell_slot[cells[i]] = -1;  // give the claim back; the voxel is dropped
-                } else {
-                    cell_slot[cells[i]] = (int32_t)slot;
-                    slot_cell[slot] = cells[i];
-                    slot_key[slot] = key_bias | (frame_idx << 32) | (unsigned)idx;
-                    first_alpha[slot] = recs[idx].alpha;
-                    recs[idx].first = 1;
-                }
-                ++slot;
+    // create the voxel if the cell is empty: the CAS winner takes the next slot.  One counter atomic per wave:
+    // winners are ranked with a ballot (a single hot word only sustains ~90 atomics/us).
+    const bool creator = ok && cell_slot[cell] == kEmpty && atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
+    const unsigned long long cmask = __ballot(creator);
+    if (cmask) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)cmask) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long)__popcll(cmask));
+        base = __shfl(base, leader, 64);
+        if (creator) {
+            const unsigned long long slot = base + __popcll(cmask & ((1ull << lane) - 1ull));
+            if ((long long)slot >= fp.capacity) {
+                atomicOr(err_flags, 1);
+                cell_slot[cell] = kEmpty;  // give the cell back; its samples are dropped in K2
+            } else {
+                cell_slot[cell] = (int32_t)slot;
+                slot_cell[slot] = cell;
             }
         }
-        __syncthreads();
-        if (tid == 0) {
-            if (overflow) atomicOr(err_flags, 1);
-            else base_s = base + chunk_total;
-        }
-        __syncthreads();
     }
-    // active point statistics
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) active_total += __shfl_xor(active_total, off, 64);
-    __shared__ long long act_s[kScanThreads / 64];
-    if (lane == 0) act_s[wave] = active_total;
-    __syncthreads();
-    if (tid == 0) {
-        long long t = 0;
-        for (int w = 0; w < kScanThreads / 64; ++w) t += act_s[w];
-        counters[0] = base_s;
-        counters[1] += t;
-    }
+    recs.alpha[s] = alpha;
+    recs.cell[s] = cell;
+    recs.fpix[s] = fpix;
+    recs.rgb[s] = rgbv;
 }
 
-// wave per sampled point.  D floats per point are contiguous (channels-last): lanes take float4 chunks.
-__global__ __launch_bounds__(256) void accumulate_kernel(int P, int D, const PointRec* __restrict__ recs,
-                                                         const int32_t* __restrict__ cell_slot, const float* __restrict__ feat,
-                                                         double* __restrict__ sum_feat, double* __restrict__ sum_w4,
-                                                         float* __restrict__ first_feat) {
-    const int lane = threadIdx.x & 63;
-    const int s = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
+                                                   Recs recs, unsigned long long* __restrict__ counters) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P) return;
-    const PointRec r = recs[s];
-    if (r.cell < 0) return;
-    const int32_t slot = cell_slot[r.cell];
-    if (slot < 0) return;  // voxel dropped on capacity overflow
-    const double alpha = r.alpha;
-    const float* f = feat + (size_t)r.fpix * D;
-    double* acc = sum_feat + (size_t)slot * D;
-    float* ff = first_feat + (size_t)slot * D;
-    if ((D & 3) == 0) {
-        for (int c = lane * 4; c < D; c += 256) {
-            const float4 v = *reinterpret_cast<const float4*>(f + c);
-            unsafeAtomicAdd(acc + c + 0, alpha * (double)v.x);
-            unsafeAtomicAdd(acc + c + 1, alpha * (double)v.y);
-            unsafeAtomicAdd(acc + c + 2, alpha * (double)v.z);
-            unsafeAtomicAdd(acc + c + 3, alpha * (double)v.w);
-            if (r.first) *reinterpret_cast<float4*>(ff + c) = v;
+    const int32_t cell = recs.cell[s];
+    int32_t slot = -1, next = -1;
+    uint8_t owner = 0;
+    if (cell >= 0) {
+        slot = cell_slot[cell];
+        if (slot >= 0) {
+            next = atomicExch(&head[slot], s);  // LIFO push; whoever finds the list empty owns it this frame
+            owner = next == -1;
         }
-    } else {
-        for (int c = lane; c < D; c += 64) {
-            const float v = f[c];
-            unsafeAtomicAdd(acc + c, alpha * (double)v);
-            if (r.first) ff[c] = v;
+    }
+    const unsigned long long amask = __ballot(slot >= 0);
+    const unsigned long long omask = __ballot(owner != 0);
+    if (amask && (threadIdx.x & 63) == __ffsll((long long)amask) - 1) {
+        atomicAdd(&counters[1], (unsigned long long)__popcll(amask));
+        if (omask) atomicAdd(&counters[2], (unsigned long long)__popcll(omask));
+    }
+    recs.slot[s] = slot;
+    recs.next[s] = next;
+    recs.owner[s] = owner;
+}
+
+// wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
+template <int CH>
+__global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, Recs recs,
+                                                   int32_t* __restrict__ head, const float* __restrict__ feat,
+                                                   double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                                   float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                                   unsigned long long* __restrict__ slot_key) {
+    const int lane = threadIdx.x & 63;
+    const int s0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (s0 >= P) return;
+    if (!recs.owner[s0]) return;
+    const int32_t slot = recs.slot[s0];
+    const bool is_new = slot_key[slot] == kNoKey;  // born this frame: accumulators hold nothing yet
+
+    double acc[CH][4];
+    float f1[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[c][e] = 0.0; f1[c][e] = 0.f; }
+    double w4 = 0.0, a1 = 0.0;
+    int min_s = INT_MAX;
+
+    int cur = head[slot];
+    while (cur >= 0) {
+        const double alpha = recs.alpha[cur];
+        const int nxt = recs.next[cur];
+        const float* f = feat + (size_t)recs.fpix[cur] * D;
+        const uint32_t rgbv = recs.rgb[cur];
+        const bool first = cur < min_s;  // wave-uniform
+        if (first) { min_s = cur; a1 = alpha; }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = c * 256 + lane * 4;
+            if (d < D) {
+                float v[4];
+                if (d + 3 < D && (D & 3) == 0) {
+                    const float4 q = *reinterpret_cast<const float4*>(f + d);
+                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = d + e < D ? f[d + e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[c][e] += alpha * (double)v[e];
+                    if (first) f1[c][e] = v[e];
+                }
+            }
         }
+        if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
+        cur = nxt;
+    }
+
+    double* sf = sum_feat + (size_t)slot * D;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int d = c * 256 + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (d + e < D) sf[d + e] = is_new ? acc[c][e] : sf[d + e] + acc[c][e];
     }
     if (lane < 4) {
-        double v = alpha;
-        if (lane > 0) v = alpha * (double)((r.rgb >> (8 * (lane - 1))) & 0xffu);
-        unsafeAtomicAdd(sum_w4 + (size_t)slot * 4 + lane, v);
+        double* w = sum_w4 + (size_t)slot * 4 + lane;
+        *w = is_new ? w4 : *w + w4;
+    }
+    if (is_new) {
+        float* ff = first_feat + (size_t)slot * D;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = c * 256 + lane * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (d + e < D) ff[d + e] = f1[c][e];
+        }
+        if (lane == 0) {
+            first_alpha[slot] = a1;
+            slot_key[slot] = frame_key | (unsigned)min_s;
+        }
+    }
+    if (lane == 0) head[slot] = -1;  // ready for the next frame
+}
+
+// generic feature width: one 256-float chunk at a time, re-walking the (short) list per chunk
+__global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigned long long frame_key, Recs recs,
+                                                           int32_t* __restrict__ head, const float* __restrict__ feat,
+                                                           double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                                           float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                                           unsigned long long* __restrict__ slot_key) {
+    const int lane = threadIdx.x & 63;
+    const int s0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (s0 >= P) return;
+    if (!recs.owner[s0]) return;
+    const int32_t slot = recs.slot[s0];
+    const bool is_new = slot_key[slot] == kNoKey;
+    const int h0 = head[slot];
+    int min_s = INT_MAX;
+    double a1 = 0.0, w4 = 0.0;
+    for (int cur = h0; cur >= 0; cur = recs.next[cur]) {
+        const double alpha = recs.alpha[cur];
+        if (cur < min_s) { min_s = cur; a1 = alpha; }
+        const uint32_t rgbv = recs.rgb[cur];
+        if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
+    }
+    double* sf = sum_feat + (size_t)slot * D;
+    float* ff = first_feat + (size_t)slot * D;
+    for (int d = lane; d < D; d += 64) {
+        double acc = 0.0;
+        float f1 = 0.f;
+        for (int cur = h0; cur >= 0; cur = recs.next[cur]) {
+            const float v = feat[(size_t)recs.fpix[cur] * D + d];
+            acc += recs.alpha[cur] * (double)v;
+            if (cur == min_s) f1 = v;
+        }
+        sf[d] = is_new ? acc : sf[d] + acc;
+        if (is_new) ff[d] = f1;
+    }
+    if (lane < 4) {
+        double* w = sum_w4 + (size_t)slot * 4 + lane;
+        *w = is_new ? w4 : *w + w4;
+    }
+    if (lane == 0) {
+        if (is_new) {
+            first_alpha[slot] = a1;
+            slot_key[slot] = frame_key | (unsigned)min_s;
+        }
+        head[slot] = -1;
     }
 }
 
-// wave per voxel row
-__global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs, int vh, const int32_t* __restrict__ cell,
-                                                       const double* __restrict__ sum_feat, const double* __restrict__ sum_w4,
-                                                       const float* __restrict__ first_feat,
+// wave per output row r; the accumulators of row r live in slot perm[r] (perm == nullptr: identity)
+__global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs, int vh, const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ cell, const double* __restrict__ sum_feat,
+                                                       const double* __restrict__ sum_w4, const float* __restrict__ first_feat,
                                                        const double* __restrict__ first_alpha, float* __restrict__ grid_feat,
                                                        int32_t* __restrict__ grid_pos, float* __restrict__ weight,
                                                        uint8_t* __restrict__ grid_rgb, int32_t* __restrict__ occupied) {
@@ -282,17 +335,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave0; r < n; r += nwaves) {
-        const double w = sum_w4[r * 4];
-        const double a1 = first_alpha[r];
+        const int64_t sl = perm ? perm[r] : r;
+        const double w = sum_w4[sl * 4];
+        const double a1 = first_alpha[sl];
         const double corr = a1 * (1.0 - a1);
         if (grid_feat) {
-            const double* s = sum_feat + r * D;
-            const float* f1 = first_feat + r * D;
+            const double* s = sum_feat + sl * D;
+            const float* f1 = first_feat + sl * D;
             float* o = grid_feat + r * D;
             for (int c = lane; c < D; c += 64) o[c] = (float)((s[c] - corr * (double)f1[c]) / w);
         }
         if (lane == 0) {
-            const int32_t cl = cell[r];
+            const int32_t cl = cell[sl];
             if (grid_pos) {
                 grid_pos[r * 3 + 0] = cl / (gs * vh);
                 grid_pos[r * 3 + 1] = (cl / vh) % gs;
@@ -303,11 +357,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
         }
         if (grid_rgb && lane < 3) {
             // running mean stored into a uint8 array (truncating cast); we truncate the exact weighted mean
-            double m = sum_w4[r * 4 + 1 + lane] / w;
+            double m = sum_w4[sl * 4 + 1 + lane] / w;
             m = fmin(fmax(m, 0.0), 255.0);
             grid_rgb[r * 3 + lane] = (uint8_t)m;
         }
     }
+}
+
+__global__ void iota_kernel(int32_t* __restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (int32_t)i;
 }
 
 // wave per imported voxel row: rebuild accumulators from a finalised map (resume, vlmap_builder.py:212-222)
@@ -336,7 +394,7 @@ __global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int g
                 cell_slot[cell] = (int32_t)r;
                 slot_cell[r] = cell;
             }
-            slot_key[r] = (unsigned long long)r;
+            slot_key[r] = (unsigned long long)r;                        // imported voxels order before any new one
             first_alpha[r] = 1.0;                                       // a1*(1-a1) == 0: no further correction
             sum_w4[r * 4] = w;
             for (int c = 0; c < 3; ++c) sum_w4[r * 4 + 1 + c] = (grid_rgb ? (double)grid_rgb[r * 3 + c] : 0.0) * w;
@@ -360,9 +418,11 @@ struct avl_builder {
     double* sum_w4 = nullptr;
     float* first_feat = nullptr;
     double* first_alpha = nullptr;
-    long long* counters = nullptr;  // [0] n_slots, [1] n_points
+    int32_t* head = nullptr;
+    unsigned long long* counters = nullptr;  // [0] slots handed out, [1] samples fused, [2] per-frame voxel groups fused
     int* err_flags = nullptr;
-    PointRec* recs = nullptr;
+    char* recs_mem = nullptr;
+    Recs recs{};
     int recs_cap = 0;
     unsigned long long key_bias = 0;  // set after import_map so that imported voxels order before new ones
 };
@@ -382,19 +442,36 @@ static int builder_check_flags(avl_builder* b, hipStream_t st) {
     return AVL_OK;
 }
 
+static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
+    if (P <= b->recs_cap) return AVL_OK;
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    if (b->recs_mem) AVL_HIP_CHECK(hipFree(b->recs_mem));
+    b->recs_mem = nullptr;
+    const size_t cap = ((size_t)P + P / 4 + 1024 + 63) / 64 * 64;
+    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, cap * (8 + 4 * 5 + 1) + 256));
+    char* p = b->recs_mem;
+    b->recs.alpha = reinterpret_cast<double*>(p); p += cap * 8;
+    b->recs.cell = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    b->recs.slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    b->recs.fpix = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    b->recs.rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+    b->recs.next = reinterpret_cast<int32_t*>(p); p += cap * 4;
+    b->recs.owner = reinterpret_cast<uint8_t*>(p);
+    b->recs_cap = (int)cap;
+    return AVL_OK;
+}
+
 extern "C" {
 
 int avl_builder_reset(avl_builder* b, void* stream) {
     AVL_REQUIRE(b, "avl_builder_reset: null handle");
     hipStream_t st = as_stream(stream);
+    // sum_feat / sum_w4 / first_* need no clearing: a voxel's first fuse is store-only
     AVL_HIP_CHECK(hipMemsetAsync(b->cell_slot, 0xFF, b->ncell * sizeof(int32_t), st));
-    AVL_HIP_CHECK(hipMemsetAsync(b->sum_feat, 0, (size_t)b->capacity * b->D * sizeof(double), st));
-    AVL_HIP_CHECK(hipMemsetAsync(b->sum_w4, 0, (size_t)b->capacity * 4 * sizeof(double), st));
-    AVL_HIP_CHECK(hipMemsetAsync(b->first_feat, 0, (size_t)b->capacity * b->D * sizeof(float), st));
-    AVL_HIP_CHECK(hipMemsetAsync(b->first_alpha, 0, (size_t)b->capacity * sizeof(double), st));
+    AVL_HIP_CHECK(hipMemsetAsync(b->head, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_cell, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_key, 0xFF, (size_t)b->capacity * sizeof(unsigned long long), st));
-    AVL_HIP_CHECK(hipMemsetAsync(b->counters, 0, 2 * sizeof(long long), st));
+    AVL_HIP_CHECK(hipMemsetAsync(b->counters, 0, 4 * sizeof(unsigned long long), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->err_flags, 0, sizeof(int), st));
     b->key_bias = 0;
     return AVL_OK;
@@ -403,8 +480,8 @@ int avl_builder_reset(avl_builder* b, void* stream) {
 int avl_builder_destroy(avl_builder* b) {
     if (!b) return AVL_OK;
     (void)hipFree(b->cell_slot); (void)hipFree(b->slot_cell); (void)hipFree(b->slot_key); (void)hipFree(b->sum_feat);
-    (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->counters);
-    (void)hipFree(b->err_flags); (void)hipFree(b->recs);
+    (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->head);
+    (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
     delete b;
     return AVL_OK;
 }
@@ -428,7 +505,8 @@ int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, in
     alloc((void**)&b->sum_w4, (size_t)capacity * 4 * sizeof(double));
     alloc((void**)&b->first_feat, (size_t)capacity * D * sizeof(float));
     alloc((void**)&b->first_alpha, (size_t)capacity * sizeof(double));
-    alloc((void**)&b->counters, 2 * sizeof(long long));
+    alloc((void**)&b->head, (size_t)capacity * sizeof(int32_t));
+    alloc((void**)&b->counters, 4 * sizeof(unsigned long long));
     alloc((void**)&b->err_flags, sizeof(int));
     if (e != hipSuccess) {
         set_error("avl_builder_create: hipMalloc failed: %s (capacity %lld x D %d)", hipGetErrorString(e), (long long)capacity, D);
@@ -452,20 +530,14 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
     AVL_REQUIRE(b, "avl_builder_integrate_frame: null handle");
     AVL_REQUIRE(H > 0 && W > 0 && Hf > 0 && Wf > 0 && P >= 0, "avl_builder_integrate_frame: bad shape");
     AVL_REQUIRE(P < (1 << 30), "avl_builder_integrate_frame: at most 2^30 samples per frame");
-    AVL_REQUIRE(frame_idx >= 0 && frame_idx < (1ll << 31), "avl_builder_integrate_frame: bad frame_idx");
+    AVL_REQUIRE(frame_idx >= 0 && frame_idx < (1ll << 30), "avl_builder_integrate_frame: bad frame_idx");
     AVL_REQUIRE(sigma_sq > 0, "avl_builder_integrate_frame: sigma_sq must be positive");
     if (P == 0) return AVL_OK;
     AVL_REQUIRE(d_depth && h_calib && h_calib_inv && h_pc_transform && d_sample_idx && d_feat && d_rgb,
                 "avl_builder_integrate_frame: null pointer");
     hipStream_t st = as_stream(stream);
-    if (P > b->recs_cap) {
-        AVL_HIP_CHECK(hipStreamSynchronize(st));
-        if (b->recs) AVL_HIP_CHECK(hipFree(b->recs));
-        b->recs = nullptr;
-        int cap = P + P / 4 + 1024;
-        AVL_HIP_CHECK(hipMalloc((void**)&b->recs, (size_t)cap * sizeof(PointRec)));
-        b->recs_cap = cap;
-    }
+    int rc = ensure_recs(b, P, st);
+    if (rc != AVL_OK) return rc;
     FrameParams fp;
     for (int i = 0; i < 9; ++i) { fp.kinv[i] = h_calib_inv[i]; fp.k[i] = h_calib[i]; fp.kf[i] = 0.0; }
     // get_sim_cam_mat(h, w): eye(3); [0,0] = [1,1] = w/2; [0,2] = w/2; [1,2] = h/2
@@ -475,26 +547,37 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
     fp.kf[8] = 1.0;
     for (int i = 0; i < 16; ++i) fp.t[i] = h_pc_transform[i];
     fp.min_depth = min_depth; fp.max_depth = max_depth;
-    fp.inv_two_sigma_sq_den = 2 * sigma_sq;
+    fp.two_sigma_sq = 2 * sigma_sq;
     fp.cs = b->cs; fp.half_gs = (double)b->gs / 2.0;
     fp.H = H; fp.W = W; fp.Hf = Hf; fp.Wf = Wf; fp.gs = b->gs; fp.vh = b->vh; fp.P = P;
-    fp.frame_idx = (unsigned long long)frame_idx;
+    fp.capacity = b->capacity;
+    const unsigned long long frame_key = b->key_bias | ((unsigned long long)frame_idx << 32);
 
-    hipLaunchKernelGGL(bp_voxelize_kernel, dim3((P + 255) / 256), dim3(256), 0, st, fp, d_depth, d_sample_idx, d_rgb,
-                       b->cell_slot, b->recs, b->err_flags);
-    hipLaunchKernelGGL(assign_slots_kernel, dim3(1), dim3(kScanThreads), 0, st, P, fp.frame_idx, b->key_bias, b->capacity, b->cell_slot,
-                       b->recs, b->slot_cell, b->slot_key, b->first_alpha, b->counters, b->err_flags);
-    hipLaunchKernelGGL(accumulate_kernel, dim3((P + 3) / 4), dim3(256), 0, st, P, b->D, b->recs, b->cell_slot, d_feat,
-                       b->sum_feat, b->sum_w4, b->first_feat);
+    const unsigned pb = (unsigned)((P + 255) / 256), wb = (unsigned)((P + 3) / 4);
+    hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, d_depth, d_sample_idx, d_rgb, b->cell_slot,
+                       b->slot_cell, b->recs, b->counters, b->err_flags);
+    hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters);
+    if (b->D <= 256)
+        hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+    else if (b->D <= 512)
+        hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+    else if (b->D <= 1024)
+        hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+    else
+        hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat,
+                           b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
 
 static int read_counter(avl_builder* b, int which, int64_t* h_n, hipStream_t st) {
-    long long v = 0;
-    AVL_HIP_CHECK(hipMemcpyAsync(&v, b->counters + which, sizeof(long long), hipMemcpyDeviceToHost, st));
+    unsigned long long v = 0;
+    AVL_HIP_CHECK(hipMemcpyAsync(&v, b->counters + which, sizeof(v), hipMemcpyDeviceToHost, st));
     AVL_HIP_CHECK(hipStreamSynchronize(st));
-    *h_n = v;
+    *h_n = (int64_t)v;
     return AVL_OK;
 }
 
@@ -502,12 +585,31 @@ int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_voxels: null argument");
     int rc = builder_check_flags(b, as_stream(stream));
     if (rc != AVL_OK) return rc;
-    return read_counter(b, 0, h_n, as_stream(stream));
+    rc = read_counter(b, 0, h_n, as_stream(stream));
+    if (rc == AVL_OK && *h_n > b->capacity) *h_n = b->capacity;
+    return rc;
 }
 
 int avl_builder_num_points(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_points: null argument");
     return read_counter(b, 1, h_n, as_stream(stream));
+}
+
+int avl_builder_num_groups(avl_builder* b, int64_t* h_n, void* stream) {
+    AVL_REQUIRE(b && h_n, "avl_builder_num_groups: null argument");
+    return read_counter(b, 2, h_n, as_stream(stream));
+}
+
+static int launch_finalize(int64_t n, int D, int gs, int vh, const int32_t* perm, const int32_t* d_cell, const double* d_sum_feat,
+                           const double* d_sum_w4, const float* d_first_feat, const double* d_first_alpha, float* d_grid_feat,
+                           int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_occupied_ids, hipStream_t st) {
+    int64_t blocks = (n + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, D, gs, vh, perm, d_cell, d_sum_feat, d_sum_w4,
+                       d_first_feat, d_first_alpha, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
 }
 
 int avl_finalize_raw(int64_t n, int D, int gs, int vh, const int32_t* d_cell, const double* d_sum_feat,
@@ -517,13 +619,8 @@ int avl_finalize_raw(int64_t n, int D, int gs, int vh, const int32_t* d_cell, co
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(d_cell && d_sum_w4 && d_first_alpha, "avl_finalize_raw: null input");
     AVL_REQUIRE(!d_grid_feat || (d_sum_feat && d_first_feat), "avl_finalize_raw: grid_feat needs sum_feat and first_feat");
-    int64_t blocks = (n + 3) / 4;
-    const int64_t maxb = (int64_t)num_cus() * 16;
-    if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n, D, gs, vh, d_cell, d_sum_feat,
-                       d_sum_w4, d_first_feat, d_first_alpha, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids);
-    AVL_HIP_CHECK(hipGetLastError());
-    return AVL_OK;
+    return launch_finalize(n, D, gs, vh, nullptr, d_cell, d_sum_feat, d_sum_w4, d_first_feat, d_first_alpha, d_grid_feat, d_grid_pos,
+                           d_weight, d_grid_rgb, d_occupied_ids, as_stream(stream));
 }
 
 int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
@@ -534,10 +631,29 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
     int rc = avl_builder_num_voxels(b, &have, stream);
     if (rc != AVL_OK) return rc;
     AVL_REQUIRE(n == have, "avl_builder_finalize: n=%lld but the map holds %lld voxels", (long long)n, (long long)have);
-    if (d_occupied_ids)  // voxel ids are assigned in reference order: the cell table IS occupied_ids
-        AVL_HIP_CHECK(hipMemcpyAsync(d_occupied_ids, b->cell_slot, b->ncell * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    rc = avl_finalize_raw(n, b->D, b->gs, b->vh, b->slot_cell, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha,
-                          d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, nullptr, stream);
+    if (d_occupied_ids) AVL_HIP_CHECK(hipMemsetAsync(d_occupied_ids, 0xFF, b->ncell * sizeof(int32_t), st));
+    if (n == 0) {
+        AVL_HIP_CHECK(hipStreamSynchronize(st));
+        return AVL_OK;
+    }
+    // rows in the reference's voxel-id order = slots sorted by first-touch key
+    unsigned long long* keys_out = nullptr;
+    int32_t *iota = nullptr, *perm = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    AVL_HIP_CHECK(hipMallocAsync((void**)&keys_out, (size_t)n * sizeof(unsigned long long), st));
+    AVL_HIP_CHECK(hipMallocAsync((void**)&iota, (size_t)n * sizeof(int32_t), st));
+    AVL_HIP_CHECK(hipMallocAsync((void**)&perm, (size_t)n * sizeof(int32_t), st));
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, iota, n);
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
+    AVL_HIP_CHECK(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
+    rc = launch_finalize(n, b->D, b->gs, b->vh, perm, b->slot_cell, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, d_grid_feat,
+                         d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, st);
+    (void)hipFreeAsync(tmp, st);
+    (void)hipFreeAsync(perm, st);
+    (void)hipFreeAsync(iota, st);
+    (void)hipFreeAsync(keys_out, st);
     if (rc != AVL_OK) return rc;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     return AVL_OK;
@@ -564,8 +680,8 @@ int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, 
     hipLaunchKernelGGL(import_map_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, b->D, b->gs, b->vh, d_grid_feat, d_grid_pos,
                        d_weight, d_grid_rgb, b->cell_slot, b->slot_cell, b->slot_key, b->sum_feat, b->sum_w4, b->first_feat,
                        b->first_alpha, b->err_flags);
-    const long long nn = n;
-    AVL_HIP_CHECK(hipMemcpyAsync(b->counters, &nn, sizeof(long long), hipMemcpyHostToDevice, st));
+    const unsigned long long nn = (unsigned long long)n;
+    AVL_HIP_CHECK(hipMemcpyAsync(b->counters, &nn, sizeof(nn), hipMemcpyHostToDevice, st));
     int flags = 0;
     AVL_HIP_CHECK(hipMemcpyAsync(&flags, b->err_flags, sizeof(int), hipMemcpyDeviceToHost, st));
     AVL_HIP_CHECK(hipStreamSynchronize(st));

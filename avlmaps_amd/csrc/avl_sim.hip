@@ -55,58 +55,78 @@ __global__ __launch_bounds__(256) void sim_exact_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    constexpr int R = 4;  // voxel rows per wave iteration: 4 x (D/256) 16-byte loads in flight per lane
 
-    for (int64_t row = wave; row < N; row += nwaves) {
-        const float* rp = feat + row * ld;
-        float acc[kExactQB];
+    for (int64_t row0 = wave * R; row0 < N; row0 += nwaves * R) {
+        const float* rp[R];
 #pragma unroll
-        for (int j = 0; j < kExactQB; ++j) acc[j] = 0.f;
+        for (int r = 0; r < R; ++r) rp[r] = feat + (row0 + r < N ? row0 + r : N - 1) * ld;
+        float acc[R][kExactQB];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < kExactQB; ++j) acc[r][j] = 0.f;
         if constexpr (VEC4) {
             const int nchunk = D >> 2;
             for (int c = lane; c < nchunk; c += 64) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(rp + 4 * c);
+                f32x4 a[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = *reinterpret_cast<const f32x4*>(rp[r] + 4 * c);
 #pragma unroll
                 for (int j = 0; j < kExactQB; ++j) {
                     const f32x4 b = *reinterpret_cast<const f32x4*>(qs + j * Dp + 4 * c);
-                    acc[j] = fmaf(a.x, b.x, acc[j]);
-                    acc[j] = fmaf(a.y, b.y, acc[j]);
-                    acc[j] = fmaf(a.z, b.z, acc[j]);
-                    acc[j] = fmaf(a.w, b.w, acc[j]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r][j] = fmaf(a[r].x, b.x, acc[r][j]);
+                        acc[r][j] = fmaf(a[r].y, b.y, acc[r][j]);
+                        acc[r][j] = fmaf(a[r].z, b.z, acc[r][j]);
+                        acc[r][j] = fmaf(a[r].w, b.w, acc[r][j]);
+                    }
                 }
             }
         } else {
             for (int d = lane; d < D; d += 64) {
-                const float a = rp[d];
 #pragma unroll
-                for (int j = 0; j < kExactQB; ++j) acc[j] = fmaf(a, qs[j * Dp + d], acc[j]);
-            }
-        }
+                for (int r = 0; r < R; ++r) {
+                    const float a = rp[r][d];
 #pragma unroll
-        for (int j = 0; j < kExactQB; ++j) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc[j] += __shfl_xor(acc[j], off, 64);
-        }
-        if (lane == 0) {
-            float bv = -INFINITY;
-            int bi = q0;
-            if (!first_chunk) {
-                if (best) bv = best[row];
-                if (argmax) bi = argmax[row];
-            }
-            bool have = !first_chunk;
-#pragma unroll
-            for (int j = 0; j < kExactQB; ++j) {
-                if (j < qn) {
-                    if (scores) scores[row * (int64_t)Q + q0 + j] = acc[j];
-                    if (!have || acc[j] > bv) {
-                        bv = acc[j];
-                        bi = q0 + j;
-                        have = true;
-                    }
+                    for (int j = 0; j < kExactQB; ++j) acc[r][j] = fmaf(a, qs[j * Dp + d], acc[r][j]);
                 }
             }
-            if (argmax) argmax[row] = bi;
-            if (best) best[row] = bv;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < kExactQB; ++j) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) acc[r][j] += __shfl_xor(acc[r][j], off, 64);
+            }
+        // lane r finishes row r
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = row0 + r;
+            if (lane == r && row < N) {
+                float bv = -INFINITY;
+                int bi = q0;
+                if (!first_chunk) {
+                    if (best) bv = best[row];
+                    if (argmax) bi = argmax[row];
+                }
+                bool have = !first_chunk;
+#pragma unroll
+                for (int j = 0; j < kExactQB; ++j) {
+                    if (j < qn) {
+                        if (scores) scores[row * (int64_t)Q + q0 + j] = acc[r][j];
+                        if (!have || acc[r][j] > bv) {
+                            bv = acc[r][j];
+                            bi = q0 + j;
+                            have = true;
+                        }
+                    }
+                }
+                if (argmax) argmax[row] = bi;
+                if (best) best[row] = bv;
+            }
         }
     }
 }
@@ -449,7 +469,7 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     AVL_REQUIRE(lds <= 160 * 1024, "avl_sim_scores: D=%d too large for the exact path", D);
     const bool vec4 = (D % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0);
     const int waves_per_block = 4;
-    int64_t blocks = (N + waves_per_block - 1) / waves_per_block;
+    int64_t blocks = (N + waves_per_block * 4 - 1) / (waves_per_block * 4);  // 4 rows per wave iteration
     const int64_t maxb = (int64_t)num_cus() * 8;
     if (blocks > maxb) blocks = maxb;
     if (blocks < 1) blocks = 1;
@@ -521,7 +541,7 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
         AVL_REQUIRE(can_split, "avl_sim_scores: SPLIT_F16 needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D,
                     (long long)ld_feat);
         use_split = true;
-    } else use_split = can_split && Q > kExactQB;
+    } else use_split = can_split;   // ~1e-6 accurate and HBM-bound for every Q; EXACT remains the fallback / on request
 
     // chaining query chunks needs a best-score buffer even if the caller does not want it
     float* best = d_best;

@@ -152,6 +152,11 @@ class VoxelAccumulator:
         _lib.check(_lib.load().avl_builder_num_points(self._h, C.byref(n), stream), "avl_builder_num_points")
         return n.value
 
+    def num_groups(self, stream=None):
+        n = C.c_int64()
+        _lib.check(_lib.load().avl_builder_num_groups(self._h, C.byref(n), stream), "avl_builder_num_groups")
+        return n.value
+
     def finalize(self, stream=None, want_occupied=True, as_numpy=True):
         """-> dict(grid_feat, grid_pos, weight, grid_rgb, occupied_ids) in the reference's voxel-id order."""
         lib = _lib.load()

@@ -141,7 +141,7 @@ def run_index(args, torch, dist, lib, rank, ws):
         config=dict(workload=f"index_map: {N} voxels x {D}-D float32 map per GPU, {Q} text queries, "
                              "scores fused with row argmax (no scores_mat write)",
                     voxels_per_gpu=N, feat_dim=D, queries=Q, parallelism=f"voxel-row shards x{ws}, no collective",
-                    kernel="sim_split_f16_kernel<2> (fp16 hi/lo split MFMA, fp32 accumulate)" if Q > 8 else "sim_exact_kernel"),
+                    kernel="sim_split_f16_kernel (fp16 hi/lo split MFMA, fp32 accumulate)"),
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                            traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes)
@@ -263,11 +263,16 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
     torch.cuda.synchronize()
     t_merge = max_over_ranks(torch, dist, ws, time.perf_counter() - t1)
     timed_all = sum_over_ranks(torch, dist, ws, timed)
-    # algorithmic bytes per frame: per active point 4 B depth + 3 B rgb + D*4 gather + 2*D*8 fp64 RMW + ~40 B records
-    pts_per_frame = npts / max(1, hi - lo)
-    alg_frame = pts_per_frame * (4 + 3 + D * 4 + 2 * D * 8 + 40) + P * (4 + 4 + 24)
+    # algorithmic bytes per frame: every sample 4 B index + 4 B depth + 29 B record; every active sample 3 B rgb + D*4 B
+    # feature gather + 29 B record re-read; every (frame, voxel) group one fp64 row store (D*8 B), plus a row load when
+    # the voxel already existed, plus the first-touch feature row (D*4 B) when it is new
+    nfr = max(1, hi - lo)
+    pts_per_frame = npts / nfr
+    groups, newv = acc.num_groups() / nfr, nvox / nfr
+    alg_frame = P * (4 + 4 + 29) + pts_per_frame * (3 + D * 4 + 29) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
     res = dict(frames_per_s=timed_all / dt, ms_per_frame=dt / max(1, timed) * 1e3, frames_timed_per_gpu=timed,
-               sampled_px_per_frame=P, active_points_per_frame=pts_per_frame, voxels_local=nvox, voxels_merged=n_merged,
+               sampled_px_per_frame=P, active_points_per_frame=pts_per_frame, voxel_groups_per_frame=groups,
+               new_voxels_per_frame=newv, voxels_local=nvox, voxels_merged=n_merged,
                merge_finalize_s=t_merge, algorithmic_bytes_per_frame=alg_frame,
                achieved_gbs=alg_frame * timed / dt / 1e9 if dt > 0 else None)
     acc.close()

@@ -73,7 +73,7 @@ AVL_API int avl_event_elapsed_ms(void* start, void* stop, float* h_ms);
  *     to the lowest query index, like np.argmax.
  * ------------------------------------------------------------------------------------------------ */
 enum {
-    AVL_SIM_AUTO = 0,   /* pick per shape: EXACT for small Q, SPLIT_F16 otherwise                       */
+    AVL_SIM_AUTO = 0,   /* SPLIT_F16 when the shape allows it (D % 64 == 0, 16-byte aligned rows), else EXACT  */
     AVL_SIM_EXACT = 1,  /* float32 FMA on the vector ALU (any N, D, Q, strides)                          */
     AVL_SIM_SPLIT_F16 = 2 /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q| */
 };
@@ -154,6 +154,8 @@ AVL_API int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_gri
 AVL_API int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream);
 /* number of sampled points that updated a voxel so far (synchronises the stream) */
 AVL_API int avl_builder_num_points(avl_builder* b, int64_t* h_n, void* stream);
+/* number of (frame, voxel) groups fused so far = voxel rows read-modified-written (synchronises the stream) */
+AVL_API int avl_builder_num_groups(avl_builder* b, int64_t* h_n, void* stream);
 
 /*
  * Produce the reference's arrays.  Slot ids are assigned in first-touch order (a deterministic prefix

@@ -157,7 +157,10 @@ def test_export_raw_and_finalize_raw_roundtrip(ops, golden):
                           g["rgbs"], g["feats"], g["samples"], capacity=2000)
     out = acc.finalize()
     raw = acc.export_raw()
-    assert np.all(np.diff(raw["first_key"].astype(np.int64)) > 0)      # slots are already in first-touch order
+    keys = raw["first_key"].astype(np.int64)
+    assert len(np.unique(keys)) == len(keys) and keys.max() < (len(g["depths"]) << 32)
+    order = np.argsort(keys)                  # slots are handed out in arrival order; reference ids = key order
+    raw = {k: v[order] for k, v in raw.items()}
     out2 = ops.finalize_raw(raw, acc.D, acc.gs, acc.vh)
     for k in ("grid_feat", "grid_pos", "weight", "grid_rgb", "occupied_ids"):
         assert np.array_equal(out[k], out2[k]), k
