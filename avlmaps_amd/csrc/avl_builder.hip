@@ -169,8 +169,17 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
     recs.rgb[s] = rgbv;
 }
 
+// optional per-sample log for the exact sequential replay of weight / grid_rgb at finalisation (position = key order)
+struct ReplayLog {
+    uint32_t* slot;            // 0xFFFFFFFF = sample did not update a voxel
+    unsigned long long* key;
+    double* alpha;
+    uint32_t* rgb;
+};
+
 __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
-                                                   Recs recs, unsigned long long* __restrict__ counters) {
+                                                   Recs recs, unsigned long long* __restrict__ counters, ReplayLog log,
+                                                   long long log_base, unsigned long long frame_key) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P) return;
     const int32_t cell = recs.cell[s];
@@ -192,6 +201,13 @@ __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restr
     recs.slot[s] = slot;
     recs.next[s] = next;
     recs.owner[s] = owner;
+    if (log.slot) {
+        const long long i = log_base + s;
+        log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
+        log.key[i] = frame_key | (unsigned)s;
+        log.alpha[i] = recs.alpha[s];
+        log.rgb[i] = recs.rgb[s];
+    }
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
@@ -364,6 +380,67 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
     }
 }
 
+// first / one-past-last position of every slot's run in the slot-sorted log
+__global__ void log_segments_kernel(const uint32_t* __restrict__ sorted_slot, long long L, long long nslots,
+                                    long long* __restrict__ seg_start, long long* __restrict__ seg_end) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (long long)gridDim.x * blockDim.x) {
+        const uint32_t sl = sorted_slot[i];
+        if (sl >= (uint32_t)nslots) continue;
+        if (i == 0 || sorted_slot[i - 1] != sl) seg_start[sl] = i;
+        if (i == L - 1 || sorted_slot[i + 1] != sl) seg_end[sl] = i + 1;
+    }
+}
+
+// Thread per output row: replay the voxel's updates in the reference's order with the reference's dtypes
+// (vlmap_builder.py:164-178; NumPy >= 2 promotion, see oracle/avl_oracle.c avlo_integrate_frame):
+//   until the first capacity doubling (_reserve_map_space, :286-311) weight is float32 and grid_rgb uint8 (truncating
+//   store at every update); afterwards weight is float64 and grid_rgb float32.  The doubling happens right after the
+//   voxel with id gs*gs - 1 was created, i.e. for every update whose key is greater than that voxel's first-touch key.
+__global__ __launch_bounds__(256) void replay_rgb_kernel(int64_t n, long long gs2, const int32_t* __restrict__ perm,
+                                                         const unsigned long long* __restrict__ keys_sorted,
+                                                         const int32_t* __restrict__ order, const long long* __restrict__ seg_start,
+                                                         const long long* __restrict__ seg_end, ReplayLog log,
+                                                         float* __restrict__ weight, uint8_t* __restrict__ grid_rgb) {
+    const unsigned long long gkey = n >= gs2 ? keys_sorted[gs2 - 1] : kNoKey;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t sl = perm[r];
+        double w = 0.0, c[3] = {0.0, 0.0, 0.0};
+        bool started = false;
+        for (long long i = seg_start[sl]; i < seg_end[sl]; ++i) {
+            const int32_t e = order[i];
+            const double alpha = log.alpha[e];
+            const uint32_t rgbv = log.rgb[e];
+            const bool grown = log.key[e] > gkey;
+            const double v[3] = {(double)(rgbv & 0xffu), (double)((rgbv >> 8) & 0xffu), (double)((rgbv >> 16) & 0xffu)};
+            if (!started) {
+                started = true;
+                for (int k = 0; k < 3; ++k) c[k] = v[k];
+                const double ww = 0.0 + alpha;
+                w = grown ? ww : (double)(float)ww;
+            } else {
+                const double denom = w + alpha;
+                if (!grown) {
+                    const float wf = (float)w;
+                    for (int k = 0; k < 3; ++k) {
+                        const float prod = (float)c[k] * wf;
+                        const double q = ((double)prod + v[k] * alpha) / denom;
+                        c[k] = (double)(uint8_t)q;
+                    }
+                    w = (double)(float)denom;
+                } else {
+                    for (int k = 0; k < 3; ++k) c[k] = (double)(float)((c[k] * w + v[k] * alpha) / denom);
+                    w = denom;
+                }
+            }
+        }
+        if (started) {
+            if (weight) weight[r] = (float)w;
+            if (grid_rgb)
+                for (int k = 0; k < 3; ++k) grid_rgb[r * 3 + k] = (uint8_t)fmin(fmax(c[k], 0.0), 255.0);
+        }
+    }
+}
+
 __global__ void iota_kernel(int32_t* __restrict__ v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (int32_t)i;
 }
@@ -425,6 +502,8 @@ struct avl_builder {
     Recs recs{};
     int recs_cap = 0;
     unsigned long long key_bias = 0;  // set after import_map so that imported voxels order before new ones
+    ReplayLog log{};
+    long long log_cap = 0, log_used = 0;
 };
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
@@ -474,6 +553,7 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     AVL_HIP_CHECK(hipMemsetAsync(b->counters, 0, 4 * sizeof(unsigned long long), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->err_flags, 0, sizeof(int), st));
     b->key_bias = 0;
+    b->log_used = 0;
     return AVL_OK;
 }
 
@@ -482,6 +562,7 @@ int avl_builder_destroy(avl_builder* b) {
     (void)hipFree(b->cell_slot); (void)hipFree(b->slot_cell); (void)hipFree(b->slot_key); (void)hipFree(b->sum_feat);
     (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->head);
     (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
+    (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
     delete b;
     return AVL_OK;
 }
@@ -523,6 +604,31 @@ int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, in
     return AVL_OK;
 }
 
+int avl_builder_enable_replay_log(avl_builder* b, int64_t max_samples) {
+    AVL_REQUIRE(b && max_samples > 0, "avl_builder_enable_replay_log: bad arguments");
+    AVL_REQUIRE(max_samples < (1ll << 31), "avl_builder_enable_replay_log: at most 2^31 - 1 samples");
+    AVL_HIP_CHECK(hipDeviceSynchronize());
+    if (b->log_used != 0) {
+        set_error("avl_builder_enable_replay_log: frames were already fused; enable the log on a fresh or reset builder");
+        return AVL_ERR_STATE;
+    }
+    (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+    b->log = ReplayLog{};
+    b->log_cap = 0;
+    hipError_t e = hipMalloc((void**)&b->log.slot, (size_t)max_samples * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->log.key, (size_t)max_samples * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->log.alpha, (size_t)max_samples * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->log.rgb, (size_t)max_samples * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+        b->log = ReplayLog{};
+        set_error("avl_builder_enable_replay_log: hipMalloc failed: %s", hipGetErrorString(e));
+        return AVL_ERR_HIP;
+    }
+    b->log_cap = max_samples;
+    return AVL_OK;
+}
+
 int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int W, const double* h_calib,
                                 const double* h_calib_inv, const double* h_pc_transform, const int32_t* d_sample_idx, int P,
                                 const float* d_feat, int Hf, int Wf, const uint8_t* d_rgb, int64_t frame_idx,
@@ -553,10 +659,16 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
     fp.capacity = b->capacity;
     const unsigned long long frame_key = b->key_bias | ((unsigned long long)frame_idx << 32);
 
+    if (b->log.slot && b->log_used + P > b->log_cap) {
+        set_error("replay log full (%lld samples): enable it with a larger max_samples", b->log_cap);
+        return AVL_ERR_CAPACITY;
+    }
     const unsigned pb = (unsigned)((P + 255) / 256), wb = (unsigned)((P + 3) / 4);
     hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, d_depth, d_sample_idx, d_rgb, b->cell_slot,
                        b->slot_cell, b->recs, b->counters, b->err_flags);
-    hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters);
+    hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters, b->log, b->log_used,
+                       frame_key);
+    if (b->log.slot) b->log_used += P;
     if (b->D <= 256)
         hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
@@ -650,6 +762,33 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
     rc = launch_finalize(n, b->D, b->gs, b->vh, perm, b->slot_cell, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, d_grid_feat,
                          d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, st);
+    if (rc == AVL_OK && b->log.slot && b->key_bias == 0 && b->log_used > 0 && (d_weight || d_grid_rgb)) {
+        // exact sequential weight / grid_rgb: stable sort of the key-ordered log by slot, then replay per voxel
+        const long long L = b->log_used;
+        uint32_t* sorted_slot = nullptr;
+        int32_t *liota = nullptr, *order = nullptr;
+        long long *seg_start = nullptr, *seg_end = nullptr;
+        void* tmp2 = nullptr;
+        size_t tmp2_bytes = 0;
+        AVL_HIP_CHECK(hipMallocAsync((void**)&sorted_slot, (size_t)L * sizeof(uint32_t), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&liota, (size_t)L * sizeof(int32_t), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&order, (size_t)L * sizeof(int32_t), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_start, (size_t)n * sizeof(long long), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_end, (size_t)n * sizeof(long long), st));
+        AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, (size_t)n * sizeof(long long), st));
+        AVL_HIP_CHECK(hipMemsetAsync(seg_end, 0, (size_t)n * sizeof(long long), st));
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, liota, (int64_t)L);
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp2_bytes, b->log.slot, sorted_slot, liota, order, (size_t)L, 0, 32, st));
+        AVL_HIP_CHECK(hipMallocAsync(&tmp2, tmp2_bytes ? tmp2_bytes : 16, st));
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp2, tmp2_bytes, b->log.slot, sorted_slot, liota, order, (size_t)L, 0, 32, st));
+        hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
+                           L, (long long)n, seg_start, seg_end);
+        hipLaunchKernelGGL(replay_rgb_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
+                           (long long)b->gs * b->gs, perm, keys_out, order, seg_start, seg_end, b->log, d_weight, d_grid_rgb);
+        if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
+        (void)hipFreeAsync(tmp2, st); (void)hipFreeAsync(seg_end, st); (void)hipFreeAsync(seg_start, st);
+        (void)hipFreeAsync(order, st); (void)hipFreeAsync(liota, st); (void)hipFreeAsync(sorted_slot, st);
+    }
     (void)hipFreeAsync(tmp, st);
     (void)hipFreeAsync(perm, st);
     (void)hipFreeAsync(iota, st);

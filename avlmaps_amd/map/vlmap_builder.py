@@ -39,6 +39,7 @@ class VLMapBuilder:
         self.capacity = None                       # voxels; default below
         self.min_depth, self.max_depth = 0.1, 6    # vlmap_builder.py:129
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
+        self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
 
     # ------------------------------------------------------------------ pose chain (host, float64)
     def frame_transforms(self, base_poses: np.ndarray) -> List[np.ndarray]:
@@ -125,6 +126,10 @@ class VLMapBuilder:
                 cap = self.capacity or max(gs * gs, 1 << 16)   # the reference starts at gs*gs rows and doubles
                 acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=cap)
                 mapped_iter_set = self._resume(acc, ws)
+                if ws == 1 and not mapped_iter_set and self.exact_rgb:
+                    # per-sample log -> finalize replays the reference's sequential weight / uint8 colour exactly
+                    npix = depth.shape[0] * depth.shape[1]
+                    acc.enable_replay_log((hi - lo) * ((npix + depth_sample_rate - 1) // depth_sample_rate))
             samples = self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
             acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
                                 calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,

@@ -107,6 +107,11 @@ class VoxelAccumulator:
     def reset(self, stream=None):
         _lib.check(_lib.load().avl_builder_reset(self._h, stream), "avl_builder_reset")
 
+    def enable_replay_log(self, max_samples):
+        """log every sampled pixel so that finalize() replays the reference's sequential weight / grid_rgb exactly"""
+        _lib.check(_lib.load().avl_builder_enable_replay_log(self._h, int(max_samples)), "avl_builder_enable_replay_log")
+        return self
+
     def integrate_frame(self, depth, calib, pc_transform, sample_idx, feat_hwc, rgb, frame_idx, calib_inv=None,
                         min_depth=0.1, max_depth=6.0, sigma_sq=0.6, stream=None):
         """Fuse one frame.  depth (H,W) f32, feat_hwc (Hf,Wf,D) f32 channels-last, rgb (H,W,3) u8,

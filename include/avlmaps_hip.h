@@ -124,6 +124,13 @@ AVL_API int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, i
 AVL_API int avl_builder_destroy(avl_builder* b);
 AVL_API int avl_builder_reset(avl_builder* b, void* stream);
 
+/* Optional: keep a 24-byte log entry per sampled pixel (up to max_samples in total) so that avl_builder_finalize can
+ * REPLAY the reference's sequential weight / grid_rgb updates exactly -- float32 weight accumulation and the truncating
+ * uint8 colour store of vlmap_builder.py:166-178, including the dtype switch at _reserve_map_space (:286-311).
+ * Without the log, finalize returns float32(sum alpha) and the once-truncated weighted mean colour.
+ * Call on a fresh (or reset) builder.  Not used after avl_builder_import_map. */
+AVL_API int avl_builder_enable_replay_log(avl_builder* b, int64_t max_samples);
+
 /*
  * Fuse one RGB-D frame.
  *   d_depth        (H, W) float32 metres

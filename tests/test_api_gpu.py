@@ -52,7 +52,8 @@ def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as):
     nz = np.argwhere(occ != -1)
     assert np.array_equal(nz, g["occ_nz"]) and np.array_equal(occ[nz[:, 0], nz[:, 1], nz[:, 2]], g["occ_nz_vals"])
     np.testing.assert_allclose(gf, g["grid_feat"], rtol=2e-5, atol=3e-4)
-    np.testing.assert_allclose(w, g["weight"], rtol=3e-6)
+    np.testing.assert_allclose(w, g["weight"], rtol=3e-7)
+    assert np.array_equal(rgb, g["grid_rgb"])                     # replay log on by default: sequential uint8 colour
     assert gf.dtype == np.float32 and w.dtype == np.float32 and rgb.dtype == np.uint8 and occ.dtype == np.int32
 
 

@@ -19,10 +19,13 @@ def ops():
     return ops
 
 
-def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samples, capacity=None, frame_offset=0):
+def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samples, capacity=None, frame_offset=0,
+                    replay=False):
     D = feats_chw.shape[1]
     vh = int(cam_h / cs)
     acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=capacity)
+    if replay:
+        acc.enable_replay_log(sum(len(s) for s in samples))
     for i in range(len(depths)):
         feat_hwc = np.ascontiguousarray(np.transpose(feats_chw[i], (1, 2, 0)))
         acc.integrate_frame(depths[i], calib, Ts[i], samples[i], feat_hwc, rgbs[i], frame_idx=frame_offset + i)
@@ -55,6 +58,15 @@ def test_builder_matches_reference_golden(ops, golden, name):
                grid_rgb=np.floor(g["grid_rgb"]) if g["grid_rgb"].dtype != np.uint8 else g["grid_rgb"])
     # the growth fixture funnels ~16k points into 463 coarse voxels: many truncating updates per voxel upstream
     compare_maps(out, ref, 14.3, rgb_lsb=16 if "growth" in name else RGB_LSB)
+    # with the replay log, weight and grid_rgb follow the reference's sequential dtype semantics EXACTLY
+    # (float32 running weight, truncating uint8 colour store, float64/float32 after the capacity doubling)
+    acc2 = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"],
+                           g["rgbs"], g["feats"], g["samples"], capacity=2000, replay=True)
+    out2 = acc2.finalize()
+    assert np.array_equal(out2["grid_pos"], g["grid_pos"])
+    assert np.array_equal(out2["grid_rgb"], np.floor(g["grid_rgb"]).astype(np.uint8))
+    wref = g["weight"].astype(np.float32)
+    assert np.mean(out2["weight"] == wref) > 0.999 and np.allclose(out2["weight"], wref, rtol=2e-7, atol=0)
 
 
 def synth_scene(rng, nfr, H, W, Hf, Wf, D):
@@ -96,6 +108,10 @@ def test_builder_vs_sequential_oracle_medium(ops):
     assert acc.num_points() == om_points
     out = acc.finalize()
     compare_maps(out, ref, 14.3)
+    accr = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000, replay=True)
+    outr = accr.finalize()
+    assert np.array_equal(outr["grid_rgb"], ref["grid_rgb"])            # sequential uint8 colour: bit exact
+    assert np.mean(outr["weight"] == ref["weight"]) > 0.999             # exp() may differ by an ulp between libms
     # determinism: a second run gives identical indices and (to fp64 round-off) identical features
     acc2 = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000)
     out2 = acc2.finalize()
