@@ -462,6 +462,25 @@ static bool make_split_plan(int D, int Q, SplitPlan& p) {
     return true;
 }
 
+// hipFuncSetAttribute is not free: raise the dynamic-LDS limit of a kernel only when a launch needs more than before
+static int ensure_dynamic_lds(const void* kern, size_t bytes) {
+    struct Entry { const void* k; size_t bytes; int dev; };
+    static thread_local Entry table[16];
+    static thread_local int used = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int i = 0; i < used; ++i)
+        if (table[i].k == kern && table[i].dev == dev) {
+            if (table[i].bytes >= bytes) return AVL_OK;
+            AVL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            table[i].bytes = bytes;
+            return AVL_OK;
+        }
+    AVL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (used < 16) table[used++] = Entry{kern, bytes, dev};
+    return AVL_OK;
+}
+
 static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
                      float* d_scores, int32_t* d_argmax, float* d_best, hipStream_t st) {
     const int Dp = (D + 3) & ~3;
@@ -474,8 +493,10 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     if (blocks > maxb) blocks = maxb;
     if (blocks < 1) blocks = 1;
     auto kern = vec4 ? sim_exact_kernel<true> : sim_exact_kernel<false>;
-    if (lds > 64 * 1024)
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc != AVL_OK) return rc;
+    }
     // a scratch best buffer is needed to chain chunks when the caller did not ask for one
     for (int q0 = 0, first = 1; q0 < Q; q0 += kExactQB, first = 0) {
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, d_feat, N, D, ld, d_q, Q, ldq, q0, d_scores,
@@ -500,7 +521,8 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
         auto kern = s8 ? (c.QT == 3 ? sim_split_f16_kernel<3, 8> : (c.QT == 2 ? sim_split_f16_kernel<2, 8> : sim_split_f16_kernel<1, 8>))
                        : (c.QT == 3 ? sim_split_f16_kernel<3, 0> : (c.QT == 2 ? sim_split_f16_kernel<2, 0> : sim_split_f16_kernel<1, 0>));
         const size_t lds = p.lds_bytes(c);
-        AVL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc != AVL_OK) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, d_feat, N, D, ld, img, inv_scale, p.Qtot, p.KC,
                            p.nkc, c.q_base, c.rows, Q, d_scores, d_argmax, d_best, ci == 0 ? 1 : 0);
     }

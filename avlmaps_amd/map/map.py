@@ -100,6 +100,19 @@ class Map:
         return NotImplementedError
 
     @staticmethod
+    def _dilate_map(binary_map: np.ndarray, dilate_iter: int = 0, gaussian_sigma: float = 1.0):
+        """2x bilinear upsample -> gaussian -> threshold -> dilation -> downsample.  Reference: map.py:169-181.
+        Navigator-side image processing (not on the accelerated path); needs OpenCV exactly like upstream."""
+        import cv2
+        from scipy.ndimage import binary_dilation, gaussian_filter
+        h, w = binary_map.shape
+        m = cv2.resize(binary_map.astype(float), (w * 2, h * 2))
+        m = gaussian_filter(m.astype(float), sigma=gaussian_sigma, truncate=3)
+        m = (m > 0.5).astype(np.uint8)
+        m = binary_dilation(m, structure=np.ones((3, 3)), iterations=dilate_iter * 2)
+        return cv2.resize(m.astype(float), (w, h))
+
+    @staticmethod
     def create(map_config) -> "Map":
         """Reference: map.py:120-129."""
         from .vlmap import VLMap

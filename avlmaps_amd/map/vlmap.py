@@ -97,5 +97,22 @@ class VLMap(Map):
         _, am, _ = ops.sim_scores(self._device_feat(), q, want_scores=False, want_argmax=True)
         return am.numpy() == 0
 
+    def customize_obstacle_map(self, potential_obstacle_names: List[str], obstacle_names: List[str], vis: bool = False):
+        """Reference: vlmap.py:127-156.  The class scoring runs on the GPU; the 2-D smoothing (Map._dilate_map,
+        map.py:169-181: cv2 resize + gaussian + dilation) is navigator-side image processing and needs OpenCV."""
+        from ..utils.index_utils import get_dynamic_obstacles_map_3d
+        if self.obstacles_cropped is None and self.obstacles_map is None:
+            self.generate_obstacle_map()
+        if not hasattr(self, "clip_model"):
+            print("init_clip in customize obstacle map")
+            self._init_clip()
+        self.obstacles_new_cropped = get_dynamic_obstacles_map_3d(
+            self.clip_model, self.obstacles_cropped, list(cfg_get(self.map_config, "potential_obstacle_names")),
+            list(cfg_get(self.map_config, "obstacle_names")), self._device_feat(), self.grid_pos, self.rmin, self.cmin,
+            self.clip_feat_dim, vis=vis)
+        self.obstacles_new_cropped = Map._dilate_map(self.obstacles_new_cropped == 0, cfg_get(self.map_config, "dilate_iter"),
+                                                     cfg_get(self.map_config, "gaussian_sigma"))
+        self.obstacles_new_cropped = self.obstacles_new_cropped == 0
+
     def get_pos(self, name: str):
         raise NotImplementedError("contour extraction (vlmap.py:158-187) is navigator-side and not on the accelerated path")

@@ -19,3 +19,34 @@ def find_similar_category_id(class_name: str, classes_list: List[str]) -> int:
         return hits[0]
     raise KeyError(f"{class_name!r} does not match one of the initialised categories {classes_list}; "
                    "upstream delegates this to an LLM (index_utils.py:8-32), which is out of scope here")
+
+
+def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstacle_classes, obstacle_classes, grid_feat,
+                                 grid_pos, rmin, cmin, clip_feat_dim, use_multiple_templates=True, avg_mode=0, vis=False):
+    """Cropped top-down map, True = free, after keeping only voxels whose best class is one of `obstacle_classes`.
+    Reference: avlmaps/utils/index_utils.py:138-184 -- the same matmul + argmax as index_map (:153-161), here the fused
+    similarity kernel (scores are never materialised), then a vectorised scatter instead of boolean Python loops.
+    `grid_feat` may be a host array or a device-resident (N, D) array."""
+    import numpy as np
+    from .. import ops
+    from .clip_utils import landmark_text_feats, _to_numpy
+    all_obstacles_mask = obstacles_cropped == 0
+    if avg_mode != 0:
+        from .clip_utils import get_lseg_score
+        scores = get_lseg_score(clip_model, list(potential_obstacle_classes), grid_feat, clip_feat_dim,
+                                use_multiple_templates=use_multiple_templates, avg_mode=avg_mode)
+        predict = np.argmax(scores, axis=1)
+    else:
+        q, _ = landmark_text_feats(clip_model, list(potential_obstacle_classes), clip_feat_dim, use_multiple_templates, True)
+        if isinstance(grid_feat, np.ndarray):
+            grid_feat = np.ascontiguousarray(grid_feat, dtype=np.float32)
+        _, am, _ = ops.sim_scores(grid_feat, q, want_scores=False, want_argmax=True)
+        predict = _to_numpy(am)
+    obs_inds = [i for obs_name in obstacle_classes for i, po in enumerate(potential_obstacle_classes) if obs_name == po]
+    print("obs_inds: ", obs_inds)
+    pts_mask = np.isin(predict, obs_inds)
+    new_obstacles = np.zeros_like(obstacles_cropped, dtype=bool)
+    obs_pts = np.asarray(grid_pos)[pts_mask]
+    new_obstacles[obs_pts[:, 0] - rmin, obs_pts[:, 1] - cmin] = 1
+    new_obstacles = np.logical_and(new_obstacles, all_obstacles_mask)
+    return np.logical_not(new_obstacles)

@@ -117,20 +117,32 @@ def run_index(args, torch, dist, lib, rank, ws):
 
     for _ in range(args.warmup):
         step()
+    # HIP events on the launch stream bracket every timed step (K + 1 records inside the timed region)
+    evs = []
+    for _ in range(args.steps + 1):
+        e = C.c_void_p()
+        lib.avl_event_create(C.byref(e))
+        evs.append(e)
     barrier_sync(torch, dist, ws)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        lib.avl_event_record(evs[i], None)
         step()
+    lib.avl_event_record(evs[-1], None)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(torch, dist, ws, dt)
     if ws > 1:
         dist.barrier()
-
-    # per-launch duration of the dominant kernel with HIP events on the launch stream
+    ms = C.c_float()
+    per_step = []
+    for i in range(args.steps):
+        lib.avl_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms))
+        per_step.append(ms.value)
+    for e in evs:
+        lib.avl_event_destroy(e)
+    ev_ms = float(np.mean(per_step))      # per-launch duration of the dominant kernel (+ the ~5 us query prep launch)
     timer = event_timer(lib)
-    ev = [timer(step) for _ in range(max(5, min(args.steps, 20)))]
-    ev_ms = float(np.mean(ev))
     alg_bytes = N * D * 4 + Q * D * 4 + N * 8            # feature stream + queries + argmax/best out
     achieved = alg_bytes / (ev_ms * 1e-3) / 1e9
 
@@ -145,7 +157,7 @@ def run_index(args, torch, dist, lib, rank, ws):
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                            traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes)
-    if rank == 0:
+    if rank == 0 and not args.profile_run:
         # variant: also materialise scores_mat (VLMap.init_categories, vlmap.py:92-102)
         sc = torch.empty((N, Q), dtype=torch.float32, device="cuda")
         for _ in range(2):
@@ -319,9 +331,11 @@ def cpu_build_baseline(frames=12):
 
 
 def load_pmc_traffic(which):
+    """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json, written by tools/publish_profiles.py
+    from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); None if absent."""
     p = ROOT / "profiles" / "pmc_traffic.json"
     try:
-        return json.loads(p.read_text()).get(which)
+        return json.loads(p.read_text())[which]["total_bytes"]
     except Exception:
         return None
 
@@ -338,7 +352,12 @@ def main():
     ap.add_argument("--build-frames", type=int, default=300)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-build-extra", action="store_true")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="only the timed kernel launches (no scores_mat variant, CPU baseline or build extra): used under rocprofv3 "
+                         "so that the trace's per-kernel average is the benchmarked launch")
     args = ap.parse_args()
+    if args.profile_run:
+        args.no_cpu = args.no_build_extra = True
     if args.steps is None:
         args.steps = 50 if args.workload == "index" else 500
     if args.warmup is None:
