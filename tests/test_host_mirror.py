@@ -99,3 +99,21 @@ def test_map_attribute_surface_and_obstacles():
     with pytest.raises(Exception, match="Categories are not preloaded"):
         m.index_map("sofa", with_init_cat=True)
     assert VLMapBuilder(Path("/tmp"), cfg, None, [], [], None, None).create_camera_map() is NotImplementedError
+
+
+def test_get_lseg_feat_protocol_matches_reference(golden):
+    """sliding-window evaluation of lseg_utils.py:20-119, device-resident channels-last output (CPU tensors here)"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    from gen_golden import FakeLSeg
+    from avlmaps_amd.utils.lseg_utils import get_lseg_feat
+    g = golden("g5_lseg_protocol.npz")
+    for name in ("pad_short", "grid_2x3", "tall"):
+        crop, base = (int(x) for x in g[f"{name}_cfg"])
+        ref = g[f"{name}_feat"]                                   # (1, D, Hf, Wf) as the reference returns it
+        f = get_lseg_feat(FakeLSeg(), g[f"{name}_img"], ["example"], None, "cpu", crop, base)
+        assert tuple(f.shape) == (ref.shape[2], ref.shape[3], ref.shape[1]) and f.is_contiguous()
+        np.testing.assert_allclose(f.numpy(), np.transpose(ref[0], (1, 2, 0)), rtol=1e-6, atol=1e-6)
+        f2 = get_lseg_feat(FakeLSeg(), g[f"{name}_img"], ["example"], None, "cpu", crop, base, channels_last=False)
+        np.testing.assert_allclose(f2.numpy(), ref, rtol=1e-6, atol=1e-6)

@@ -368,6 +368,7 @@ def main():
     gen_g3(m, np.random.default_rng(33))
     gen_g4(m, np.random.default_rng(44))
     gen_templates_hash(m)
+    gen_g5_lseg_protocol()
     os.system(f"ls -la {OUT}")
 
 
@@ -381,6 +382,49 @@ def gen_templates_hash(m):
     h = hashlib.sha256("\n".join(ref).encode()).hexdigest()
     json.dump({"n_templates": len(ref), "sha256_of_newline_joined": h,
                "source": "avlmaps/utils/clip_utils.py:10-74 (hash only)"}, open(OUT / "templates.json", "w"), indent=1)
+
+
+
+# --------------------------------------------------------------------------------------
+class FakeLSeg:
+    """deterministic stand-in for LSegEncNet: per-pixel features that depend on the pixel value AND on the position inside
+    the crop, so that the sliding-window offsets / overlap averaging / padding of get_lseg_feat are all observable"""
+    out_c = 6
+
+    def __call__(self, x, labels):
+        import torch
+        b, c, h, w = x.shape
+        yy = torch.linspace(0, 1, h).view(1, 1, h, 1).expand(b, 1, h, w)
+        xx = torch.linspace(0, 1, w).view(1, 1, 1, w).expand(b, 1, h, w)
+        f = torch.cat([x, x.mean(1, keepdim=True) * yy, xx * yy, torch.sin(3 * x[:, :1]) + xx], dim=1)
+        logits = torch.cat([x[:, :1] * 0 + float(i) for i in range(len(labels))], dim=1)
+        return f, logits
+
+
+def gen_g5_lseg_protocol():
+    """avlmaps/utils/lseg_utils.py:20-119 get_lseg_feat (real function, fake model, CPU)"""
+    import importlib
+    import torch
+    for name in ["avlmaps.lseg.additional_utils.models", "avlmaps.utils.lseg_utils"]:
+        sys.modules.pop(name, None)
+    lu = importlib.import_module("avlmaps.utils.lseg_utils")
+    rng = np.random.default_rng(55)
+
+    def tfm(img):
+        t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1).float().div(255.0)
+        return (t - 0.5) / 0.5
+
+    out = {}
+    # (base_size <= crop_size is not covered: the reference itself raises UnboundLocalError on that branch, lseg_utils.py:103)
+    cases = {"pad_short": (72, 108, 48, 52), "grid_2x3": (80, 100, 48, 100), "tall": (110, 60, 40, 90)}
+    for name, (H, W, crop, base) in cases.items():
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        f = lu.get_lseg_feat(FakeLSeg(), img, ["example"], tfm, "cpu", crop, base, [0.5] * 3, [0.5] * 3)
+        out[f"{name}_img"] = img
+        out[f"{name}_cfg"] = np.array([crop, base])
+        out[f"{name}_feat"] = f
+    np.savez_compressed(OUT / "g5_lseg_protocol.npz", **out)
+    print("G5 written", {k: v.shape for k, v in out.items() if k.endswith("_feat")})
 
 
 if __name__ == "__main__":
