@@ -117,3 +117,22 @@ def test_full_size_properties(ops):
     sub = feat[:200_000]
     s12, _, _ = ops.sim_scores(sub, q[:32] + q[32:], want_argmax=False)
     assert (s12 - (sc[:200_000, :32] + sc[:200_000, 32:])).abs().max() < 1e-4
+
+
+def test_fused_multimodal_block_queries(ops):
+    """BASELINE config 5 shape family: 512 visual || 1024 audio feature columns, 128 queries each non-zero in one block."""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(11)
+    N, D, Q = 4096, 1536, 128
+    feat = rng.standard_normal((N, D)).astype(np.float32)
+    feat[:, :512] *= 14.2857 / np.linalg.norm(feat[:, :512], axis=1, keepdims=True)
+    feat[:, 512:] /= np.linalg.norm(feat[:, 512:], axis=1, keepdims=True)
+    q = np.zeros((Q, D), np.float32)
+    q[:64, :512] = rng.standard_normal((64, 512))
+    q[64:, 512:] = rng.standard_normal((64, 1024))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    ref = feat.astype(np.float64) @ q.astype(np.float64).T
+    assert np.abs(O.sim_scores(feat, q) - ref).max() < 1e-4
+    sc, am, best = ops.sim_scores(feat, q, want_best=True)
+    _check(sc, am, best, ref, 1e-4)
+    assert np.abs(sc - ref).max() < 5e-6
