@@ -21,6 +21,9 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
     """
     lib = _lib.load()
     _lib.require_gpu()
+    if stream is None and _is_torch(feat):
+        from .device import torch_stream_ptr
+        stream = torch_stream_ptr()           # launch on torch's current stream so torch-side ordering holds
     fptr, fshape, fkeep = as_device(feat, np.float32, stream)
     qptr, qshape, qkeep = as_device(queries, np.float32, stream)
     if len(fshape) != 2 or len(qshape) != 2 or fshape[1] != qshape[1]:

@@ -48,9 +48,10 @@ def init_distributed(backend: Optional[str] = None):
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        if backend is None:   # AVLMAPS_DIST_BACKEND=gloo lets several ranks share one GPU (testing the choreography)
+            backend = os.environ.get("AVLMAPS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, ws, local
@@ -108,6 +109,34 @@ def merge_raw(raw: Dict[str, "torch.Tensor"], dst: int = 0, group=None):
     dist.reduce(fa, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if rank != dst:
         return None
+    order = torch.argsort(gkey)
+    return dict(cell=union[order].to(torch.int32), first_key=gkey[order], sum_feat=acc[order, :D].contiguous(),
+                sum_w4=acc[order, D:].contiguous(), first_feat=ff[order], first_alpha=fa[order])
+
+
+def merge_raw_local(raws):
+    """Same merge as merge_raw for several raw exports held by ONE process (e.g. two accumulators on one GPU):
+    sums add, the smallest first-touch key owns the first-touch row, rows come out in key order."""
+    import torch
+    dev = raws[0]["cell"].device
+    D = raws[0]["sum_feat"].shape[1]
+    union = torch.unique(torch.cat([r["cell"] for r in raws]))
+    M = union.shape[0]
+    gkey = torch.full((M,), I64_MAX, dtype=torch.int64, device=dev)
+    acc = torch.zeros((M, D + 4), dtype=torch.float64, device=dev)
+    idxs = []
+    for r in raws:
+        idx = torch.searchsorted(union, r["cell"])
+        idxs.append(idx)
+        gkey[idx] = torch.minimum(gkey[idx], r["first_key"])
+        acc[idx, :D] += r["sum_feat"]
+        acc[idx, D:] += r["sum_w4"]
+    ff = torch.zeros((M, D), dtype=torch.float32, device=dev)
+    fa = torch.zeros((M,), dtype=torch.float64, device=dev)
+    for r, idx in zip(raws, idxs):
+        owner = r["first_key"] == gkey[idx]
+        ff[idx[owner]] = r["first_feat"][owner]
+        fa[idx[owner]] = r["first_alpha"][owner]
     order = torch.argsort(gkey)
     return dict(cell=union[order].to(torch.int32), first_key=gkey[order], sum_feat=acc[order, :D].contiguous(),
                 sum_w4=acc[order, D:].contiguous(), first_feat=ff[order], first_alpha=fa[order])

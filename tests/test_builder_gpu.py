@@ -180,3 +180,30 @@ def test_export_raw_and_finalize_raw_roundtrip(ops, golden):
     out2 = ops.finalize_raw(raw, acc.D, acc.gs, acc.vh)
     for k in ("grid_feat", "grid_pos", "weight", "grid_rgb", "occupied_ids"):
         assert np.array_equal(out[k], out2[k]), k
+
+
+def test_sharded_build_merges_to_the_single_gpu_map(ops, golden):
+    """frames split over two accumulators (global frame indices), merged with the multi-GPU merge math:
+    identical voxel ids / order, features equal to rounding"""
+    import torch
+    from avlmaps_amd import parallel
+    from oracle import avl_oracle as O
+    g = golden("g2a_builder_small.npz")
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    args = (int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"])
+    whole = run_gpu_builder(ops, *args, Ts, g["depths"], g["rgbs"], g["feats"], g["samples"], capacity=2000).finalize()
+    k = 3
+    a = run_gpu_builder(ops, *args, Ts[:k], g["depths"][:k], g["rgbs"][:k], g["feats"][:k], g["samples"][:k], capacity=2000)
+    b = run_gpu_builder(ops, *args, Ts[k:], g["depths"][k:], g["rgbs"][k:], g["feats"][k:], g["samples"][k:], capacity=2000,
+                        frame_offset=k)
+    raws = [ops.export_raw_torch(x) for x in (a, b)]
+    merged = parallel.merge_raw_local(raws)
+    out = ops.finalize_raw({kk: v for kk, v in merged.items() if kk != "first_key"}, a.D, a.gs, a.vh)
+    assert np.array_equal(out["grid_pos"], whole["grid_pos"]) and np.array_equal(out["occupied_ids"], whole["occupied_ids"])
+    np.testing.assert_allclose(out["grid_feat"], whole["grid_feat"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out["weight"], whole["weight"], rtol=1e-6)
+    assert np.abs(out["grid_rgb"].astype(int) - whole["grid_rgb"].astype(int)).max() <= 1
+    # and the collective version degenerates to the same thing for one rank
+    one = parallel.merge_raw(ops.export_raw_torch(run_gpu_builder(ops, *args, Ts, g["depths"], g["rgbs"], g["feats"], g["samples"],
+                                                                   capacity=2000)))
+    assert torch.equal(one["cell"].cpu(), merged["cell"].cpu())

@@ -61,6 +61,9 @@ def _worker(rank, ws, port, tmpdir):
     if rank == 0:
         cells, table = expected_merge(raws)
         assert merged["cell"].tolist() == cells
+        local = parallel.merge_raw_local(raws)                   # single-process variant: same result
+        for k in merged:
+            assert torch.allclose(local[k].double(), merged[k].double(), rtol=1e-15, atol=1e-15), k
         for i, c in enumerate(cells):
             e = table[c]
             assert int(merged["first_key"][i]) == e["key"]
