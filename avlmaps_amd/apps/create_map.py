@@ -1,0 +1,52 @@
+"""Build a VLMap for one scene directory.  Counterpart of the reference's application/create_map.py:7-17.
+
+    python -m avlmaps_amd.apps.create_map --data-dir <scene> [--config cfg.yaml] [--features lseg|hash] [--seed N]
+
+<scene>/ holds rgb/*.png, depth/*.npy (float32 metres) and poses.txt (x y z qx qy qz qw per line), the layout of the
+reference's dataset/README.md:76-93; the map goes to <scene>/vlmap/vlmaps.h5df (HDF5 if h5py is installed, else .npz).
+Multi-GPU: launch with torchrun; frames are sharded over ranks and merged with one sparse RCCL reduce."""
+from __future__ import annotations
+
+import argparse
+import time
+
+import numpy as np
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--data-dir", required=True)
+    ap.add_argument("--config", default=None, help="YAML with params / map_config overrides")
+    ap.add_argument("--features", choices=["lseg", "hash"], default="lseg",
+                    help="lseg = upstream LSegEncNet + demo_e200.ckpt on PyTorch-ROCm; hash = model-free stand-in for smoke runs")
+    ap.add_argument("--feat-dim", type=int, default=512)
+    ap.add_argument("--seed", type=int, default=None, help="seed of the global NumPy RNG that orders the pixel sampling")
+    ap.add_argument("--capacity", type=int, default=None, help="voxel capacity (default gs*gs)")
+    args = ap.parse_args(argv)
+
+    from avlmaps_amd import parallel
+    from avlmaps_amd.apps.common import HashFeatureExtractor, load_config
+    from avlmaps_amd.map import AVLMap
+    rank, ws, _ = parallel.init_distributed()
+    cfg = load_config(args.config)
+    if args.seed is not None:
+        np.random.seed(args.seed)
+    extractor = HashFeatureExtractor(args.feat_dim) if args.features == "hash" else None
+    avlmap = AVLMap(cfg, data_dir=args.data_dir)
+    if args.capacity:
+        import avlmaps_amd.map.vlmap_builder as vb
+        orig = vb.VLMapBuilder.__init__
+
+        def patched(self, *a, **k):
+            orig(self, *a, **k)
+            self.capacity = args.capacity
+        vb.VLMapBuilder.__init__ = patched
+    t0 = time.perf_counter()
+    avlmap.create_map(args.data_dir, feat_extractor=extractor)
+    if rank == 0:
+        n = len(avlmap.vlmap.map_builder.last_map["grid_pos"]) if hasattr(avlmap.vlmap.map_builder, "last_map") else -1
+        print(f"map with {n} voxels written to {avlmap.vlmap.map_builder.map_save_path} in {time.perf_counter() - t0:.2f} s")
+
+
+if __name__ == "__main__":
+    main()

@@ -40,7 +40,7 @@ def crop_image(img, h0, h1, w0, w1):
 def default_transform(image: np.ndarray):
     """ToTensor + Normalize(0.5, 0.5) of the reference (vlmap_builder.py:257-262) without torchvision"""
     import torch
-    t = torch.from_numpy(np.ascontiguousarray(image)).permute(2, 0, 1).float().div_(255.0)
+    t = torch.from_numpy(np.array(image, copy=True)).permute(2, 0, 1).float().div_(255.0)
     return (t - 0.5) / 0.5
 
 

@@ -169,3 +169,24 @@ def test_dynamic_obstacles_map_matches_numpy_restatement(golden):
     if safe.all():
         assert np.array_equal(got, want)
     assert got.dtype == bool and got.shape == cropped.shape and (got != want).mean() < 0.01
+
+
+def test_cli_create_then_index_on_disk_dataset(tmp_path):
+    """apps.create_map + apps.index_map on a synthetic scene in the reference's on-disk layout (png / npy / poses.txt)"""
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import yaml
+    from make_synth_dataset import make
+    from avlmaps_amd.apps import create_map, index_map
+    from avlmaps_amd.utils.mapping_utils import load_3d_map
+    scene = make(tmp_path / "scene", frames=6, H=96, W=128)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"map_config": {"cam_calib_mat": [64, 0, 64, 0, 64, 48, 0, 0, 1], "depth_sample_rate": 3,
+                                                  "grid_size": 400, "cell_size": 0.05}, "params": {"gs": 400, "cs": 0.05}}))
+    create_map.main(["--data-dir", str(scene), "--config", str(cfg), "--features", "hash", "--feat-dim", "64", "--seed", "3"])
+    it, gf, gp, w, occ, rgb = load_3d_map(scene / "vlmap" / "vlmaps.h5df")
+    assert it == list(range(6)) and gf.shape[1] == 64 and len(gp) > 500 and occ.shape == (400, 400, 30)
+    assert (occ >= 0).sum() == len(gp) and np.array_equal(occ[gp[:, 0], gp[:, 1], gp[:, 2]], np.arange(len(gp)))
+    heat = index_map.main(["--data-dir", str(scene), "--config", str(cfg), "--query", "sofa", "--text-model", "hash"])
+    assert heat.shape == (len(gp),) and heat.max() == 1.0 and 0 < (heat == 1.0).sum() < len(gp)
