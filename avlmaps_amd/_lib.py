@@ -47,11 +47,15 @@ _SIGS = {
     "avl_mask_from_argmax": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "avl_argmax_f32": (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(C.c_float), _vp]),
     "avl_builder_create": (C.c_int, [C.POINTER(_vp), C.c_int, _f64, C.c_int, C.c_int, _i64]),
+    "avl_builder_create_grid": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _f64, C.c_int, _i64]),
     "avl_builder_destroy": (C.c_int, [_vp]),
     "avl_builder_reset": (C.c_int, [_vp, _vp]),
     "avl_builder_enable_replay_log": (C.c_int, [_vp, _i64]),
     "avl_builder_integrate_frame": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int,
                                               C.c_int, _vp, _i64, _f64, _f64, _f64, _vp]),
+    "avl_builder_integrate_frame_global": (C.c_int, [_vp, _vp, C.c_int, _f64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp,
+                                                     C.c_int, C.c_int, _vp, _i64, _f64, _f64, _f64, _vp, _vp]),
+    "avl_points_bbox": (C.c_int, [_vp, C.c_int, _f64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _f64, _vp, _vp]),
     "avl_builder_import_map": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_num_voxels": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_num_points": (C.c_int, [_vp, C.POINTER(_i64), _vp]),

@@ -52,7 +52,11 @@ struct FrameParams {
     double t[16];     // pc_transform          (vlmap_builder.py:133)
     double min_depth, max_depth, two_sigma_sq;
     double cs, half_gs;
-    int H, W, Hf, Wf, gs, vh, P;
+    double pcd_min[3];   // global mode: lower corner of the pass-1 bounding box (vlmap_builder_multi_floor.py:117)
+    double depth_div;    // uint16 depth images: metres = value / depth_div (multi-floor: / 1000.0, :105)
+    int H, W, Hf, Wf, n0, n1, n2, P;   // grid: n0 rows x n1 cols x n2 heights (mobile-base mode: gs, gs, vh)
+    int mode;            // 0 = mobile-base map (vlmap_builder.py), 1 = global multi-floor map (vlmap_builder_multi_floor.py)
+    int depth_u16;
     long long capacity;
 };
 
@@ -97,7 +101,8 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
     double pl0 = 0, pl1 = 0, pl2 = 0;
     if (ok) {
         // depth2pc: p_2d = (u + 0.5, v + 0.5, 1); pc = Kinv @ p_2d (dgemm: FMA chain over k); pc *= z
-        const double x = (double)(pix % fp.W) + 0.5, y = (double)(pix / fp.W) + 0.5, z = (double)depth[pix];
+        const double x = (double)(pix % fp.W) + 0.5, y = (double)(pix / fp.W) + 0.5;
+        const double z = fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(depth)[pix] / fp.depth_div : (double)depth[pix];
         pl0 = fma(fp.kinv[2], 1.0, fma(fp.kinv[1], y, fp.kinv[0] * x)) * z;
         pl1 = fma(fp.kinv[5], 1.0, fma(fp.kinv[4], y, fp.kinv[3] * x)) * z;
         pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
@@ -109,11 +114,21 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
         const double g0 = fma(fp.t[3], 1.0, fma(fp.t[2], pl2, fma(fp.t[1], pl1, fp.t[0] * pl0)));
         const double g1 = fma(fp.t[7], 1.0, fma(fp.t[6], pl2, fma(fp.t[5], pl1, fp.t[4] * pl0)));
         const double g2 = fma(fp.t[11], 1.0, fma(fp.t[10], pl2, fma(fp.t[9], pl1, fp.t[8] * pl0)));
-        // base_pos2grid_id_3d: int(gs/2 - int(x/cs)) with a true fp64 divide
-        row = py_int(fp.half_gs - (double)py_int(g0 / fp.cs));
-        col = py_int(fp.half_gs - (double)py_int(g1 / fp.cs));
-        h = py_int(g2 / fp.cs);
-        ok = !(col >= fp.gs || row >= fp.gs || h >= fp.vh || col < 0 || row < 0 || h < 0);
+        if (fp.mode == 0) {
+            // base_pos2grid_id_3d: int(gs/2 - int(x/cs)) with a true fp64 divide
+            row = py_int(fp.half_gs - (double)py_int(g0 / fp.cs));
+            col = py_int(fp.half_gs - (double)py_int(g1 / fp.cs));
+            h = py_int(g2 / fp.cs);
+        } else {
+            // row, height, col = np.round((p - pcd_min) / cs).astype(int)   (vlmap_builder_multi_floor.py:146; half-to-even)
+            row = py_int(rint((g0 - fp.pcd_min[0]) / fp.cs));
+            h = py_int(rint((g1 - fp.pcd_min[1]) / fp.cs));
+            col = py_int(rint((g2 - fp.pcd_min[2]) / fp.cs));
+        }
+        ok = !(col >= fp.n1 || row >= fp.n0 || h >= fp.n2 || col < 0 || row < 0 || h < 0);
+        // global mode: the reference only tests the upper row/col bounds and otherwise wraps or raises; a point outside
+        // the pass-1 bounding box is dropped here and reported
+        if (!ok && fp.mode == 1) atomicOr(err_flags, 8);
     }
     if (ok) {
         // project_point(calib, p_local) -> rgb[py, px] with numpy's negative-index wrap
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
     if (ok) {
         const double radial = (pl0 * pl0 + pl1 * pl1) + pl2 * pl2;  // np.sum(np.square(p_local))
         alpha = exp(-radial / fp.two_sigma_sq);
-        cell = (int32_t)((row * fp.gs + col) * fp.vh + h);
+        cell = (int32_t)((row * fp.n1 + col) * fp.n2 + h);
     }
     // create the voxel if the cell is empty: the CAS winner takes the next slot.  One counter atomic per wave:
     // winners are ranked with a ballot (a single hot word only sustains ~90 atomics/us).
@@ -446,7 +461,7 @@ __global__ void iota_kernel(int32_t* __restrict__ v, int64_t n) {
 }
 
 // wave per imported voxel row: rebuild accumulators from a finalised map (resume, vlmap_builder.py:212-222)
-__global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int gs, int vh, const float* __restrict__ grid_feat,
+__global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int n0, int gs, int vh, const float* __restrict__ grid_feat,
                                                          const int32_t* __restrict__ grid_pos, const float* __restrict__ weight,
                                                          const uint8_t* __restrict__ grid_rgb, int32_t* __restrict__ cell_slot,
                                                          int32_t* __restrict__ slot_cell, unsigned long long* __restrict__ slot_key,
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int g
         }
         if (lane == 0) {
             const int row = grid_pos[r * 3], col = grid_pos[r * 3 + 1], h = grid_pos[r * 3 + 2];
-            if (row < 0 || row >= gs || col < 0 || col >= gs || h < 0 || h >= vh) {
+            if (row < 0 || row >= n0 || col < 0 || col >= gs || h < 0 || h >= vh) {
                 atomicOr(err_flags, 4);
             } else {
                 const int32_t cell = (row * gs + col) * vh + h;
@@ -479,12 +494,41 @@ __global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int g
     }
 }
 
+// pass 1 of the global (multi-floor) builder: bounding box of the transformed sampled points
+// (vlmap_builder_multi_floor.py:97-118).  minmax = [min xyz, max xyz] as order-preserving uint64 keys of the doubles.
+__device__ __forceinline__ unsigned long long f64_key(double v) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(FrameParams fp, const float* __restrict__ depth,
+                                                   const int32_t* __restrict__ sample_idx, unsigned long long* __restrict__ minmax) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= fp.P) return;
+    const int pix = sample_idx[s];
+    if (pix < 0 || pix >= fp.H * fp.W) return;
+    const double x = (double)(pix % fp.W) + 0.5, y = (double)(pix / fp.W) + 0.5;
+    const double z = fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(depth)[pix] / fp.depth_div : (double)depth[pix];
+    const double pl0 = fma(fp.kinv[2], 1.0, fma(fp.kinv[1], y, fp.kinv[0] * x)) * z;
+    const double pl1 = fma(fp.kinv[5], 1.0, fma(fp.kinv[4], y, fp.kinv[3] * x)) * z;
+    const double pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
+    if (!((pl2 > fp.min_depth) && (pl2 < fp.max_depth))) return;
+    const double g[3] = {fma(fp.t[3], 1.0, fma(fp.t[2], pl2, fma(fp.t[1], pl1, fp.t[0] * pl0))),
+                         fma(fp.t[7], 1.0, fma(fp.t[6], pl2, fma(fp.t[5], pl1, fp.t[4] * pl0))),
+                         fma(fp.t[11], 1.0, fma(fp.t[10], pl2, fma(fp.t[9], pl1, fp.t[8] * pl0)))};
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long k = f64_key(g[c]);
+        atomicMin(&minmax[c], k);
+        atomicMax(&minmax[3 + c], k);
+    }
+}
+
 }  // namespace avl
 
 using namespace avl;
 
 struct avl_builder {
-    int gs, vh, D;
+    int n0, gs, vh, D;   // grid n0 x gs x vh (n0 == gs for the square mobile-base map)
     double cs;
     int64_t capacity;
     size_t ncell;
@@ -518,7 +562,7 @@ static int builder_check_flags(avl_builder* b, hipStream_t st) {
         set_error("a sampled point projected outside the RGB image (the reference raises IndexError here)");
         return AVL_ERR_INVALID;
     }
-    return AVL_OK;
+    return AVL_OK;   // bit 8 (global mode: samples outside the pass-1 bounding box were dropped) is informational
 }
 
 static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
@@ -567,16 +611,16 @@ int avl_builder_destroy(avl_builder* b) {
     return AVL_OK;
 }
 
-int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, int64_t capacity) {
+int avl_builder_create_grid(avl_builder** h_out, int n0, int gs, int vh, double cs, int D, int64_t capacity) {
     AVL_REQUIRE(h_out, "avl_builder_create: null output");
     *h_out = nullptr;
-    AVL_REQUIRE(gs > 0 && vh > 0 && D > 0 && cs > 0 && capacity > 0, "avl_builder_create: bad parameters");
-    const double ncell_d = (double)gs * gs * vh;
+    AVL_REQUIRE(n0 > 0 && gs > 0 && vh > 0 && D > 0 && cs > 0 && capacity > 0, "avl_builder_create: bad parameters");
+    const double ncell_d = (double)n0 * gs * vh;
     AVL_REQUIRE(ncell_d < 2.0e9, "avl_builder_create: gs*gs*vh = %.0f cells exceeds the int32 cell index", ncell_d);
     AVL_REQUIRE(capacity < (1ll << 31), "avl_builder_create: capacity must fit int32 voxel ids");
     avl_builder* b = new avl_builder();
-    b->gs = gs; b->vh = vh; b->D = D; b->cs = cs; b->capacity = capacity;
-    b->ncell = (size_t)gs * gs * vh;
+    b->n0 = n0; b->gs = gs; b->vh = vh; b->D = D; b->cs = cs; b->capacity = capacity;
+    b->ncell = (size_t)n0 * gs * vh;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
     alloc((void**)&b->cell_slot, b->ncell * sizeof(int32_t));
@@ -629,10 +673,14 @@ int avl_builder_enable_replay_log(avl_builder* b, int64_t max_samples) {
     return AVL_OK;
 }
 
-int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int W, const double* h_calib,
-                                const double* h_calib_inv, const double* h_pc_transform, const int32_t* d_sample_idx, int P,
-                                const float* d_feat, int Hf, int Wf, const uint8_t* d_rgb, int64_t frame_idx,
-                                double min_depth, double max_depth, double sigma_sq, void* stream) {
+int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, int64_t capacity) {
+    return avl_builder_create_grid(h_out, gs, gs, vh, cs, D, capacity);
+}
+
+static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, double depth_div, int H, int W, const double* h_calib,
+                          const double* h_calib_inv, const double* h_pc_transform, const int32_t* d_sample_idx, int P,
+                          const float* d_feat, int Hf, int Wf, const uint8_t* d_rgb, int64_t frame_idx, double min_depth,
+                          double max_depth, double sigma_sq, const double* h_pcd_min, void* stream) {
     AVL_REQUIRE(b, "avl_builder_integrate_frame: null handle");
     AVL_REQUIRE(H > 0 && W > 0 && Hf > 0 && Wf > 0 && P >= 0, "avl_builder_integrate_frame: bad shape");
     AVL_REQUIRE(P < (1 << 30), "avl_builder_integrate_frame: at most 2^30 samples per frame");
@@ -655,7 +703,11 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
     fp.min_depth = min_depth; fp.max_depth = max_depth;
     fp.two_sigma_sq = 2 * sigma_sq;
     fp.cs = b->cs; fp.half_gs = (double)b->gs / 2.0;
-    fp.H = H; fp.W = W; fp.Hf = Hf; fp.Wf = Wf; fp.gs = b->gs; fp.vh = b->vh; fp.P = P;
+    fp.H = H; fp.W = W; fp.Hf = Hf; fp.Wf = Wf; fp.n0 = b->n0; fp.n1 = b->gs; fp.n2 = b->vh; fp.P = P;
+    fp.mode = h_pcd_min ? 1 : 0;
+    for (int i = 0; i < 3; ++i) fp.pcd_min[i] = h_pcd_min ? h_pcd_min[i] : 0.0;
+    fp.depth_u16 = depth_u16;
+    fp.depth_div = depth_div;
     fp.capacity = b->capacity;
     const unsigned long long frame_key = b->key_bias | ((unsigned long long)frame_idx << 32);
 
@@ -664,7 +716,7 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
         return AVL_ERR_CAPACITY;
     }
     const unsigned pb = (unsigned)((P + 255) / 256), wb = (unsigned)((P + 3) / 4);
-    hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, d_depth, d_sample_idx, d_rgb, b->cell_slot,
+    hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb, b->cell_slot,
                        b->slot_cell, b->recs, b->counters, b->err_flags);
     hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters, b->log, b->log_used,
                        frame_key);
@@ -683,6 +735,25 @@ int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int
                            b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
+}
+
+int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int W, const double* h_calib,
+                                const double* h_calib_inv, const double* h_pc_transform, const int32_t* d_sample_idx, int P,
+                                const float* d_feat, int Hf, int Wf, const uint8_t* d_rgb, int64_t frame_idx,
+                                double min_depth, double max_depth, double sigma_sq, void* stream) {
+    return integrate_impl(b, d_depth, 0, 1.0, H, W, h_calib, h_calib_inv, h_pc_transform, d_sample_idx, P, d_feat, Hf, Wf, d_rgb,
+                          frame_idx, min_depth, max_depth, sigma_sq, nullptr, stream);
+}
+
+int avl_builder_integrate_frame_global(avl_builder* b, const void* d_depth, int depth_is_u16, double depth_div, int H, int W,
+                                       const double* h_calib, const double* h_calib_inv, const double* h_transform,
+                                       const int32_t* d_sample_idx, int P, const float* d_feat, int Hf, int Wf,
+                                       const uint8_t* d_rgb, int64_t frame_idx, double min_depth, double max_depth,
+                                       double sigma_sq, const double* h_pcd_min, void* stream) {
+    AVL_REQUIRE(h_pcd_min, "avl_builder_integrate_frame_global: pcd_min is required");
+    AVL_REQUIRE(!depth_is_u16 || depth_div > 0, "avl_builder_integrate_frame_global: depth_div must be positive");
+    return integrate_impl(b, d_depth, depth_is_u16 ? 1 : 0, depth_div, H, W, h_calib, h_calib_inv, h_transform, d_sample_idx, P, d_feat,
+                          Hf, Wf, d_rgb, frame_idx, min_depth, max_depth, sigma_sq, h_pcd_min, stream);
 }
 
 static int read_counter(avl_builder* b, int which, int64_t* h_n, hipStream_t st) {
@@ -784,7 +855,7 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
         hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
                            L, (long long)n, seg_start, seg_end);
         hipLaunchKernelGGL(replay_rgb_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
-                           (long long)b->gs * b->gs, perm, keys_out, order, seg_start, seg_end, b->log, d_weight, d_grid_rgb);
+                           (long long)b->n0 * b->gs, perm, keys_out, order, seg_start, seg_end, b->log, d_weight, d_grid_rgb);
         if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
         (void)hipFreeAsync(tmp2, st); (void)hipFreeAsync(seg_end, st); (void)hipFreeAsync(seg_start, st);
         (void)hipFreeAsync(order, st); (void)hipFreeAsync(liota, st); (void)hipFreeAsync(sorted_slot, st);
@@ -816,7 +887,7 @@ int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, 
     int64_t blocks = (n + 3) / 4;
     const int64_t maxb = (int64_t)num_cus() * 16;
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(import_map_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, b->D, b->gs, b->vh, d_grid_feat, d_grid_pos,
+    hipLaunchKernelGGL(import_map_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, b->D, b->n0, b->gs, b->vh, d_grid_feat, d_grid_pos,
                        d_weight, d_grid_rgb, b->cell_slot, b->slot_cell, b->slot_key, b->sum_feat, b->sum_w4, b->first_feat,
                        b->first_alpha, b->err_flags);
     const unsigned long long nn = (unsigned long long)n;
@@ -851,6 +922,45 @@ int avl_builder_export_raw(avl_builder* b, int64_t n, int32_t* d_cell, uint64_t*
     AVL_HIP_CHECK(cp(d_sum_w4, b->sum_w4, (size_t)n * 4 * sizeof(double)));
     AVL_HIP_CHECK(cp(d_first_feat, b->first_feat, (size_t)n * D * sizeof(float)));
     AVL_HIP_CHECK(cp(d_first_alpha, b->first_alpha, (size_t)n * sizeof(double)));
+    return AVL_OK;
+}
+
+int avl_points_bbox(const void* d_depth, int depth_is_u16, double depth_div, int H, int W, const double* h_calib_inv,
+                    const double* h_transform, const int32_t* d_sample_idx, int P, double min_depth, double max_depth,
+                    double* h_minmax, void* stream) {
+    AVL_REQUIRE(H > 0 && W > 0 && P >= 0 && h_calib_inv && h_transform && h_minmax, "avl_points_bbox: bad arguments");
+    if (P == 0) return AVL_OK;
+    AVL_REQUIRE(d_depth && d_sample_idx, "avl_points_bbox: null pointer");
+    hipStream_t st = as_stream(stream);
+    auto key = [](double v) {
+        unsigned long long u;
+        memcpy(&u, &v, 8);
+        return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    };
+    auto unkey = [](unsigned long long k) {
+        unsigned long long u = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+        double v;
+        memcpy(&v, &u, 8);
+        return v;
+    };
+    unsigned long long h_keys[6];
+    for (int i = 0; i < 6; ++i) h_keys[i] = key(h_minmax[i]);
+    unsigned long long* d_keys = nullptr;
+    AVL_HIP_CHECK(hipMallocAsync((void**)&d_keys, sizeof(h_keys), st));
+    AVL_HIP_CHECK(hipMemcpyAsync(d_keys, h_keys, sizeof(h_keys), hipMemcpyHostToDevice, st));
+    FrameParams fp{};
+    for (int i = 0; i < 9; ++i) fp.kinv[i] = h_calib_inv[i];
+    for (int i = 0; i < 16; ++i) fp.t[i] = h_transform[i];
+    fp.min_depth = min_depth; fp.max_depth = max_depth;
+    fp.H = H; fp.W = W; fp.P = P;
+    fp.depth_u16 = depth_is_u16 ? 1 : 0;
+    fp.depth_div = depth_div;
+    hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth),
+                       d_sample_idx, d_keys);
+    AVL_HIP_CHECK(hipMemcpyAsync(h_keys, d_keys, sizeof(h_keys), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFreeAsync(d_keys, st);
+    for (int i = 0; i < 6; ++i) h_minmax[i] = unkey(h_keys[i]);
     return AVL_OK;
 }
 

@@ -70,7 +70,7 @@ def as_device(x, dtype, stream=None):
     if _is_torch(x):
         import torch
         want = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
-                np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64}[dtype]
+                np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64, np.dtype(np.int16): torch.int16}[dtype]
         if not x.is_cuda:
             raise TypeError("torch tensors passed to avlmaps_amd must live on the GPU")
         if x.dtype != want:

@@ -118,4 +118,7 @@ class Map:
         from .vlmap import VLMap
         if cfg_get(map_config, "map_type") == "vlmap":
             return VLMap(map_config)
-        raise NotImplementedError(f"map_type {cfg_get(map_config, 'map_type')!r}: only 'vlmap' is on the accelerated path")
+        if cfg_get(map_config, "map_type") == "vlmap_openmap":
+            from .vlmap_multi_floor import VLMapMultiFloor
+            return VLMapMultiFloor(map_config)
+        raise NotImplementedError(f"map_type {cfg_get(map_config, 'map_type')!r}: only 'vlmap' and 'vlmap_openmap' are on the accelerated path")

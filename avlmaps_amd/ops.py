@@ -91,13 +91,16 @@ class VoxelAccumulator:
     inside VLMapBuilder.create_mobile_base_map (vlmap_builder.py:86-95), living in HBM.
     """
 
-    def __init__(self, gs, cs, vh, D, capacity=None):
+    def __init__(self, gs, cs, vh, D, capacity=None, n_rows=None):
+        """grid (gs, gs, vh) -- or (n_rows, gs, vh) for the rectangular global multi-floor map"""
         lib = _lib.load()
         _lib.require_gpu()
         self.gs, self.cs, self.vh, self.D = int(gs), float(cs), int(vh), int(D)
-        self.capacity = int(capacity) if capacity else min(self.gs * self.gs, self.gs * self.gs * self.vh)
+        self.n_rows = int(n_rows) if n_rows else self.gs
+        self.capacity = int(capacity) if capacity else min(self.n_rows * self.gs, self.n_rows * self.gs * self.vh)
         h = C.c_void_p()
-        _lib.check(lib.avl_builder_create(C.byref(h), self.gs, self.cs, self.vh, self.D, self.capacity), "avl_builder_create")
+        _lib.check(lib.avl_builder_create_grid(C.byref(h), self.n_rows, self.gs, self.vh, self.cs, self.D, self.capacity),
+                   "avl_builder_create_grid")
         self._h = h
 
     def close(self):
@@ -134,6 +137,32 @@ class VoxelAccumulator:
                                              float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_frame")
         self._keep = (k1, k2, k3, k4)   # inputs must outlive the asynchronous launches
+        return self
+
+    def integrate_frame_global(self, depth, calib, transform, sample_idx, feat_hwc, rgb, frame_idx, pcd_min, depth_div=1000.0,
+                               calib_inv=None, min_depth=0.1, max_depth=100.0, sigma_sq=0.6, stream=None):
+        """Global (multi-floor) fusion, vlmap_builder_multi_floor.py:137-199.  depth: (H,W) uint16 (metres = value /
+        depth_div, like the reference's PNG / 1000.0) or float32 metres; transform = camera_pose_tf @ habitat2cam_rot_tf."""
+        lib = _lib.load()
+        depth_np_u16 = isinstance(depth, np.ndarray) and depth.dtype == np.uint16
+        is_u16 = depth_np_u16 or (_is_torch(depth) and str(depth.dtype) in ("torch.uint16", "torch.int16"))
+        if isinstance(depth, np.ndarray):
+            dp, dshape, k1 = as_device(depth.view(np.int16) if depth_np_u16 else depth, np.int16 if is_u16 else np.float32, stream)
+        else:
+            dp, dshape, k1 = depth.data_ptr(), tuple(depth.shape), depth
+        fp_, fshape, k2 = as_device(feat_hwc, np.float32, stream)
+        rp, rshape, k3 = as_device(rgb, np.uint8, stream)
+        sp, sshape, k4 = as_device(sample_idx, np.int32, stream)
+        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
+        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
+        T = np.ascontiguousarray(np.asarray(transform, dtype=np.float64).reshape(4, 4))
+        pm = np.ascontiguousarray(pcd_min, dtype=np.float64)
+        rc = lib.avl_builder_integrate_frame_global(self._h, dp, int(is_u16), float(depth_div), dshape[0], dshape[1], K.ctypes.data,
+                                                    Kinv.ctypes.data, T.ctypes.data, sp, int(np.prod(sshape)), fp_, fshape[0],
+                                                    fshape[1], rp, int(frame_idx), float(min_depth), float(max_depth),
+                                                    float(sigma_sq), pm.ctypes.data, stream)
+        _lib.check(rc, "avl_builder_integrate_frame_global")
+        self._keep = (k1, k2, k3, k4)
         return self
 
     def import_map(self, grid_feat, grid_pos, weight, grid_rgb=None, stream=None):
@@ -173,7 +202,7 @@ class VoxelAccumulator:
         gp = DeviceArray((n, 3), np.int32)
         w = DeviceArray((n,), np.float32)
         rgb = DeviceArray((n, 3), np.uint8)
-        occ = DeviceArray((self.gs, self.gs, self.vh), np.int32) if want_occupied else None
+        occ = DeviceArray((self.n_rows, self.gs, self.vh), np.int32) if want_occupied else None
         _lib.check(lib.avl_builder_finalize(self._h, n, gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr if occ else None, stream),
                    "avl_builder_finalize")
         out = dict(grid_feat=gf, grid_pos=gp, weight=w, grid_rgb=rgb, occupied_ids=occ)
@@ -193,7 +222,23 @@ class VoxelAccumulator:
         return {k: v.numpy(stream) for k, v in arrs.items()} if as_numpy else arrs
 
 
-def finalize_raw(raw, D, gs, vh, stream=None):
+def points_bbox(minmax, depth, calib, transform, sample_idx, depth_div=1000.0, min_depth=0.1, max_depth=100.0, stream=None):
+    """Pass 1 of the global builder (vlmap_builder_multi_floor.py:97-118): fold one frame's transformed sampled points into
+    minmax (6,) float64 [min xyz, max xyz] in place.  depth: uint16 (value / depth_div metres) or float32 metres."""
+    lib = _lib.load()
+    is_u16 = isinstance(depth, np.ndarray) and depth.dtype == np.uint16
+    dp, dshape, k1 = as_device(depth.view(np.int16) if is_u16 else depth, np.int16 if is_u16 else np.float32, stream)
+    sp, sshape, k2 = as_device(sample_idx, np.int32, stream)
+    Kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(calib, dtype=np.float64).reshape(3, 3)))
+    T = np.ascontiguousarray(np.asarray(transform, dtype=np.float64).reshape(4, 4))
+    assert minmax.dtype == np.float64 and minmax.flags["C_CONTIGUOUS"] and minmax.shape == (6,)
+    rc = lib.avl_points_bbox(dp, int(is_u16), float(depth_div), dshape[0], dshape[1], Kinv.ctypes.data, T.ctypes.data, sp,
+                             int(np.prod(sshape)), float(min_depth), float(max_depth), minmax.ctypes.data, stream)
+    _lib.check(rc, "avl_points_bbox")
+    return minmax
+
+
+def finalize_raw(raw, D, gs, vh, stream=None, n_rows=None):
     """Stateless finalisation of (merged) raw accumulators -> the reference's arrays (numpy in, numpy out)."""
     lib = _lib.load()
     n = len(raw["cell"])
@@ -201,7 +246,7 @@ def finalize_raw(raw, D, gs, vh, stream=None):
                                                           ("first_feat", np.float32), ("first_alpha", np.float64))}
     gf, gp = DeviceArray((n, D), np.float32), DeviceArray((n, 3), np.int32)
     w, rgb = DeviceArray((n,), np.float32), DeviceArray((n, 3), np.uint8)
-    occ = DeviceArray((gs, gs, vh), np.int32)
+    occ = DeviceArray((n_rows or gs, gs, vh), np.int32)
     _lib.check(lib.avl_memset(occ.ptr, 0xFF, occ.nbytes, stream))
     rc = lib.avl_finalize_raw(n, D, gs, vh, dev["cell"][0], dev["sum_feat"][0], dev["sum_w4"][0], dev["first_feat"][0],
                               dev["first_alpha"][0], gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr, stream)

@@ -121,6 +121,9 @@ typedef struct avl_builder avl_builder;
 /* gs, cs, vh: grid size, cell size (m), cells in height (= int(camera_height / cs), vlmap_builder.py:201)
  * D: feature dimension; capacity: maximum number of occupied voxels the handle can hold. */
 AVL_API int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, int64_t capacity);
+/* Rectangular grid n0 rows x n1 cols x n2 heights (the global multi-floor map: grid_size[[0, 2, 1]],
+ * vlmap_builder_multi_floor.py:222-224). */
+AVL_API int avl_builder_create_grid(avl_builder** h_out, int n0, int n1, int n2, double cs, int D, int64_t capacity);
 AVL_API int avl_builder_destroy(avl_builder* b);
 AVL_API int avl_builder_reset(avl_builder* b, void* stream);
 
@@ -150,6 +153,26 @@ AVL_API int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, in
                                         const int32_t* d_sample_idx, int P, const float* d_feat, int Hf, int Wf,
                                         const uint8_t* d_rgb, int64_t frame_idx, double min_depth,
                                         double max_depth, double sigma_sq, void* stream);
+
+/*
+ * Global (multi-floor) variant of the frame fusion: replaces vlmap_builder_multi_floor.py:137-199.
+ *   voxel index = np.round((p_global - pcd_min) / cs) per axis, (row, height, col) = (x, y, z) (:146);
+ *   d_depth is float32 metres, or uint16 with metres = value / depth_div (depth PNGs / 1000.0, :105);
+ *   h_transform = camera_pose_tf @ habitat2cam_rot_tf (:141); h_pcd_min = lower bounding-box corner from pass 1.
+ * Samples that fall outside the grid are dropped (the reference wraps negative indices or raises).
+ */
+AVL_API int avl_builder_integrate_frame_global(avl_builder* b, const void* d_depth, int depth_is_u16, double depth_div, int H,
+                                               int W, const double* h_calib, const double* h_calib_inv,
+                                               const double* h_transform, const int32_t* d_sample_idx, int P,
+                                               const float* d_feat, int Hf, int Wf, const uint8_t* d_rgb, int64_t frame_idx,
+                                               double min_depth, double max_depth, double sigma_sq, const double* h_pcd_min,
+                                               void* stream);
+
+/* Pass 1 of the global builder (vlmap_builder_multi_floor.py:97-118): fold the transformed, depth-masked sampled points of
+ * one frame into h_minmax = [min x, min y, min z, max x, max y, max z] (in/out; start from +inf / -inf).  Synchronous. */
+AVL_API int avl_points_bbox(const void* d_depth, int depth_is_u16, double depth_div, int H, int W, const double* h_calib_inv,
+                            const double* h_transform, const int32_t* d_sample_idx, int P, double min_depth, double max_depth,
+                            double* h_minmax, void* stream);
 
 /* Seed an EMPTY builder from a finished map so that more frames can be fused on top (the reference's resume path,
  * vlmap_builder.py:212-222): d_grid_feat (n,D) f32, d_grid_pos (n,3) i32, d_weight (n,) f32, d_grid_rgb (n,3) u8 or NULL.

@@ -78,7 +78,8 @@ AVLO_API void avlo_transform_point(const double T[16], const double p[3], double
  * Sequential map state: avlmaps/map/vlmap_builder.py:195-224 (_init_map), :286-311 (_reserve_map_space)
  * ================================================================================================= */
 typedef struct avlo_map {
-    int gs, vh, D;
+    int n0;               /* rows; == gs for the square mobile-base map */
+    int gs, vh, D;        /* gs = columns, vh = heights */
     double cs;
     long long cap, max_id;
     float* grid_feat;     /* (cap, D) float32 */
@@ -90,19 +91,22 @@ typedef struct avlo_map {
     long long n_points;   /* points that updated a voxel (statistics) */
 } avlo_map;
 
-AVLO_API avlo_map* avlo_map_create(int gs, double cs, int vh, int D) {
+/* rectangular grid n0 x n1 x n2: vlmap_builder_multi_floor.py:222-228 (occupied_ids = grid_size[[0, 2, 1]], capacity n0*n1) */
+AVLO_API avlo_map* avlo_map_create_grid(int n0, int gs, int vh, double cs, int D) {
     avlo_map* m = (avlo_map*)calloc(1, sizeof(avlo_map));
-    m->gs = gs; m->cs = cs; m->vh = vh; m->D = D;
-    m->cap = (long long)gs * gs;                      /* vlmap_builder.py:202 */
+    m->n0 = n0; m->gs = gs; m->cs = cs; m->vh = vh; m->D = D;
+    m->cap = (long long)n0 * gs;                      /* vlmap_builder.py:202 / vlmap_builder_multi_floor.py:225 */
     m->grid_feat = (float*)calloc((size_t)m->cap * D, sizeof(float));
     m->grid_pos = (int32_t*)calloc((size_t)m->cap * 3, sizeof(int32_t));
     m->weight = (double*)calloc((size_t)m->cap, sizeof(double));
     m->grid_rgb = (double*)calloc((size_t)m->cap * 3, sizeof(double));
-    size_t ncell = (size_t)gs * gs * vh;
+    size_t ncell = (size_t)n0 * gs * vh;
     m->occupied = (int32_t*)malloc(ncell * sizeof(int32_t));
     for (size_t i = 0; i < ncell; ++i) m->occupied[i] = -1;
     return m;
 }
+
+AVLO_API avlo_map* avlo_map_create(int gs, double cs, int vh, int D) { return avlo_map_create_grid(gs, gs, vh, cs, D); }
 
 AVLO_API void avlo_map_destroy(avlo_map* m) {
     if (!m) return;
@@ -123,6 +127,70 @@ static void avlo_grow(avlo_map* m) {                  /* vlmap_builder.py:286-31
     m->grown += 1;   /* weight: f32 ++ int32 zeros -> float64;  grid_rgb: uint8 ++ f32 zeros -> float32 */
 }
 
+/* vlmap_builder.py:141-178 == vlmap_builder_multi_floor.py:148-194: everything after the voxel index is known.
+ * returns 1 if a voxel was updated, 0 if the sample was skipped, -1 where the reference would raise IndexError */
+static int avlo_update_voxel(avlo_map* m, long long row, long long col, long long h, const double pl[3], const double K[9],
+                             const double Kf[9], int H, int W, const float* feat, int Hf, int Wf, const uint8_t* rgb) {
+    const int D = m->D, gs = m->gs, vh = m->vh;
+    long long px, py; double pz;
+    avlo_project_point(K, pl, &px, &py, &pz);                                        /* :141 */
+    if (px < 0) px += W;                  /* numpy negative-index wrap of rgb[py, px, :] (:142) */
+    if (py < 0) py += H;
+    if (px < 0 || px >= W || py < 0 || py >= H) return -1;
+    const uint8_t* rgb_v = rgb + ((size_t)py * W + px) * 3;
+    avlo_project_point(Kf, pl, &px, &py, &pz);                                       /* :143 */
+
+    if (m->max_id >= m->cap) avlo_grow(m);                                           /* :151-152 */
+
+    double radial = (pl[0] * pl[0] + pl[1] * pl[1]) + pl[2] * pl[2];                 /* :156 */
+    double alpha = exp(-radial / (2 * 0.6));                                         /* :157-158 */
+
+    if (px < 0 || py < 0 || px >= Wf || py >= Hf) return 0;                          /* :161 */
+    const float* f = feat + (size_t)py * Wf + px;          /* pix_feats[0, :, py, px], stride Hf*Wf */
+    const size_t fs = (size_t)Hf * Wf;
+    int32_t* cell = &m->occupied[((size_t)row * gs + col) * vh + h];
+    if (*cell == -1) {                                                               /* :164-170 */
+        long long id_new = m->max_id;
+        *cell = (int32_t)id_new;
+        float* gf = m->grid_feat + (size_t)id_new * D;
+        for (int d = 0; d < D; ++d) gf[d] = (float)((double)f[d * fs] * alpha);      /* f32*f64 -> f64 -> f32 */
+        for (int c = 0; c < 3; ++c) m->grid_rgb[id_new * 3 + c] = (double)rgb_v[c];
+        double w = m->weight[id_new] + alpha;
+        m->weight[id_new] = m->grown ? w : (double)(float)w;
+        m->grid_pos[id_new * 3 + 0] = (int32_t)row;
+        m->grid_pos[id_new * 3 + 1] = (int32_t)col;
+        m->grid_pos[id_new * 3 + 2] = (int32_t)h;
+        m->max_id++;
+    } else {                                                                         /* :171-178 */
+        long long oid = *cell;
+        float* gf = m->grid_feat + (size_t)oid * D;
+        double w = m->weight[oid];
+        double denom = w + alpha;
+        if (!m->grown) {
+            /* weight[oid] is np.float32: grid_feat*w is a float32 product, grid_rgb(u8)*w is float32 */
+            float wf = (float)w;
+            for (int d = 0; d < D; ++d)
+                gf[d] = (float)(((double)(gf[d] * wf) + (double)f[d * fs] * alpha) / denom);
+            for (int c = 0; c < 3; ++c) {
+                float prod = (float)m->grid_rgb[oid * 3 + c] * wf;
+                double v = ((double)prod + (double)rgb_v[c] * alpha) / denom;
+                m->grid_rgb[oid * 3 + c] = (double)(uint8_t)v;                       /* store into uint8 array */
+            }
+            m->weight[oid] = (double)(float)denom;
+        } else {
+            /* after _reserve_map_space: weight float64, grid_rgb float32 */
+            for (int d = 0; d < D; ++d)
+                gf[d] = (float)(((double)gf[d] * w + (double)f[d * fs] * alpha) / denom);
+            for (int c = 0; c < 3; ++c) {
+                double v = (m->grid_rgb[oid * 3 + c] * w + (double)rgb_v[c] * alpha) / denom;
+                m->grid_rgb[oid * 3 + c] = (double)(float)v;
+            }
+            m->weight[oid] = denom;
+        }
+    }
+    return 1;
+}
+
 /* ---- avlmaps/map/vlmap_builder.py:129-178: one frame of create_mobile_base_map -----------------
  * depth (H,W) f32; Kinv = inv(calib) f64; K = calib; Kf = get_sim_cam_mat(Hf,Wf); T = pc_transform
  * (vlmap_builder.py:133, computed on the host in float64); sample_idx = shuffle_mask[::rate]
@@ -133,7 +201,7 @@ AVLO_API long long avlo_integrate_frame(avlo_map* m, const float* depth, int H, 
                                         const double K[9], const double Kf[9], const double T[16],
                                         const int32_t* sample_idx, int P, const float* feat, int Hf, int Wf,
                                         const uint8_t* rgb, double min_depth, double max_depth) {
-    const int D = m->D, gs = m->gs, vh = m->vh;
+    const int gs = m->gs, vh = m->vh;
     long long used = 0;
     for (int s = 0; s < P; ++s) {
         double pl[3], pg[3];
@@ -144,66 +212,63 @@ AVLO_API long long avlo_integrate_frame(avlo_map* m, const float* depth, int H, 
         long long row = id[0], col = id[1], h = id[2];
         if (col >= gs || row >= gs || h >= vh || col < 0 || row < 0 || h < 0) continue;   /* :283-284 */
 
-        long long px, py; double pz;
-        avlo_project_point(K, pl, &px, &py, &pz);                                        /* :141 */
-        if (px < 0) px += W;                  /* numpy negative-index wrap of rgb[py, px, :] (:142) */
-        if (py < 0) py += H;
-        if (px < 0 || px >= W || py < 0 || py >= H) return -1;
-        const uint8_t* rgb_v = rgb + ((size_t)py * W + px) * 3;
-        avlo_project_point(Kf, pl, &px, &py, &pz);                                       /* :143 */
-
-        if (m->max_id >= m->cap) avlo_grow(m);                                           /* :151-152 */
-
-        double radial = (pl[0] * pl[0] + pl[1] * pl[1]) + pl[2] * pl[2];                 /* :156 */
-        double alpha = exp(-radial / (2 * 0.6));                                         /* :157-158 */
-
-        if (px < 0 || py < 0 || px >= Wf || py >= Hf) continue;                          /* :161 */
-        const float* f = feat + (size_t)py * Wf + px;          /* pix_feats[0, :, py, px], stride Hf*Wf */
-        const size_t fs = (size_t)Hf * Wf;
-        int32_t* cell = &m->occupied[((size_t)row * gs + col) * vh + h];
-        used++;
-        if (*cell == -1) {                                                               /* :164-170 */
-            long long id_new = m->max_id;
-            *cell = (int32_t)id_new;
-            float* gf = m->grid_feat + (size_t)id_new * D;
-            for (int d = 0; d < D; ++d) gf[d] = (float)((double)f[d * fs] * alpha);      /* f32*f64 -> f64 -> f32 */
-            for (int c = 0; c < 3; ++c) m->grid_rgb[id_new * 3 + c] = (double)rgb_v[c];
-            double w = m->weight[id_new] + alpha;
-            m->weight[id_new] = m->grown ? w : (double)(float)w;
-            m->grid_pos[id_new * 3 + 0] = (int32_t)row;
-            m->grid_pos[id_new * 3 + 1] = (int32_t)col;
-            m->grid_pos[id_new * 3 + 2] = (int32_t)h;
-            m->max_id++;
-        } else {                                                                         /* :171-178 */
-            long long oid = *cell;
-            float* gf = m->grid_feat + (size_t)oid * D;
-            double w = m->weight[oid];
-            double denom = w + alpha;
-            if (!m->grown) {
-                /* weight[oid] is np.float32: grid_feat*w is a float32 product, grid_rgb(u8)*w is float32 */
-                float wf = (float)w;
-                for (int d = 0; d < D; ++d)
-                    gf[d] = (float)(((double)(gf[d] * wf) + (double)f[d * fs] * alpha) / denom);
-                for (int c = 0; c < 3; ++c) {
-                    float prod = (float)m->grid_rgb[oid * 3 + c] * wf;
-                    double v = ((double)prod + (double)rgb_v[c] * alpha) / denom;
-                    m->grid_rgb[oid * 3 + c] = (double)(uint8_t)v;                       /* store into uint8 array */
-                }
-                m->weight[oid] = (double)(float)denom;
-            } else {
-                /* after _reserve_map_space: weight float64, grid_rgb float32 */
-                for (int d = 0; d < D; ++d)
-                    gf[d] = (float)(((double)gf[d] * w + (double)f[d * fs] * alpha) / denom);
-                for (int c = 0; c < 3; ++c) {
-                    double v = (m->grid_rgb[oid * 3 + c] * w + (double)rgb_v[c] * alpha) / denom;
-                    m->grid_rgb[oid * 3 + c] = (double)(float)v;
-                }
-                m->weight[oid] = denom;
-            }
-        }
+        int u = avlo_update_voxel(m, row, col, h, pl, K, Kf, H, W, feat, Hf, Wf, rgb);
+        if (u < 0) return -1;
+        used += u;
     }
     m->n_points += used;
     return used;
+}
+
+/* ---- avlmaps/map/vlmap_builder_multi_floor.py:137-199: one frame of create_global_map ------------------------
+ * depth_m (H,W) float64 metres (= uint16 png / 1000.0, :138); T = camera_pose_tf @ habitat2cam_rot_tf (:141);
+ * voxel index row, height, col = np.round((p - pcd_min) / cs).astype(int) (:146).  A sample outside the grid is
+ * skipped (the reference only tests the upper row/col bounds and otherwise wraps around or raises). */
+AVLO_API int avlo_depth2pc_pixel_f64(const double* depth, int W, const double Kinv[9], int pix, double min_depth,
+                                     double max_depth, double pc[3]) {
+    double x = (double)(pix % W) + 0.5, y = (double)(pix / W) + 0.5, z = depth[pix];
+    for (int i = 0; i < 3; ++i) {
+        double acc = Kinv[3 * i + 0] * x;
+        acc = fma(Kinv[3 * i + 1], y, acc);
+        acc = fma(Kinv[3 * i + 2], 1.0, acc);
+        pc[i] = acc * z;
+    }
+    return (pc[2] > min_depth) && (pc[2] < max_depth);
+}
+
+AVLO_API long long avlo_integrate_frame_global(avlo_map* m, const double* depth_m, int H, int W, const double Kinv[9],
+                                               const double K[9], const double Kf[9], const double T[16],
+                                               const int32_t* sample_idx, int P, const float* feat, int Hf, int Wf,
+                                               const uint8_t* rgb, double min_depth, double max_depth, const double pcd_min[3]) {
+    long long used = 0;
+    for (int s = 0; s < P; ++s) {
+        double pl[3], pg[3];
+        if (!avlo_depth2pc_pixel_f64(depth_m, W, Kinv, sample_idx[s], min_depth, max_depth, pl)) continue;
+        avlo_transform_point(T, pl, pg);
+        long long row = (long long)rint((pg[0] - pcd_min[0]) / m->cs);      /* np.round: half to even */
+        long long h = (long long)rint((pg[1] - pcd_min[1]) / m->cs);
+        long long col = (long long)rint((pg[2] - pcd_min[2]) / m->cs);
+        if (col >= m->gs || row >= m->n0 || h >= m->vh || col < 0 || row < 0 || h < 0) continue;
+        int u = avlo_update_voxel(m, row, col, h, pl, K, Kf, H, W, feat, Hf, Wf, rgb);
+        if (u < 0) return -1;
+        used += u;
+    }
+    m->n_points += used;
+    return used;
+}
+
+/* pass 1 (vlmap_builder_multi_floor.py:97-118): fold one frame's transformed sampled points into minmax[6] */
+AVLO_API void avlo_points_bbox(const double* depth_m, int W, const double Kinv[9], const double T[16], const int32_t* sample_idx,
+                               int P, double min_depth, double max_depth, double minmax[6]) {
+    for (int s = 0; s < P; ++s) {
+        double pl[3], pg[3];
+        if (!avlo_depth2pc_pixel_f64(depth_m, W, Kinv, sample_idx[s], min_depth, max_depth, pl)) continue;
+        avlo_transform_point(T, pl, pg);
+        for (int c = 0; c < 3; ++c) {
+            if (pg[c] < minmax[c]) minmax[c] = pg[c];
+            if (pg[c] > minmax[3 + c]) minmax[3 + c] = pg[c];
+        }
+    }
 }
 
 AVLO_API long long avlo_map_size(const avlo_map* m) { return m->max_id; }
@@ -217,7 +282,7 @@ AVLO_API void avlo_map_export(const avlo_map* m, float* grid_feat, int32_t* grid
     if (grid_pos) memcpy(grid_pos, m->grid_pos, n * 3 * sizeof(int32_t));
     if (weight) memcpy(weight, m->weight, n * sizeof(double));
     if (grid_rgb) memcpy(grid_rgb, m->grid_rgb, n * 3 * sizeof(double));
-    if (occupied) memcpy(occupied, m->occupied, (size_t)m->gs * m->gs * m->vh * sizeof(int32_t));
+    if (occupied) memcpy(occupied, m->occupied, (size_t)m->n0 * m->gs * m->vh * sizeof(int32_t));
 }
 
 /* ---- avlmaps/utils/clip_utils.py:227-229 + avlmaps/map/vlmap.py:123-124 -------------------------

@@ -48,6 +48,12 @@ def lib():
         L.avlo_transform_point.argtypes = [dp, dp, dp]
         L.avlo_map_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int]
         L.avlo_map_create.restype = C.c_void_p
+        L.avlo_map_create_grid.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+        L.avlo_map_create_grid.restype = C.c_void_p
+        L.avlo_integrate_frame_global.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, dp, dp, dp, dp, ip, C.c_int, fp, C.c_int,
+                                                  C.c_int, up, C.c_double, C.c_double, dp]
+        L.avlo_integrate_frame_global.restype = C.c_longlong
+        L.avlo_points_bbox.argtypes = [dp, C.c_int, dp, dp, ip, C.c_int, C.c_double, C.c_double, dp]
         L.avlo_map_destroy.argtypes = [C.c_void_p]
         L.avlo_integrate_frame.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, dp, dp, dp, dp, ip, C.c_int, fp,
                                            C.c_int, C.c_int, up, C.c_double, C.c_double]
@@ -198,6 +204,70 @@ class OracleMap:
         weight = w if grown else w.astype(np.float32)
         grid_rgb = rgb.astype(np.float32) if grown else rgb.astype(np.uint8)
         return dict(grid_feat=gf, grid_pos=gp, weight=weight, grid_rgb=grid_rgb, occupied_ids=occ, grown=grown)
+
+
+HABITAT2CAM_ROT = np.diag([1.0, -1.0, -1.0, 1.0])     # vlmap_builder_multi_floor.py:77-79
+
+
+def points_bbox(minmax, depth_m, calib, transform, sample_idx, min_depth=0.1, max_depth=100.0):
+    """fold one frame into minmax (6,) float64 in place -- pass 1 of create_global_map (:97-118)"""
+    d = np.ascontiguousarray(depth_m, dtype=np.float64)
+    Kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(calib, dtype=np.float64).reshape(3, 3)))
+    T = np.ascontiguousarray(transform, dtype=np.float64)
+    idx = np.ascontiguousarray(sample_idx, dtype=np.int32)
+    lib().avlo_points_bbox(_p(d, C.c_double), d.shape[1], _p(Kinv, C.c_double), _p(T, C.c_double), _p(idx, C.c_int32), len(idx),
+                           min_depth, max_depth, _p(minmax, C.c_double))
+    return minmax
+
+
+class OracleGlobalMap(OracleMap):
+    """Sequential multi-floor builder (vlmap_builder_multi_floor.py:120-199) on a (n0, n1, n2) grid."""
+
+    def __init__(self, pcd_min, pcd_max, cs, D):
+        self.pcd_min = np.ascontiguousarray(pcd_min, dtype=np.float64)
+        self.grid_size = np.ceil((np.asarray(pcd_max) - self.pcd_min) / cs + 1).astype(int)      # :222 (x, y, z)
+        self.n0, self.gs, self.vh = int(self.grid_size[0]), int(self.grid_size[2]), int(self.grid_size[1])
+        self.cs, self.D = float(cs), int(D)
+        self._h = lib().avlo_map_create_grid(self.n0, self.gs, self.vh, self.cs, self.D)
+
+    def integrate(self, depth_m, calib, transform, sample_idx, feat_chw, rgb, min_depth=0.1, max_depth=100.0):
+        d = np.ascontiguousarray(depth_m, dtype=np.float64)
+        H, W = d.shape
+        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
+        Kinv = np.ascontiguousarray(np.linalg.inv(K))
+        feat = np.ascontiguousarray(feat_chw, dtype=np.float32)
+        if feat.ndim == 4:
+            feat = feat[0]
+        _, Hf, Wf = feat.shape
+        Kf = np.ascontiguousarray(get_sim_cam_mat(Hf, Wf))
+        T = np.ascontiguousarray(transform, dtype=np.float64)
+        idx = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        n = lib().avlo_integrate_frame_global(self._h, _p(d, C.c_double), H, W, _p(Kinv, C.c_double), _p(K, C.c_double),
+                                              _p(Kf, C.c_double), _p(T, C.c_double), _p(idx, C.c_int32), len(idx),
+                                              _p(feat, C.c_float), Hf, Wf, _p(rgb, C.c_uint8), min_depth, max_depth,
+                                              _p(self.pcd_min, C.c_double))
+        if n < 0:
+            raise IndexError("rgb index out of bounds (the reference would raise here too)")
+        return n
+
+    def export(self):
+        gs = self.gs
+        self.gs = self.n0          # OracleMap.export allocates (gs, gs, vh); the global grid is (n0, n1, n2)
+        try:
+            n = lib().avlo_map_size(self._h)
+            gf = np.zeros((n, self.D), dtype=np.float32)
+            gp = np.zeros((n, 3), dtype=np.int32)
+            w = np.zeros(n, dtype=np.float64)
+            rgb = np.zeros((n, 3), dtype=np.float64)
+            occ = np.zeros((self.n0, gs, self.vh), dtype=np.int32)
+            lib().avlo_map_export(self._h, _p(gf, C.c_float), _p(gp, C.c_int32), _p(w, C.c_double), _p(rgb, C.c_double),
+                                  _p(occ, C.c_int32))
+        finally:
+            self.gs = gs
+        grown = lib().avlo_map_grown(self._h)
+        return dict(grid_feat=gf, grid_pos=gp, weight=w if grown else w.astype(np.float32),
+                    grid_rgb=rgb.astype(np.float32) if grown else rgb.astype(np.uint8), occupied_ids=occ, grown=grown)
 
 
 def sample_indices(rng_state: np.random.RandomState, n_pix: int, rate: int):

@@ -190,3 +190,36 @@ def test_cli_create_then_index_on_disk_dataset(tmp_path):
     assert (occ >= 0).sum() == len(gp) and np.array_equal(occ[gp[:, 0], gp[:, 1], gp[:, 2]], np.arange(len(gp)))
     heat = index_map.main(["--data-dir", str(scene), "--config", str(cfg), "--query", "sofa", "--text-model", "hash"])
     assert heat.shape == (len(gp),) and heat.max() == 1.0 and 0 < (heat == 1.0).sum() < len(gp)
+
+
+def test_multi_floor_builder_reproduces_reference_map(golden, tmp_path):
+    """VLMapBuilderMultiFloor.create_global_map vs the reference run (two passes, np.round indices, capacity doubling)"""
+    from avlmaps_amd.map import VLMapBuilderMultiFloor
+    g = golden("g6_multi_floor.npz")
+    nfr = len(g["depths_u16"])
+    cfg = Cfg(cell_size=float(g["cs"]), depth_sample_rate=int(g["rate"]), skip_frame=1, grid_size=1000,
+              cam_calib_mat=[float(x) for x in g["calib"]], pose_info=Cfg(camera_height=1.5, building_init_height=0.0))
+    counter = {"i": 0}
+
+    def extractor(rgb):
+        f = g["feats"][counter["i"]][None]
+        counter["i"] += 1
+        return f
+
+    b = VLMapBuilderMultiFloor(tmp_path, cfg, [None] * nfr, [None] * nfr, [None] * nfr, None, None, feat_extractor=extractor)
+    b.load_frame = lambda i: (g["rgbs"][i], g["depths_u16"][i])
+    b.load_pose = lambda i: g["poses"][i]
+    b.capacity = 8000
+    np.random.seed(777)                      # the seed the reference run had (tools/gen_golden.py)
+    b.create_global_map()
+    assert np.array_equal(b.pcd_min, g["pcd_min"]) and np.array_equal(b.pcd_max, g["pcd_max"])      # bit-exact bbox
+    assert np.array_equal(b.grid_size, g["grid_size"])
+    it, gf, gp, w, occ, rgb, pmin, pmax, cs = VLMapBuilderMultiFloor.load_3d_map(tmp_path / "vlmap_multi_floor" / "vlmaps_multi_floor.h5df")
+    assert it == list(range(nfr)) and cs == float(g["cs"]) and np.array_equal(pmin, g["pcd_min"])
+    assert np.array_equal(gp, g["grid_pos"])                                                         # ids + order
+    assert tuple(occ.shape) == tuple(g["occ_shape"])
+    nz = np.argwhere(occ != -1)
+    assert np.array_equal(nz, g["occ_nz"]) and np.array_equal(occ[nz[:, 0], nz[:, 1], nz[:, 2]], g["occ_nz_vals"])
+    np.testing.assert_allclose(gf, g["grid_feat"], rtol=2e-5, atol=3e-4)
+    np.testing.assert_allclose(w, g["weight"].astype(np.float32), rtol=3e-7)
+    assert np.array_equal(rgb, np.floor(g["grid_rgb"]).astype(np.uint8))       # sequential replay incl. the dtype switch

@@ -111,3 +111,29 @@ def test_heatmap_matches_reference(golden):
         h = O.heatmap_from_mask(g["grid_pos"], g["mask"], 0.05, decay)
         np.testing.assert_allclose(h, g[f"heat_{decay}"], rtol=0, atol=1e-6)
         assert np.array_equal(h == 1.0, g[f"heat_{decay}"] == 1.0)
+
+
+def test_multi_floor_builder_matches_reference(golden):
+    """vlmap_builder_multi_floor.py:60-199 (two passes: bounding box, then fusion with np.round voxel indices)"""
+    g = golden("g6_multi_floor.npz")
+    nfr = len(g["depths_u16"])
+    depth_m = g["depths_u16"] / 1000.0                                   # :105 -- float64 metres
+    minmax = np.array([np.inf] * 3 + [-np.inf] * 3)
+    for i in range(nfr):
+        O.points_bbox(minmax, depth_m[i], g["calib"], g["poses"][i] @ O.HABITAT2CAM_ROT, g["samples_pass1"][i])
+    assert np.array_equal(minmax[:3], g["pcd_min"]) and np.array_equal(minmax[3:], g["pcd_max"])
+    D = g["feats"].shape[1]
+    m = O.OracleGlobalMap(minmax[:3], minmax[3:], float(g["cs"]), D)
+    assert np.array_equal(m.grid_size, g["grid_size"])
+    for i in range(nfr):
+        m.integrate(depth_m[i], g["calib"], g["poses"][i] @ O.HABITAT2CAM_ROT, g["samples_pass2"][i], g["feats"][i], g["rgbs"][i])
+    out = m.export()
+    assert np.array_equal(out["grid_pos"], g["grid_pos"]) and len(out["grid_pos"]) == int(g["max_id"])
+    occ = out["occupied_ids"]
+    assert tuple(occ.shape) == tuple(g["occ_shape"])
+    nz = np.argwhere(occ != -1)
+    assert np.array_equal(nz, g["occ_nz"]) and np.array_equal(occ[nz[:, 0], nz[:, 1], nz[:, 2]], g["occ_nz_vals"])
+    assert out["weight"].dtype == g["weight"].dtype == np.float64       # capacity doubled (n0*n1 rows < voxels)
+    np.testing.assert_allclose(out["weight"], g["weight"], rtol=2e-7)
+    np.testing.assert_allclose(out["grid_feat"], g["grid_feat"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(out["grid_rgb"], g["grid_rgb"], rtol=1e-5, atol=1e-4)

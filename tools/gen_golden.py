@@ -369,6 +369,7 @@ def main():
     gen_g4(m, np.random.default_rng(44))
     gen_templates_hash(m)
     gen_g5_lseg_protocol()
+    gen_g6_multi_floor(np.random.default_rng(66))
     os.system(f"ls -la {OUT}")
 
 
@@ -425,6 +426,105 @@ def gen_g5_lseg_protocol():
         out[f"{name}_feat"] = f
     np.savez_compressed(OUT / "g5_lseg_protocol.npz", **out)
     print("G5 written", {k: v.shape for k, v in out.items() if k.endswith("_feat")})
+
+
+
+# --------------------------------------------------------------------------------------
+class _FakePCD:
+    """minimal stand-in for open3d.geometry.PointCloud (points container with +=)"""
+
+    def __init__(self):
+        self.points = np.zeros((0, 3))
+
+    def __iadd__(self, other):
+        self.points = np.concatenate([np.asarray(self.points).reshape(-1, 3), np.asarray(other.points).reshape(-1, 3)], 0)
+        return self
+
+
+def gen_g6_multi_floor(rng):
+    """avlmaps/map/vlmap_builder_multi_floor.py:60-199 VLMapBuilderMultiFloor.create_global_map (real loop, fake I/O)"""
+    import importlib
+    vbm = importlib.import_module("avlmaps.map.vlmap_builder_multi_floor")
+    H, W, Hf, Wf, D, nfr = 24, 32, 11, 15, 8, 6
+    calib = [W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1]
+    cfg = make_map_config(gs=1000, cs=0.1, cam_h=1.5, calib=calib, rate=1)
+    cfg["skip_frame"] = 1
+    cfg.pose_info["building_init_height"] = 0.0
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    depths, rgbs, feats, poses = [], [], [], []
+    from scipy.spatial.transform import Rotation as R
+    for i in range(nfr):
+        d = 2.0 + 0.8 * np.sin(2 * xx + 0.4 * i) * np.cos(yy) + 0.3 * yy
+        d[rng.random(d.shape) < 0.05] = 0.0
+        depths.append(np.round(d * 1000).astype(np.uint16))
+        rgbs.append(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+        f = rng.standard_normal((1, D, Hf, Wf)).astype(np.float32)
+        feats.append((f / np.linalg.norm(f, axis=1, keepdims=True) * 14.2857).astype(np.float16).astype(np.float32))
+        T = np.eye(4)
+        T[:3, :3] = R.from_euler("yxz", [0.3 * i, 0.05 * i, 0.02 * i]).as_matrix()
+        T[:3, 3] = [0.3 * i, 0.1 + 0.6 * (i // 3), -0.2 * i]          # second "floor" after 3 frames
+        poses.append(T)
+    tmp = Path(tempfile.mkdtemp(prefix="avl_golden_mf_"))
+    pose_paths = []
+    for i, T in enumerate(poses):
+        p = tmp / f"{i:06d}.txt"
+        np.savetxt(p, T)
+        pose_paths.append(p)
+    poses_rt = np.stack([np.loadtxt(p).reshape(4, 4) for p in pose_paths])
+    rgb_paths = [tmp / f"{i:06d}.png" for i in range(nfr)]
+    depth_paths = [tmp / f"{i:06d}_d.png" for i in range(nfr)]
+    builder = vbm.VLMapBuilderMultiFloor(tmp, cfg, pose_paths, rgb_paths, depth_paths, None, None)
+    captured, samples = {}, []
+    counter = {"i": 0}
+
+    def fake_lseg(*a, **k):
+        f = feats[counter["i"]]
+        counter["i"] += 1
+        return f
+
+    def fake_init_lseg(self):
+        self.device, self.clip_feat_dim = "cpu", D
+        return None, None, 480, 520, [0.5] * 3, [0.5] * 3
+
+    def fake_save(self, grid_feat, grid_pos, weight, grid_rgb, occupied_ids, mapped_iter_set, max_id):
+        captured.update(grid_feat=np.array(grid_feat[:max_id]), grid_pos=np.array(grid_pos[:max_id]),
+                        weight=np.array(weight[:max_id]), grid_rgb=np.array(grid_rgb[:max_id]),
+                        occupied_ids=np.array(occupied_ids), max_id=max_id, pcd_min=np.array(self.pcd_min),
+                        pcd_max=np.array(self.pcd_max), grid_size=np.array(self.grid_size),
+                        mapped_iter_list=np.array(sorted(mapped_iter_set), dtype=np.int32))
+
+    orig_shuffle = np.random.shuffle
+
+    def rec_shuffle(x):
+        orig_shuffle(x)
+        samples.append(np.array(x[::cfg.depth_sample_rate], dtype=np.int32))
+
+    vbm.cv2.imread = lambda p: rgbs[int(Path(p).stem)][:, :, ::-1].copy()
+    vbm.cv2.cvtColor = lambda bgr, code: bgr[:, :, ::-1].copy()
+    vbm.load_depth_img = lambda p: depths[int(Path(p).stem.split("_")[0])]
+    vbm.get_lseg_feat = fake_lseg
+    vbm.VLMapBuilderMultiFloor._init_lseg = fake_init_lseg
+    vbm.VLMapBuilderMultiFloor.save_3d_map = fake_save
+    vbm.tqdm = lambda it, **k: _NoBar(it)
+    vbm.o3d.geometry.PointCloud = _FakePCD
+    vbm.o3d.utility.Vector3dVector = lambda a: np.asarray(a)
+    np.random.seed(777)
+    np.random.shuffle = rec_shuffle
+    try:
+        builder.create_global_map()
+    finally:
+        np.random.shuffle = orig_shuffle
+    occ = captured["occupied_ids"]
+    nz = np.argwhere(occ != -1).astype(np.int32)
+    out = dict(cs=cfg.cell_size, rate=cfg.depth_sample_rate, calib=np.array(calib, dtype=np.float64), depths_u16=np.stack(depths),
+               rgbs=np.stack(rgbs), feats=np.concatenate(feats, 0), poses=poses_rt,
+               samples_pass1=np.stack(samples[:nfr]), samples_pass2=np.stack(samples[nfr:]),
+               pcd_min=captured["pcd_min"], pcd_max=captured["pcd_max"], grid_size=captured["grid_size"],
+               grid_feat=captured["grid_feat"], grid_pos=captured["grid_pos"], weight=captured["weight"],
+               grid_rgb=captured["grid_rgb"], occ_shape=np.array(occ.shape), occ_nz=nz,
+               occ_nz_vals=occ[nz[:, 0], nz[:, 1], nz[:, 2]].astype(np.int32), max_id=captured["max_id"])
+    np.savez_compressed(OUT / "g6_multi_floor.npz", **out)
+    print("G6 written: voxels", captured["max_id"], "grid", captured["grid_size"], "occ", occ.shape, "weight", captured["weight"].dtype)
 
 
 if __name__ == "__main__":
