@@ -377,6 +377,145 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// exact fp32 on the matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit a k-ordered fmaf chain (no reduced-precision
+// operands) at the fp32 vector rate.  Same data flow as the split kernel (queries = MFMA rows from LDS, voxels = MFMA
+// columns straight from HBM, lane (voxel j, half kg) owns a 128-byte line per 64-wide k step, fused argmax), one MFMA
+// per lane-float: HBM-bound up to Q = 32, ~1 ms at Q = 64 (vs 11.5 ms for the vector-ALU kernel).
+// image layout: [nkc][Qtot][KC + 4] float32 (row pad 16 B -> conflict-free ds_read_b128)
+// ------------------------------------------------------------------------------------------------
+constexpr int kRowPadF32 = 4;
+
+__global__ __launch_bounds__(256) void sim_prep_queries_f32_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq,
+                                                                   float* __restrict__ img, int Qtot, int KC, int nkc) {
+    const int qg = blockIdx.x;
+    const int rowlen = KC + kRowPadF32;
+    for (int kc = 0; kc < nkc; ++kc) {
+        float* dst = img + ((int64_t)kc * Qtot + qg) * rowlen;
+        for (int kk = threadIdx.x; kk < rowlen; kk += blockDim.x) {
+            const int k = kc * KC + kk;
+            dst[kk] = (qg < Q && kk < KC && k < D) ? q[(int64_t)qg * ldq + k] : 0.f;
+        }
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(kSplitThreads) void sim_mfma_f32_kernel(
+    const float* __restrict__ feat, int64_t N, int D, int64_t ld, const float* __restrict__ img, int Qtot, int KC, int nkc,
+    int q_base, int rows, int Q, float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best,
+    int first_chunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    const int row_b = (KC + kRowPadF32) * 4;
+    const int img_b = rows * row_b;
+
+    auto fill_lds = [&](int kc) {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(img) + ((int64_t)kc * Qtot + q_base) * row_b);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < img_b / 16; i += kSplitThreads) dst[i] = src[i];
+    };
+    if (nkc == 1) fill_lds(0);
+    __syncthreads();
+
+    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    const char* a_base[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) a_base[t] = smem + min(t * 32 + j, rows - 1) * row_b + kg * 128;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * kTileRows + wave * 32 + j;
+        const int64_t rowc = row < N ? row : N - 1;
+        const float* rp = feat + rowc * ld + 32 * kg;
+        f32x16 acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            if (nkc > 1) {
+                __syncthreads();
+                fill_lds(kc);
+                __syncthreads();
+            }
+            const int nsteps = min(KC, D - kc * KC) >> 6;
+            const float* p = rp + kc * KC;
+            f32x4 buf0[8], buf1[8];
+            auto load = [&](f32x4(&b)[8], int s) {
+                const f32x4* g = reinterpret_cast<const f32x4*>(p + 64 * s);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[t] = g[t];
+            };
+            auto compute = [&](const f32x4(&b)[8], int s) {
+#pragma unroll
+                for (int m4 = 0; m4 < 8; ++m4) {
+                    const float bv[4] = {b[m4].x, b[m4].y, b[m4].z, b[m4].w};
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(a_base[t] + (s * 64 + 4 * m4) * 4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[0], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[1], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[3], acc[t], 0, 0, 0);
+                    }
+                }
+            };
+            load(buf0, 0);
+            for (int s = 0; s < nsteps; s += 2) {
+                if (s + 1 < nsteps) load(buf1, s + 1);
+                compute(buf0, s);
+                if (s + 1 < nsteps) {
+                    if (s + 2 < nsteps) load(buf0, s + 2);
+                    compute(buf1, s + 1);
+                }
+            }
+        }
+
+        const int qend = q_base + rows;
+        float bv = -INFINITY;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qg = q_base + t * 32 + 8 * g + 4 * kg;
+                f32x4 v;
+                v.x = acc[t][4 * g + 0]; v.y = acc[t][4 * g + 1]; v.z = acc[t][4 * g + 2]; v.w = acc[t][4 * g + 3];
+                if (scores && row < N) {
+                    float* sp = scores + row * (int64_t)Q + qg;
+                    if (qg + 3 < qend && (Q & 3) == 0) {
+                        *reinterpret_cast<f32x4*>(sp) = v;
+                    } else {
+                        if (qg + 0 < qend) sp[0] = v.x;
+                        if (qg + 1 < qend) sp[1] = v.y;
+                        if (qg + 2 < qend) sp[2] = v.z;
+                        if (qg + 3 < qend) sp[3] = v.w;
+                    }
+                }
+                if (qg + 0 < qend && v.x > bv) { bv = v.x; bi = qg + 0; }
+                if (qg + 1 < qend && v.y > bv) { bv = v.y; bi = qg + 1; }
+                if (qg + 2 < qend && v.z > bv) { bv = v.z; bi = qg + 2; }
+                if (qg + 3 < qend && v.w > bv) { bv = v.w; bi = qg + 3; }
+            }
+        }
+        if (argmax || best) {
+            const float ov = __shfl_xor(bv, 32, 64);
+            const int oi = __shfl_xor(bi, 32, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            if (kg == 0 && row < N) {
+                if (bi == INT_MAX) bi = q_base;
+                if (!first_chunk) {
+                    const float pv = best[row];
+                    if (!(bv > pv)) { bv = pv; bi = argmax ? argmax[row] : bi; }
+                }
+                if (argmax) argmax[row] = bi;
+                if (best) best[row] = bv;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
 __global__ void mask_from_argmax_kernel(const int32_t* __restrict__ am, int64_t N, int32_t cat, uint8_t* __restrict__ mask) {
@@ -526,6 +665,26 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     return AVL_OK;
 }
 
+static int run_mfma_f32(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
+                        float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
+    float* img = reinterpret_cast<float*>(d_ws);   // needs nkc*Qtot*(KC+4)*4 bytes <= the split image of the same plan
+    hipLaunchKernelGGL(sim_prep_queries_f32_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Q, D, ldq, img, p.Qtot, p.KC, p.nkc);
+    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    int64_t blocks = ntiles < num_cus() ? ntiles : num_cus();
+    if (blocks < 1) blocks = 1;
+    for (int ci = 0; ci < p.nchunks; ++ci) {
+        const SplitChunk& c = p.chunks[ci];
+        auto kern = c.QT == 3 ? sim_mfma_f32_kernel<3> : (c.QT == 2 ? sim_mfma_f32_kernel<2> : sim_mfma_f32_kernel<1>);
+        const size_t lds = (size_t)c.rows * (p.KC + kRowPadF32) * sizeof(float);
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc != AVL_OK) return rc;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, d_feat, N, D, ld, img, p.Qtot, p.KC, p.nkc, c.q_base,
+                           c.rows, Q, d_scores, d_argmax, d_best, ci == 0 ? 1 : 0);
+    }
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
 }  // namespace avl
 
 using namespace avl;
@@ -544,7 +703,7 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
                       void* d_workspace, size_t workspace_bytes, void* stream) {
     AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores: bad shape N=%lld D=%d Q=%d", (long long)N, D, Q);
     AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
-    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_SPLIT_F16, "avl_sim_scores: bad precision %d", precision);
+    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_EXACT_VALU, "avl_sim_scores: bad precision %d", precision);
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat && d_queries, "avl_sim_scores: null input");
     hipStream_t st = as_stream(stream);
@@ -553,9 +712,12 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     const bool aligned = (ld_feat % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0) &&
                          (!d_scores || (reinterpret_cast<uintptr_t>(d_scores) & 15) == 0);
     const bool can_split = make_split_plan(D, Q, p) && aligned;
-    bool use_split;
-    if (precision == AVL_SIM_EXACT) use_split = false;
-    else if (precision == AVL_SIM_SPLIT_F16) {
+    bool use_split, use_f32_mfma = false;
+    if (precision == AVL_SIM_EXACT_VALU) use_split = false;
+    else if (precision == AVL_SIM_EXACT) {
+        use_split = false;
+        use_f32_mfma = can_split;     // same shape constraints; otherwise the vector-ALU kernel
+    } else if (precision == AVL_SIM_SPLIT_F16) {
         AVL_REQUIRE(can_split, "avl_sim_scores: SPLIT_F16 needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D,
                     (long long)ld_feat);
         use_split = true;
@@ -564,20 +726,21 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     // chaining query chunks needs a best-score buffer even if the caller does not want it
     float* best = d_best;
     float* tmp_best = nullptr;
-    const int nchunks = use_split ? p.nchunks : (Q + kExactQB - 1) / kExactQB;
+    const int nchunks = (use_split || use_f32_mfma) ? p.nchunks : (Q + kExactQB - 1) / kExactQB;
     if (!best && d_argmax && nchunks > 1) {
         AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_best), (size_t)N * sizeof(float), st));
         best = tmp_best;
     }
     int rc;
-    if (use_split) {
+    if (use_split || use_f32_mfma) {
         void* ws = d_workspace;
         void* tmp_ws = nullptr;
         if (!ws || workspace_bytes < p.ws_bytes) {
             AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, p.ws_bytes, st));
             ws = tmp_ws;
         }
-        rc = run_split(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st);
+        rc = use_split ? run_split(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st)
+                       : run_mfma_f32(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st);
         if (tmp_ws) (void)hipFreeAsync(tmp_ws, st);
     } else {
         rc = run_exact(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, st);

@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray, as_device, _is_torch
 
-PRECISION = {"auto": _lib.SIM_AUTO, "exact": _lib.SIM_EXACT, "split_f16": _lib.SIM_SPLIT_F16}
+PRECISION = {"auto": _lib.SIM_AUTO, "exact": _lib.SIM_EXACT, "split_f16": _lib.SIM_SPLIT_F16, "exact_valu": _lib.SIM_EXACT_VALU}
 
 
 def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=False, precision="auto", stream=None,

@@ -73,9 +73,11 @@ AVL_API int avl_event_elapsed_ms(void* start, void* stop, float* h_ms);
  *     to the lowest query index, like np.argmax.
  * ------------------------------------------------------------------------------------------------ */
 enum {
-    AVL_SIM_AUTO = 0,   /* SPLIT_F16 when the shape allows it (D % 64 == 0, 16-byte aligned rows), else EXACT  */
-    AVL_SIM_EXACT = 1,  /* float32 FMA on the vector ALU (any N, D, Q, strides)                          */
-    AVL_SIM_SPLIT_F16 = 2 /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q| */
+    AVL_SIM_AUTO = 0,      /* SPLIT_F16 when the shape allows it (D % 64 == 0, 16-byte aligned rows), else EXACT        */
+    AVL_SIM_EXACT = 1,     /* float32 products and accumulation (an fmaf chain): v_mfma_f32_32x32x2_f32 on the matrix
+                              cores when the shape allows it, otherwise the vector-ALU kernel (any N, D, Q, strides)     */
+    AVL_SIM_SPLIT_F16 = 2, /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q|, HBM-bound    */
+    AVL_SIM_EXACT_VALU = 3 /* force the vector-ALU float32 kernel                                                        */
 };
 
 /*

@@ -22,7 +22,7 @@ def _check(sc, am, best, ref, atol):
         np.testing.assert_allclose(best, ref.max(axis=1), rtol=0, atol=atol)
 
 
-@pytest.mark.parametrize("precision", ["exact", "split_f16", "auto"])
+@pytest.mark.parametrize("precision", ["exact", "exact_valu", "split_f16", "auto"])
 @pytest.mark.parametrize("case", ["q1", "q2", "q64", "q40_other_last"])
 def test_golden_scores(ops, golden, case, precision):
     g = golden("g3_similarity.npz")
@@ -35,7 +35,7 @@ def test_golden_scores(ops, golden, case, precision):
     assert agree == 1.0, agree
 
 
-@pytest.mark.parametrize("precision", ["exact", "split_f16"])
+@pytest.mark.parametrize("precision", ["exact", "exact_valu", "split_f16"])
 def test_exact_ties_first_index_wins(ops, golden, precision):
     g = golden("g3_similarity.npz")
     sc, am, _ = ops.sim_scores(g["feat"], g["tie_queries"], precision=precision)
@@ -63,7 +63,7 @@ def test_shapes_vs_oracle(ops, N, D, Q):
     q /= np.linalg.norm(q, axis=1, keepdims=True) * rng.uniform(1, 3, (Q, 1)).astype(np.float32)
     ref = (feat.astype(np.float64) @ q.astype(np.float64).T)
     assert np.abs(O.sim_scores(feat, q) - ref).max() < 1e-4
-    for precision in ("exact", "auto") + (("split_f16",) if D % 64 == 0 else ()):
+    for precision in ("exact", "exact_valu", "auto") + (("split_f16",) if D % 64 == 0 else ()):
         sc, am, best = ops.sim_scores(feat, q, want_best=True, precision=precision)
         _check(sc, am, best, ref, 1e-4)
         sc2, am2, _ = ops.sim_scores(feat, q, want_scores=False, precision=precision)

@@ -49,7 +49,7 @@ def main():
         lib.avl_sim_workspace_bytes(a.D, Q, C.byref(wsb))
         ws = torch.empty((wsb.value,), dtype=torch.uint8, device="cuda")
         for mode in a.modes:
-            prec = {"auto": 0, "exact": 1, "split_f16": 2}[mode]
+            prec = {"auto": 0, "exact": 1, "split_f16": 2, "exact_valu": 3}[mode]
             for name, scp in (("argmax-only", None), ("scores+argmax", sc.data_ptr())):
                 def fn():
                     rc = lib.avl_sim_scores_ws(feat.data_ptr(), a.N, a.D, a.D, q.data_ptr(), Q, a.D, scp, am.data_ptr(),
