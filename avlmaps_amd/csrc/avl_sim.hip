@@ -215,6 +215,8 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ inv_scale, int Qtot, int KC, int nkc, int q_base, int rows, int Q,
     float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NA = QT == 1 ? 3 : (QT == 2 ? 2 : 1);   // accumulator sets per tile (register budget: 16 VGPRs each)
+    constexpr int X1 = NA > 1 ? 1 : 0, X2 = NA > 2 ? 2 : X1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kg = lane >> 5;
     const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
@@ -247,11 +249,15 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         const int64_t rowc = row < N ? row : N - 1;
         const float* rp = feat + rowc * ld + 32 * kg;
 
-        f32x16 acc[QT];
+        // NA independent accumulator sets per query tile (hi*hi | cross terms) so that back-to-back MFMAs never wait on
+        // each other's result: a dependent 32x32x16 MFMA cannot issue until its predecessor retires
+        f32x16 acc[QT][NA];
 #pragma unroll
         for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][a][e] = 0.f;
 
         for (int kc = 0; kc < nkc; ++kc) {
             if (nkc > 1) {
@@ -275,24 +281,29 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                     half8 bh, bl;
                     split8(b[2 * m], b[2 * m + 1], bh, bl);
                     const int off = (s * 64 + 8 * m) * 2;
+                    half8 ah[QT], al[QT];
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
 #ifdef AVL_ABL_NOLDS
-                        half8 ah, al;
-                        for (int e = 0; e < 8; ++e) { ah[e] = (_Float16)1; al[e] = (_Float16)2; }
-                        asm volatile("" : "+v"(ah), "+v"(al));
+                        for (int e = 0; e < 8; ++e) { ah[t][e] = (_Float16)1; al[t][e] = (_Float16)2; }
+                        asm volatile("" : "+v"(ah[t]), "+v"(al[t]));
 #else
-                        const half8 ah = *reinterpret_cast<const half8*>(a_base[t] + off);
-                        const half8 al = *reinterpret_cast<const half8*>(a_base[t] + off + img_b);
-#endif
-#ifdef AVL_ABL_NOMFMA
-                        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
-#else
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                        ah[t] = *reinterpret_cast<const half8*>(a_base[t] + off);
+                        al[t] = *reinterpret_cast<const half8*>(a_base[t] + off + img_b);
 #endif
                     }
+#ifdef AVL_ABL_NOMFMA
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) asm volatile("" ::"v"(ah[t]), "v"(al[t]), "v"(bh), "v"(bl));
+#else
+                    // term-major, tile-minor issue order: consecutive MFMAs target different accumulators
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][X1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][X1], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][X2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][X2], 0, 0, 0);
+#endif
                 }
             };
             if constexpr (NSTEPS > 0) {
@@ -332,10 +343,15 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                 const int qg = q_base + ql;
                 const f32x4 is4 = *reinterpret_cast<const f32x4*>(isc + ql);
                 f32x4 v;
-                v.x = acc[t][4 * g + 0] * is4.x;
-                v.y = acc[t][4 * g + 1] * is4.y;
-                v.z = acc[t][4 * g + 2] * is4.z;
-                v.w = acc[t][4 * g + 3] * is4.w;
+                f32x4 r = {acc[t][0][4 * g + 0], acc[t][0][4 * g + 1], acc[t][0][4 * g + 2], acc[t][0][4 * g + 3]};
+#pragma unroll
+                for (int a = 1; a < NA; ++a) {   // small cross-term sums first would be more accurate still; fp32 add suffices
+                    r.x += acc[t][a][4 * g + 0]; r.y += acc[t][a][4 * g + 1]; r.z += acc[t][a][4 * g + 2]; r.w += acc[t][a][4 * g + 3];
+                }
+                v.x = r.x * is4.x;
+                v.y = r.y * is4.y;
+                v.z = r.z * is4.z;
+                v.w = r.w * is4.w;
                 if (scores && row < N) {
                     float* sp = scores + row * (int64_t)Q + qg;
                     if (qg + 3 < qend && (Q & 3) == 0) {
