@@ -1,4 +1,5 @@
 // libavlmaps_hip.so -- library / device plumbing entry points (include/avlmaps_hip.h, first block).
+#include <cmath>
 #include <cstring>
 
 #include "avl_common.h"
@@ -25,6 +26,43 @@ int num_cus() {
         cached_dev = dev;
     }
     return cached;
+}
+
+}  // namespace avl
+
+namespace avl {
+
+// read-only streaming probes: what this box's HBM delivers to a kernel that does nothing but read
+__global__ __launch_bounds__(256) void probe_coalesced_kernel(const float4* __restrict__ p, size_t n, float* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+    }
+    for (; i < n; i += stride) { const float4 a = p[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 123.456f) *sink = acc;
+}
+
+// the access pattern of the similarity kernels: lane (row j, half kg) walks one 128-byte line with 8 x 16-byte loads
+__global__ __launch_bounds__(512) void probe_rowline_kernel(const float* __restrict__ feat, long long N, int D, float* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, kg = lane >> 5;
+    const long long ntiles = (N + 255) / 256;
+    float acc = 0.f;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long long row = tile * 256 + wave * 32 + j;
+        if (row >= N) row = N - 1;
+        const float4* g = reinterpret_cast<const float4*>(feat + row * D + 32 * kg);
+        for (int s = 0; s < D / 64; ++s) {
+            float4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = g[s * 16 + t];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc += v[t].x + v[t].y + v[t].z + v[t].w;
+        }
+    }
+    if (acc == 123.456f) *sink = acc;
 }
 
 }  // namespace avl
@@ -114,6 +152,38 @@ int avl_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
 
 int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
     AVL_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return AVL_OK;
+}
+
+int avl_hbm_read_probe(const void* d_buf, int64_t rows, int row_floats, int pattern, int iters, float* h_best_gbs, void* stream) {
+    AVL_REQUIRE(d_buf && rows > 0 && row_floats > 0 && iters > 0 && h_best_gbs, "avl_hbm_read_probe: bad arguments");
+    AVL_REQUIRE(pattern == 0 || (row_floats % 64 == 0), "avl_hbm_read_probe: the row-line pattern needs row_floats %% 64 == 0");
+    hipStream_t st = as_stream(stream);
+    float* sink = nullptr;
+    AVL_HIP_CHECK(hipMallocAsync((void**)&sink, sizeof(float), st));
+    hipEvent_t e0, e1;
+    AVL_HIP_CHECK(hipEventCreate(&e0));
+    AVL_HIP_CHECK(hipEventCreate(&e1));
+    const double bytes = (double)rows * row_floats * 4.0;
+    float best = 0.f;
+    for (int it = 0; it < iters + 2; ++it) {
+        AVL_HIP_CHECK(hipEventRecord(e0, st));
+        if (pattern == 0)
+            hipLaunchKernelGGL(probe_coalesced_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const float4*>(d_buf),
+                               (size_t)(bytes / 16), sink);
+        else
+            hipLaunchKernelGGL(probe_rowline_kernel, dim3(num_cus() * 2), dim3(512), 0, st, reinterpret_cast<const float*>(d_buf),
+                               (long long)rows, row_floats, sink);
+        AVL_HIP_CHECK(hipEventRecord(e1, st));
+        AVL_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        AVL_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (it >= 2 && ms > 0.f) best = fmaxf(best, (float)(bytes / (ms * 1e-3) / 1e9));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFreeAsync(sink, st);
+    *h_best_gbs = best;
     return AVL_OK;
 }
 

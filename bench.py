@@ -157,6 +157,14 @@ def run_index(args, torch, dist, lib, rank, ws):
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                            traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes)
+    if rank == 0:
+        # what a kernel that ONLY reads the same 4.1 GB gets on this box (spec peak is 8 TB/s; boxes differ by ~15 %)
+        g0, g1 = C.c_float(), C.c_float()
+        lib.avl_hbm_read_probe(feat.data_ptr(), N, D, 0, 5, C.byref(g0), None)
+        lib.avl_hbm_read_probe(feat.data_ptr(), N, D, 1, 5, C.byref(g1), None)
+        ceiling = max(g0.value, g1.value)
+        out["roofline"].update(measured_read_ceiling=dict(coalesced_gbs=g0.value, rowline_gbs=g1.value),
+                               frac_of_measured_ceiling=achieved / ceiling if ceiling > 0 else None)
     if rank == 0 and not args.profile_run:
         # variant: also materialise scores_mat (VLMap.init_categories, vlmap.py:92-102)
         sc = torch.empty((N, Q), dtype=torch.float32, device="cuda")
