@@ -47,6 +47,7 @@ _SIGS = {
     "avl_sim_scores_host": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),
     "avl_mask_from_argmax": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "avl_argmax_f32": (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(C.c_float), _vp]),
+    "avl_topk_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp]),
     "avl_builder_create": (C.c_int, [C.POINTER(_vp), C.c_int, _f64, C.c_int, C.c_int, _i64]),
     "avl_builder_create_grid": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, _f64, C.c_int, _i64]),
     "avl_builder_destroy": (C.c_int, [_vp]),

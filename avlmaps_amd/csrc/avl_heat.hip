@@ -16,6 +16,9 @@
 //   * brute force: targets staged through LDS, every thread owns one voxel (used when the window would
 //     be larger than the target list or the dense grid would not fit).
 #include <climits>
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "avl_common.h"
 
@@ -207,5 +210,35 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
         (void)hipFreeAsync(cnt, st);
     }
     AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+namespace avl {
+__global__ void iota64_kernel(int64_t* __restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = i;
+}
+}  // namespace avl
+
+// k largest values of a float32 vector with their indices, descending; equal values keep ascending index order (the
+// order np.argsort(-v, kind="stable") gives).  The k = 1 case is the navigator's goal voxel (habitat_lang_robot.py:427-430).
+extern "C" int avl_topk_f32(const float* d_vals, int64_t N, int k, int64_t* h_index, float* h_value, void* stream) {
+    AVL_REQUIRE(d_vals && N > 0 && k > 0 && k <= N, "avl_topk_f32: bad arguments (N=%lld k=%d)", (long long)N, k);
+    AVL_REQUIRE(N < (1ll << 31), "avl_topk_f32: N must fit 31 bits");
+    hipStream_t st = as_stream(stream);
+    float* keys_out = nullptr;
+    int64_t *iota = nullptr, *order = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    AVL_HIP_CHECK(hipMallocAsync((void**)&keys_out, (size_t)N * sizeof(float), st));
+    AVL_HIP_CHECK(hipMallocAsync((void**)&iota, (size_t)N * sizeof(int64_t), st));
+    AVL_HIP_CHECK(hipMallocAsync((void**)&order, (size_t)N * sizeof(int64_t), st));
+    hipLaunchKernelGGL(avl::iota64_kernel, dim3((unsigned)((N + 255) / 256 > 4096 ? 4096 : (N + 255) / 256)), dim3(256), 0, st, iota, N);
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, d_vals, keys_out, iota, order, (size_t)N, 0, 32, st));
+    AVL_HIP_CHECK(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, d_vals, keys_out, iota, order, (size_t)N, 0, 32, st));
+    if (h_index) AVL_HIP_CHECK(hipMemcpyAsync(h_index, order, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (h_value) AVL_HIP_CHECK(hipMemcpyAsync(h_value, keys_out, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(order, st); (void)hipFreeAsync(iota, st); (void)hipFreeAsync(keys_out, st);
     return AVL_OK;
 }

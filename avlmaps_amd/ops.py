@@ -295,3 +295,13 @@ def export_raw_torch(acc: "VoxelAccumulator", device=None, stream=None):
     _lib.check(lib.avl_builder_export_raw(acc._h, n, *(v.data_ptr() for v in t.values()), stream), "avl_builder_export_raw")
     _lib.check(lib.avl_stream_sync(stream))
     return t
+
+
+def topk_f32(vals, k, stream=None):
+    """(indices (k,) int64, values (k,) float32) of the k largest entries, descending, ties by ascending index."""
+    lib = _lib.load()
+    vp, vshape, vk = as_device(vals, np.float32, stream)
+    idx = np.empty((k,), dtype=np.int64)
+    val = np.empty((k,), dtype=np.float32)
+    _lib.check(lib.avl_topk_f32(vp, int(np.prod(vshape)), int(k), idx.ctypes.data, val.ctypes.data, stream), "avl_topk_f32")
+    return idx, val

@@ -115,6 +115,10 @@ AVL_API int avl_mask_from_argmax(const int32_t* d_argmax, int64_t N, int32_t cat
  * heatmap argmax, avlmaps/robot/habitat_lang_robot.py:427-430.  Synchronous (returns host scalars). */
 AVL_API int avl_argmax_f32(const float* d_vals, int64_t N, int64_t* h_index, float* h_value, void* stream);
 
+/* the k largest values with their indices, descending, ties in ascending index order (np.argsort(-v, kind="stable")[:k]);
+ * h_index (k,) int64 and h_value (k,) float32 are host buffers.  Synchronous. */
+AVL_API int avl_topk_f32(const float* d_vals, int64_t N, int k, int64_t* h_index, float* h_value, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * (2) map builder: depth back-projection + voxelisation + weighted feature fusion
  *     replaces  avlmaps/map/vlmap_builder.py:129-178 (per-frame body of create_mobile_base_map)

@@ -163,6 +163,10 @@ def test_heatmap_matches_reference(ops, golden):
     # navigator argmax: first maximum wins
     idx, val = ops.argmax_f32(g["heat_0.01"])
     assert idx == int(np.argmax(g["heat_0.01"])) and val == 1.0
+    heat = g["heat_0.01"]
+    ti, tv = ops.topk_f32(heat, 100)            # heatmap top-k: ties (many voxels at heat 1.0) keep ascending index order
+    want = np.argsort(-heat, kind="stable")[:100]
+    assert np.array_equal(ti, want) and np.array_equal(tv, heat[want]) and ti[0] == idx
 
 
 def test_export_raw_and_finalize_raw_roundtrip(ops, golden):
