@@ -12,7 +12,8 @@
 // Two strategies, same results:
 //   * windowed: heat is exactly 0 once ||d|| >= R = cell_size / decay, so only targets inside the cube of
 //     radius ceil(R) around a voxel matter.  Targets are scattered into a dense byte grid over the map's
-//     bounding box (tens of MB, L2/MALL resident) and every voxel scans its (2R+1)^3 window.
+//     bounding box as a BIT grid (64 z cells per word: 4 MB for a 1000 x 1000 x 30 map, L2 resident); every voxel scans
+//     the (2R+1)^2 columns of its window and finds the nearest set bit of each column with clz / ffs.
 //   * brute force: targets staged through LDS, every thread owns one voxel (used when the window would
 //     be larger than the target list or the dense grid would not fit).
 #include <climits>
@@ -47,12 +48,14 @@ __global__ void heat_bbox_kernel(const int32_t* __restrict__ pos, int64_t N, int
     }
 }
 
+// targets as a bit grid: one 64-bit word covers 64 consecutive z cells of an (x, y) column
 __global__ void heat_scatter_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask, int64_t N, int ox,
-                                    int oy, int oz, int ny, int nz, uint8_t* __restrict__ grid) {
+                                    int oy, int oz, int ny, int wz, unsigned long long* __restrict__ grid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask[i]) {
-            size_t g = ((size_t)(pos[i * 3] - ox) * ny + (pos[i * 3 + 1] - oy)) * nz + (pos[i * 3 + 2] - oz);
-            grid[g] = 1;
+            const int z = pos[i * 3 + 2] - oz;
+            const size_t w = ((size_t)(pos[i * 3] - ox) * ny + (pos[i * 3 + 1] - oy)) * wz + (z >> 6);
+            atomicOr(&grid[w], 1ull << (z & 63));
         }
     }
 }
@@ -64,10 +67,32 @@ __device__ __forceinline__ float heat_from_d2(long long d2, double cell_size, do
     return (float)v;
 }
 
+// smallest |c - z| over the set bits c of `word` (bit b = cell wbase + b) restricted to [z0, z1]; INT_MAX if none
+__device__ __forceinline__ int nearest_bit(unsigned long long word, int wbase, int z, int z0, int z1) {
+    const int lo = max(z0 - wbase, 0), hi = min(z1 - wbase, 63);
+    if (lo > hi || word == 0) return INT_MAX;
+    const unsigned long long range = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+    const unsigned long long m = word & range;
+    if (!m) return INT_MAX;
+    const int zl = z - wbase;  // may lie outside [0, 63]
+    int best = INT_MAX;
+    // highest set bit at or below zl
+    if (zl >= 0) {
+        const unsigned long long below = zl >= 63 ? m : (m & ((1ull << (zl + 1)) - 1ull));
+        if (below) best = zl - (63 - __clzll((long long)below));
+    }
+    // lowest set bit above zl
+    if (zl < 63) {
+        const unsigned long long above = zl < 0 ? m : (m & ~((1ull << (zl + 1)) - 1ull));
+        if (above) best = min(best, (__ffsll((long long)above) - 1) - zl);
+    }
+    return best;
+}
+
 __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
-                                                          int64_t N, int ox, int oy, int oz, int nx, int ny, int nz, int R,
-                                                          const uint8_t* __restrict__ grid, double cell_size, double decay,
-                                                          float* __restrict__ heat) {
+                                                          int64_t N, int ox, int oy, int oz, int nx, int ny, int nz, int wz, int R,
+                                                          const unsigned long long* __restrict__ grid, double cell_size,
+                                                          double decay, float* __restrict__ heat) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask[i]) {
             heat[i] = 1.0f;
@@ -77,6 +102,7 @@ __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restr
         const int x0 = max(0, x - R), x1 = min(nx - 1, x + R);
         const int y0 = max(0, y - R), y1 = min(ny - 1, y + R);
         const int z0 = max(0, z - R), z1 = min(nz - 1, z + R);
+        const int w0 = z0 >> 6, w1 = z1 >> 6;
         int best = INT_MAX;
         for (int a = x0; a <= x1; ++a) {
             const int dx2 = (a - x) * (a - x);
@@ -84,9 +110,11 @@ __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restr
             for (int b = y0; b <= y1; ++b) {
                 const int dxy2 = dx2 + (b - y) * (b - y);
                 if (dxy2 >= best) continue;
-                const uint8_t* gp = grid + ((size_t)a * ny + b) * nz;
-                for (int c = z0; c <= z1; ++c)
-                    if (gp[c]) best = min(best, dxy2 + (c - z) * (c - z));
+                const unsigned long long* gp = grid + ((size_t)a * ny + b) * wz;
+                for (int w = w0; w <= w1; ++w) {
+                    const int dz = nearest_bit(gp[w], w << 6, z, z0, z1);
+                    if (dz != INT_MAX) best = min(best, dxy2 + dz * dz);
+                }
             }
         }
         // a target outside the window is at distance > R >= cell_size/decay: its heat clips to exactly 0
@@ -184,18 +212,19 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
                      nz = (double)h_bbox[5] - h_bbox[2] + 1;
         const double cells = nx * ny * nz;
         const double window = (2.0 * R + 1) * (2.0 * R + 1) * (2.0 * R + 1);
-        if (cells > 4.0e9 || window > 40000.0) windowed = false;
+        if (cells > 3.2e10 || window > 40000.0) windowed = false;   // bit grid: 1 bit per cell
     }
     if (windowed) {
         const int nx = h_bbox[3] - h_bbox[0] + 1, ny = h_bbox[4] - h_bbox[1] + 1, nz = h_bbox[5] - h_bbox[2] + 1;
-        const size_t cells = (size_t)nx * ny * nz;
-        uint8_t* grid = nullptr;
-        AVL_HIP_CHECK(hipMallocAsync((void**)&grid, cells, st));
-        AVL_HIP_CHECK(hipMemsetAsync(grid, 0, cells, st));
+        const int wz = (nz + 63) / 64;
+        const size_t words = (size_t)nx * ny * wz;
+        unsigned long long* grid = nullptr;
+        AVL_HIP_CHECK(hipMallocAsync((void**)&grid, words * sizeof(unsigned long long), st));
+        AVL_HIP_CHECK(hipMemsetAsync(grid, 0, words * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(heat_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                           h_bbox[1], h_bbox[2], ny, nz, grid);
+                           h_bbox[1], h_bbox[2], ny, wz, grid);
         hipLaunchKernelGGL(heat_window_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                           h_bbox[1], h_bbox[2], nx, ny, nz, R, grid, cell_size, decay_rate, d_heat);
+                           h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cell_size, decay_rate, d_heat);
         (void)hipFreeAsync(grid, st);
     } else {
         int32_t* tpos = nullptr;

@@ -181,6 +181,26 @@ def run_index(args, torch, dist, lib, rank, ws):
             scores_mat_variant=dict(ms=ms_sc, similarities_per_s=N * Q / (ms_sc * 1e-3),
                                     gbs=(alg_bytes + N * Q * 4) / (ms_sc * 1e-3) / 1e9),
             parity_sample=dict(rows=8192, max_abs_err_vs_fp64=err, argmax_agreement=am_ok, tolerance=1e-4))
+        # the step after the mask in AVLMap.index_object: nearest-target decay heat over the same 2M voxels
+        # (visualize_utils.py:29-49 is an O(N_other * N_target) Python loop upstream: hours at this size)
+        try:
+            g = torch.Generator(device="cuda").manual_seed(11)
+            side = int(round((N / 0.07) ** (1 / 3))) + 1      # ~7 % occupancy of a cube, unique voxel positions
+            lin = torch.randperm(side ** 3, device="cuda", generator=g)[:N]
+            pos = torch.stack([lin // (side * side), (lin // side) % side, lin % side], 1).to(torch.int32).contiguous()
+            mask = (am == 0).to(torch.uint8)
+            heat = torch.empty((N,), dtype=torch.float32, device="cuda")
+
+            def heat_step():
+                _lib.check(lib.avl_heatmap_from_mask(pos.data_ptr(), mask.data_ptr(), N, 0.05, 0.01, heat.data_ptr(), None))
+            heat_step()
+            torch.cuda.synchronize()
+            ms_heat = float(np.median([timer(heat_step) for _ in range(5)]))
+            out["extra"]["heatmap_from_mask"] = dict(ms=ms_heat, voxels=N, targets=int(mask.sum().item()), decay_rate=0.01,
+                                                     nonzero_heat=int((heat > 0).sum().item()))
+            del pos, mask, heat, lin
+        except Exception as e:  # the extra must never break the benchmark line
+            out["extra"]["heatmap_from_mask"] = dict(error=str(e))
         if ws == 1 and not args.no_cpu:
             feat_h, q_h = feat.cpu().numpy(), q.cpu().numpy()
             t_cpu, threads, am_cpu = cpu_index_baseline(feat_h, q_h)
