@@ -136,3 +136,39 @@ def test_fused_multimodal_block_queries(ops):
     sc, am, best = ops.sim_scores(feat, q, want_best=True)
     _check(sc, am, best, ref, 1e-4)
     assert np.abs(sc - ref).max() < 5e-6
+
+
+def test_row_strides_through_the_c_abi(ops):
+    """ld_feat > D and ld_q > D (column sub-blocks of wider device arrays), straight through avl_sim_scores"""
+    import ctypes as C
+    import torch
+    from avlmaps_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    N, Dw, D, Q = 3000, 1536, 512, 40
+    wide = torch.randn((N, Dw), device="cuda", generator=g)
+    qwide = torch.randn((Q, 640), device="cuda", generator=g)
+    feat, q = wide[:, 512:1024], qwide[:, 128:640]                  # views: row strides 1536 / 640 floats
+    ref = feat.double() @ q.double().T
+    for prec in (_lib.SIM_SPLIT_F16, _lib.SIM_EXACT, _lib.SIM_EXACT_VALU):
+        sc = torch.empty((N, Q), device="cuda")
+        am = torch.empty((N,), dtype=torch.int32, device="cuda")
+        rc = lib.avl_sim_scores(feat.data_ptr(), N, D, Dw, q.data_ptr(), Q, 640, sc.data_ptr(), am.data_ptr(), None, prec, None)
+        _lib.check(rc, "avl_sim_scores")
+        torch.cuda.synchronize()
+        assert (sc.double() - ref).abs().max() < 1e-4
+        assert torch.equal(am.long(), sc.argmax(dim=1))
+    # bad strides are rejected, not read out of bounds
+    assert lib.avl_sim_scores(feat.data_ptr(), N, D, 100, q.data_ptr(), Q, 640, None, am.data_ptr(), None, 0, None) != 0
+    assert b"stride" in lib.avl_last_error()
+
+
+def test_many_queries_and_tiny_maps(ops):
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(21)
+    for N, Q in ((5, 300), (31, 79), (32, 157), (1, 64)):
+        feat = rng.standard_normal((N, 512)).astype(np.float32)
+        q = rng.standard_normal((Q, 512)).astype(np.float32) / 22.0
+        ref = feat.astype(np.float64) @ q.astype(np.float64).T
+        sc, am, best = ops.sim_scores(feat, q, want_best=True)
+        _check(sc, am, best, ref, 1e-4)
