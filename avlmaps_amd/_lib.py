@@ -9,7 +9,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AVLMAPS_HIP_LIB", _PKG / "lib" / "libavlmaps_hip.so"))
 
 AVL_OK = 0
-SIM_AUTO, SIM_EXACT, SIM_SPLIT_F16, SIM_EXACT_VALU = 0, 1, 2, 3
+SIM_AUTO, SIM_EXACT, SIM_SPLIT_F16, SIM_EXACT_VALU, SIM_PREPARED = 0, 1, 2, 3, 4
 
 
 class AvlError(RuntimeError):
@@ -41,6 +41,7 @@ _SIGS = {
     "avl_event_record": (C.c_int, [_vp, _vp]),
     "avl_event_sync": (C.c_int, [_vp]),
     "avl_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "avl_sim_prepare_map": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp]),
     "avl_sim_scores": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp]),
     "avl_sim_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(_sz)]),
     "avl_sim_scores_ws": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),

@@ -207,9 +207,28 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi
 #endif
 }
 
+// in-place conversion of a float32 map to the split layout: group g of 8 floats (32 B) -> hi[8] fp16 (16 B) | lo[8] fp16 (16 B),
+// the same split8() the kernel applies on the fly, so prepared and raw maps give bit-identical scores
+__global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict__ feat, int64_t N, int D, int64_t ld) {
+    const int gpr = D >> 3;  // groups per row
+    const int64_t total = N * gpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / gpr;
+        const int g = (int)(i - row * gpr);
+        f32x4* p = reinterpret_cast<f32x4*>(feat + row * ld + 8 * g);
+        const f32x4 v0 = p[0], v1 = p[1];
+        half8 hi, lo;
+        split8(v0, v1, hi, lo);
+        p[0] = __builtin_bit_cast(f32x4, hi);
+        p[1] = __builtin_bit_cast(f32x4, lo);
+    }
+}
+
 // QT = number of 32-query MFMA tiles of this chunk (1..3); `rows` = valid query rows of the chunk (<= 32*QT):
 // only those rows are resident in LDS (lanes of a partial tile re-read the last valid row; their results are masked).
-template <int QT, int NSTEPS>
+// PRE: the map was converted in place by sim_prepare_map_kernel -- every 8 floats hold their fp16 hi[8] | lo[8] images, so
+// the loaded registers ARE the MFMA operands and the fp32->fp16 split (8 % of the kernel time when power-throttled) is gone
+template <int QT, int NSTEPS, bool PRE>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int KC, int nkc, int q_base, int rows, int Q,
@@ -279,7 +298,12 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     half8 bh, bl;
-                    split8(b[2 * m], b[2 * m + 1], bh, bl);
+                    if constexpr (PRE) {
+                        bh = __builtin_bit_cast(half8, b[2 * m]);
+                        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
+                    } else {
+                        split8(b[2 * m], b[2 * m + 1], bh, bl);
+                    }
                     const int off = (s * 64 + 8 * m) * 2;
                     half8 ah[QT], al[QT];
 #pragma unroll
@@ -657,6 +681,7 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     return AVL_OK;
 }
 
+template <bool PRE>
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
     float* inv_scale = reinterpret_cast<float*>(d_ws);
@@ -669,8 +694,8 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
         const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
-        auto kern = s8 ? (c.QT == 3 ? sim_split_f16_kernel<3, 8> : (c.QT == 2 ? sim_split_f16_kernel<2, 8> : sim_split_f16_kernel<1, 8>))
-                       : (c.QT == 3 ? sim_split_f16_kernel<3, 0> : (c.QT == 2 ? sim_split_f16_kernel<2, 0> : sim_split_f16_kernel<1, 0>));
+        auto kern = s8 ? (c.QT == 3 ? sim_split_f16_kernel<3, 8, PRE> : (c.QT == 2 ? sim_split_f16_kernel<2, 8, PRE> : sim_split_f16_kernel<1, 8, PRE>))
+                       : (c.QT == 3 ? sim_split_f16_kernel<3, 0, PRE> : (c.QT == 2 ? sim_split_f16_kernel<2, 0, PRE> : sim_split_f16_kernel<1, 0, PRE>));
         const size_t lds = p.lds_bytes(c);
         int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc != AVL_OK) return rc;
@@ -719,7 +744,7 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
                       void* d_workspace, size_t workspace_bytes, void* stream) {
     AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores: bad shape N=%lld D=%d Q=%d", (long long)N, D, Q);
     AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
-    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_EXACT_VALU, "avl_sim_scores: bad precision %d", precision);
+    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED, "avl_sim_scores: bad precision %d", precision);
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat && d_queries, "avl_sim_scores: null input");
     hipStream_t st = as_stream(stream);
@@ -733,7 +758,7 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     else if (precision == AVL_SIM_EXACT) {
         use_split = false;
         use_f32_mfma = can_split;     // same shape constraints; otherwise the vector-ALU kernel
-    } else if (precision == AVL_SIM_SPLIT_F16) {
+    } else if (precision == AVL_SIM_SPLIT_F16 || precision == AVL_SIM_PREPARED) {
         AVL_REQUIRE(can_split, "avl_sim_scores: SPLIT_F16 needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D,
                     (long long)ld_feat);
         use_split = true;
@@ -755,7 +780,9 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
             AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, p.ws_bytes, st));
             ws = tmp_ws;
         }
-        rc = use_split ? run_split(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st)
+        rc = use_split ? (precision == AVL_SIM_PREPARED
+                              ? run_split<true>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st)
+                              : run_split<false>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st))
                        : run_mfma_f32(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st);
         if (tmp_ws) (void)hipFreeAsync(tmp_ws, st);
     } else {
@@ -763,6 +790,20 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     }
     if (tmp_best) (void)hipFreeAsync(tmp_best, st);
     return rc;
+}
+
+int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, void* stream) {
+    AVL_REQUIRE(N >= 0 && D > 0 && ld_feat >= D, "avl_sim_prepare_map: bad shape");
+    AVL_REQUIRE(D % 64 == 0 && ld_feat % 4 == 0 && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0,
+                "avl_sim_prepare_map: needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D, (long long)ld_feat);
+    if (N == 0) return AVL_OK;
+    AVL_REQUIRE(d_feat, "avl_sim_prepare_map: null pointer");
+    int64_t blocks = (N * (D >> 3) + 255) / 256;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(sim_prepare_map_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_feat, N, D, ld_feat);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
 }
 
 int avl_sim_scores(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q, int64_t ld_q,

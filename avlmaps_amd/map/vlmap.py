@@ -67,18 +67,26 @@ class VLMap(Map):
 
     # ------------------------------------------------------------------ index
     def _device_feat(self):
-        """grid_feat mirrored into HBM once (re-uploaded only if the host array object changes)"""
+        """grid_feat mirrored into HBM once (re-uploaded only if the host array object changes).  The private device copy
+        is converted to the split-fp16 layout the matrix-core kernel consumes directly (avl_sim_prepare_map: same bytes,
+        bit-identical scores, no per-query conversion work); self._sim_precision tells the kernels which form it has."""
+        from .. import ops
         from ..device import DeviceArray
         if self._dev_feat is None or self._dev_feat_src is not self.grid_feat:
             self._dev_feat = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_feat, dtype=np.float32))
             self._dev_feat_src = self.grid_feat
+            self._sim_precision = "auto"
+            if self._dev_feat.shape[1] % 64 == 0 and self._dev_feat.shape[0] > 0:
+                ops.prepare_map(self._dev_feat)
+                self._sim_precision = "prepared"
         return self._dev_feat
 
     def init_categories(self, categories: List[str]) -> np.ndarray:
         """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
         self.categories = categories
-        self.scores_mat = get_lseg_score(self.clip_model, self.categories, self._device_feat(), self.clip_feat_dim,
-                                         use_multiple_templates=True, add_other=True)
+        feat = self._device_feat()
+        self.scores_mat = get_lseg_score(self.clip_model, self.categories, feat, self.clip_feat_dim,
+                                         use_multiple_templates=True, add_other=True, precision=self._sim_precision)
         return self.scores_mat
 
     def index_map(self, language_desc: str, with_init_cat: bool = True):
@@ -94,7 +102,8 @@ class VLMap(Map):
         # fused path: scores never leave the GPU, only the (N,) argmax comes back
         q, _ = landmark_text_feats(self.clip_model, [language_desc], self.clip_feat_dim, use_multiple_templates=True,
                                    add_other=True)
-        _, am, _ = ops.sim_scores(self._device_feat(), q, want_scores=False, want_argmax=True)
+        feat = self._device_feat()
+        _, am, _ = ops.sim_scores(feat, q, want_scores=False, want_argmax=True, precision=self._sim_precision)
         return am.numpy() == 0
 
     def customize_obstacle_map(self, potential_obstacle_names: List[str], obstacle_names: List[str], vis: bool = False):
@@ -109,7 +118,7 @@ class VLMap(Map):
         self.obstacles_new_cropped = get_dynamic_obstacles_map_3d(
             self.clip_model, self.obstacles_cropped, list(cfg_get(self.map_config, "potential_obstacle_names")),
             list(cfg_get(self.map_config, "obstacle_names")), self._device_feat(), self.grid_pos, self.rmin, self.cmin,
-            self.clip_feat_dim, vis=vis)
+            self.clip_feat_dim, vis=vis, precision=self._sim_precision)
         self.obstacles_new_cropped = Map._dilate_map(self.obstacles_new_cropped == 0, cfg_get(self.map_config, "dilate_iter"),
                                                      cfg_get(self.map_config, "gaussian_sigma"))
         self.obstacles_new_cropped = self.obstacles_new_cropped == 0

@@ -8,7 +8,8 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray, as_device, _is_torch
 
-PRECISION = {"auto": _lib.SIM_AUTO, "exact": _lib.SIM_EXACT, "split_f16": _lib.SIM_SPLIT_F16, "exact_valu": _lib.SIM_EXACT_VALU}
+PRECISION = {"auto": _lib.SIM_AUTO, "exact": _lib.SIM_EXACT, "split_f16": _lib.SIM_SPLIT_F16, "exact_valu": _lib.SIM_EXACT_VALU,
+             "prepared": _lib.SIM_PREPARED}
 
 
 def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=False, precision="auto", stream=None,
@@ -59,6 +60,17 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
         res = tuple(k.numpy(stream) if k is not None else None for k in (sk, ak, bk))
         return res
     return sk, ak, bk
+
+
+def prepare_map(feat_dev, stream=None):
+    """Convert a DEVICE-resident float32 map in place into the split-fp16 layout (avl_sim_prepare_map); afterwards call
+    sim_scores(..., precision="prepared").  feat_dev: DeviceArray or torch CUDA tensor (N, D), D % 64 == 0."""
+    lib = _lib.load()
+    if isinstance(feat_dev, np.ndarray):
+        raise TypeError("prepare_map works on a device-resident map (DeviceArray / torch CUDA tensor), not a host array")
+    fptr, fshape, _ = as_device(feat_dev, np.float32, stream)
+    _lib.check(lib.avl_sim_prepare_map(fptr, fshape[0], fshape[1], fshape[1], stream), "avl_sim_prepare_map")
+    return feat_dev
 
 
 def mask_from_argmax(argmax, cat_id, stream=None):

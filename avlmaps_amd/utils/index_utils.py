@@ -22,7 +22,8 @@ def find_similar_category_id(class_name: str, classes_list: List[str]) -> int:
 
 
 def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstacle_classes, obstacle_classes, grid_feat,
-                                 grid_pos, rmin, cmin, clip_feat_dim, use_multiple_templates=True, avg_mode=0, vis=False):
+                                 grid_pos, rmin, cmin, clip_feat_dim, use_multiple_templates=True, avg_mode=0, vis=False,
+                                 precision="auto"):
     """Cropped top-down map, True = free, after keeping only voxels whose best class is one of `obstacle_classes`.
     Reference: avlmaps/utils/index_utils.py:138-184 -- the same matmul + argmax as index_map (:153-161), here the fused
     similarity kernel (scores are never materialised), then a vectorised scatter instead of boolean Python loops.
@@ -34,13 +35,13 @@ def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstac
     if avg_mode != 0:
         from .clip_utils import get_lseg_score
         scores = get_lseg_score(clip_model, list(potential_obstacle_classes), grid_feat, clip_feat_dim,
-                                use_multiple_templates=use_multiple_templates, avg_mode=avg_mode)
+                                use_multiple_templates=use_multiple_templates, avg_mode=avg_mode, precision=precision)
         predict = np.argmax(scores, axis=1)
     else:
         q, _ = landmark_text_feats(clip_model, list(potential_obstacle_classes), clip_feat_dim, use_multiple_templates, True)
         if isinstance(grid_feat, np.ndarray):
             grid_feat = np.ascontiguousarray(grid_feat, dtype=np.float32)
-        _, am, _ = ops.sim_scores(grid_feat, q, want_scores=False, want_argmax=True)
+        _, am, _ = ops.sim_scores(grid_feat, q, want_scores=False, want_argmax=True, precision=precision)
         predict = _to_numpy(am)
     obs_inds = [i for obs_name in obstacle_classes for i, po in enumerate(potential_obstacle_classes) if obs_name == po]
     print("obs_inds: ", obs_inds)

@@ -82,8 +82,16 @@ enum {
     AVL_SIM_EXACT = 1,     /* float32 products and accumulation (an fmaf chain): v_mfma_f32_32x32x2_f32 on the matrix
                               cores when the shape allows it, otherwise the vector-ALU kernel (any N, D, Q, strides)     */
     AVL_SIM_SPLIT_F16 = 2, /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q|, HBM-bound    */
-    AVL_SIM_EXACT_VALU = 3 /* force the vector-ALU float32 kernel                                                        */
+    AVL_SIM_EXACT_VALU = 3,/* force the vector-ALU float32 kernel                                                        */
+    AVL_SIM_PREPARED = 4   /* d_feat was converted by avl_sim_prepare_map: SPLIT_F16 without the on-the-fly split,
+                              bit-identical scores                                                                       */
 };
+
+/* One-off, IN-PLACE conversion of a device-resident float32 map (N, D; D % 64 == 0, 16-byte aligned rows) into the split
+ * layout the matrix-core kernel consumes directly: every group of 8 floats (32 bytes) becomes fp16 hi[8] | fp16 lo[8]
+ * (same 4 bytes per element, same row stride).  Meant for a map that is indexed many times (VLMap keeps its private device
+ * copy in this form); pass AVL_SIM_PREPARED to avl_sim_scores afterwards.  The float32 values are not recoverable exactly. */
+AVL_API int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, void* stream);
 
 /*
  * d_feat     (N, D) float32 row-major with row stride ld_feat (elements)  -- VLMap.grid_feat

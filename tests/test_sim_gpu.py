@@ -172,3 +172,19 @@ def test_many_queries_and_tiny_maps(ops):
         ref = feat.astype(np.float64) @ q.astype(np.float64).T
         sc, am, best = ops.sim_scores(feat, q, want_best=True)
         _check(sc, am, best, ref, 1e-4)
+
+
+def test_prepared_map_gives_bit_identical_scores(ops):
+    """avl_sim_prepare_map hoists the fp32 -> fp16 hi/lo split to load time: same operands, same scores, bit for bit"""
+    from avlmaps_amd.device import DeviceArray
+    rng = np.random.default_rng(8)
+    for N, D, Q in ((3001, 512, 64), (700, 512, 65), (999, 1024, 33), (513, 192, 7)):
+        feat = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-6, 2.5, (N, D)))).astype(np.float32)
+        q = rng.standard_normal((Q, D)).astype(np.float32) / np.sqrt(D)
+        sc0, am0, b0 = ops.sim_scores(feat, q, want_best=True, precision="split_f16")
+        dev = DeviceArray.from_numpy(feat)
+        ops.prepare_map(dev)
+        sc1, am1, b1 = ops.sim_scores(dev, q, want_best=True, precision="prepared")
+        assert np.array_equal(sc1.numpy(), sc0) and np.array_equal(am1.numpy(), am0) and np.array_equal(b1.numpy(), b0)
+    with pytest.raises(TypeError):
+        ops.prepare_map(feat)
