@@ -14,16 +14,48 @@ import numpy as np
 from . import _lib
 
 
+# Freed buffers are kept on a size-keyed free list (hipMalloc / hipFree cost ~100 us each and hipFree synchronises): the
+# per-frame staging buffers of the builder are then recycled instead of reallocated.  Bounded; oversize buffers go back.
+_POOL: dict = {}
+_POOL_BYTES = [0]
+_POOL_LIMIT = 2 << 30
+_POOL_MAX_ITEM = 256 << 20
+
+
+def _pool_alloc(nbytes: int) -> int:
+    lst = _POOL.get(nbytes)
+    if lst:
+        _POOL_BYTES[0] -= nbytes
+        return lst.pop()
+    p = C.c_void_p()
+    _lib.check(_lib.load().avl_malloc(C.byref(p), nbytes), "avl_malloc")
+    return p.value or 0
+
+
+def _pool_free(ptr: int, nbytes: int) -> None:
+    if 0 < nbytes <= _POOL_MAX_ITEM and _POOL_BYTES[0] + nbytes <= _POOL_LIMIT:
+        _POOL.setdefault(nbytes, []).append(ptr)
+        _POOL_BYTES[0] += nbytes
+    else:
+        _lib.load().avl_free(ptr)
+
+
+def empty_pool() -> None:
+    for nbytes, lst in list(_POOL.items()):
+        for p in lst:
+            _lib.load().avl_free(p)
+    _POOL.clear()
+    _POOL_BYTES[0] = 0
+
+
 class DeviceArray:
-    """Minimal owning device array (shape + dtype + pointer) backed by avl_malloc."""
+    """Minimal owning device array (shape + dtype + pointer) backed by avl_malloc (pooled)."""
 
     def __init__(self, shape, dtype):
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        p = C.c_void_p()
-        _lib.check(_lib.load().avl_malloc(C.byref(p), self.nbytes), "avl_malloc")
-        self.ptr = p.value or 0
+        self.ptr = _pool_alloc(max(self.nbytes, 1))
 
     @classmethod
     def from_numpy(cls, a, stream=None):
@@ -46,7 +78,7 @@ class DeviceArray:
 
     def free(self):
         if getattr(self, "ptr", 0):
-            _lib.load().avl_free(self.ptr)
+            _pool_free(self.ptr, max(self.nbytes, 1))
             self.ptr = 0
 
     def __del__(self):
