@@ -38,12 +38,23 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "avl_common.h"
 
 namespace avl {
+
+// one frame of a batch (avl_builder_integrate_batch): what differs between the frames of one launch
+struct BatchEntry {
+    double t[16];                 // pc_transform of the frame
+    const float* depth;
+    const int32_t* samples;
+    const uint8_t* rgb;
+    const float* feat;
+    unsigned long long frame_key; // key_bias | frame_idx << 32
+};
 
 struct FrameParams {
     double kinv[9];   // inv(calib)            (mapping_utils.py:237)
@@ -55,6 +66,8 @@ struct FrameParams {
     double pcd_min[3];   // global mode: lower corner of the pass-1 bounding box (vlmap_builder_multi_floor.py:117)
     double depth_div;    // uint16 depth images: metres = value / depth_div (multi-floor: / 1000.0, :105)
     int H, W, Hf, Wf, n0, n1, n2, P;   // grid: n0 rows x n1 cols x n2 heights (mobile-base mode: gs, gs, vh)
+    const BatchEntry* batch;   // nullptr: single frame (pointers / transform passed directly); else P = B * P_frame samples
+    int P_frame;
     int mode;            // 0 = mobile-base map (vlmap_builder.py), 1 = global multi-floor map (vlmap_builder_multi_floor.py)
     int depth_u16;
     long long capacity;
@@ -85,18 +98,23 @@ __device__ __forceinline__ double gemv3(const double* a, double x0, double x1, d
     return fma(a[2], x2, fma(a[0], x0, a[1] * x1));
 }
 
-__global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const float* __restrict__ depth,
-                                                          const int32_t* __restrict__ sample_idx,
-                                                          const uint8_t* __restrict__ rgb, int32_t* __restrict__ cell_slot,
+__global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const float* depth, const int32_t* __restrict__ sample_idx,
+                                                          const uint8_t* rgb, int32_t* __restrict__ cell_slot,
                                                           int32_t* __restrict__ slot_cell, Recs recs,
                                                           unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;   // global sample index: frame-major within a batch
     if (s >= fp.P) return;
     double alpha = 0.0;
     int32_t cell = -1, fpix = 0;
     uint32_t rgbv = 0;
 
-    const int pix = sample_idx[s];
+    const BatchEntry* be = fp.batch ? fp.batch + s / fp.P_frame : nullptr;
+    const double* T = be ? be->t : fp.t;
+    if (be) {
+        depth = be->depth;
+        rgb = be->rgb;
+    }
+    const int pix = be ? be->samples[s % fp.P_frame] : sample_idx[s];
     bool ok = pix >= 0 && pix < fp.H * fp.W;
     double pl0 = 0, pl1 = 0, pl2 = 0;
     if (ok) {
@@ -111,9 +129,9 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
     long long row = 0, col = 0, h = 0;
     if (ok) {
         // transform_pc: pose @ [pc; 1]  (dgemm FMA chain k = 0..3)
-        const double g0 = fma(fp.t[3], 1.0, fma(fp.t[2], pl2, fma(fp.t[1], pl1, fp.t[0] * pl0)));
-        const double g1 = fma(fp.t[7], 1.0, fma(fp.t[6], pl2, fma(fp.t[5], pl1, fp.t[4] * pl0)));
-        const double g2 = fma(fp.t[11], 1.0, fma(fp.t[10], pl2, fma(fp.t[9], pl1, fp.t[8] * pl0)));
+        const double g0 = fma(T[3], 1.0, fma(T[2], pl2, fma(T[1], pl1, T[0] * pl0)));
+        const double g1 = fma(T[7], 1.0, fma(T[6], pl2, fma(T[5], pl1, T[4] * pl0)));
+        const double g2 = fma(T[11], 1.0, fma(T[10], pl2, fma(T[9], pl1, T[8] * pl0)));
         if (fp.mode == 0) {
             // base_pos2grid_id_3d: int(gs/2 - int(x/cs)) with a true fp64 divide
             row = py_int(fp.half_gs - (double)py_int(g0 / fp.cs));
@@ -194,7 +212,8 @@ struct ReplayLog {
 
 __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
                                                    Recs recs, unsigned long long* __restrict__ counters, ReplayLog log,
-                                                   long long log_base, unsigned long long frame_key) {
+                                                   long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                                   int P_frame) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= P) return;
     const int32_t cell = recs.cell[s];
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restr
     if (log.slot) {
         const long long i = log_base + s;
         log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
-        log.key[i] = frame_key | (unsigned)s;
+        log.key[i] = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
         log.alpha[i] = recs.alpha[s];
         log.rgb[i] = recs.rgb[s];
     }
@@ -227,8 +246,8 @@ __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restr
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
 template <int CH>
-__global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, Recs recs,
-                                                   int32_t* __restrict__ head, const float* __restrict__ feat,
+__global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                                   int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                                    double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
                                                    unsigned long long* __restrict__ slot_key) {
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
     while (cur >= 0) {
         const double alpha = recs.alpha[cur];
         const int nxt = recs.next[cur];
-        const float* f = feat + (size_t)recs.fpix[cur] * D;
+        const float* f = (batch ? batch[cur / P_frame].feat : feat) + (size_t)recs.fpix[cur] * D;
         const uint32_t rgbv = recs.rgb[cur];
         const bool first = cur < min_s;  // wave-uniform
         if (first) { min_s = cur; a1 = alpha; }
@@ -302,14 +321,15 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
         }
         if (lane == 0) {
             first_alpha[slot] = a1;
-            slot_key[slot] = frame_key | (unsigned)min_s;
+            slot_key[slot] = batch ? (batch[min_s / P_frame].frame_key | (unsigned)(min_s % P_frame)) : (frame_key | (unsigned)min_s);
         }
     }
     if (lane == 0) head[slot] = -1;  // ready for the next frame
 }
 
 // generic feature width: one 256-float chunk at a time, re-walking the (short) list per chunk
-__global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigned long long frame_key, Recs recs,
+__global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigned long long frame_key,
+                                                           const BatchEntry* __restrict__ batch, int P_frame, Recs recs,
                                                            int32_t* __restrict__ head, const float* __restrict__ feat,
                                                            double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                            float* __restrict__ first_feat, double* __restrict__ first_alpha,
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigne
         double acc = 0.0;
         float f1 = 0.f;
         for (int cur = h0; cur >= 0; cur = recs.next[cur]) {
-            const float v = feat[(size_t)recs.fpix[cur] * D + d];
+            const float v = (batch ? batch[cur / P_frame].feat : feat)[(size_t)recs.fpix[cur] * D + d];
             acc += recs.alpha[cur] * (double)v;
             if (cur == min_s) f1 = v;
         }
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigne
     if (lane == 0) {
         if (is_new) {
             first_alpha[slot] = a1;
-            slot_key[slot] = frame_key | (unsigned)min_s;
+            slot_key[slot] = batch ? (batch[min_s / P_frame].frame_key | (unsigned)(min_s % P_frame)) : (frame_key | (unsigned)min_s);
         }
         head[slot] = -1;
     }
@@ -548,6 +568,8 @@ struct avl_builder {
     unsigned long long key_bias = 0;  // set after import_map so that imported voxels order before new ones
     ReplayLog log{};
     long long log_cap = 0, log_used = 0;
+    BatchEntry* d_table = nullptr;
+    int table_cap = 0;
 };
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
@@ -607,6 +629,7 @@ int avl_builder_destroy(avl_builder* b) {
     (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->head);
     (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
     (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+    (void)hipFree(b->d_table);
     delete b;
     return AVL_OK;
 }
@@ -677,21 +700,51 @@ int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, in
     return avl_builder_create_grid(h_out, gs, gs, vh, cs, D, capacity);
 }
 
+// B == 0: one frame, pointers passed directly.  B > 0: h_*_ptrs[B] give the per-frame device buffers, h_pc_transform holds B 4x4s,
+// frames frame_idx .. frame_idx + B - 1 are fused by ONE K1/K2/K3 triple (samples of a voxel from different frames share one list).
 static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, double depth_div, int H, int W, const double* h_calib,
                           const double* h_calib_inv, const double* h_pc_transform, const int32_t* d_sample_idx, int P,
                           const float* d_feat, int Hf, int Wf, const uint8_t* d_rgb, int64_t frame_idx, double min_depth,
-                          double max_depth, double sigma_sq, const double* h_pcd_min, void* stream) {
+                          double max_depth, double sigma_sq, const double* h_pcd_min, void* stream, int B = 0,
+                          const void* const* h_depth_ptrs = nullptr, const int32_t* const* h_sample_ptrs = nullptr,
+                          const float* const* h_feat_ptrs = nullptr, const uint8_t* const* h_rgb_ptrs = nullptr) {
     AVL_REQUIRE(b, "avl_builder_integrate_frame: null handle");
     AVL_REQUIRE(H > 0 && W > 0 && Hf > 0 && Wf > 0 && P >= 0, "avl_builder_integrate_frame: bad shape");
     AVL_REQUIRE(P < (1 << 30), "avl_builder_integrate_frame: at most 2^30 samples per frame");
-    AVL_REQUIRE(frame_idx >= 0 && frame_idx < (1ll << 30), "avl_builder_integrate_frame: bad frame_idx");
+    AVL_REQUIRE(B >= 0 && (int64_t)(B > 0 ? B : 1) * P < (1ll << 30), "avl_builder_integrate_batch: at most 2^30 samples per launch");
+    AVL_REQUIRE(frame_idx >= 0 && frame_idx + B < (1ll << 30), "avl_builder_integrate_frame: bad frame_idx");
     AVL_REQUIRE(sigma_sq > 0, "avl_builder_integrate_frame: sigma_sq must be positive");
     if (P == 0) return AVL_OK;
-    AVL_REQUIRE(d_depth && h_calib && h_calib_inv && h_pc_transform && d_sample_idx && d_feat && d_rgb,
-                "avl_builder_integrate_frame: null pointer");
+    AVL_REQUIRE(h_calib && h_calib_inv && h_pc_transform, "avl_builder_integrate_frame: null pointer");
+    if (B == 0) AVL_REQUIRE(d_depth && d_sample_idx && d_feat && d_rgb, "avl_builder_integrate_frame: null pointer");
+    else AVL_REQUIRE(h_depth_ptrs && h_sample_ptrs && h_feat_ptrs && h_rgb_ptrs, "avl_builder_integrate_batch: null pointer table");
     hipStream_t st = as_stream(stream);
+    const int P_frame = P;
+    if (B > 0) P = B * P_frame;   // total samples of the launch
     int rc = ensure_recs(b, P, st);
     if (rc != AVL_OK) return rc;
+    const unsigned long long key_bias = b->key_bias;
+    if (B > 0) {
+        if (B > b->table_cap) {
+            AVL_HIP_CHECK(hipStreamSynchronize(st));
+            if (b->d_table) AVL_HIP_CHECK(hipFree(b->d_table));
+            b->d_table = nullptr;
+            AVL_HIP_CHECK(hipMalloc((void**)&b->d_table, (size_t)(B + 16) * sizeof(BatchEntry)));
+            b->table_cap = B + 16;
+        }
+        std::vector<BatchEntry> tab((size_t)B);
+        for (int i = 0; i < B; ++i) {
+            AVL_REQUIRE(h_depth_ptrs[i] && h_sample_ptrs[i] && h_feat_ptrs[i] && h_rgb_ptrs[i], "avl_builder_integrate_batch: null frame %d", i);
+            memcpy(tab[i].t, h_pc_transform + 16 * i, 16 * sizeof(double));
+            tab[i].depth = reinterpret_cast<const float*>(h_depth_ptrs[i]);
+            tab[i].samples = h_sample_ptrs[i];
+            tab[i].rgb = h_rgb_ptrs[i];
+            tab[i].feat = h_feat_ptrs[i];
+            tab[i].frame_key = key_bias | ((unsigned long long)(frame_idx + i) << 32);
+        }
+        // pageable source: the runtime stages the bytes before returning, so `tab` may go out of scope
+        AVL_HIP_CHECK(hipMemcpyAsync(b->d_table, tab.data(), (size_t)B * sizeof(BatchEntry), hipMemcpyHostToDevice, st));
+    }
     FrameParams fp;
     for (int i = 0; i < 9; ++i) { fp.kinv[i] = h_calib_inv[i]; fp.k[i] = h_calib[i]; fp.kf[i] = 0.0; }
     // get_sim_cam_mat(h, w): eye(3); [0,0] = [1,1] = w/2; [0,2] = w/2; [1,2] = h/2
@@ -704,6 +757,8 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     fp.two_sigma_sq = 2 * sigma_sq;
     fp.cs = b->cs; fp.half_gs = (double)b->gs / 2.0;
     fp.H = H; fp.W = W; fp.Hf = Hf; fp.Wf = Wf; fp.n0 = b->n0; fp.n1 = b->gs; fp.n2 = b->vh; fp.P = P;
+    fp.batch = B > 0 ? b->d_table : nullptr;
+    fp.P_frame = P_frame;
     fp.mode = h_pcd_min ? 1 : 0;
     for (int i = 0; i < 3; ++i) fp.pcd_min[i] = h_pcd_min ? h_pcd_min[i] : 0.0;
     fp.depth_u16 = depth_u16;
@@ -719,19 +774,19 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb, b->cell_slot,
                        b->slot_cell, b->recs, b->counters, b->err_flags);
     hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters, b->log, b->log_used,
-                       frame_key);
+                       frame_key, fp.batch, P_frame);
     if (b->log.slot) b->log_used += P;
     if (b->D <= 256)
-        hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
+        hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
     else if (b->D <= 512)
-        hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
+        hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
     else if (b->D <= 1024)
-        hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat, b->sum_feat,
+        hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
     else
-        hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, b->recs, b->head, d_feat,
+        hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat,
                            b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
@@ -754,6 +809,16 @@ int avl_builder_integrate_frame_global(avl_builder* b, const void* d_depth, int 
     AVL_REQUIRE(!depth_is_u16 || depth_div > 0, "avl_builder_integrate_frame_global: depth_div must be positive");
     return integrate_impl(b, d_depth, depth_is_u16 ? 1 : 0, depth_div, H, W, h_calib, h_calib_inv, h_transform, d_sample_idx, P, d_feat,
                           Hf, Wf, d_rgb, frame_idx, min_depth, max_depth, sigma_sq, h_pcd_min, stream);
+}
+
+int avl_builder_integrate_batch(avl_builder* b, int B, const float* const* h_depth_ptrs, int H, int W, const double* h_calib,
+                                const double* h_calib_inv, const double* h_pc_transforms, const int32_t* const* h_sample_ptrs, int P,
+                                const float* const* h_feat_ptrs, int Hf, int Wf, const uint8_t* const* h_rgb_ptrs, int64_t frame_idx0,
+                                double min_depth, double max_depth, double sigma_sq, void* stream) {
+    AVL_REQUIRE(B > 0, "avl_builder_integrate_batch: B must be positive");
+    return integrate_impl(b, nullptr, 0, 1.0, H, W, h_calib, h_calib_inv, h_pc_transforms, nullptr, P, nullptr, Hf, Wf, nullptr, frame_idx0,
+                          min_depth, max_depth, sigma_sq, nullptr, stream, B, reinterpret_cast<const void* const*>(h_depth_ptrs),
+                          h_sample_ptrs, h_feat_ptrs, h_rgb_ptrs);
 }
 
 static int read_counter(avl_builder* b, int which, int64_t* h_n, hipStream_t st) {

@@ -151,6 +151,41 @@ class VoxelAccumulator:
         self._keep = (k1, k2, k3, k4)   # inputs must outlive the asynchronous launches
         return self
 
+    def integrate_batch(self, depths, calib, pc_transforms, sample_idxs, feats_hwc, rgbs, frame_idx0, calib_inv=None,
+                        min_depth=0.1, max_depth=6.0, sigma_sq=0.6, stream=None):
+        """Fuse len(depths) consecutive frames with one launch triple (avl_builder_integrate_batch).  Arguments are lists of
+        per-frame arrays (numpy / DeviceArray / torch CUDA) with identical shapes; results equal frame-by-frame fusion."""
+        lib = _lib.load()
+        B = len(depths)
+        assert B > 0 and len(pc_transforms) == len(sample_idxs) == len(feats_hwc) == len(rgbs) == B
+        keep, dptr, sptr, fptr, rptr = [], [], [], [], []
+        shapes = None
+        for i in range(B):
+            dp, dshape, k1 = as_device(depths[i], np.float32, stream)
+            fp_, fshape, k2 = as_device(feats_hwc[i], np.float32, stream)
+            rp, rshape, k3 = as_device(rgbs[i], np.uint8, stream)
+            sp, sshape, k4 = as_device(sample_idxs[i], np.int32, stream)
+            sh = (tuple(dshape), tuple(fshape), tuple(rshape), int(np.prod(sshape)))
+            if shapes is None:
+                shapes = sh
+            elif sh != shapes:
+                raise ValueError("all frames of a batch must share their shapes")
+            keep += [k1, k2, k3, k4]
+            dptr.append(dp); fptr.append(fp_); rptr.append(rp); sptr.append(sp)
+        (H, W), (Hf, Wf, D), _, P = shapes
+        if D != self.D:
+            raise ValueError(f"feature dim {D} != {self.D}")
+        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
+        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
+        T = np.ascontiguousarray(np.asarray(pc_transforms, dtype=np.float64).reshape(B, 16))
+        arr = lambda ptrs: (C.c_void_p * B)(*ptrs)
+        a_d, a_s, a_f, a_r = arr(dptr), arr(sptr), arr(fptr), arr(rptr)
+        rc = lib.avl_builder_integrate_batch(self._h, B, a_d, H, W, K.ctypes.data, Kinv.ctypes.data, T.ctypes.data, a_s, P, a_f, Hf, Wf,
+                                             a_r, int(frame_idx0), float(min_depth), float(max_depth), float(sigma_sq), stream)
+        _lib.check(rc, "avl_builder_integrate_batch")
+        self._keep = keep
+        return self
+
     def integrate_frame_global(self, depth, calib, transform, sample_idx, feat_hwc, rgb, frame_idx, pcd_min, depth_div=1000.0,
                                calib_inv=None, min_depth=0.1, max_depth=100.0, sigma_sq=0.6, stream=None):
         """Global (multi-floor) fusion, vlmap_builder_multi_floor.py:137-199.  depth: (H,W) uint16 (metres = value /

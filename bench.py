@@ -231,6 +231,9 @@ def run_index(args, torch, dist, lib, rank, ws):
                 del sc
                 torch.cuda.empty_cache()
                 out["extra"]["map_build"] = run_build_core(args, torch, dist, lib, 0, 1, frames=args.build_frames, quiet=True)
+                args.build_batch = 16      # 16 frames per launch triple (avl_builder_integrate_batch)
+                out["extra"]["map_build_batched"] = run_build_core(args, torch, dist, lib, 0, 1, frames=args.build_frames * 4, quiet=True)
+                args.build_batch = 1
     return out
 
 
@@ -291,17 +294,28 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
     P = int(samples[0].numel())
     acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=args.capacity)
 
+    BATCH = max(1, int(args.build_batch))
+
     def fuse(i):
         b = i % nbuf
         acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
+
+    def fuse_batch(i0, i1):
+        idx = [i % nbuf for i in range(i0, i1)]
+        acc.integrate_batch([depths[b] for b in idx], calib, Ts[i0:i1], [samples[b] for b in idx], [feats[b] for b in idx],
+                            [rgbs[b] for b in idx], frame_idx0=i0)
 
     nwarm = min(args.warmup, hi - lo)
     for i in range(lo, lo + nwarm):
         fuse(i)
     barrier_sync(torch, dist, ws)
     t0 = time.perf_counter()
-    for i in range(lo + nwarm, hi):
-        fuse(i)
+    if BATCH == 1:
+        for i in range(lo + nwarm, hi):
+            fuse(i)
+    else:
+        for i0 in range(lo + nwarm, hi, BATCH):
+            fuse_batch(i0, min(hi, i0 + BATCH))
     torch.cuda.synchronize()
     dt = max_over_ranks(torch, dist, ws, time.perf_counter() - t0)
     timed = hi - lo - nwarm
@@ -326,7 +340,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
     pts_per_frame = npts / nfr
     groups, newv = acc.num_groups() / nfr, nvox / nfr
     alg_frame = P * (4 + 4 + 29) + pts_per_frame * (3 + D * 4 + 29) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
-    res = dict(frames_per_s=timed_all / dt, ms_per_frame=dt / max(1, timed) * 1e3, frames_timed_per_gpu=timed,
+    res = dict(frames_per_launch=BATCH, frames_per_s=timed_all / dt, ms_per_frame=dt / max(1, timed) * 1e3, frames_timed_per_gpu=timed,
                sampled_px_per_frame=P, active_points_per_frame=pts_per_frame, voxel_groups_per_frame=groups,
                new_voxels_per_frame=newv, voxels_local=nvox, voxels_merged=n_merged,
                merge_finalize_s=t_merge, algorithmic_bytes_per_frame=alg_frame,
@@ -394,6 +408,7 @@ def main():
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--capacity", type=int, default=1_500_000)
     ap.add_argument("--build-frames", type=int, default=300)
+    ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch triple (avl_builder_integrate_batch)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-build-extra", action="store_true")
     ap.add_argument("--profile-run", action="store_true",

@@ -174,6 +174,20 @@ AVL_API int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, in
                                         double max_depth, double sigma_sq, void* stream);
 
 /*
+ * Fuse B consecutive frames (frame_idx0 .. frame_idx0 + B - 1) with ONE launch triple.  Same semantics and results as B calls
+ * of avl_builder_integrate_frame; the samples of a voxel coming from different frames share one list, so the voxel row is
+ * read-modified-written once per batch instead of once per frame, and the per-launch latencies are amortised.
+ * All frames share H, W, P, Hf, Wf and the camera matrix.  h_*_ptrs are HOST arrays of B DEVICE pointers
+ * (depth (H,W) f32, samples (P,) i32, feat (Hf,Wf,D) f32 channels-last, rgb (H,W,3) u8); h_pc_transforms is (B, 16) float64.
+ * The per-frame device buffers must stay valid until the launches have run (stream order).
+ */
+AVL_API int avl_builder_integrate_batch(avl_builder* b, int B, const float* const* h_depth_ptrs, int H, int W,
+                                        const double* h_calib, const double* h_calib_inv, const double* h_pc_transforms,
+                                        const int32_t* const* h_sample_ptrs, int P, const float* const* h_feat_ptrs, int Hf,
+                                        int Wf, const uint8_t* const* h_rgb_ptrs, int64_t frame_idx0, double min_depth,
+                                        double max_depth, double sigma_sq, void* stream);
+
+/*
  * Global (multi-floor) variant of the frame fusion: replaces vlmap_builder_multi_floor.py:137-199.
  *   voxel index = np.round((p_global - pcd_min) / cs) per axis, (row, height, col) = (x, y, z) (:146);
  *   d_depth is float32 metres, or uint16 with metres = value / depth_div (depth PNGs / 1000.0, :105);

@@ -211,3 +211,26 @@ def test_sharded_build_merges_to_the_single_gpu_map(ops, golden):
     one = parallel.merge_raw(ops.export_raw_torch(run_gpu_builder(ops, *args, Ts, g["depths"], g["rgbs"], g["feats"], g["samples"],
                                                                    capacity=2000)))
     assert torch.equal(one["cell"].cpu(), merged["cell"].cpu())
+
+
+@pytest.mark.parametrize("batch", [2, 3, 6])
+def test_batched_fusion_equals_frame_by_frame(ops, golden, batch):
+    """avl_builder_integrate_batch: several frames per launch triple, same map (ids and colour exact, features to rounding)"""
+    from oracle import avl_oracle as O
+    g = golden("g2a_builder_small.npz")
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    args = (int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"])
+    ref = run_gpu_builder(ops, *args, Ts, g["depths"], g["rgbs"], g["feats"], g["samples"], capacity=2000, replay=True).finalize()
+    D = g["feats"].shape[1]
+    acc = ops.VoxelAccumulator(args[0], args[1], int(args[2] / args[1]), D, capacity=2000)
+    acc.enable_replay_log(sum(len(s) for s in g["samples"]))
+    n = len(g["depths"])
+    for i0 in range(0, n, batch):
+        sl = slice(i0, min(n, i0 + batch))
+        feats = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in g["feats"][sl]]
+        acc.integrate_batch(list(g["depths"][sl]), g["calib"], Ts[sl], list(g["samples"][sl]), feats, list(g["rgbs"][sl]), frame_idx0=i0)
+    out = acc.finalize()
+    assert acc.num_points() > 0 and np.array_equal(out["grid_pos"], ref["grid_pos"])
+    assert np.array_equal(out["grid_pos"], g["grid_pos"]) and np.array_equal(out["occupied_ids"], ref["occupied_ids"])
+    assert np.array_equal(out["grid_rgb"], ref["grid_rgb"]) and np.array_equal(out["weight"], ref["weight"])
+    np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=1e-6, atol=1e-6)
