@@ -40,6 +40,7 @@ class VLMapBuilder:
         self.min_depth, self.max_depth = 0.1, 6    # vlmap_builder.py:129
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
+        self.batch_frames = 1                      # >1: fuse that many frames per launch triple (same map, fewer launches)
 
     # ------------------------------------------------------------------ pose chain (host, float64)
     def frame_transforms(self, base_poses: np.ndarray) -> List[np.ndarray]:
@@ -117,6 +118,7 @@ class VLMapBuilder:
         vh = int(camera_height / cs)                 # vlmap_builder.py:201
         acc = None
         mapped_iter_set = set()
+        pending = []
         for frame_i in range(lo, hi):
             rgb, depth = self.load_frame(frame_i)
             feat = self._features_hwc(rgb)
@@ -131,16 +133,39 @@ class VLMapBuilder:
                     npix = depth.shape[0] * depth.shape[1]
                     acc.enable_replay_log((hi - lo) * ((npix + depth_sample_rate - 1) // depth_sample_rate))
             samples = self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
-            acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
-                                calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,
-                                sigma_sq=self.sigma_sq)
+            if self.batch_frames > 1:
+                pending.append((frame_i, depth, samples, feat, rgb))
+                if len(pending) >= self.batch_frames:
+                    self._flush(acc, pending, calib_mat, calib_inv, transforms)
+            else:
+                acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
+                                    calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,
+                                    sigma_sq=self.sigma_sq)
             mapped_iter_set.add(frame_i)
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
+                self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
                 self._save_3d_map(acc.finalize(), mapped_iter_set)
         if acc is None:
             raise RuntimeError("no frames to map")
+        self._flush(acc, pending, calib_mat, calib_inv, transforms)
         self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
+
+    def _flush(self, acc, pending, calib_mat, calib_inv, transforms):
+        """fuse the buffered frames (consecutive indices, equal shapes) with one launch triple"""
+        if not pending:
+            return
+        i0 = pending[0][0]
+        same = all(p[1].shape == pending[0][1].shape and tuple(p[3].shape) == tuple(pending[0][3].shape) for p in pending)
+        if same and len(pending) > 1 and [p[0] for p in pending] == list(range(i0, i0 + len(pending))):
+            acc.integrate_batch([p[1] for p in pending], calib_mat, [transforms[p[0]] for p in pending], [p[2] for p in pending],
+                                [p[3] for p in pending], [p[4] for p in pending], frame_idx0=i0, calib_inv=calib_inv,
+                                min_depth=self.min_depth, max_depth=self.max_depth, sigma_sq=self.sigma_sq)
+        else:
+            for fi, depth, samples, feat, rgb in pending:
+                acc.integrate_frame(depth, calib_mat, transforms[fi], samples, feat, rgb, frame_idx=fi, calib_inv=calib_inv,
+                                    min_depth=self.min_depth, max_depth=self.max_depth, sigma_sq=self.sigma_sq)
+        pending.clear()
 
     def create_camera_map(self):
         """Upstream returns (does not raise) NotImplementedError.  Reference: vlmap_builder.py:187-193."""

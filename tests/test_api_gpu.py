@@ -39,11 +39,12 @@ class MemoryBuilder:
         return b
 
 
-@pytest.mark.parametrize("feats_as", ["numpy_chw", "torch_hwc"])
-def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as):
+@pytest.mark.parametrize("feats_as,batch", [("numpy_chw", 1), ("torch_hwc", 1), ("torch_hwc", 4), ("numpy_chw", 2)])
+def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as, batch):
     from avlmaps_amd.utils.mapping_utils import load_3d_map
     g = golden("g2a_builder_small.npz")
     b = MemoryBuilder.make(g, tmp_path, feats_as)
+    b.batch_frames = batch
     np.random.seed(1234)                     # same global-RNG state the reference run had
     b.create_mobile_base_map()
     it, gf, gp, w, occ, rgb = load_3d_map(tmp_path / "vlmap" / "vlmaps.h5df")
