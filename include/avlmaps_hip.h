@@ -57,9 +57,11 @@ AVL_API int avl_memset(void* d_ptr, int value, size_t bytes, void* stream);
 AVL_API int avl_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 AVL_API int avl_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
-/* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32: best GB/s of `iters` passes.
- * pattern 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk.  Used by bench.py to
- * report the box's practical HBM read ceiling next to the 8 TB/s spec peak.  Synchronous. */
+/* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32.
+ * pattern bit 0: 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk;
+ * pattern bit 1: 0 = best GB/s of `iters` individually synchronised passes (burst rate),
+ *                2 = mean GB/s of `iters` back-to-back passes (sustained rate at the package's power operating point).
+ * Used by bench.py to report the box's practical HBM read ceiling next to the 8 TB/s spec peak.  Synchronous. */
 AVL_API int avl_hbm_read_probe(const void* d_buf, int64_t rows, int row_floats, int pattern, int iters, float* h_best_gbs,
                                void* stream);
 /* HIP-event timing on `stream` (bench.py measures kernels on the stream they are launched on) */
