@@ -157,7 +157,7 @@ int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
 
 int avl_hbm_read_probe(const void* d_buf, int64_t rows, int row_floats, int pattern, int iters, float* h_best_gbs, void* stream) {
     AVL_REQUIRE(d_buf && rows > 0 && row_floats > 0 && iters > 0 && h_best_gbs, "avl_hbm_read_probe: bad arguments");
-    AVL_REQUIRE(pattern >= 0 && pattern <= 3, "avl_hbm_read_probe: pattern must be 0..3");
+    AVL_REQUIRE(pattern >= 0 && pattern <= 15, "avl_hbm_read_probe: pattern must be 0..15");
     const bool rowline = (pattern & 1) != 0, sustained = (pattern & 2) != 0;
     AVL_REQUIRE(!rowline || (row_floats % 64 == 0), "avl_hbm_read_probe: the row-line pattern needs row_floats %% 64 == 0");
     hipStream_t st = as_stream(stream);
@@ -172,7 +172,7 @@ int avl_hbm_read_probe(const void* d_buf, int64_t rows, int row_floats, int patt
             hipLaunchKernelGGL(probe_coalesced_kernel, dim3(8192), dim3(256), 0, st, reinterpret_cast<const float4*>(d_buf),
                                (size_t)(bytes / 16), sink);
         else
-            hipLaunchKernelGGL(probe_rowline_kernel, dim3(num_cus() * 2), dim3(512), 0, st, reinterpret_cast<const float*>(d_buf),
+            hipLaunchKernelGGL(probe_rowline_kernel, dim3(num_cus() * ((pattern & 4) ? 1 : ((pattern & 8) ? 3 : 2))), dim3(512), 0, st, reinterpret_cast<const float*>(d_buf),
                                (long long)rows, row_floats, sink);
     };
     float best = 0.f;

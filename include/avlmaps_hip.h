@@ -60,7 +60,8 @@ AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* s
 /* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32.
  * pattern bit 0: 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk;
  * pattern bit 1: 0 = best GB/s of `iters` individually synchronised passes (burst rate),
- *                2 = mean GB/s of `iters` back-to-back passes (sustained rate at the package's power operating point).
+ *                2 = mean GB/s of `iters` back-to-back passes (sustained rate at the package's power operating point);
+ * pattern bits 2-3 (row-line walk only): workgroups per CU, 0 = two (default), 4 = one, 8 = three.
  * Used by bench.py to report the box's practical HBM read ceiling next to the 8 TB/s spec peak.  Synchronous. */
 AVL_API int avl_hbm_read_probe(const void* d_buf, int64_t rows, int row_floats, int pattern, int iters, float* h_best_gbs,
                                void* stream);

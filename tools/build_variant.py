@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Builds an experiment variant of the library: avl_sim.hip recompiled with extra -D flags, linked with the stock objects.
+
+  python tools/build_variant.py NAME -DAVL_ABL_NOMFMA ...   ->  variants/libavlmaps_hip_NAME.so
+Select it at run time with AVLMAPS_HIP_LIB=variants/libavlmaps_hip_NAME.so (same-box A/B runs; box-to-box spread is ~10 %)."""
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from avlmaps_amd import build as B  # noqa: E402
+
+
+def main():
+    name, flags = sys.argv[1], sys.argv[2:]
+    B.build()
+    out = ROOT / "variants"
+    out.mkdir(exist_ok=True)
+    obj = out / f"avl_sim_{name}.o"
+    cmd = [B._hipcc(), *B.COMMON, *flags, "-c", str(B.CSRC / "avl_sim.hip"), "-o", str(obj)]
+    subprocess.run(cmd, check=True)
+    objs = [str(obj)] + [str(B.PKG / "build" / (Path(s).stem + ".o")) for s in B.SOURCES if s != "avl_sim.hip"]
+    lib = out / f"libavlmaps_hip_{name}.so"
+    subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", str(lib), *objs], check=True)
+    print(lib)
+
+
+if __name__ == "__main__":
+    main()

@@ -88,8 +88,12 @@ def main():
     CARD = pick_card()
     print("card:", CARD)
     print("idle", sensors())
+    import os
+    only = os.environ.get("PP_KERNELS")
     for name, fn, per in (("split_f16", k_split, 1), ("prepared", k_prep, 1), ("exact_f32_mfma", k_exact_mfma, 1),
                           ("probe_rowline", k_probe_row, 40), ("probe_coalesced", k_probe_coal, 40)):
+        if only and name not in only.split(","):
+            continue
         samples = []
         stop = False
 
