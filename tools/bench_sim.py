@@ -12,22 +12,22 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from avlmaps_amd import _lib  # noqa: E402
 
 
-def time_call(lib, fn, iters=10, warmup=3):
+def time_call(lib, fn, iters=60, warmup=40):
+    """sustained per-launch time: `iters` back-to-back launches between one event pair after `warmup` untimed ones
+    (the first ~30 launches after an idle gap run slow while the power controller settles); returns (mean, mean)"""
     e0, e1 = C.c_void_p(), C.c_void_p()
     lib.avl_event_create(C.byref(e0)); lib.avl_event_create(C.byref(e1))
     for _ in range(warmup):
         fn()
-    lib.avl_device_sync()
-    ts = []
+    lib.avl_event_record(e0, None)
     for _ in range(iters):
-        lib.avl_event_record(e0, None)
         fn()
-        lib.avl_event_record(e1, None)
-        lib.avl_event_sync(e1)
-        ms = C.c_float()
-        lib.avl_event_elapsed_ms(e0, e1, C.byref(ms))
-        ts.append(ms.value)
-    return np.median(ts), np.min(ts)
+    lib.avl_event_record(e1, None)
+    lib.avl_event_sync(e1)
+    ms = C.c_float()
+    lib.avl_event_elapsed_ms(e0, e1, C.byref(ms))
+    lib.avl_event_destroy(e0); lib.avl_event_destroy(e1)
+    return ms.value / iters, ms.value / iters
 
 
 def main():

@@ -23,7 +23,12 @@ for name in ("pmc_index.json", "pmc_build.json"):
     d = {k: v for k, v in json.load(open(src / name)).items() if "avl" in k}
     json.dump(d, open(dst / f"{tag}_{name}", "w"), indent=1)
     pmc[name] = d
-for name in ("index_bench.log", "build_bench.log"):
+import shutil
+if (src / "power_probe.txt").exists():
+    shutil.copy(src / "power_probe.txt", dst / f"{tag}_power_probe.txt")
+for name in ("index_bench.log", "build_bench.log", "bench_default.log"):
+    if not (src / name).exists():
+        continue
     lines = [l for l in open(src / name) if l.startswith("{")]
     open(dst / f"{tag}_{name.replace('.log', '.json')}", "w").writelines(lines)
 
