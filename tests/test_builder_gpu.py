@@ -234,3 +234,82 @@ def test_batched_fusion_equals_frame_by_frame(ops, golden, batch):
     assert np.array_equal(out["grid_pos"], g["grid_pos"]) and np.array_equal(out["occupied_ids"], ref["occupied_ids"])
     assert np.array_equal(out["grid_rgb"], ref["grid_rgb"]) and np.array_equal(out["weight"], ref["weight"])
     np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=1e-6, atol=1e-6)
+
+
+def test_full_size_build_properties(ops):
+    """BASELINE config-3 frame shape (720x1080 depth, 347x520x512 features, 7 776 samples per frame): properties that do
+    not need the sequential oracle -- id order is first-touch order, occupied_ids inverts grid_pos, frame-by-frame ==
+    batched == two shards merged, a second finalize is idempotent, and a sample of voxels agrees with a float64
+    recomputation of the closed form from the raw accumulators."""
+    import torch
+    import bench
+    from avlmaps_amd import parallel
+    H, W, Hf, Wf, D, rate, F = 720, 1080, 347, 520, 512, 100, 48
+    nbuf = 4
+    depths, rgbs, feats = bench.make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=3)
+    Ts = bench.pc_transforms(bench.trajectory(F))
+    calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
+    rs = np.random.RandomState(17)
+    samples = []
+    for _ in range(nbuf):
+        m = np.arange(H * W)
+        rs.shuffle(m)
+        samples.append(torch.from_numpy(m[::rate].astype(np.int32)).cuda())
+    assert samples[0].numel() == 7776
+
+    def build(lo, hi, batch=1, replay=True):
+        acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=400_000)
+        if replay:
+            acc.enable_replay_log((hi - lo) * 7776)
+        i = lo
+        while i < hi:
+            j = min(hi, i + batch)
+            idx = [k % nbuf for k in range(i, j)]
+            if batch == 1:
+                acc.integrate_frame(depths[idx[0]], calib, Ts[i], samples[idx[0]], feats[idx[0]], rgbs[idx[0]], frame_idx=i)
+            else:
+                acc.integrate_batch([depths[b] for b in idx], calib, Ts[i:j], [samples[b] for b in idx], [feats[b] for b in idx],
+                                    [rgbs[b] for b in idx], frame_idx0=i)
+            i = j
+        return acc
+
+    a = build(0, F)
+    out = a.finalize()
+    n = out["grid_pos"].shape[0]
+    assert n > 50_000 and a.num_points() > 100_000
+    # occupied_ids is the inverse of grid_pos and ids are dense 0..n-1
+    pos = out["grid_pos"].astype(np.int64)
+    assert np.array_equal(out["occupied_ids"][pos[:, 0], pos[:, 1], pos[:, 2]], np.arange(n, dtype=np.int32))
+    assert int((out["occupied_ids"] >= 0).sum()) == n
+    assert np.all(out["weight"] > 0) and np.isfinite(out["grid_feat"]).all()
+    # idempotent finalize
+    out2 = a.finalize()
+    for k in ("grid_pos", "grid_feat", "weight", "grid_rgb", "occupied_ids"):
+        assert np.array_equal(out[k], out2[k]), k
+    # first-touch order: exported keys ascend in id order
+    raw = ops.export_raw_torch(a)
+    order = torch.argsort(raw["first_key"])
+    cells = raw["cell"][order].cpu().numpy().astype(np.int64)
+    lin = (pos[:, 0] * 1000 + pos[:, 1]) * 30 + pos[:, 2]
+    assert np.array_equal(np.sort(cells), np.sort(lin))
+    # closed form in float64 from the raw accumulators on a sample of voxels
+    rs2 = np.random.RandomState(1)
+    pick = torch.from_numpy(rs2.choice(n, 512, replace=False)).cuda()
+    sel = order[pick]
+    sf, sw = raw["sum_feat"][sel], raw["sum_w4"][sel][:, 0:1]
+    a1, f1 = raw["first_alpha"][sel][:, None], raw["first_feat"][sel].double()
+    want = ((sf - a1 * (1.0 - a1) * f1) / sw).cpu().numpy()
+    got = out["grid_feat"][pick.cpu().numpy()]
+    np.testing.assert_allclose(got, want.astype(np.float32), rtol=2e-6, atol=1e-6)
+    # batched fusion: identical ids / colour / weight, features to rounding
+    b = build(0, F, batch=8).finalize()
+    assert np.array_equal(b["grid_pos"], out["grid_pos"]) and np.array_equal(b["occupied_ids"], out["occupied_ids"])
+    assert np.array_equal(b["grid_rgb"], out["grid_rgb"]) and np.array_equal(b["weight"], out["weight"])
+    np.testing.assert_allclose(b["grid_feat"], out["grid_feat"], rtol=1e-6, atol=1e-6)
+    # two frame shards merged with the multi-GPU merge math
+    raws = [ops.export_raw_torch(build(0, F // 2, replay=False)), ops.export_raw_torch(build(F // 2, F, replay=False))]
+    merged = parallel.merge_raw_local(raws)
+    m = ops.finalize_raw({kk: v for kk, v in merged.items() if kk != "first_key"}, D, 1000, 30)
+    assert np.array_equal(m["grid_pos"], out["grid_pos"]) and np.array_equal(m["occupied_ids"], out["occupied_ids"])
+    np.testing.assert_allclose(m["grid_feat"], out["grid_feat"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(m["weight"], out["weight"], rtol=1e-6)
