@@ -147,7 +147,7 @@ constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup it
 // image layout: [nkc][2 (hi, lo)][Qtot][KC + pad] fp16, Qtot = Q rounded up to 32
 __global__ __launch_bounds__(256) void sim_prep_queries_kernel(const float* __restrict__ q, int Q, int D, int64_t ldq,
                                                                float* __restrict__ inv_scale, _Float16* __restrict__ img,
-                                                               int Qtot, int KC, int nkc) {
+                                                               int Qtot, int KC, int nkc, int interleaved) {
     __shared__ float red[4];
     __shared__ float scale_s;
     const int qg = blockIdx.x;
@@ -170,6 +170,26 @@ __global__ __launch_bounds__(256) void sim_prep_queries_kernel(const float* __re
     __syncthreads();
     const float scale = scale_s;
     const int rowlen = KC + kRowPadHalves;
+    if (interleaved) {
+        // streaming kernel: [nkc][Qtot][hi KC | lo KC | pad] -- a query chunk's rows are one contiguous block
+        const int rowblk = 2 * KC + kRowPadHalves;
+        for (int kc = 0; kc < nkc; ++kc) {
+            _Float16* hi = img + ((int64_t)kc * Qtot + qg) * rowblk;
+            for (int kk = threadIdx.x; kk < KC + kRowPadHalves; kk += blockDim.x) {
+                const int k = kc * KC + kk;
+                float v = 0.f;
+                if (live && kk < KC && k < D) v = row[k] * scale;
+                const half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(v, 0.f));
+                if (kk < KC) {
+                    hi[kk] = h[0];
+                    hi[KC + kk] = (_Float16)(v - (float)h[0]);
+                } else {
+                    hi[KC + kk] = (_Float16)0;
+                }
+            }
+        }
+        return;
+    }
     for (int kc = 0; kc < nkc; ++kc) {
         _Float16* hi = img + ((int64_t)(kc * 2) * Qtot + qg) * rowlen;
         _Float16* lo = hi + (int64_t)Qtot * rowlen;
@@ -205,6 +225,72 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi
         lo[2 * p + 1] = l[1];
     }
 #endif
+}
+
+// epilogue shared by the split-fp16 kernels: this lane holds voxel `row`, queries q_base + t*32 + 8g + 4kg + e (g<4, e<4) in
+// acc[t][a][4g+e]; the NA partial accumulators are summed, scaled back by the per-query 2^-S, optionally stored, and reduced
+// to the row's first maximum (one cross-half shuffle); later query chunks chain through `best`
+template <int QT, int NA>
+__device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], const float* isc, int q_base, int rows, int Q,
+                                               float* __restrict__ scores, int32_t* __restrict__ argmax,
+                                               float* __restrict__ best, int64_t row, int64_t N, int kg, int first_chunk) {
+    const int qend = q_base + rows;  // first query index NOT in this chunk
+    float bv = -INFINITY;
+    int bi = INT_MAX;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ql = t * 32 + 8 * g + 4 * kg;
+            const int qg = q_base + ql;
+            const f32x4 is4 = *reinterpret_cast<const f32x4*>(isc + ql);
+            f32x4 v;
+            f32x4 r = {acc[t][0][4 * g + 0], acc[t][0][4 * g + 1], acc[t][0][4 * g + 2], acc[t][0][4 * g + 3]};
+#pragma unroll
+            for (int a = 1; a < NA; ++a) {   // small cross-term sums first would be more accurate still; fp32 add suffices
+                r.x += acc[t][a][4 * g + 0]; r.y += acc[t][a][4 * g + 1]; r.z += acc[t][a][4 * g + 2]; r.w += acc[t][a][4 * g + 3];
+            }
+            v.x = r.x * is4.x;
+            v.y = r.y * is4.y;
+            v.z = r.z * is4.z;
+            v.w = r.w * is4.w;
+            if (scores && row < N) {
+                float* sp = scores + row * (int64_t)Q + qg;
+                if (qg + 3 < qend && (Q & 3) == 0) {
+                    *reinterpret_cast<f32x4*>(sp) = v;
+                } else {
+                    if (qg + 0 < qend) sp[0] = v.x;
+                    if (qg + 1 < qend) sp[1] = v.y;
+                    if (qg + 2 < qend) sp[2] = v.z;
+                    if (qg + 3 < qend) sp[3] = v.w;
+                }
+            }
+            if (qg + 0 < qend && v.x > bv) { bv = v.x; bi = qg + 0; }
+            if (qg + 1 < qend && v.y > bv) { bv = v.y; bi = qg + 1; }
+            if (qg + 2 < qend && v.z > bv) { bv = v.z; bi = qg + 2; }
+            if (qg + 3 < qend && v.w > bv) { bv = v.w; bi = qg + 3; }
+        }
+    }
+    if (argmax || best) {
+        const float ov = __shfl_xor(bv, 32, 64);
+        const int oi = __shfl_xor(bi, 32, 64);
+        if (ov > bv || (ov == bv && oi < bi)) {
+            bv = ov;
+            bi = oi;
+        }
+        if (kg == 0 && row < N) {
+            if (bi == INT_MAX) bi = q_base;
+            if (!first_chunk) {  // earlier chunks hold smaller indices: they win ties
+                const float pv = best[row];
+                if (!(bv > pv)) {
+                    bv = pv;
+                    bi = argmax ? argmax[row] : bi;
+                }
+            }
+            if (argmax) argmax[row] = bi;
+            if (best) best[row] = bv;
+        }
+    }
 }
 
 // in-place conversion of a float32 map to the split layout: group g of 8 floats (32 B) -> hi[8] fp16 (16 B) | lo[8] fp16 (16 B),
@@ -355,64 +441,146 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             }
         }
 
-        // ---- epilogue: this lane holds voxel `row`, queries q_base + t*32 + 8g + 4kg + e (g<4, e<4) in acc[t][4g+e]
-        const int qend = q_base + rows;  // first query index NOT in this chunk
-        float bv = -INFINITY;
-        int bi = INT_MAX;
+        split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming variant of the split kernel for query sets that do not fit LDS whole (Q > 78 at D = 512, or D > 512):
+// ONE pass over the map for up to 128 queries (QT <= 4 MFMA tiles, one accumulator set each).  The query image streams
+// through LDS in K chunks of KS = 64 * SPC columns, double buffered: while the eight waves contract chunk c out of one
+// buffer, every thread stages 16-byte pieces of chunk c+1 (L2-resident, identical for every tile, cyclic) in registers and
+// drops them into the other buffer at the end of the chunk; one raw s_barrier per chunk (the LDS writes are drained with
+// lgkmcnt only, so the voxel prefetch stays in flight across it).  Voxel rows come straight from HBM exactly as in the
+// resident kernel (lane (voxel j, half kg) walks one 128-byte line per 64-wide k step, 2 register buffers), and the last
+// step of a tile prefetches step 0 of the workgroup's next tile.
+// image layout: [nch][Qtot][hi KS | lo KS | pad 8] fp16 (sim_prep_queries_kernel, interleaved) -- a chunk's rows are one
+// contiguous block, copied linearly; the 16-byte pad keeps ds_read_b128 of 32 consecutive rows conflict-free
+// ------------------------------------------------------------------------------------------------
+constexpr int kStreamFill = 9;   // 16-byte staging registers per thread: one LDS buffer <= 9 * 512 * 16 B = 72 KB
+
+template <int QT, int SPC, bool PRE>
+__global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
+    const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
+    const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
+    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
+    static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = 64 * SPC;
+    constexpr int row_b = (2 * KS + kRowPadHalves) * 2;   // bytes per query row of one chunk: hi[KS] | lo[KS] | pad
+    constexpr int lo_b = 2 * KS;                          // byte offset of the lo half inside a row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    const int buf_b = rows * row_b;                       // one LDS buffer = the chunk's rows, a linear copy of the image
+    float* isc = reinterpret_cast<float*>(smem + 2 * buf_b);
+    if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    const int units = buf_b >> 4;
+
+    // the next chunk is staged in SPC slices, one per k step (registers: 5 x 16 B at SPC = 2, 3 x 16 B at SPC = 4)
+    constexpr int NSTG = kStreamFill - ((SPC - 1) * kStreamFill) / SPC;
+    f32x4 stg[NSTG];
+    auto stage_load = [&](int c, int i0, int i1) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + ((int64_t)c * Qtot + q_base) * row_b);
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
+        for (int i = i0; i < i1; ++i) {
+            const int u = threadIdx.x + i * kSplitThreads;
+            if (u < units) stg[i - i0] = src[u];
+        }
+    };
+    auto stage_store = [&](int b, int i0, int i1) {
+        f32x4* dst = reinterpret_cast<f32x4*>(smem + b * buf_b);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ql = t * 32 + 8 * g + 4 * kg;
-                const int qg = q_base + ql;
-                const f32x4 is4 = *reinterpret_cast<const f32x4*>(isc + ql);
-                f32x4 v;
-                f32x4 r = {acc[t][0][4 * g + 0], acc[t][0][4 * g + 1], acc[t][0][4 * g + 2], acc[t][0][4 * g + 3]};
+        for (int i = i0; i < i1; ++i) {
+            const int u = threadIdx.x + i * kSplitThreads;
+            if (u < units) dst[u] = stg[i - i0];
+        }
+    };
+
+    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    auto tile_ptr = [&](int64_t tile) {
+        const int64_t r = tile * kTileRows + wave * 32 + j;
+        return feat + (r < N ? r : N - 1) * ld + 32 * kg;
+    };
+    f32x4 ring[2][8];
+    auto load = [&](f32x4(&b)[8], const float* src) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-                for (int a = 1; a < NA; ++a) {   // small cross-term sums first would be more accurate still; fp32 add suffices
-                    r.x += acc[t][a][4 * g + 0]; r.y += acc[t][a][4 * g + 1]; r.z += acc[t][a][4 * g + 2]; r.w += acc[t][a][4 * g + 3];
+        for (int t = 0; t < 8; ++t) b[t] = g[t];
+    };
+    load(ring[0], tile_ptr(blockIdx.x));   // first tile, step 0: in flight while chunk 0 is brought in
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) {
+        stage_load(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
+        stage_store(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
+    }
+    __syncthreads();
+    int cur = 0;
+
+    int a_off[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) a_off[t] = min(t * 32 + j, rows - 1) * row_b + kg * 64;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * kTileRows + wave * 32 + j;
+        const float* rp = tile_ptr(tile);
+        const bool has_next = tile + gridDim.x < ntiles;
+        const float* p_next = has_next ? tile_ptr(tile + gridDim.x) : rp;
+
+        f32x16 acc[QT][1];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][0][e] = 0.f;
+
+        for (int c = 0; c < nch; ++c) {
+            const int cn = c + 1 < nch ? c + 1 : 0;
+            const char* ab = smem + cur * buf_b;
+#pragma unroll
+            for (int s = 0; s < SPC; ++s) {
+                const int i0 = (s * kStreamFill) / SPC, i1 = ((s + 1) * kStreamFill) / SPC;
+                stage_load(cn, i0, i1);               // issued ahead of this step's voxel prefetch (older in vmcnt order)
+                const float* nxt = rp + 64 * (c * SPC + s + 1);
+                if (s + 1 < SPC) {
+                    load(ring[(s + 1) & 1], nxt);
+                } else if (c + 1 < nch) {
+                    load(ring[0], nxt);
+                } else if (has_next) {
+                    load(ring[0], p_next);
                 }
-                v.x = r.x * is4.x;
-                v.y = r.y * is4.y;
-                v.z = r.z * is4.z;
-                v.w = r.w * is4.w;
-                if (scores && row < N) {
-                    float* sp = scores + row * (int64_t)Q + qg;
-                    if (qg + 3 < qend && (Q & 3) == 0) {
-                        *reinterpret_cast<f32x4*>(sp) = v;
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4(&b)[8] = ring[s & 1];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    half8 bh, bl;
+                    if constexpr (PRE) {
+                        bh = __builtin_bit_cast(half8, b[2 * m]);
+                        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
                     } else {
-                        if (qg + 0 < qend) sp[0] = v.x;
-                        if (qg + 1 < qend) sp[1] = v.y;
-                        if (qg + 2 < qend) sp[2] = v.z;
-                        if (qg + 3 < qend) sp[3] = v.w;
+                        split8(b[2 * m], b[2 * m + 1], bh, bl);
                     }
-                }
-                if (qg + 0 < qend && v.x > bv) { bv = v.x; bi = qg + 0; }
-                if (qg + 1 < qend && v.y > bv) { bv = v.y; bi = qg + 1; }
-                if (qg + 2 < qend && v.z > bv) { bv = v.z; bi = qg + 2; }
-                if (qg + 3 < qend && v.w > bv) { bv = v.w; bi = qg + 3; }
-            }
-        }
-        if (argmax || best) {
-            const float ov = __shfl_xor(bv, 32, 64);
-            const int oi = __shfl_xor(bi, 32, 64);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
-            if (kg == 0 && row < N) {
-                if (bi == INT_MAX) bi = q_base;
-                if (!first_chunk) {  // earlier chunks hold smaller indices: they win ties
-                    const float pv = best[row];
-                    if (!(bv > pv)) {
-                        bv = pv;
-                        bi = argmax ? argmax[row] : bi;
+                    const int off = (s * 64 + 8 * m) * 2;
+                    half8 ah[QT], al[QT];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        ah[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off);
+                        al[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off + lo_b);
                     }
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][0], 0, 0, 0);
                 }
-                if (argmax) argmax[row] = bi;
-                if (best) best[row] = bv;
+                stage_store(cur ^ 1, i0, i1);
             }
+            // publish the next chunk / retire this one: LDS traffic only, the voxel prefetch stays in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            cur ^= 1;
         }
+        split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk);
     }
 }
 
@@ -599,15 +767,27 @@ struct SplitChunk {
 
 struct SplitPlan {
     int Qtot, KC, nkc, nchunks, max_rows;
+    bool stream;   // sim_stream_f16_kernel: KC = 64 * SPC columns per LDS buffer, nkc chunks streamed per tile
+    int SPC;
     SplitChunk chunks[64];
     size_t hdr_bytes, ws_bytes;
-    size_t lds_bytes(const SplitChunk& c) const { return (size_t)4 * c.rows * (KC + kRowPadHalves) + (size_t)c.QT * 32 * sizeof(float); }
+    size_t lds_bytes(const SplitChunk& c) const {
+        if (stream) return (size_t)2 * c.rows * (2 * KC + kRowPadHalves) * 2 + (size_t)c.QT * 32 * sizeof(float);
+        return (size_t)4 * c.rows * (KC + kRowPadHalves) + (size_t)c.QT * 32 * sizeof(float);
+    }
 };
 
 constexpr size_t kLdsBudget = 163840 - 512;  // 160 KiB per workgroup minus slack
 
-static bool make_split_plan(int D, int Q, SplitPlan& p) {
+static bool stream_fits(int rows, int KS) {
+    const size_t buf = (size_t)rows * (2 * KS + kRowPadHalves) * 2;   // one chunk: rows x (hi | lo | pad)
+    return 2 * buf + 128 * sizeof(float) <= kLdsBudget && buf <= (size_t)kStreamFill * kSplitThreads * 16;
+}
+
+static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true) {
     if (D % 64 != 0 || D <= 0 || Q <= 0) return false;
+    p.stream = false;
+    p.SPC = 0;
     p.Qtot = (Q + 31) / 32 * 32;
     // rows that fit next to a <=512-wide K chunk: up to 3 MFMA tiles (96 rows) in one pass, e.g. the reference's
     // "64 categories + other" (Q = 65) runs as ONE pass with 65 resident rows instead of 64 + 1
@@ -634,6 +814,29 @@ static bool make_split_plan(int D, int Q, SplitPlan& p) {
     p.nkc = (D + p.KC - 1) / p.KC;
     p.hdr_bytes = (((size_t)p.Qtot * sizeof(float)) + kHdrAlign - 1) / kHdrAlign * kHdrAlign;
     p.ws_bytes = p.hdr_bytes + (size_t)p.nkc * 2 * p.Qtot * (p.KC + kRowPadHalves) * sizeof(_Float16);
+    // one streamed pass handles up to 128 queries at any D: take it when it saves map passes (Q > 78 at D = 512) or when
+    // the resident plan would have to refill LDS per K chunk anyway (D > 512)
+    if (allow_stream && D % 128 == 0) {
+        const int npass_s = (Q + 127) / 128;
+        const int per_s = (Q + npass_s - 1) / npass_s;
+        if (npass_s <= 64 && (p.nkc > 1 || npass_s < p.nchunks)) {
+            const int spc = (D % 256 == 0 && stream_fits(per_s, 256)) ? 4 : 2;
+            if (stream_fits(per_s, 64 * spc)) {
+                p.stream = true;
+                p.SPC = spc;
+                p.KC = 64 * spc;
+                p.nkc = D / p.KC;
+                p.nchunks = 0;
+                p.max_rows = 0;
+                for (int base = 0; base < Q; base += per_s) {
+                    const int take = Q - base < per_s ? Q - base : per_s;
+                    p.chunks[p.nchunks++] = SplitChunk{base, take, (take + 31) / 32};
+                    if (take > p.max_rows) p.max_rows = take;
+                }
+                p.ws_bytes = p.hdr_bytes + (size_t)p.nkc * p.Qtot * (2 * p.KC + kRowPadHalves) * sizeof(_Float16);
+            }
+        }
+    }
     return true;
 }
 
@@ -681,16 +884,42 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     return AVL_OK;
 }
 
+template <int SPC, bool PRE>
+static const void* pick_stream_kernel(int QT) {
+    switch (QT) {
+        case 1: return reinterpret_cast<const void*>(sim_stream_f16_kernel<1, SPC, PRE>);
+        case 2: return reinterpret_cast<const void*>(sim_stream_f16_kernel<2, SPC, PRE>);
+        case 3: return reinterpret_cast<const void*>(sim_stream_f16_kernel<3, SPC, PRE>);
+        default: return reinterpret_cast<const void*>(sim_stream_f16_kernel<4, SPC, PRE>);
+    }
+}
+
 template <bool PRE>
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
     float* inv_scale = reinterpret_cast<float*>(d_ws);
     _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
     hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Q, D, ldq, inv_scale, img, p.Qtot, p.KC,
-                       p.nkc);
+                       p.nkc, p.stream ? 1 : 0);
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
     int64_t blocks = ntiles < num_cus() ? ntiles : num_cus();
     if (blocks < 1) blocks = 1;
+    if (p.stream) {
+        for (int ci = 0; ci < p.nchunks; ++ci) {
+            const SplitChunk& c = p.chunks[ci];
+            const void* kern = p.SPC == 4 ? pick_stream_kernel<4, PRE>(c.QT) : pick_stream_kernel<2, PRE>(c.QT);
+            const size_t lds = p.lds_bytes(c);
+            int rc = ensure_dynamic_lds(kern, lds);
+            if (rc != AVL_OK) return rc;
+            const _Float16* img_c = img;
+            const float* isc_c = inv_scale;
+            int Qtot = p.Qtot, nch = p.nkc, q_base = c.q_base, rows = c.rows, first = ci == 0 ? 1 : 0;
+            void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &nch, &q_base, &rows, &Q, &d_scores, &d_argmax, &d_best, &first};
+            AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
+        }
+        AVL_HIP_CHECK(hipGetLastError());
+        return AVL_OK;
+    }
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
         const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
@@ -734,8 +963,11 @@ extern "C" {
 
 int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes) {
     AVL_REQUIRE(h_bytes, "avl_sim_workspace_bytes: null output");
-    SplitPlan p;
-    *h_bytes = make_split_plan(D, Q, p) ? p.ws_bytes : (size_t)kHdrAlign;
+    SplitPlan p, r;
+    size_t b = kHdrAlign;   // enough for either plan: the exact fp32-MFMA mode always uses the resident one
+    if (make_split_plan(D, Q, p, true) && p.ws_bytes > b) b = p.ws_bytes;
+    if (make_split_plan(D, Q, r, false) && r.ws_bytes > b) b = r.ws_bytes;
+    *h_bytes = b;
     return AVL_OK;
 }
 
@@ -752,7 +984,7 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     SplitPlan p;
     const bool aligned = (ld_feat % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0) &&
                          (!d_scores || (reinterpret_cast<uintptr_t>(d_scores) & 15) == 0);
-    const bool can_split = make_split_plan(D, Q, p) && aligned;
+    const bool can_split = make_split_plan(D, Q, p, precision != AVL_SIM_EXACT) && aligned;
     bool use_split, use_f32_mfma = false;
     if (precision == AVL_SIM_EXACT_VALU) use_split = false;
     else if (precision == AVL_SIM_EXACT) {

@@ -53,7 +53,10 @@ def test_mask_matches_reference_index_map(ops, golden):
 
 @pytest.mark.parametrize("N,D,Q", [(1, 512, 1), (33, 512, 3), (257, 512, 9), (1000, 512, 33), (777, 512, 65),
                                    (300, 768, 40), (129, 1024, 64), (260, 1536, 128), (50, 100, 5), (64, 64, 70),
-                                   (513, 192, 96)])
+                                   (513, 192, 96),
+                                   # streamed query image (sim_stream_f16_kernel): Q > 78 at D = 512, D > 512
+                                   (1000, 512, 96), (513, 512, 128), (700, 512, 200), (257, 256, 130), (300, 1024, 100),
+                                   (100, 640, 90), (2049, 1536, 64), (90, 2048, 27), (300, 1280, 129)])
 def test_shapes_vs_oracle(ops, N, D, Q):
     from oracle import avl_oracle as O
     rng = np.random.default_rng(N * 7 + D + Q)
@@ -178,7 +181,7 @@ def test_prepared_map_gives_bit_identical_scores(ops):
     """avl_sim_prepare_map hoists the fp32 -> fp16 hi/lo split to load time: same operands, same scores, bit for bit"""
     from avlmaps_amd.device import DeviceArray
     rng = np.random.default_rng(8)
-    for N, D, Q in ((3001, 512, 64), (700, 512, 65), (999, 1024, 33), (513, 192, 7)):
+    for N, D, Q in ((3001, 512, 64), (700, 512, 65), (999, 1024, 33), (513, 192, 7), (777, 512, 128), (300, 1536, 100)):
         feat = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-6, 2.5, (N, D)))).astype(np.float32)
         q = rng.standard_normal((Q, D)).astype(np.float32) / np.sqrt(D)
         sc0, am0, b0 = ops.sim_scores(feat, q, want_best=True, precision="split_f16")
