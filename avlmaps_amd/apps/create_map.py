@@ -22,6 +22,8 @@ def main(argv=None):
     ap.add_argument("--feat-dim", type=int, default=512)
     ap.add_argument("--seed", type=int, default=None, help="seed of the global NumPy RNG that orders the pixel sampling")
     ap.add_argument("--capacity", type=int, default=None, help="voxel capacity (default gs*gs)")
+    ap.add_argument("--prefetch", type=int, default=None, help="frames decoded ahead on host threads (default 4, 0 = inline)")
+    ap.add_argument("--batch-frames", type=int, default=None, help="frames fused per launch triple (default 1)")
     args = ap.parse_args(argv)
 
     from avlmaps_amd import parallel
@@ -33,13 +35,18 @@ def main(argv=None):
         np.random.seed(args.seed)
     extractor = HashFeatureExtractor(args.feat_dim) if args.features == "hash" else None
     avlmap = AVLMap(cfg, data_dir=args.data_dir)
-    if args.capacity:
+    if args.capacity or args.prefetch is not None or args.batch_frames:
         import avlmaps_amd.map.vlmap_builder as vb
         orig = vb.VLMapBuilder.__init__
 
         def patched(self, *a, **k):
             orig(self, *a, **k)
-            self.capacity = args.capacity
+            if args.capacity:
+                self.capacity = args.capacity
+            if args.prefetch is not None:
+                self.prefetch_frames = args.prefetch
+            if args.batch_frames:
+                self.batch_frames = args.batch_frames
         vb.VLMapBuilder.__init__ = patched
     t0 = time.perf_counter()
     avlmap.create_map(args.data_dir, feat_extractor=extractor)

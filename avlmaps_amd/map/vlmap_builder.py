@@ -41,6 +41,7 @@ class VLMapBuilder:
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
         self.batch_frames = 1                      # >1: fuse that many frames per launch triple (same map, fewer launches)
+        self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
 
     # ------------------------------------------------------------------ pose chain (host, float64)
     def frame_transforms(self, base_poses: np.ndarray) -> List[np.ndarray]:
@@ -69,6 +70,61 @@ class VLMapBuilder:
         rgb = load_rgb_png(self.rgb_paths[frame_i])
         depth = load_depth_npy(self.depth_paths[frame_i])
         return rgb, depth
+
+    def _frame_stream(self, lo: int, hi: int, depth_sample_rate: int):
+        """(frame_i, rgb, depth, samples) in frame order.  With prefetch_frames > 0 the PNG / npy decoding of the next
+        frames runs on host threads and ONE sampler thread draws the pixel shuffles, strictly in frame order, so the
+        global NumPy RNG is consumed exactly as in the reference loop (vlmap_builder.py:275-277) - provided nothing else
+        draws from np.random while the map is being built (upstream's loop does not).  Pillow, np.load and
+        np.random.shuffle release the GIL, so all of this overlaps with the GPU work of the current frame."""
+        n = int(self.prefetch_frames or 0)
+        if n <= 0 or hi - lo <= 1:
+            for i in range(lo, hi):
+                rgb, depth = self.load_frame(i)
+                yield i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
+            return
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        out = queue.Queue(maxsize=n)
+        stop = threading.Event()
+
+        def sampler(ex):
+            try:
+                futs = {}
+                nxt = lo
+                for i in range(lo, hi):
+                    while nxt < hi and nxt <= i + n:
+                        futs[nxt] = ex.submit(self.load_frame, nxt)
+                        nxt += 1
+                    rgb, depth = futs.pop(i).result()
+                    item = (i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate))
+                    while not stop.is_set():
+                        try:
+                            out.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                out.put(None)
+            except BaseException as e:     # surfaced on the consuming thread
+                out.put(e)
+
+        with ThreadPoolExecutor(max_workers=min(n, 8), thread_name_prefix="avl-frame") as ex:
+            th = threading.Thread(target=sampler, args=(ex,), name="avl-sampler", daemon=True)
+            th.start()
+            try:
+                while True:
+                    item = out.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    yield item
+            finally:
+                stop.set()
+                th.join()
 
     def _init_lseg(self):
         """Reference: vlmap_builder.py:226-264 builds LSegEncNet from demo_e200.ckpt.  The model is not part of this
@@ -119,8 +175,7 @@ class VLMapBuilder:
         acc = None
         mapped_iter_set = set()
         pending = []
-        for frame_i in range(lo, hi):
-            rgb, depth = self.load_frame(frame_i)
+        for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate):
             feat = self._features_hwc(rgb)
             if acc is None:
                 D = int(feat.shape[2])
@@ -132,7 +187,6 @@ class VLMapBuilder:
                     # per-sample log -> finalize replays the reference's sequential weight / uint8 colour exactly
                     npix = depth.shape[0] * depth.shape[1]
                     acc.enable_replay_log((hi - lo) * ((npix + depth_sample_rate - 1) // depth_sample_rate))
-            samples = self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
             if self.batch_frames > 1:
                 pending.append((frame_i, depth, samples, feat, rgb))
                 if len(pending) >= self.batch_frames:
@@ -145,7 +199,7 @@ class VLMapBuilder:
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
-                self._save_3d_map(acc.finalize(), mapped_iter_set)
+                self._save_3d_map(acc.finalize(), mapped_iter_set, background=True)
         if acc is None:
             raise RuntimeError("no frames to map")
         self._flush(acc, pending, calib_mat, calib_inv, transforms)
@@ -194,11 +248,35 @@ class VLMapBuilder:
             self._save_3d_map(fin, set(i for s in sets for i in s))
         dist.barrier()
 
-    def _save_3d_map(self, arrays, mapped_iter_set) -> None:
-        """Reference: vlmap_builder.py:313-327 -> mapping_utils.save_3d_map."""
+    def _save_3d_map(self, arrays, mapped_iter_set, background: bool = False) -> None:
+        """Reference: vlmap_builder.py:313-327 -> mapping_utils.save_3d_map.  The periodic checkpoints (every
+        `save_every` frames upstream rewrites the whole file) are written by a host thread while fusion continues; the
+        final save, and any save that follows an unfinished one, waits."""
         self.last_map = arrays
-        save_3d_map(self.map_save_path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"],
-                    list(mapped_iter_set), arrays["grid_rgb"])
+        prev = getattr(self, "_save_thread", None)
+        if prev is not None:
+            prev.join()
+            self._save_thread = None
+            if getattr(self, "_save_error", None) is not None:
+                err, self._save_error = self._save_error, None
+                raise err
+        iters = list(mapped_iter_set)
+
+        def write():
+            try:
+                save_3d_map(self.map_save_path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"],
+                            iters, arrays["grid_rgb"])
+            except BaseException as e:
+                self._save_error = e
+                if not background:
+                    raise
+        if background and self.prefetch_frames:
+            import threading
+            self._save_error = None
+            self._save_thread = threading.Thread(target=write, name="avl-save", daemon=False)
+            self._save_thread.start()
+        else:
+            write()
 
 
 def _dist_rank_ws():

@@ -191,6 +191,20 @@ def test_cli_create_then_index_on_disk_dataset(tmp_path):
     assert (occ >= 0).sum() == len(gp) and np.array_equal(occ[gp[:, 0], gp[:, 1], gp[:, 2]], np.arange(len(gp)))
     heat = index_map.main(["--data-dir", str(scene), "--config", str(cfg), "--query", "sofa", "--text-model", "hash"])
     assert heat.shape == (len(gp),) and heat.max() == 1.0 and 0 < (heat == 1.0).sum() < len(gp)
+    # host-side pipelining (frame decode threads, sampler thread, batched launches) must not change a single bit:
+    # the default above ran with prefetch 4; inline loading and 3-frame batches give the same file contents
+    first = (it, gf, gp, w, occ, rgb)
+    for extra in (["--prefetch", "0"], ["--prefetch", "2", "--batch-frames", "3"]):
+        for f in (scene / "vlmap").iterdir():
+            f.unlink()
+        create_map.main(["--data-dir", str(scene), "--config", str(cfg), "--features", "hash", "--feat-dim", "64", "--seed", "3"] + extra)
+        again = load_3d_map(scene / "vlmap" / "vlmaps.h5df")
+        assert again[0] == first[0]
+        for a, b, name in zip(again[1:], first[1:], ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")):
+            if name == "grid_feat" and extra[-2:] == ["--batch-frames", "3"]:
+                np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)     # fp64 sums in a different order
+            else:
+                assert np.array_equal(a, b), (name, extra)
 
 
 def test_multi_floor_builder_reproduces_reference_map(golden, tmp_path):

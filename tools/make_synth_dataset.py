@@ -31,5 +31,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
     ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--height", type=int, default=120)
+    ap.add_argument("--width", type=int, default=160)
     a = ap.parse_args()
-    print(make(a.out, a.frames))
+    print(make(a.out, a.frames, a.height, a.width))
