@@ -538,7 +538,9 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #pragma unroll
             for (int s = 0; s < SPC; ++s) {
                 const int i0 = (s * kStreamFill) / SPC, i1 = ((s + 1) * kStreamFill) / SPC;
+#ifndef AVL_ABL_NOSTAGE
                 stage_load(cn, i0, i1);               // issued ahead of this step's voxel prefetch (older in vmcnt order)
+#endif
                 const float* nxt = rp + 64 * (c * SPC + s + 1);
                 if (s + 1 < SPC) {
                     load(ring[(s + 1) & 1], nxt);
@@ -572,12 +574,16 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #pragma unroll
                     for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][0], 0, 0, 0);
                 }
+#ifndef AVL_ABL_NOSTAGE
                 stage_store(cur ^ 1, i0, i1);
+#endif
             }
             // publish the next chunk / retire this one: LDS traffic only, the voxel prefetch stays in flight
+#ifndef AVL_ABL_NOBARRIER
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#endif
             cur ^= 1;
         }
         split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk);

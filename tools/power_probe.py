@@ -54,7 +54,8 @@ def sensors():
 def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
     lib = _lib.load()
-    N, D, Q = 2_000_000, 512, 64
+    import os
+    N, D, Q = 2_000_000, int(os.environ.get('PP_D', 512)), int(os.environ.get('PP_Q', 64))
     feat = torch.randn((N, D), device="cuda")
     prep = feat.clone()
     assert lib.avl_sim_prepare_map(prep.data_ptr(), N, D, D, None) == 0
