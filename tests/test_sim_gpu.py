@@ -73,6 +73,27 @@ def test_shapes_vs_oracle(ops, N, D, Q):
         assert sc2 is None and np.array_equal(am2, am)
 
 
+def test_randomised_shape_sweep(ops):
+    """60 seeded random (N, D, Q) shapes around the tile (256 rows), MFMA-tile (32 queries), resident/streamed (78 / 128
+    queries) and K-chunk (128 / 256 columns) boundaries, every default-path kernel variant against float64"""
+    rng = np.random.default_rng(2024)
+    Ns = [1, 31, 32, 33, 255, 256, 257, 511, 513, 1000, 1279]
+    Ds = [64, 128, 192, 256, 320, 384, 512, 640, 768, 1024, 1536]
+    Qs = [1, 2, 31, 32, 33, 63, 64, 65, 78, 79, 95, 96, 97, 127, 128, 129, 157, 200, 257]
+    for _ in range(60):
+        N, D, Q = int(rng.choice(Ns)), int(rng.choice(Ds)), int(rng.choice(Qs))
+        feat = rng.standard_normal((N, D)).astype(np.float32)
+        feat *= (rng.uniform(0.05, 14.3, (N, 1)) / np.linalg.norm(feat, axis=1, keepdims=True)).astype(np.float32)
+        q = rng.standard_normal((Q, D)).astype(np.float32)
+        q *= (rng.uniform(1e-3, 1.0, (Q, 1)) / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+        ref = feat.astype(np.float64) @ q.astype(np.float64).T
+        sc, am, best = ops.sim_scores(feat, q, want_best=True)
+        assert np.abs(sc - ref).max() < 2e-5, (N, D, Q, np.abs(sc - ref).max())
+        _check(sc, am, best, ref, 1e-4)
+        _, am2, best2 = ops.sim_scores(feat, q, want_scores=False, want_best=True)
+        assert np.array_equal(am2, am) and np.array_equal(best2, best), (N, D, Q)
+
+
 def test_empty_and_errors(ops):
     from avlmaps_amd._lib import AvlError
     sc, am, _ = ops.sim_scores(np.zeros((0, 512), np.float32), np.ones((3, 512), np.float32))
