@@ -83,10 +83,17 @@ class VLMap(Map):
 
     def init_categories(self, categories: List[str]) -> np.ndarray:
         """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
+        from .. import ops
         self.categories = categories
         feat = self._device_feat()
-        self.scores_mat = get_lseg_score(self.clip_model, self.categories, feat, self.clip_feat_dim,
-                                         use_multiple_templates=True, add_other=True, precision=self._sim_precision)
+        q, _ = landmark_text_feats(self.clip_model, self.categories, self.clip_feat_dim, use_multiple_templates=True,
+                                   add_other=True)
+        # one launch gives scores_mat AND its row argmax (same values, first maximum wins like np.argmax), so index_map
+        # does not have to rescan the (N, Q) host matrix per query as upstream does (vlmap.py:123)
+        sc, am, _ = ops.sim_scores(feat, q, want_scores=True, want_argmax=True, precision=self._sim_precision)
+        self.scores_mat = sc.numpy() if hasattr(sc, "numpy") and not isinstance(sc, np.ndarray) else np.asarray(sc)
+        self._argmax = am.numpy() if hasattr(am, "numpy") and not isinstance(am, np.ndarray) else np.asarray(am)
+        self._argmax_src = self.scores_mat
         return self.scores_mat
 
     def index_map(self, language_desc: str, with_init_cat: bool = True):
@@ -95,7 +102,9 @@ class VLMap(Map):
         if with_init_cat and self.scores_mat is not None and self.categories is not None:
             from ..utils.index_utils import find_similar_category_id
             cat_id = find_similar_category_id(language_desc, self.categories)
-            return np.argmax(self.scores_mat, axis=1) == cat_id
+            if getattr(self, "_argmax_src", None) is self.scores_mat:
+                return self._argmax == cat_id
+            return np.argmax(self.scores_mat, axis=1) == cat_id      # scores_mat was replaced from outside
         if with_init_cat:
             raise Exception(
                 "Categories are not preloaded. Call init_categories(categories: List[str]) to initialize categories.")
