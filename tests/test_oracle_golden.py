@@ -78,6 +78,19 @@ def test_growth_fixture_really_grew(golden):
     assert int(g["max_id"]) > int(g["gs"]) ** 2
 
 
+def test_wide_query_similarity_matches_reference(golden):
+    """g7: 100 / 128 query columns at D = 512 and a 1536-column fused map through the reference's get_lseg_score"""
+    g = golden("g7_similarity_wide.npz")
+    for tag, Q in (("d512_q100", 100), ("d512_q128", 128), ("d1536_q128", 128)):
+        sc = O.sim_scores(g[f"{tag}_feat"], g[f"{tag}_mean_feats"])
+        assert sc.shape == g[f"{tag}_scores"].shape and sc.shape[1] == Q
+        np.testing.assert_allclose(sc, g[f"{tag}_scores"], rtol=0, atol=2e-5)
+        sc2, am2 = O.sim_scores_scalar(g[f"{tag}_feat"], g[f"{tag}_mean_feats"])
+        np.testing.assert_allclose(sc2, g[f"{tag}_scores"], rtol=0, atol=3e-5)
+        ref = g[f"{tag}_scores"]
+        assert np.all(ref[np.arange(len(ref)), am2] >= ref.max(axis=1) - 6e-5)
+
+
 def test_similarity_matches_reference(golden):
     g = golden("g3_similarity.npz")
     feat = g["feat"]

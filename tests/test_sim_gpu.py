@@ -35,6 +35,27 @@ def test_golden_scores(ops, golden, case, precision):
     assert agree == 1.0, agree
 
 
+@pytest.mark.parametrize("precision", ["exact", "split_f16", "auto", "prepared"])
+@pytest.mark.parametrize("tag", ["d512_q100", "d512_q128", "d1536_q128"])
+def test_golden_wide_queries(ops, golden, tag, precision):
+    """g7 (reference get_lseg_score, 100 / 128 columns, D = 512 / 1536): the streamed-query kernel and the exact modes"""
+    from avlmaps_amd.device import DeviceArray
+    g = golden("g7_similarity_wide.npz")
+    feat, q, ref = g[f"{tag}_feat"], g[f"{tag}_mean_feats"], g[f"{tag}_scores"]
+    if precision == "prepared":
+        feat = DeviceArray.from_numpy(feat)
+        ops.prepare_map(feat)
+    sc, am, best = ops.sim_scores(feat, q, want_best=True, precision=precision)
+    sc, am, best = (x.numpy() if hasattr(x, "numpy") and not isinstance(x, np.ndarray) else x for x in (sc, am, best))
+    np.testing.assert_allclose(sc, ref, rtol=0, atol=1e-4)          # north_star tolerance
+    assert np.abs(sc - ref).max() < 3e-5                               # what the kernels actually achieve vs the sgemm result
+    rows = np.arange(len(ref))
+    assert np.all(ref[rows, am] >= ref.max(axis=1) - 6e-5)
+    agree = np.mean(am == g[f"{tag}_argmax"])
+    assert agree > 0.99, agree                                         # the rest are float32 near-ties of the reference itself
+    assert np.array_equal(am, np.argmax(sc, axis=1))                   # fused argmax == argmax of the returned scores
+
+
 @pytest.mark.parametrize("precision", ["exact", "exact_valu", "split_f16"])
 def test_exact_ties_first_index_wins(ops, golden, precision):
     g = golden("g3_similarity.npz")

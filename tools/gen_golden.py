@@ -362,6 +362,9 @@ def gen_g4(m, rng):
 
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--only-g7" in sys.argv:
+        gen_g7_wide(import_reference(), np.random.default_rng(77))
+        return
     m = import_reference()
     gen_g1(m, np.random.default_rng(11))
     gen_g2(m, np.random.default_rng(22))
@@ -370,9 +373,47 @@ def main():
     gen_templates_hash(m)
     gen_g5_lseg_protocol()
     gen_g6_multi_floor(np.random.default_rng(66))
+    if "--only-g7" in sys.argv or "--all" in sys.argv or not (OUT / "g7_similarity_wide.npz").exists():
+        gen_g7_wide(import_reference(), np.random.default_rng(77))
     os.system(f"ls -la {OUT}")
 
 
+
+
+def gen_g7_wide(m, rng):
+    """avlmaps/utils/clip_utils.py:196-242 get_lseg_score (real function) on query sets wider than one LDS-resident image
+    (100 and 128 columns at D = 512) and on a 1536-column fused visual|audio feature map (BASELINE config 5 shape family)"""
+    cu = m["clip_utils"]
+    table = {}
+
+    def fake_text_feats(in_text, clip_model, clip_feat_dim, batch_size=64):
+        r = np.zeros((len(in_text), clip_feat_dim), dtype=np.float32)
+        for i, t in enumerate(in_text):
+            r[i] = table[(t, clip_feat_dim)]
+        return r
+
+    cu.get_text_feats = fake_text_feats
+    out = {}
+    for tag, N, D, nq, blocks in (("d512_q100", 320, 512, 99, False), ("d512_q128", 320, 512, 127, False),
+                                  ("d1536_q128", 192, 1536, 127, True)):
+        feat = rng.standard_normal((N, D)).astype(np.float32)
+        feat *= (rng.uniform(0.2, 14.2857, (N, 1)) / np.linalg.norm(feat, axis=1, keepdims=True)).astype(np.float32)
+        lms = [f"{tag}_{i}" for i in range(nq)]
+        for qi, lm in enumerate(lms + ["other"]):
+            for t in cu.multiple_templates:
+                v = rng.standard_normal(D).astype(np.float32)
+                if blocks:                       # text queries live in the visual block, "audio" queries in the audio block
+                    v[512:] = 0 if qi % 2 == 0 else v[512:]
+                    v[:512] = v[:512] if qi % 2 == 0 else 0
+                table[(t.format(lm), D)] = v / np.linalg.norm(v)
+        sc = cu.get_lseg_score(None, list(lms), feat, D, use_multiple_templates=True, add_other=True)
+        tf = np.stack([np.stack([table[(t.format(lm), D)] for t in cu.multiple_templates]) for lm in lms + ["other"]])
+        out[f"{tag}_feat"] = feat
+        out[f"{tag}_mean_feats"] = np.mean(tf.astype(np.float32), axis=1)
+        out[f"{tag}_scores"] = sc
+        out[f"{tag}_argmax"] = np.argmax(sc, axis=1).astype(np.int32)
+    np.savez_compressed(OUT / "g7_similarity_wide.npz", **out)
+    print("G7 written", {k: v.shape for k, v in out.items() if k.endswith("scores")})
 
 
 def gen_templates_hash(m):
