@@ -360,7 +360,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
         rs.shuffle(m)
         samples.append(torch.from_numpy(m[::rate].astype(np.int32)).cuda())
     P = int(samples[0].numel())
-    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=args.capacity)
+    cap = args.capacity or max(1_500_000, 200_000 + 600 * (hi - lo))
+    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=cap)
 
     BATCH = max(1, int(args.build_batch))
 
@@ -475,7 +476,9 @@ def main():
     ap.add_argument("--voxels", type=int, default=2_000_000)
     ap.add_argument("--queries", type=int, default=64)
     ap.add_argument("--feat-dim", type=int, default=512, help="feature width of the index workload (config 5: 1536 with --queries 128)")
-    ap.add_argument("--capacity", type=int, default=1_500_000)
+    ap.add_argument("--capacity", type=int, default=None,
+                    help="voxel capacity of the builder (default: 1.5 M, grown with the frame count: config 3's 5 000 frames "
+                         "create 2.1 M voxels)")
     ap.add_argument("--build-frames", type=int, default=300)
     ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch triple (avl_builder_integrate_batch)")
     ap.add_argument("--event-mode", choices=["pair", "each"], default="pair",
