@@ -81,7 +81,7 @@ struct Recs {
     int32_t* fpix;    // py*Wf + px into the (Hf, Wf, D) feature map
     uint32_t* rgb;    // r | g<<8 | b<<16
     int32_t* next;    // next sample of the same voxel in this frame, -1 = end
-    uint8_t* owner;   // 1 = this sample's wave fuses the voxel's list
+    uint8_t* owner;   // 1 = this sample found its voxel's list empty: it is the list's TAIL and its wave fuses the list
 };
 
 constexpr int kEmpty = -1, kPending = -2;
@@ -214,37 +214,51 @@ __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restr
                                                    Recs recs, unsigned long long* __restrict__ counters, ReplayLog log,
                                                    long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
                                                    int P_frame) {
+    // statistics counters are aggregated per workgroup in LDS: a single hot device word sustains only ~90 atomics/us,
+    // which at one atomic per wave was most of this kernel's time in batched launches
+    __shared__ unsigned blk_cnt[2];
+    if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= P) return;
-    const int32_t cell = recs.cell[s];
+    const bool valid = s < P;
     int32_t slot = -1, next = -1;
     uint8_t owner = 0;
-    if (cell >= 0) {
-        slot = cell_slot[cell];
-        if (slot >= 0) {
-            next = atomicExch(&head[slot], s);  // LIFO push; whoever finds the list empty owns it this frame
-            owner = next == -1;
+    if (valid) {
+        const int32_t cell = recs.cell[s];
+        if (cell >= 0) {
+            slot = cell_slot[cell];
+            if (slot >= 0) {
+                next = atomicExch(&head[slot], s);  // LIFO push; whoever finds the list empty owns it this launch
+                owner = next == -1;
+            }
         }
     }
     const unsigned long long amask = __ballot(slot >= 0);
     const unsigned long long omask = __ballot(owner != 0);
     if (amask && (threadIdx.x & 63) == __ffsll((long long)amask) - 1) {
-        atomicAdd(&counters[1], (unsigned long long)__popcll(amask));
-        if (omask) atomicAdd(&counters[2], (unsigned long long)__popcll(omask));
+        atomicAdd(&blk_cnt[0], (unsigned)__popcll(amask));
+        if (omask) atomicAdd(&blk_cnt[1], (unsigned)__popcll(omask));
     }
-    recs.slot[s] = slot;
-    recs.next[s] = next;
-    recs.owner[s] = owner;
-    if (log.slot) {
-        const long long i = log_base + s;
-        log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
-        log.key[i] = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
-        log.alpha[i] = recs.alpha[s];
-        log.rgb[i] = recs.rgb[s];
+    if (valid) {
+        recs.slot[s] = slot;
+        recs.next[s] = next;
+        recs.owner[s] = owner;
+        if (log.slot) {
+            const long long i = log_base + s;
+            log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
+            log.key[i] = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
+            log.alpha[i] = recs.alpha[s];
+            log.rgb[i] = recs.rgb[s];
+        }
     }
+    __syncthreads();
+    if (threadIdx.x < 2 && blk_cnt[threadIdx.x]) atomicAdd(&counters[1 + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
+// The owner sample s0 is the wave's own index and the TAIL of the LIFO list, so its record is fetched (scalar loads, the
+// index is wave-uniform) together with the owner flag, and its feature row, the list head and the accumulator row go out in
+// the next round trip; the rest of the list (1.3 samples per group on average) is walked from the head down to s0.
 template <int CH>
 __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
@@ -252,11 +266,16 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
                                                    unsigned long long* __restrict__ slot_key) {
     const int lane = threadIdx.x & 63;
-    const int s0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int s0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (s0 >= P) return;
-    if (!recs.owner[s0]) return;
+    const uint8_t own = recs.owner[s0];
     const int32_t slot = recs.slot[s0];
-    const bool is_new = slot_key[slot] == kNoKey;  // born this frame: accumulators hold nothing yet
+    const double alpha0 = recs.alpha[s0];
+    const int32_t fpix0 = recs.fpix[s0];
+    const uint32_t rgb0 = recs.rgb[s0];
+    if (!own) return;
+    const bool is_new = slot_key[slot] == kNoKey;  // born in this launch: accumulators hold nothing yet
+    const int h0 = head[slot];
 
     double acc[CH][4];
     float f1[CH][4];
@@ -267,12 +286,8 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
     double w4 = 0.0, a1 = 0.0;
     int min_s = INT_MAX;
 
-    int cur = head[slot];
-    while (cur >= 0) {
-        const double alpha = recs.alpha[cur];
-        const int nxt = recs.next[cur];
-        const float* f = (batch ? batch[cur / P_frame].feat : feat) + (size_t)recs.fpix[cur] * D;
-        const uint32_t rgbv = recs.rgb[cur];
+    auto add = [&](int cur, double alpha, int32_t fpix, uint32_t rgbv) {
+        const float* f = (batch ? batch[cur / P_frame].feat : feat) + (size_t)fpix * D;
         const bool first = cur < min_s;  // wave-uniform
         if (first) { min_s = cur; a1 = alpha; }
 #pragma unroll
@@ -295,6 +310,11 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
             }
         }
         if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
+    };
+    add(s0, alpha0, fpix0, rgb0);
+    for (int cur = h0; cur != s0;) {
+        const int nxt = recs.next[cur];
+        add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
         cur = nxt;
     }
 
@@ -324,7 +344,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
             slot_key[slot] = batch ? (batch[min_s / P_frame].frame_key | (unsigned)(min_s % P_frame)) : (frame_key | (unsigned)min_s);
         }
     }
-    if (lane == 0) head[slot] = -1;  // ready for the next frame
+    if (lane == 0) head[slot] = -1;  // ready for the next launch
 }
 
 // generic feature width: one 256-float chunk at a time, re-walking the (short) list per chunk

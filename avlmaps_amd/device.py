@@ -92,6 +92,17 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
 
+_TORCH_DTYPES = {}
+
+
+def _torch_dtype(dtype):
+    if not _TORCH_DTYPES:
+        import torch
+        _TORCH_DTYPES.update({np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
+                              np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64, np.dtype(np.int16): torch.int16})
+    return _TORCH_DTYPES[dtype]
+
+
 def as_device(x, dtype, stream=None):
     """-> (ptr, shape, keepalive).  Raises if a torch tensor is not a contiguous CUDA tensor of `dtype`."""
     dtype = np.dtype(dtype)
@@ -100,9 +111,7 @@ def as_device(x, dtype, stream=None):
             raise TypeError(f"expected {dtype}, got {x.dtype}")
         return x.ptr, x.shape, x
     if _is_torch(x):
-        import torch
-        want = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
-                np.dtype(np.int64): torch.int64, np.dtype(np.float64): torch.float64, np.dtype(np.int16): torch.int16}[dtype]
+        want = _torch_dtype(dtype)
         if not x.is_cuda:
             raise TypeError("torch tensors passed to avlmaps_amd must live on the GPU")
         if x.dtype != want:

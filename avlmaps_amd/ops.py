@@ -96,6 +96,15 @@ def argmax_f32(vals, stream=None):
     return idx.value, val.value
 
 
+class BatchPlan:
+    """resolved device-pointer tables of one batch of frames (VoxelAccumulator.make_batch_plan)"""
+    __slots__ = ("B", "H", "W", "Hf", "Wf", "P", "depth", "samples", "feat", "rgb", "keep")
+
+    def __init__(self, B, H, W, Hf, Wf, P, depth, samples, feat, rgb, keep):
+        self.B, self.H, self.W, self.Hf, self.Wf, self.P = B, H, W, Hf, Wf, P
+        self.depth, self.samples, self.feat, self.rgb, self.keep = depth, samples, feat, rgb, keep
+
+
 class VoxelAccumulator:
     """Device-resident map under construction (handle over avl_builder_*).
 
@@ -151,13 +160,21 @@ class VoxelAccumulator:
         self._keep = (k1, k2, k3, k4)   # inputs must outlive the asynchronous launches
         return self
 
-    def integrate_batch(self, depths, calib, pc_transforms, sample_idxs, feats_hwc, rgbs, frame_idx0, calib_inv=None,
+    def integrate_batch(self, depths, calib, pc_transforms, sample_idxs=None, feats_hwc=None, rgbs=None, frame_idx0=0, calib_inv=None,
                         min_depth=0.1, max_depth=6.0, sigma_sq=0.6, stream=None):
         """Fuse len(depths) consecutive frames with one launch triple (avl_builder_integrate_batch).  Arguments are lists of
         per-frame arrays (numpy / DeviceArray / torch CUDA) with identical shapes; results equal frame-by-frame fusion."""
-        lib = _lib.load()
+        if isinstance(depths, BatchPlan):
+            plan = depths
+        else:
+            plan = self.make_batch_plan(depths, sample_idxs, feats_hwc, rgbs, stream)
+        return self._integrate_plan(plan, calib, pc_transforms, frame_idx0, calib_inv, min_depth, max_depth, sigma_sq, stream)
+
+    def make_batch_plan(self, depths, sample_idxs, feats_hwc, rgbs, stream=None):
+        """Resolve the per-frame device pointers of a batch once.  A pipeline that cycles through a ring of frame buffers can
+        keep the plan and pass it as `depths` to integrate_batch (sample_idxs / feats_hwc / rgbs are then ignored)."""
         B = len(depths)
-        assert B > 0 and len(pc_transforms) == len(sample_idxs) == len(feats_hwc) == len(rgbs) == B
+        assert B > 0 and len(sample_idxs) == len(feats_hwc) == len(rgbs) == B
         keep, dptr, sptr, fptr, rptr = [], [], [], [], []
         shapes = None
         for i in range(B):
@@ -175,15 +192,20 @@ class VoxelAccumulator:
         (H, W), (Hf, Wf, D), _, P = shapes
         if D != self.D:
             raise ValueError(f"feature dim {D} != {self.D}")
+        arr = lambda ptrs: (C.c_void_p * B)(*ptrs)
+        return BatchPlan(B, H, W, Hf, Wf, P, arr(dptr), arr(sptr), arr(fptr), arr(rptr), keep)
+
+    def _integrate_plan(self, plan, calib, pc_transforms, frame_idx0, calib_inv, min_depth, max_depth, sigma_sq, stream):
+        lib = _lib.load()
+        B = plan.B
         K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
         Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
         T = np.ascontiguousarray(np.asarray(pc_transforms, dtype=np.float64).reshape(B, 16))
-        arr = lambda ptrs: (C.c_void_p * B)(*ptrs)
-        a_d, a_s, a_f, a_r = arr(dptr), arr(sptr), arr(fptr), arr(rptr)
-        rc = lib.avl_builder_integrate_batch(self._h, B, a_d, H, W, K.ctypes.data, Kinv.ctypes.data, T.ctypes.data, a_s, P, a_f, Hf, Wf,
-                                             a_r, int(frame_idx0), float(min_depth), float(max_depth), float(sigma_sq), stream)
+        rc = lib.avl_builder_integrate_batch(self._h, B, plan.depth, plan.H, plan.W, K.ctypes.data, Kinv.ctypes.data, T.ctypes.data,
+                                             plan.samples, plan.P, plan.feat, plan.Hf, plan.Wf, plan.rgb, int(frame_idx0),
+                                             float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_batch")
-        self._keep = keep
+        self._keep = plan.keep
         return self
 
     def integrate_frame_global(self, depth, calib, transform, sample_idx, feat_hwc, rgb, frame_idx, pcd_min, depth_div=1000.0,

@@ -360,7 +360,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
         rs.shuffle(m)
         samples.append(torch.from_numpy(m[::rate].astype(np.int32)).cuda())
     P = int(samples[0].numel())
-    cap = args.capacity or max(1_500_000, 200_000 + 600 * (hi - lo))
+    cap = args.capacity or max(1_500_000, 300_000 + 800 * (hi - lo))
     acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=cap)
 
     BATCH = max(1, int(args.build_batch))
@@ -369,10 +369,16 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
         b = i % nbuf
         acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
 
+    plans = {}
+
     def fuse_batch(i0, i1):
-        idx = [i % nbuf for i in range(i0, i1)]
-        acc.integrate_batch([depths[b] for b in idx], calib, Ts[i0:i1], [samples[b] for b in idx], [feats[b] for b in idx],
-                            [rgbs[b] for b in idx], frame_idx0=i0)
+        # the frame buffers form a ring of nbuf: the pointer table of a batch is resolved once per ring phase
+        idx = tuple(i % nbuf for i in range(i0, i1))
+        plan = plans.get(idx)
+        if plan is None:
+            plan = plans[idx] = acc.make_batch_plan([depths[b] for b in idx], [samples[b] for b in idx], [feats[b] for b in idx],
+                                                    [rgbs[b] for b in idx])
+        acc.integrate_batch(plan, calib, Ts[i0:i1], frame_idx0=i0)
 
     nwarm = min(args.warmup, hi - lo)
     for i in range(lo, lo + nwarm):
