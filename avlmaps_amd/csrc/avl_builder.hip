@@ -85,6 +85,7 @@ struct Recs {
 };
 
 constexpr int kEmpty = -1, kPending = -2;
+constexpr int kAggregateSamples = 32768;   // launches at least this large allocate slots per workgroup instead of per wave
 constexpr unsigned long long kNoKey = ~0ull;
 
 __device__ __forceinline__ long long py_int(double v) {
@@ -102,19 +103,25 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
                                                           const uint8_t* rgb, int32_t* __restrict__ cell_slot,
                                                           int32_t* __restrict__ slot_cell, Recs recs,
                                                           unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
+    // slots are allocated per workgroup: creators are counted in LDS and ONE device atomic per 256 samples reserves the
+    // block's range (a single hot device word only sustains ~90 atomics/us)
+    __shared__ unsigned blk_new;
+    __shared__ unsigned long long blk_base;
+    if (threadIdx.x == 0) blk_new = 0;
+    __syncthreads();
     const int s = blockIdx.x * blockDim.x + threadIdx.x;   // global sample index: frame-major within a batch
-    if (s >= fp.P) return;
+    const bool valid = s < fp.P;
     double alpha = 0.0;
     int32_t cell = -1, fpix = 0;
     uint32_t rgbv = 0;
 
-    const BatchEntry* be = fp.batch ? fp.batch + s / fp.P_frame : nullptr;
+    const BatchEntry* be = (fp.batch && valid) ? fp.batch + s / fp.P_frame : nullptr;
     const double* T = be ? be->t : fp.t;
     if (be) {
         depth = be->depth;
         rgb = be->rgb;
     }
-    const int pix = be ? be->samples[s % fp.P_frame] : sample_idx[s];
+    const int pix = !valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]);
     bool ok = pix >= 0 && pix < fp.H * fp.W;
     double pl0 = 0, pl1 = 0, pl2 = 0;
     if (ok) {
@@ -179,27 +186,40 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
     // winners are ranked with a ballot (a single hot word only sustains ~90 atomics/us).
     const bool creator = ok && cell_slot[cell] == kEmpty && atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
     const unsigned long long cmask = __ballot(creator);
-    if (cmask) {
-        const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (fp.P >= kAggregateSamples) {   // kernel-uniform: batched launches take the two barriers, single frames do not
+        unsigned woff = 0;
+        if (cmask) {
+            const int leader = __ffsll((long long)cmask) - 1;
+            if (lane == leader) woff = atomicAdd(&blk_new, (unsigned)__popcll(cmask));   // LDS: the wave's offset in the block
+            woff = __shfl(woff, leader, 64);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && blk_new) blk_base = atomicAdd(&counters[0], (unsigned long long)blk_new);
+        __syncthreads();
+        base = blk_base + woff;
+    } else if (cmask) {
         const int leader = __ffsll((long long)cmask) - 1;
-        unsigned long long base = 0;
         if (lane == leader) base = atomicAdd(&counters[0], (unsigned long long)__popcll(cmask));
         base = __shfl(base, leader, 64);
-        if (creator) {
-            const unsigned long long slot = base + __popcll(cmask & ((1ull << lane) - 1ull));
-            if ((long long)slot >= fp.capacity) {
-                atomicOr(err_flags, 1);
-                cell_slot[cell] = kEmpty;  // give the cell back; its samples are dropped in K2
-            } else {
-                cell_slot[cell] = (int32_t)slot;
-                slot_cell[slot] = cell;
-            }
+    }
+    if (creator) {
+        const unsigned long long slot = base + __popcll(cmask & ((1ull << lane) - 1ull));
+        if ((long long)slot >= fp.capacity) {
+            atomicOr(err_flags, 1);
+            cell_slot[cell] = kEmpty;  // give the cell back; its samples are dropped in K2
+        } else {
+            cell_slot[cell] = (int32_t)slot;
+            slot_cell[slot] = cell;
         }
     }
-    recs.alpha[s] = alpha;
-    recs.cell[s] = cell;
-    recs.fpix[s] = fpix;
-    recs.rgb[s] = rgbv;
+    if (valid) {
+        recs.alpha[s] = alpha;
+        recs.cell[s] = cell;
+        recs.fpix[s] = fpix;
+        recs.rgb[s] = rgbv;
+    }
 }
 
 // optional per-sample log for the exact sequential replay of weight / grid_rgb at finalisation (position = key order)
