@@ -11,7 +11,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 ours = lambda name: "avl" in name or "rocclr" in name or "rocprim" in name
-for name in ("index_kernel_stats.csv", "build_kernel_stats.csv"):
+for name in ("index_kernel_stats.csv", "build_kernel_stats.csv", "config5_kernel_stats.csv", "build_b64_kernel_stats.csv"):
+    if not (src / name).exists():
+        continue
     rows = list(csv.reader(open(src / name)))
     keep = [rows[0]] + [r for r in rows[1:] if ours(r[0])]
     other = [r for r in rows[1:] if not ours(r[0])]
@@ -26,7 +28,7 @@ for name in ("pmc_index.json", "pmc_build.json"):
 import shutil
 if (src / "power_probe.txt").exists():
     shutil.copy(src / "power_probe.txt", dst / f"{tag}_power_probe.txt")
-for name in ("index_bench.log", "build_bench.log", "bench_default.log"):
+for name in ("index_bench.log", "build_bench.log", "bench_default.log", "config5_bench.log", "build_b64_bench.log", "build_config3.log"):
     if not (src / name).exists():
         continue
     lines = [l for l in open(src / name) if l.startswith("{")]
