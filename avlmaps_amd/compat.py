@@ -1,0 +1,101 @@
+"""Switch an importable upstream `avlmaps` package onto the HIP path without editing it.
+
+    import avlmaps_amd.compat as compat
+    compat.install()            # patches avlmaps.* in place; compat.uninstall() restores the originals
+
+What is replaced (every module of the upstream package that holds a reference to one of these objects is re-pointed,
+so `from avlmaps.utils.clip_utils import get_lseg_score` in avlmaps/map/vlmap.py:24 is covered too):
+
+  avlmaps.utils.clip_utils.get_lseg_score          (clip_utils.py:196-242)   -> voxel x query similarity kernels
+  avlmaps.utils.index_utils.get_lseg_score         (index_utils.py:64-108, verbatim duplicate)
+  avlmaps.utils.index_utils.get_dynamic_obstacles_map_3d (index_utils.py:138-184)
+  avlmaps.utils.visualize_utils.get_heatmap_from_mask_3d (visualize_utils.py:29-49) -> heat kernels
+  avlmaps.utils.visualize_utils.pool_3d_label_to_2d      (visualize_utils.py:77-83)
+  avlmaps.map.vlmap_builder.VLMapBuilder.create_mobile_base_map (vlmap_builder.py:54-185) -> builder kernels
+
+The upstream objects keep their classes, attributes and files (vlmaps.h5df): VLMap / AVLMap / the Habitat navigator run
+unchanged on top.  CLIP text encoding and LSeg stay the upstream PyTorch models.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+from typing import Dict, List, Tuple
+
+_INSTALLED: Dict[str, List[Tuple[object, str, object]]] = {}
+
+
+def _repoint(upstream: str, old, new, log):
+    """replace every module-level reference to `old` inside the upstream package"""
+    for name, mod in list(sys.modules.items()):
+        if mod is None or not (name == upstream or name.startswith(upstream + ".")):
+            continue
+        try:
+            items = list(vars(mod).items())
+        except TypeError:
+            continue
+        for attr, val in items:
+            if val is old:
+                setattr(mod, attr, new)
+                log.append((mod, attr, old))
+
+
+def _builder_adapter():
+    def create_mobile_base_map(self):
+        """avlmaps.map.vlmap_builder.VLMapBuilder.create_mobile_base_map on the HIP builder (same inputs, same output file)"""
+        from .map.vlmap_builder import VLMapBuilder as HipBuilder
+        hb = HipBuilder(self.data_dir, self.map_config, self.pose_path, self.rgb_paths, self.depth_paths, self.base2cam_tf,
+                        self.base_transform, feat_extractor=getattr(self, "feat_extractor", None))
+        hb.create_mobile_base_map()
+        self.map_save_dir, self.map_save_path = hb.map_save_dir, hb.map_save_path
+        return None
+    return create_mobile_base_map
+
+
+def install(upstream: str = "avlmaps") -> Dict[str, int]:
+    """Patch the upstream package (must be importable).  Returns {patched name: number of references re-pointed}."""
+    if upstream in _INSTALLED:
+        return {}
+    from .utils import clip_utils as my_cu
+    from .utils import index_utils as my_iu
+    from .utils import visualize_utils as my_vu
+    log: List[Tuple[object, str, object]] = []
+    counts: Dict[str, int] = {}
+
+    def swap(modname, attr, new):
+        try:
+            mod = importlib.import_module(f"{upstream}.{modname}")
+        except Exception:
+            return
+        old = getattr(mod, attr, None)
+        if old is None or old is new:
+            return
+        n0 = len(log)
+        _repoint(upstream, old, new, log)
+        if getattr(mod, attr) is not new:          # not a plain module attribute any more (e.g. wrapped): set it directly
+            setattr(mod, attr, new)
+            log.append((mod, attr, old))
+        counts[f"{modname}.{attr}"] = len(log) - n0
+
+    swap("utils.clip_utils", "get_lseg_score", my_cu.get_lseg_score)
+    swap("utils.index_utils", "get_lseg_score", my_cu.get_lseg_score)
+    swap("utils.index_utils", "get_dynamic_obstacles_map_3d", my_iu.get_dynamic_obstacles_map_3d)
+    swap("utils.visualize_utils", "get_heatmap_from_mask_3d", my_vu.get_heatmap_from_mask_3d)
+    swap("utils.visualize_utils", "pool_3d_label_to_2d", my_vu.pool_3d_label_to_2d)
+    try:
+        vb = importlib.import_module(f"{upstream}.map.vlmap_builder")
+        cls = vb.VLMapBuilder
+        old = cls.__dict__.get("create_mobile_base_map")
+        if old is not None:
+            setattr(cls, "create_mobile_base_map", _builder_adapter())
+            log.append((cls, "create_mobile_base_map", old))
+            counts["map.vlmap_builder.VLMapBuilder.create_mobile_base_map"] = 1
+    except Exception:
+        pass
+    _INSTALLED[upstream] = log
+    return counts
+
+
+def uninstall(upstream: str = "avlmaps") -> None:
+    for owner, attr, old in reversed(_INSTALLED.pop(upstream, [])):
+        setattr(owner, attr, old)
