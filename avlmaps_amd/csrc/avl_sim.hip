@@ -314,11 +314,14 @@ __global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict_
 // only those rows are resident in LDS (lanes of a partial tile re-read the last valid row; their results are masked).
 // PRE: the map was converted in place by sim_prepare_map_kernel -- every 8 floats hold their fp16 hi[8] | lo[8] images, so
 // the loaded registers ARE the MFMA operands and the fp32->fp16 split (8 % of the kernel time when power-throttled) is gone
-template <int QT, int NSTEPS, bool PRE>
+// FQ (needs nkc == 1 and D <= 512): the workgroup builds its LDS query image itself from the raw float32 query rows -- the
+// same arithmetic as sim_prep_queries_kernel, so the scores are bit-identical -- instead of copying a prepared image: no
+// prep launch and no workspace, which is ~8 us per query on maps of a few hundred thousand voxels.
+template <int QT, int NSTEPS, bool PRE, bool FQ>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
-    const float* __restrict__ inv_scale, int Qtot, int KC, int nkc, int q_base, int rows, int Q,
-    float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
+    const float* __restrict__ inv_scale, const float* __restrict__ q_raw, int64_t ldq, int Qtot, int KC, int nkc, int q_base,
+    int rows, int Q, float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NA = QT == 1 ? 3 : (QT == 2 ? 2 : 1);   // accumulator sets per tile (register budget: 16 VGPRs each)
     constexpr int X1 = NA > 1 ? 1 : 0, X2 = NA > 2 ? 2 : X1;
@@ -327,7 +330,55 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
     const int img_b = rows * row_b;              // bytes of the hi (or lo) image resident in LDS
     float* isc = reinterpret_cast<float*>(smem + 2 * img_b);  // per-query 2^-S of this chunk
-    if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    if constexpr (!FQ) {
+        if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    } else {
+        if (threadIdx.x >= rows && threadIdx.x < QT * 32) isc[threadIdx.x] = 0.f;
+        // wave w converts query rows w, w+8, ...: the loads of four rows are issued together (lane owns k = lane + 64 t),
+        // then row max -> power-of-two scale -> fp16 hi/lo straight into the LDS image, all from registers
+        constexpr int RB = 4, NW = kSplitThreads / 64;
+        for (int r0 = wave; r0 < rows; r0 += NW * RB) {
+            float v[RB][8];
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int r = r0 + NW * b;
+                const float* qr = q_raw + (int64_t)(q_base + (r < rows ? r : rows - 1)) * ldq;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[b][t] = (lane + 64 * t < D) ? qr[lane + 64 * t] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < RB; ++b) {
+                const int r = r0 + NW * b;
+                if (r < rows) {
+                    float m = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) m = fmaxf(m, fabsf(v[b][t]));
+                    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                    int S = 0;
+                    if (m > 0.f && isfinite(m)) S = 9 - ilogbf(m);
+                    S = max(-60, min(60, S));
+                    const float scale = ldexpf(1.f, S);
+                    if (lane == 0) isc[r] = ldexpf(1.f, -S);
+                    _Float16* hi = reinterpret_cast<_Float16*>(smem + r * row_b);
+                    _Float16* lo = reinterpret_cast<_Float16*>(smem + img_b + r * row_b);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const int k = lane + 64 * t;
+                        if (k < KC) {
+                            const float x = v[b][t] * scale;
+                            const half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(x, 0.f));
+                            hi[k] = h[0];
+                            lo[k] = (_Float16)(x - (float)h[0]);
+                        }
+                    }
+                    if (lane < kRowPadHalves) {
+                        hi[KC + lane] = (_Float16)0;
+                        lo[KC + lane] = (_Float16)0;
+                    }
+                }
+            }
+        }
+    }
 
     auto fill_lds = [&](int kc) {
         const char* hi = reinterpret_cast<const char*>(img) + ((int64_t)(kc * 2) * Qtot + q_base) * row_b;
@@ -341,7 +392,9 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             d1[i] = s1[i];
         }
     };
-    if (nkc == 1) fill_lds(0);
+    if constexpr (!FQ) {
+        if (nkc == 1) fill_lds(0);
+    }
     __syncthreads();
 
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
@@ -900,13 +953,24 @@ static const void* pick_stream_kernel(int QT) {
     }
 }
 
+static bool split_plan_is_fused(const SplitPlan& p, int D) { return !p.stream && p.nkc == 1 && D <= 512; }
+
+template <int QT, bool PRE>
+static const void* pick_split_kernel(bool s8, bool fq) {
+    if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, PRE, true>)
+                      : reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, true>);
+    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, false>);
+}
+
 template <bool PRE>
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
     float* inv_scale = reinterpret_cast<float*>(d_ws);
     _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
-    hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Q, D, ldq, inv_scale, img, p.Qtot, p.KC,
-                       p.nkc, p.stream ? 1 : 0);
+    const bool fq = split_plan_is_fused(p, D);   // resident image built inside the kernel: no prep launch, no workspace
+    if (!fq)
+        hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Q, D, ldq, inv_scale, img, p.Qtot, p.KC,
+                           p.nkc, p.stream ? 1 : 0);
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
     int64_t blocks = ntiles < num_cus() ? ntiles : num_cus();
     if (blocks < 1) blocks = 1;
@@ -929,13 +993,17 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
         const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
-        auto kern = s8 ? (c.QT == 3 ? sim_split_f16_kernel<3, 8, PRE> : (c.QT == 2 ? sim_split_f16_kernel<2, 8, PRE> : sim_split_f16_kernel<1, 8, PRE>))
-                       : (c.QT == 3 ? sim_split_f16_kernel<3, 0, PRE> : (c.QT == 2 ? sim_split_f16_kernel<2, 0, PRE> : sim_split_f16_kernel<1, 0, PRE>));
+        const void* kern = c.QT == 3 ? pick_split_kernel<3, PRE>(s8, fq)
+                                     : (c.QT == 2 ? pick_split_kernel<2, PRE>(s8, fq) : pick_split_kernel<1, PRE>(s8, fq));
         const size_t lds = p.lds_bytes(c);
-        int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        int rc = ensure_dynamic_lds(kern, lds);
         if (rc != AVL_OK) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kSplitThreads), lds, st, d_feat, N, D, ld, img, inv_scale, p.Qtot, p.KC,
-                           p.nkc, c.q_base, c.rows, Q, d_scores, d_argmax, d_best, ci == 0 ? 1 : 0);
+        const _Float16* img_c = img;
+        const float* isc_c = inv_scale;
+        int Qtot = p.Qtot, KC = p.KC, nkc = p.nkc, q_base = c.q_base, rows = c.rows, first = ci == 0 ? 1 : 0;
+        void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &d_q, &ldq, &Qtot, &KC, &nkc, &q_base, &rows, &Q,
+                        &d_scores, &d_argmax, &d_best, &first};
+        AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
     }
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
@@ -1014,7 +1082,8 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     if (use_split || use_f32_mfma) {
         void* ws = d_workspace;
         void* tmp_ws = nullptr;
-        if (!ws || workspace_bytes < p.ws_bytes) {
+        const bool needs_ws = use_f32_mfma || !split_plan_is_fused(p, D);   // the fused-prep path keeps the query image in LDS only
+        if (needs_ws && (!ws || workspace_bytes < p.ws_bytes)) {
             AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, p.ws_bytes, st));
             ws = tmp_ws;
         }
