@@ -241,6 +241,21 @@ def run_index(args, torch, dist, lib, rank, ws):
             scores_mat_variant=dict(ms=ms_sc, similarities_per_s=N * Q / (ms_sc * 1e-3),
                                     gbs=(alg_bytes + N * Q * 4) / (ms_sc * 1e-3) / 1e9),
             parity_sample=dict(rows=8192, max_abs_err_vs_fp64=err, argmax_agreement=am_ok, tolerance=1e-4))
+        # a map of the size real scenes produce (a few hundred thousand voxels), "64 categories + other" as the reference's
+        # init_categories scores them (65 columns), and the two-column query of index_map(with_init_cat=False)
+        try:
+            n3 = min(300_000, N)
+            am3 = torch.empty((n3,), dtype=torch.int32, device="cuda")
+            res3 = {}
+            for q3n in (2, 65):
+                q3 = torch.cat([q] * ((q3n + Q - 1) // Q))[:q3n].contiguous()
+                fn3 = lambda: _lib.check(lib.avl_sim_scores_ws(feat.data_ptr(), n3, D, D, q3.data_ptr(), q3n, D, None, am3.data_ptr(),
+                                                               None, _lib.SIM_AUTO, None, 0, None), "sim")
+                ms3 = sustained_ms(lib, fn3, launches=200, warm=100)
+                res3[f"q{q3n}"] = dict(us=ms3 * 1e3, gbs=n3 * D * 4 / (ms3 * 1e-3) / 1e9, similarities_per_s=n3 * q3n / (ms3 * 1e-3))
+            out["extra"]["scene_sized_map_300k_voxels"] = res3
+        except Exception as e:
+            out["extra"]["scene_sized_map_300k_voxels"] = dict(error=str(e))
         # the step after the mask in AVLMap.index_object: nearest-target decay heat over the same 2M voxels
         # (visualize_utils.py:29-49 is an O(N_other * N_target) Python loop upstream: hours at this size)
         try:
