@@ -328,7 +328,10 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kg = lane >> 5;
     const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
-    const int img_b = rows * row_b;              // bytes of the hi (or lo) image resident in LDS
+    // FQ: a partial last MFMA tile gets one extra all-zero row that its padding lanes read -- multiplying zeros toggles far
+    // fewer matrix-core bits than re-reading a valid row, and at the power cap that is time (Q = 65: see DESIGN.md)
+    const int zrow = (FQ && rows < 32 * QT) ? 1 : 0;
+    const int img_b = (rows + zrow) * row_b;     // bytes of the hi (or lo) image resident in LDS
     float* isc = reinterpret_cast<float*>(smem + 2 * img_b);  // per-query 2^-S of this chunk
     if constexpr (!FQ) {
         if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
@@ -378,6 +381,14 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                 }
             }
         }
+        if (zrow) {
+            uint32_t* zh = reinterpret_cast<uint32_t*>(smem + rows * row_b);
+            uint32_t* zl = reinterpret_cast<uint32_t*>(smem + img_b + rows * row_b);
+            for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
+                zh[i] = 0u;
+                zl[i] = 0u;
+            }
+        }
     }
 
     auto fill_lds = [&](int kc) {
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
     const char* a_base[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) a_base[t] = smem + min(t * 32 + j, rows - 1) * row_b + kg * 64;
+    for (int t = 0; t < QT; ++t) a_base[t] = smem + min(t * 32 + j, rows - 1 + zrow) * row_b + kg * 64;
 
     // work split: full rounds of interleaved 256-row tiles (all workgroups sweep one compact window of the map: measured
     // 1.2 % faster at 2 M voxels than one contiguous range per workgroup), then ONE tail round in which what is left
@@ -541,10 +552,18 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     constexpr int lo_b = 2 * KS;                          // byte offset of the lo half inside a row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kg = lane >> 5;
-    const int buf_b = rows * row_b;                       // one LDS buffer = the chunk's rows, a linear copy of the image
+    // a partial last MFMA tile reads one extra all-zero row per buffer instead of re-reading a valid row: zeros toggle far
+    // fewer matrix-core bits, and at the power cap that is time
+    const int zrow = rows < 32 * QT ? 1 : 0;
+    const int buf_b = (rows + zrow) * row_b;              // one LDS buffer = the chunk's rows, a linear copy of the image
     float* isc = reinterpret_cast<float*>(smem + 2 * buf_b);
     if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
-    const int units = buf_b >> 4;
+    const int units = (rows * row_b) >> 4;
+    if (zrow)
+        for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
+            reinterpret_cast<uint32_t*>(smem + rows * row_b)[i] = 0u;
+            reinterpret_cast<uint32_t*>(smem + buf_b + rows * row_b)[i] = 0u;
+        }
 
     // the next chunk is staged in SPC slices, one per k step (registers: 5 x 16 B at SPC = 2, 3 x 16 B at SPC = 4)
     constexpr int NSTG = kStreamFill - ((SPC - 1) * kStreamFill) / SPC;
@@ -588,7 +607,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 
     int a_off[QT];
 #pragma unroll
-    for (int t = 0; t < QT; ++t) a_off[t] = min(t * 32 + j, rows - 1) * row_b + kg * 64;
+    for (int t = 0; t < QT; ++t) a_off[t] = min(t * 32 + j, rows - 1 + zrow) * row_b + kg * 64;
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row = tile * kTileRows + wave * 32 + j;
@@ -848,8 +867,8 @@ struct SplitPlan {
     SplitChunk chunks[64];
     size_t hdr_bytes, ws_bytes;
     size_t lds_bytes(const SplitChunk& c) const {
-        if (stream) return (size_t)2 * c.rows * (2 * KC + kRowPadHalves) * 2 + (size_t)c.QT * 32 * sizeof(float);
-        return (size_t)4 * c.rows * (KC + kRowPadHalves) + (size_t)c.QT * 32 * sizeof(float);
+        if (stream) return (size_t)2 * (c.rows + 1) * (2 * KC + kRowPadHalves) * 2 + (size_t)c.QT * 32 * sizeof(float);
+        return (size_t)4 * (c.rows + 1) * (KC + kRowPadHalves) + (size_t)c.QT * 32 * sizeof(float);   // + the zero row
     }
 };
 
@@ -857,7 +876,8 @@ constexpr size_t kLdsBudget = 163840 - 512;  // 160 KiB per workgroup minus slac
 
 static bool stream_fits(int rows, int KS) {
     const size_t buf = (size_t)rows * (2 * KS + kRowPadHalves) * 2;   // one chunk: rows x (hi | lo | pad)
-    return 2 * buf + 128 * sizeof(float) <= kLdsBudget && buf <= (size_t)kStreamFill * kSplitThreads * 16;
+    const size_t zero_row = (size_t)(2 * KS + kRowPadHalves) * 2;     // + one all-zero row per buffer
+    return 2 * (buf + zero_row) + 128 * sizeof(float) <= kLdsBudget && buf <= (size_t)kStreamFill * kSplitThreads * 16;
 }
 
 static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true) {
@@ -868,7 +888,7 @@ static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true
     // rows that fit next to a <=512-wide K chunk: up to 3 MFMA tiles (96 rows) in one pass, e.g. the reference's
     // "64 categories + other" (Q = 65) runs as ONE pass with 65 resident rows instead of 64 + 1
     const int kc0 = D < 512 ? D : 512;
-    int r3 = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)(kc0 + kRowPadHalves)));
+    int r3 = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)(kc0 + kRowPadHalves))) - 1;   // one row is the zero row
     if (r3 > 96) r3 = 96;
     // fewest passes over the feature map, balanced: npass = ceil(Q / r3) chunks of ceil(Q / npass) rows
     const int npass = (Q + r3 - 1) / r3;
@@ -881,7 +901,7 @@ static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true
         p.chunks[p.nchunks++] = SplitChunk{base, take, (take + 31) / 32};
         if (take > p.max_rows) p.max_rows = take;
     }
-    int kcmax = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)p.max_rows)) - kRowPadHalves;
+    int kcmax = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)(p.max_rows + 1))) - kRowPadHalves;
     kcmax = (kcmax / 64) * 64;
     if (kcmax < 64) return false;
     p.nkc = (D + kcmax - 1) / kcmax;
