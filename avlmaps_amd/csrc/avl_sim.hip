@@ -939,7 +939,7 @@ static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true
 // hipFuncSetAttribute is not free: raise the dynamic-LDS limit of a kernel only when a launch needs more than before
 static int ensure_dynamic_lds(const void* kern, size_t bytes) {
     struct Entry { const void* k; size_t bytes; int dev; };
-    static thread_local Entry table[16];
+    static thread_local Entry table[64];   // > number of kernel instantiations in this file
     static thread_local int used = 0;
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -951,7 +951,7 @@ static int ensure_dynamic_lds(const void* kern, size_t bytes) {
             return AVL_OK;
         }
     AVL_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    if (used < 16) table[used++] = Entry{kern, bytes, dev};
+    if (used < 64) table[used++] = Entry{kern, bytes, dev};
     return AVL_OK;
 }
 
