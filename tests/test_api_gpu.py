@@ -238,3 +238,27 @@ def test_multi_floor_builder_reproduces_reference_map(golden, tmp_path):
     np.testing.assert_allclose(gf, g["grid_feat"], rtol=2e-5, atol=3e-4)
     np.testing.assert_allclose(w, g["weight"].astype(np.float32), rtol=3e-7)
     assert np.array_equal(rgb, np.floor(g["grid_rgb"]).astype(np.uint8))       # sequential replay incl. the dtype switch
+
+
+def test_get_lseg_feat_protocol_on_the_gpu(golden):
+    """the sliding-window LSeg evaluation (lseg_utils.py:20-119) with the image, crops, flips and the averaged output all
+    resident on the GPU, channels-last, against the reference run (fake model)"""
+    import sys
+    from pathlib import Path
+    import torch
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    from gen_golden import FakeLSeg
+    from avlmaps_amd.utils.lseg_utils import get_lseg_feat
+
+    class CudaFake(FakeLSeg):
+        def __call__(self, x, labels):
+            f, logits = FakeLSeg.__call__(self, x.cpu(), labels)     # same arithmetic as the generator, result moved back
+            return f.to(x.device), logits.to(x.device)
+
+    g = golden("g5_lseg_protocol.npz")
+    for name in ("pad_short", "grid_2x3", "tall"):
+        crop, base = (int(x) for x in g[f"{name}_cfg"])
+        ref = g[f"{name}_feat"]
+        f = get_lseg_feat(CudaFake(), g[f"{name}_img"], ["example"], None, "cuda", crop, base)
+        assert f.is_cuda and f.is_contiguous() and tuple(f.shape) == (ref.shape[2], ref.shape[3], ref.shape[1])
+        np.testing.assert_allclose(f.cpu().numpy(), np.transpose(ref[0], (1, 2, 0)), rtol=1e-5, atol=1e-5)
