@@ -26,13 +26,22 @@ class AVLMap:
 
     def index_object(self, object_name: str, init_categories: List[str] = None, decay_rate: float = 0.1) -> np.ndarray:
         """(N,) float32 heat.  Reference: avlmap.py:67-76."""
+        cs = cfg_get(cfg_get(self.config, "params"), "cs")
         if init_categories is not None:
             self.vlmap.init_categories(init_categories[1:-1])
             mask = self.vlmap.index_map(object_name, with_init_cat=True)
-        else:
-            mask = self.vlmap.index_map(object_name, with_init_cat=False)
-        cs = cfg_get(cfg_get(self.config, "params"), "cs")
-        return get_heatmap_from_mask_3d(self.vlmap.grid_pos, mask, cell_size=cs, decay_rate=decay_rate)
+            return get_heatmap_from_mask_3d(self.vlmap.grid_pos, mask, cell_size=cs, decay_rate=decay_rate)
+        # query -> argmax -> mask -> heat without leaving the GPU: only the (N,) float32 heat comes back
+        from .. import ops
+        from ..utils.clip_utils import landmark_text_feats
+        vm = self.vlmap
+        q, _ = landmark_text_feats(vm.clip_model, [object_name], vm.clip_feat_dim, use_multiple_templates=True, add_other=True)
+        _, am, _ = ops.sim_scores(vm._device_feat(), q, want_scores=False, want_argmax=True, precision=vm._sim_precision)
+        mask = ops.mask_from_argmax(am, 0)
+        heat = ops.heatmap_from_mask(vm._device_pos(), mask, cs, decay_rate)
+        if vm.grid_pos.shape[0] and ops.argmax_f32(heat)[1] < 1.0:      # a target voxel has heat exactly 1
+            raise ValueError("attempt to get argmin of an empty sequence")   # what np.argmin raises upstream (no voxel matched)
+        return heat.numpy()
 
     def index_sound(self, *a, **k):
         raise NotImplementedError("sound indexing (AudioCLIP segment map) is outside the accelerated voxel path")

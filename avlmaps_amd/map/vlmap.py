@@ -81,6 +81,14 @@ class VLMap(Map):
                 self._sim_precision = "prepared"
         return self._dev_feat
 
+    def _device_pos(self):
+        """grid_pos mirrored into HBM once (int32, re-uploaded only if the host array object changes)"""
+        from ..device import DeviceArray
+        if getattr(self, "_dev_pos", None) is None or self._dev_pos_src is not self.grid_pos:
+            self._dev_pos = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_pos, dtype=np.int32))
+            self._dev_pos_src = self.grid_pos
+        return self._dev_pos
+
     def init_categories(self, categories: List[str]) -> np.ndarray:
         """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
         from .. import ops
