@@ -300,6 +300,8 @@ def run_index(args, torch, dist, lib, rank, ws):
                     torch.cuda.empty_cache()
                     D5, Q5 = 1536, 128
                     f5, q5 = make_index_inputs(torch, N, D5, Q5, seed=77)
+                    q5[:64, 512:] = 0          # 64 text queries live in the 512 visual columns,
+                    q5[64:, :512] = 0          # 64 audio queries in the 1024 AudioCLIP columns
                     w5 = C.c_size_t()
                     lib.avl_sim_workspace_bytes(D5, Q5, C.byref(w5))
                     ws5 = torch.empty((max(w5.value, 64),), dtype=torch.uint8, device="cuda")
