@@ -102,7 +102,13 @@ def make_index_inputs(torch, N, D, Q, seed):
     base = torch.randn((Q, 1, D), device="cuda", generator=g)
     t = base + 0.7 * torch.randn((Q, 63, D), device="cuda", generator=g)
     t /= t.norm(dim=2, keepdim=True)
-    return feat, t.mean(dim=1).contiguous()
+    qm = t.mean(dim=1).contiguous()
+    if D == 1536:
+        # config 5 (fused visual | audio map): the first half of the queries are text queries living in the 512 visual
+        # columns, the second half audio queries living in the 1024 AudioCLIP columns
+        qm[: Q // 2, 512:] = 0
+        qm[Q // 2:, :512] = 0
+    return feat, qm
 
 
 def cpu_index_baseline(feat_h, q_h, repeats=3):
@@ -300,8 +306,6 @@ def run_index(args, torch, dist, lib, rank, ws):
                     torch.cuda.empty_cache()
                     D5, Q5 = 1536, 128
                     f5, q5 = make_index_inputs(torch, N, D5, Q5, seed=77)
-                    q5[:64, 512:] = 0          # 64 text queries live in the 512 visual columns,
-                    q5[64:, :512] = 0          # 64 audio queries in the 1024 AudioCLIP columns
                     w5 = C.c_size_t()
                     lib.avl_sim_workspace_bytes(D5, Q5, C.byref(w5))
                     ws5 = torch.empty((max(w5.value, 64),), dtype=torch.uint8, device="cuda")
