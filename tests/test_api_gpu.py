@@ -262,3 +262,29 @@ def test_get_lseg_feat_protocol_on_the_gpu(golden):
         f = get_lseg_feat(CudaFake(), g[f"{name}_img"], ["example"], None, "cuda", crop, base)
         assert f.is_cuda and f.is_contiguous() and tuple(f.shape) == (ref.shape[2], ref.shape[3], ref.shape[1])
         np.testing.assert_allclose(f.cpu().numpy(), np.transpose(ref[0], (1, 2, 0)), rtol=1e-5, atol=1e-5)
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads (metric/value/unit/n_gpus/steps/warmup/ms_per_step/
+    higher_is_better/scaling/vs_baseline/dtype/data/config) plus the roofline object; small shapes, a few steps"""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--no-build-extra", "--no-cpu"], "voxel_query_similarities_per_sec"),
+                          (["--workload", "build", "--no-cpu"], "map_build_frames_per_sec")):
+        r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in d, k
+        assert d["metric"] == metric and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None
+        assert d["value"] > 0 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+        assert "workload" in d["config"] and "model" not in d["config"]
+        rf = d["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
