@@ -288,3 +288,28 @@ def test_bench_line_contract():
         assert "workload" in d["config"] and "model" not in d["config"]
         rf = d["roofline"]
         assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """the N > 1 launch path of bench.py (torch.distributed.run, one rank per process, barrier + max-over-ranks timing) with
+    two ranks on this box's single GPU: gloo instead of RCCL via AVLMAPS_DIST_BACKEND, everything else as the driver runs it"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, AVLMAPS_DIST_BACKEND="gloo")
+    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2"], "voxel_query_similarities_per_sec"),
+                          (["--workload", "build"], "map_build_frames_per_sec")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+        d = json.loads(lines[0])
+        assert d["metric"] == metric and d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["scaling"] == "weak"
+        if metric.startswith("map_build"):
+            ex = d["extra"]
+            assert ex["voxels_merged"] >= ex["voxels_local"] > 0        # the sparse merge ran and rank 0 finalised the union
