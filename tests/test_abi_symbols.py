@@ -58,3 +58,25 @@ def test_product_never_imports_oracle():
     for p in (ROOT / "avlmaps_amd").rglob("*.py"):
         src = p.read_text()
         assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_header_is_plain_c_and_the_c_caller_links(tmp_path):
+    """include/avlmaps_hip.h compiles as C (gcc, -std=c99 -pedantic) and examples/c_caller.c links against the library:
+    the boundary really is a C ABI, usable without Python or torch"""
+    import shutil
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "avlmaps_hip.h"\nint main(void) { return avl_version() < 0; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", str(root / "include"), "-c", str(probe), "-o",
+                        str(tmp_path / "probe.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = root / "avlmaps_amd" / "lib"
+    r = subprocess.run([gcc, "-O1", "-I", str(root / "include"), str(root / "examples" / "c_caller.c"), "-L", str(lib), "-lavlmaps_hip",
+                        f"-Wl,-rpath,{lib}", "-lm", "-o", str(tmp_path / "c_caller")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
