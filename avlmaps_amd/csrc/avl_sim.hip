@@ -213,11 +213,15 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi
     lo = __builtin_bit_cast(half8, v1);
 #else
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    float m1 = -1.0f;
+    asm("" : "+v"(m1));   // opaque -1: keeps fma(hi, -1, x) from being rewritten as x - cvt(hi)
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         half2 h = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(x[2 * p], x[2 * p + 1]));
-        float r0 = x[2 * p] - (float)h[0];
-        float r1 = x[2 * p + 1] - (float)h[1];
+        // x - hi as fma(hi, -1, x): same value (the difference is exact), and the f16 -> f32 extension folds into
+        // v_fma_mix_f32 instead of a separate v_cvt_f32_f16
+        float r0 = __builtin_fmaf((float)h[0], m1, x[2 * p]);
+        float r1 = __builtin_fmaf((float)h[1], m1, x[2 * p + 1]);
         half2 l = __builtin_bit_cast(half2, __builtin_amdgcn_cvt_pkrtz(r0, r1));
         hi[2 * p] = h[0];
         hi[2 * p + 1] = h[1];
