@@ -233,3 +233,25 @@ def test_prepared_map_gives_bit_identical_scores(ops):
         assert np.array_equal(sc1.numpy(), sc0) and np.array_equal(am1.numpy(), am0) and np.array_equal(b1.numpy(), b0)
     with pytest.raises(TypeError):
         ops.prepare_map(feat)
+
+
+def test_large_map_64bit_offsets(ops):
+    """a 10 GB map (byte offsets beyond 2^33; MI355X holds 288 GB): resident and streamed kernels index rows in 64 bits"""
+    import ctypes as C
+    import torch
+    from avlmaps_amd import _lib
+    lib = _lib.load()
+    N, D = 5_000_000, 512
+    feat = torch.randn((N, D), device="cuda")
+    am = torch.empty((N,), dtype=torch.int32, device="cuda")
+    best = torch.empty((N,), device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    idx = torch.cat([torch.arange(0, 1024, device="cuda"), torch.arange(N - 1024, N, device="cuda"),
+                     torch.randint(0, N, (4096,), device="cuda", generator=g)])
+    for Q in (64, 100):
+        q = torch.randn((Q, D), device="cuda", generator=g) / 22
+        rc = lib.avl_sim_scores(feat.data_ptr(), N, D, D, q.data_ptr(), Q, D, None, am.data_ptr(), best.data_ptr(), _lib.SIM_AUTO, None)
+        assert rc == 0, lib.avl_last_error()
+        ref = feat[idx].double() @ q.double().T
+        assert torch.equal(ref.argmax(1), am[idx].long())
+        assert (ref.max(1).values - best[idx].double()).abs().max().item() < 1e-4
