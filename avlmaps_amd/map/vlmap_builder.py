@@ -42,6 +42,8 @@ class VLMapBuilder:
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
         self.batch_frames = 1                      # >1: fuse that many frames per launch triple (same map, fewer launches)
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
+        self.skip_mapped_frames = False            # True: a resumed run skips the frames listed in the map file's
+                                                   # mapped_iter_list (upstream restores the list but re-fuses every frame)
 
     # ------------------------------------------------------------------ pose chain (host, float64)
     def frame_transforms(self, base_poses: np.ndarray) -> List[np.ndarray]:
@@ -176,6 +178,8 @@ class VLMapBuilder:
         mapped_iter_set = set()
         pending = []
         for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate):
+            if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
+                continue        # the pixel shuffle of the skipped frame was still drawn, so later frames sample as upstream
             feat = self._features_hwc(rgb)
             if acc is None:
                 D = int(feat.shape[2])
@@ -183,6 +187,9 @@ class VLMapBuilder:
                 cap = self.capacity or max(gs * gs, 1 << 16)   # the reference starts at gs*gs rows and doubles
                 acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=cap)
                 mapped_iter_set = self._resume(acc, ws)
+                self._resumed_frames = frozenset(mapped_iter_set)
+                if self.skip_mapped_frames and frame_i in self._resumed_frames:
+                    continue
                 if ws == 1 and not mapped_iter_set and self.exact_rgb:
                     # per-sample log -> finalize replays the reference's sequential weight / uint8 colour exactly
                     npix = depth.shape[0] * depth.shape[1]

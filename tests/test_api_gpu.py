@@ -73,6 +73,15 @@ def test_resume_appends_on_top_of_saved_map(golden, tmp_path):
     # second pass: no voxel is new, so row = (old_row * W + sum alpha*f) / 2W = old_row + a1(1-a1) f1 / 2W:
     # identical direction, bounded by the largest feature magnitude (14.29 * alpha quirk aside)
     assert np.isfinite(second[1]).all() and np.abs(second[1]).max() <= 14.3
+    # opt-in fix of the upstream quirk: skip the frames the file already lists -> nothing is fused again, the map is unchanged
+    np.random.seed(1234)
+    b = MemoryBuilder.make(g, tmp_path)
+    b.skip_mapped_frames = True
+    b.create_mobile_base_map()
+    third = load_3d_map(tmp_path / "vlmap" / "vlmaps.h5df")
+    assert third[0] == second[0] and np.array_equal(third[2], second[2])
+    np.testing.assert_allclose(third[3], second[3], rtol=1e-6)
+    np.testing.assert_allclose(third[1], second[1], rtol=1e-5, atol=1e-5)
 
 
 class FakeClip:
