@@ -203,6 +203,17 @@ def test_row_strides_through_the_c_abi(ops):
         torch.cuda.synchronize()
         assert (sc.double() - ref).abs().max() < 1e-4
         assert torch.equal(am.long(), sc.argmax(dim=1))
+    # the streamed-query kernel (Q > 78) and a wider column block (D = 1024 -> K-chunked) with the same strided views
+    for (c0, c1), Qs in (((512, 1024), 100), ((0, 1024), 64)):
+        fv = wide[:, c0:c1]
+        qw = torch.randn((Qs, 1100), device="cuda", generator=g) / 32
+        qv = qw[:, 4:4 + (c1 - c0)]
+        refs = fv.double() @ qv.double().T
+        sc = torch.empty((N, Qs), device="cuda")
+        rc = lib.avl_sim_scores(fv.data_ptr(), N, c1 - c0, Dw, qv.data_ptr(), Qs, 1100, sc.data_ptr(), am.data_ptr(), None, 0, None)
+        _lib.check(rc, "avl_sim_scores")
+        torch.cuda.synchronize()
+        assert (sc.double() - refs).abs().max() < 1e-4 and torch.equal(am.long(), sc.argmax(dim=1))
     # bad strides are rejected, not read out of bounds
     assert lib.avl_sim_scores(feat.data_ptr(), N, D, 100, q.data_ptr(), Q, 640, None, am.data_ptr(), None, 0, None) != 0
     assert b"stride" in lib.avl_last_error()
