@@ -200,7 +200,8 @@ def run_index(args, torch, dist, lib, rank, ws):
                             "sim_stream_f16_kernel (fp16 hi/lo split MFMA, fp32 accumulate, query image streamed through LDS)")),
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                           traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes)
+                           traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes,
+                           mfma_busy_frac=load_pmc_mfma_busy() if (D == 512 and Q == 64) else None)
     if rank == 0:
         # what a kernel that ONLY reads the same 4.1 GB gets on this box (spec peak is 8 TB/s; boxes differ by ~15 %)
         g0, g1 = C.c_float(), C.c_float()
@@ -493,6 +494,19 @@ def load_pmc_traffic(which):
         return json.loads(p.read_text())[which]["total_bytes"]
     except Exception:
         return None
+
+
+def load_pmc_mfma_busy():
+    """fraction of the kernel during which a SIMD's matrix pipe is busy, from the committed SQ counter pass
+    (SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs / (GRBM_GUI_ACTIVE summed over 8 XCDs / 8)); None if absent"""
+    try:
+        d = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_index.json"))[-1].read_text())
+        for k, v in d.items():
+            if "sim_split_f16_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+                return v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * v["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+    except Exception:
+        pass
+    return None
 
 
 def main():
