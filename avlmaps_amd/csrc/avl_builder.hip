@@ -415,26 +415,34 @@ __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigne
     }
 }
 
-// wave per output row r; the accumulators of row r live in slot perm[r] (perm == nullptr: identity)
-__global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs, int vh, const int32_t* __restrict__ perm,
+// wave per output row r; the accumulators of row r live in slot perm[r] (perm == nullptr: identity).  sum_feat rows have
+// stride ld_sf, the [sum alpha, sum alpha*rgb] quadruple of a row sits at sum_w4 + row * ld_w4.  first_feat == nullptr: the
+// first-touch correction has already been folded into sum_feat (merged accumulators, scatter_merge_kernel).  Output row r
+// is voxel id row0 + r (row0 != 0: one rank finalises one block of a reduce-scattered map).
+__global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs, int vh, int64_t row0, const int32_t* __restrict__ perm,
                                                        const int32_t* __restrict__ cell, const double* __restrict__ sum_feat,
-                                                       const double* __restrict__ sum_w4, const float* __restrict__ first_feat,
-                                                       const double* __restrict__ first_alpha, float* __restrict__ grid_feat,
-                                                       int32_t* __restrict__ grid_pos, float* __restrict__ weight,
-                                                       uint8_t* __restrict__ grid_rgb, int32_t* __restrict__ occupied) {
+                                                       int64_t ld_sf, const double* __restrict__ sum_w4, int64_t ld_w4,
+                                                       const float* __restrict__ first_feat, const double* __restrict__ first_alpha,
+                                                       float* __restrict__ grid_feat, int32_t* __restrict__ grid_pos,
+                                                       float* __restrict__ weight, uint8_t* __restrict__ grid_rgb,
+                                                       int32_t* __restrict__ occupied) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave0; r < n; r += nwaves) {
         const int64_t sl = perm ? perm[r] : r;
-        const double w = sum_w4[sl * 4];
-        const double a1 = first_alpha[sl];
-        const double corr = a1 * (1.0 - a1);
+        const double w = sum_w4[sl * ld_w4];
         if (grid_feat) {
-            const double* s = sum_feat + sl * D;
-            const float* f1 = first_feat + sl * D;
+            const double* s = sum_feat + sl * ld_sf;
             float* o = grid_feat + r * D;
-            for (int c = lane; c < D; c += 64) o[c] = (float)((s[c] - corr * (double)f1[c]) / w);
+            if (first_feat) {
+                const double a1 = first_alpha[sl];
+                const double corr = a1 * (1.0 - a1);
+                const float* f1 = first_feat + sl * D;
+                for (int c = lane; c < D; c += 64) o[c] = (float)((s[c] - corr * (double)f1[c]) / w);
+            } else {
+                for (int c = lane; c < D; c += 64) o[c] = (float)(s[c] / w);
+            }
         }
         if (lane == 0) {
             const int32_t cl = cell[sl];
@@ -444,14 +452,45 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
                 grid_pos[r * 3 + 2] = cl % vh;
             }
             if (weight) weight[r] = (float)w;
-            if (occupied) occupied[cl] = (int32_t)r;
+            if (occupied) occupied[cl] = (int32_t)(row0 + r);
         }
         if (grid_rgb && lane < 3) {
             // running mean stored into a uint8 array (truncating cast); we truncate the exact weighted mean
-            double m = sum_w4[sl * 4 + 1 + lane] / w;
+            double m = sum_w4[sl * ld_w4 + 1 + lane] / w;
             m = fmin(fmax(m, 0.0), 255.0);
             grid_rgb[r * 3 + lane] = (uint8_t)m;
         }
+    }
+}
+
+// Multi-GPU merge, step "scatter" (avlmaps_amd/parallel.py): wave per local slot s.  The slot's accumulators go to row
+// row_of_slot[s] of the dense (M, D + 4) float64 buffer every rank reduces -- straight from the builder's own arrays, no
+// export copy.  The rank that OWNS the voxel's global first touch (its slot_key equals the all-reduced MIN key) subtracts the
+// reference's first-touch term a1 (1 - a1) f1 here (vlmap_builder.py:166-174 closed form), so that the
+// reduced rows only need dividing by sum alpha: ONE sum-reduce carries the whole merge.
+__global__ __launch_bounds__(256) void scatter_merge_kernel(int64_t n, int D, const int64_t* __restrict__ row_of_slot,
+                                                            const unsigned long long* __restrict__ global_key,
+                                                            const unsigned long long* __restrict__ slot_key,
+                                                            const double* __restrict__ sum_feat, const double* __restrict__ sum_w4,
+                                                            const float* __restrict__ first_feat, const double* __restrict__ first_alpha,
+                                                            double* __restrict__ acc, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t s = wave0; s < n; s += nwaves) {
+        const int64_t row = row_of_slot[s];
+        const bool owner = slot_key[s] == global_key[row];
+        const double a1 = first_alpha[s];
+        const double corr = a1 * (1.0 - a1);
+        const double* sf = sum_feat + s * D;
+        const float* f1 = first_feat + s * D;
+        double* o = acc + row * ld;
+        if (owner && corr != 0.0) {
+            for (int c = lane; c < D; c += 64) o[c] = sf[c] - corr * (double)f1[c];
+        } else {
+            for (int c = lane; c < D; c += 64) o[c] = sf[c];
+        }
+        if (lane < 4) o[D + lane] = sum_w4[s * 4 + lane];
     }
 }
 
@@ -466,11 +505,38 @@ __global__ void log_segments_kernel(const uint32_t* __restrict__ sorted_slot, lo
     }
 }
 
-// Thread per output row: replay the voxel's updates in the reference's order with the reference's dtypes
-// (vlmap_builder.py:164-178; NumPy >= 2 promotion, see oracle/avl_oracle.c avlo_integrate_frame):
+// One update of the reference's running weight / colour with the reference's dtypes (vlmap_builder.py:164-178; NumPy >= 2
+// promotion, see oracle/avl_oracle.c avlo_integrate_frame):
 //   until the first capacity doubling (_reserve_map_space, :286-311) weight is float32 and grid_rgb uint8 (truncating
 //   store at every update); afterwards weight is float64 and grid_rgb float32.  The doubling happens right after the
-//   voxel with id gs*gs - 1 was created, i.e. for every update whose key is greater than that voxel's first-touch key.
+//   voxel with id gs*gs - 1 was created, i.e. for every update whose key is greater than that voxel's first-touch key
+//   (`grown`).  c[] holds uint8 or float32 values exactly.
+__device__ __forceinline__ void replay_step(double& w, double (&c)[3], bool& started, double alpha, uint32_t rgbv, bool grown) {
+    const double v[3] = {(double)(rgbv & 0xffu), (double)((rgbv >> 8) & 0xffu), (double)((rgbv >> 16) & 0xffu)};
+    if (!started) {
+        started = true;
+        for (int k = 0; k < 3; ++k) c[k] = v[k];
+        const double ww = 0.0 + alpha;
+        w = grown ? ww : (double)(float)ww;
+    } else {
+        const double denom = w + alpha;
+        if (!grown) {
+            const float wf = (float)w;
+            for (int k = 0; k < 3; ++k) {
+                const float prod = (float)c[k] * wf;
+                const double q = ((double)prod + v[k] * alpha) / denom;
+                c[k] = (double)(uint8_t)q;
+            }
+            w = (double)(float)denom;
+        } else {
+            for (int k = 0; k < 3; ++k) c[k] = (double)(float)((c[k] * w + v[k] * alpha) / denom);
+            w = denom;
+        }
+    }
+}
+
+// Thread per output row: replay the voxel's updates in the reference's order (the log is in key order, `order` is its stable
+// sort by slot).
 __global__ __launch_bounds__(256) void replay_rgb_kernel(int64_t n, long long gs2, const int32_t* __restrict__ perm,
                                                          const unsigned long long* __restrict__ keys_sorted,
                                                          const int32_t* __restrict__ order, const long long* __restrict__ seg_start,
@@ -483,36 +549,53 @@ __global__ __launch_bounds__(256) void replay_rgb_kernel(int64_t n, long long gs
         bool started = false;
         for (long long i = seg_start[sl]; i < seg_end[sl]; ++i) {
             const int32_t e = order[i];
-            const double alpha = log.alpha[e];
-            const uint32_t rgbv = log.rgb[e];
-            const bool grown = log.key[e] > gkey;
-            const double v[3] = {(double)(rgbv & 0xffu), (double)((rgbv >> 8) & 0xffu), (double)((rgbv >> 16) & 0xffu)};
-            if (!started) {
-                started = true;
-                for (int k = 0; k < 3; ++k) c[k] = v[k];
-                const double ww = 0.0 + alpha;
-                w = grown ? ww : (double)(float)ww;
-            } else {
-                const double denom = w + alpha;
-                if (!grown) {
-                    const float wf = (float)w;
-                    for (int k = 0; k < 3; ++k) {
-                        const float prod = (float)c[k] * wf;
-                        const double q = ((double)prod + v[k] * alpha) / denom;
-                        c[k] = (double)(uint8_t)q;
-                    }
-                    w = (double)(float)denom;
-                } else {
-                    for (int k = 0; k < 3; ++k) c[k] = (double)(float)((c[k] * w + v[k] * alpha) / denom);
-                    w = denom;
-                }
-            }
+            replay_step(w, c, started, log.alpha[e], log.rgb[e], log.key[e] > gkey);
         }
         if (started) {
             if (weight) weight[r] = (float)w;
             if (grid_rgb)
                 for (int k = 0; k < 3; ++k) grid_rgb[r * 3 + k] = (uint8_t)fmin(fmax(c[k], 0.0), 255.0);
         }
+    }
+}
+
+// Multi-GPU: the sequential replay is a CHAIN over ranks (frames are sharded contiguously, so every update of rank r comes
+// before every update of rank r + 1): a rank receives the per-voxel state left by its predecessors, continues it with its own
+// log and passes it on -- 24 bytes per voxel per hop instead of shipping the logs (avlmaps_amd/parallel.py).
+struct ReplayState {
+    double w;
+    float c[3];
+    uint32_t started;
+};
+static_assert(sizeof(ReplayState) == 24, "ReplayState is exchanged between ranks as 3 x int64");
+
+__global__ __launch_bounds__(256) void replay_chain_kernel(int64_t n, unsigned long long gkey, const int64_t* __restrict__ row_of_slot,
+                                                           const int32_t* __restrict__ order, const long long* __restrict__ seg_start,
+                                                           const long long* __restrict__ seg_end, ReplayLog log,
+                                                           ReplayState* __restrict__ state) {
+    for (int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sl < n; sl += (int64_t)gridDim.x * blockDim.x) {
+        if (seg_start[sl] >= seg_end[sl]) continue;
+        ReplayState& st = state[row_of_slot[sl]];
+        double w = st.w, c[3] = {(double)st.c[0], (double)st.c[1], (double)st.c[2]};
+        bool started = st.started != 0;
+        for (long long i = seg_start[sl]; i < seg_end[sl]; ++i) {
+            const int32_t e = order[i];
+            replay_step(w, c, started, log.alpha[e], log.rgb[e], log.key[e] > gkey);
+        }
+        st.w = w;
+        for (int k = 0; k < 3; ++k) st.c[k] = (float)c[k];
+        st.started = started ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void replay_apply_kernel(int64_t n, const ReplayState* __restrict__ state, float* __restrict__ weight,
+                                                           uint8_t* __restrict__ grid_rgb) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const ReplayState st = state[r];
+        if (!st.started) continue;
+        if (weight) weight[r] = (float)st.w;
+        if (grid_rgb)
+            for (int k = 0; k < 3; ++k) grid_rgb[r * 3 + k] = (uint8_t)fminf(fmaxf(st.c[k], 0.f), 255.f);
     }
 }
 
@@ -610,6 +693,8 @@ struct avl_builder {
     long long log_cap = 0, log_used = 0;
     BatchEntry* d_table = nullptr;
     int table_cap = 0;
+    int64_t vox_bound = 0;       // host-side upper bound on the voxel counter (every fused sample may create one voxel)
+    int64_t max_capacity = 0;    // 0: the capacity is fixed; else the accumulators double up to this many voxels
 };
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
@@ -625,6 +710,14 @@ static int builder_check_flags(avl_builder* b, hipStream_t st) {
         return AVL_ERR_INVALID;
     }
     return AVL_OK;   // bit 8 (global mode: samples outside the pass-1 bounding box were dropped) is informational
+}
+
+static int read_counter(avl_builder* b, int which, int64_t* h_n, hipStream_t st) {
+    unsigned long long v = 0;
+    AVL_HIP_CHECK(hipMemcpyAsync(&v, b->counters + which, sizeof(v), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    *h_n = (int64_t)v;
+    return AVL_OK;
 }
 
 static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
@@ -646,6 +739,79 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     return AVL_OK;
 }
 
+// The reference doubles its arrays when max_id reaches their length (_reserve_map_space, vlmap_builder.py:286-311).  Here the
+// per-slot arrays are reallocated at (at least) twice the size and copied device-to-device; cell_slot is indexed by cell and
+// does not change.  Called between launches only (stream drained first).
+static int grow_builder(avl_builder* b, int64_t want, hipStream_t st) {
+    int64_t cap = b->capacity;
+    while (cap < want) cap *= 2;
+    if (cap > b->max_capacity) cap = b->max_capacity;
+    if (cap < want) {
+        set_error("voxel capacity %lld exhausted and growth is limited to %lld: raise max_capacity", (long long)b->capacity,
+                  (long long)b->max_capacity);
+        return AVL_ERR_CAPACITY;
+    }
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t oc = (size_t)b->capacity, nc = (size_t)cap, D = (size_t)b->D;
+    auto regrow = [&](void** p, size_t elem, int fill) -> hipError_t {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, nc * elem);
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(q, *p, oc * elem, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && fill >= 0) e = hipMemsetAsync(static_cast<char*>(q) + oc * elem, fill, (nc - oc) * elem, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(q); return e; }
+        (void)hipFree(*p);
+        *p = q;
+        return hipSuccess;
+    };
+    hipError_t e = regrow((void**)&b->slot_cell, sizeof(int32_t), 0xFF);
+    if (e == hipSuccess) e = regrow((void**)&b->slot_key, sizeof(unsigned long long), 0xFF);
+    if (e == hipSuccess) e = regrow((void**)&b->head, sizeof(int32_t), 0xFF);
+    if (e == hipSuccess) e = regrow((void**)&b->sum_feat, D * sizeof(double), -1);
+    if (e == hipSuccess) e = regrow((void**)&b->sum_w4, 4 * sizeof(double), -1);
+    if (e == hipSuccess) e = regrow((void**)&b->first_feat, D * sizeof(float), -1);
+    if (e == hipSuccess) e = regrow((void**)&b->first_alpha, sizeof(double), -1);
+    if (e != hipSuccess) {
+        set_error("growing the voxel accumulators from %lld to %lld voxels failed: %s", (long long)b->capacity, (long long)cap,
+                  hipGetErrorString(e));
+        return AVL_ERR_HIP;   // arrays already regrown keep their new size; the handle stays usable at the old capacity
+    }
+    b->capacity = cap;
+    return AVL_OK;
+}
+
+// the key-ordered replay log, stably sorted by slot: order[i] = log position, [seg_start[s], seg_end[s]) = the run of slot s
+struct LogSegments {
+    uint32_t* sorted_slot = nullptr;
+    int32_t *liota = nullptr, *order = nullptr;
+    long long *seg_start = nullptr, *seg_end = nullptr;
+    void* tmp = nullptr;
+    int build(avl_builder* b, int64_t n, hipStream_t st) {
+        const long long L = b->log_used;
+        size_t tmp_bytes = 0;
+        AVL_HIP_CHECK(hipMallocAsync((void**)&sorted_slot, (size_t)L * sizeof(uint32_t), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&liota, (size_t)L * sizeof(int32_t), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&order, (size_t)L * sizeof(int32_t), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_start, (size_t)n * sizeof(long long), st));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_end, (size_t)n * sizeof(long long), st));
+        AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, (size_t)n * sizeof(long long), st));
+        AVL_HIP_CHECK(hipMemsetAsync(seg_end, 0, (size_t)n * sizeof(long long), st));
+        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, liota, (int64_t)L);
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, b->log.slot, sorted_slot, liota, order, (size_t)L, 0, 32, st));
+        AVL_HIP_CHECK(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, b->log.slot, sorted_slot, liota, order, (size_t)L, 0, 32, st));
+        hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
+                           L, (long long)n, seg_start, seg_end);
+        AVL_HIP_CHECK(hipGetLastError());
+        return AVL_OK;
+    }
+    void release(hipStream_t st) {
+        (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(seg_end, st); (void)hipFreeAsync(seg_start, st);
+        (void)hipFreeAsync(order, st); (void)hipFreeAsync(liota, st); (void)hipFreeAsync(sorted_slot, st);
+    }
+};
+
 extern "C" {
 
 int avl_builder_reset(avl_builder* b, void* stream) {
@@ -660,6 +826,7 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     AVL_HIP_CHECK(hipMemsetAsync(b->err_flags, 0, sizeof(int), st));
     b->key_bias = 0;
     b->log_used = 0;
+    b->vox_bound = 0;
     return AVL_OK;
 }
 
@@ -736,6 +903,20 @@ int avl_builder_enable_replay_log(avl_builder* b, int64_t max_samples) {
     return AVL_OK;
 }
 
+int avl_builder_set_max_capacity(avl_builder* b, int64_t max_capacity) {
+    AVL_REQUIRE(b, "avl_builder_set_max_capacity: null handle");
+    AVL_REQUIRE(max_capacity == 0 || (max_capacity >= b->capacity && max_capacity < (1ll << 31)),
+                "avl_builder_set_max_capacity: must be 0 (fixed) or in [capacity, 2^31)");
+    b->max_capacity = max_capacity;
+    return AVL_OK;
+}
+
+int avl_builder_capacity(avl_builder* b, int64_t* h_capacity) {
+    AVL_REQUIRE(b && h_capacity, "avl_builder_capacity: null argument");
+    *h_capacity = b->capacity;
+    return AVL_OK;
+}
+
 int avl_builder_create(avl_builder** h_out, int gs, double cs, int vh, int D, int64_t capacity) {
     return avl_builder_create_grid(h_out, gs, gs, vh, cs, D, capacity);
 }
@@ -763,6 +944,19 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     if (B > 0) P = B * P_frame;   // total samples of the launch
     int rc = ensure_recs(b, P, st);
     if (rc != AVL_OK) return rc;
+    // worst case every sample of this launch creates a voxel: when the host-side bound reaches the capacity, read the real
+    // counter (one sync, rare: the bound advances ~20x faster than the map) and double the accumulators if it is really close
+    if (b->max_capacity > b->capacity && b->vox_bound + P > b->capacity) {
+        int64_t have = 0;
+        rc = read_counter(b, 0, &have, st);
+        if (rc != AVL_OK) return rc;
+        b->vox_bound = have;
+        if (have + P > b->capacity) {
+            rc = grow_builder(b, have + P, st);
+            if (rc != AVL_OK) return rc;
+        }
+    }
+    b->vox_bound += P;
     const unsigned long long key_bias = b->key_bias;
     if (B > 0) {
         if (B > b->table_cap) {
@@ -861,14 +1055,6 @@ int avl_builder_integrate_batch(avl_builder* b, int B, const float* const* h_dep
                           h_sample_ptrs, h_feat_ptrs, h_rgb_ptrs);
 }
 
-static int read_counter(avl_builder* b, int which, int64_t* h_n, hipStream_t st) {
-    unsigned long long v = 0;
-    AVL_HIP_CHECK(hipMemcpyAsync(&v, b->counters + which, sizeof(v), hipMemcpyDeviceToHost, st));
-    AVL_HIP_CHECK(hipStreamSynchronize(st));
-    *h_n = (int64_t)v;
-    return AVL_OK;
-}
-
 int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_voxels: null argument");
     int rc = builder_check_flags(b, as_stream(stream));
@@ -888,14 +1074,15 @@ int avl_builder_num_groups(avl_builder* b, int64_t* h_n, void* stream) {
     return read_counter(b, 2, h_n, as_stream(stream));
 }
 
-static int launch_finalize(int64_t n, int D, int gs, int vh, const int32_t* perm, const int32_t* d_cell, const double* d_sum_feat,
-                           const double* d_sum_w4, const float* d_first_feat, const double* d_first_alpha, float* d_grid_feat,
-                           int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_occupied_ids, hipStream_t st) {
+static int launch_finalize(int64_t n, int D, int gs, int vh, int64_t row0, const int32_t* perm, const int32_t* d_cell,
+                           const double* d_sum_feat, int64_t ld_sf, const double* d_sum_w4, int64_t ld_w4, const float* d_first_feat,
+                           const double* d_first_alpha, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
+                           uint8_t* d_grid_rgb, int32_t* d_occupied_ids, hipStream_t st) {
     int64_t blocks = (n + 3) / 4;
     const int64_t maxb = (int64_t)num_cus() * 16;
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, D, gs, vh, perm, d_cell, d_sum_feat, d_sum_w4,
-                       d_first_feat, d_first_alpha, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, D, gs, vh, row0, perm, d_cell, d_sum_feat, ld_sf,
+                       d_sum_w4, ld_w4, d_first_feat, d_first_alpha, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
@@ -907,8 +1094,44 @@ int avl_finalize_raw(int64_t n, int D, int gs, int vh, const int32_t* d_cell, co
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(d_cell && d_sum_w4 && d_first_alpha, "avl_finalize_raw: null input");
     AVL_REQUIRE(!d_grid_feat || (d_sum_feat && d_first_feat), "avl_finalize_raw: grid_feat needs sum_feat and first_feat");
-    return launch_finalize(n, D, gs, vh, nullptr, d_cell, d_sum_feat, d_sum_w4, d_first_feat, d_first_alpha, d_grid_feat, d_grid_pos,
-                           d_weight, d_grid_rgb, d_occupied_ids, as_stream(stream));
+    return launch_finalize(n, D, gs, vh, 0, nullptr, d_cell, d_sum_feat, D, d_sum_w4, 4, d_first_feat, d_first_alpha, d_grid_feat,
+                           d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, as_stream(stream));
+}
+
+int avl_finalize_merged(int64_t n, int64_t row0, int D, int gs, int vh, const int32_t* d_cell, const double* d_acc,
+                        int64_t ld_acc, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb,
+                        int32_t* d_occupied_ids, void* stream) {
+    AVL_REQUIRE(n >= 0 && row0 >= 0 && D > 0 && gs > 0 && vh > 0 && ld_acc >= D + 4, "avl_finalize_merged: bad shape");
+    AVL_REQUIRE(row0 + n < (1ll << 31), "avl_finalize_merged: voxel ids must fit int32");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_cell && d_acc, "avl_finalize_merged: null input");
+    return launch_finalize(n, D, gs, vh, row0, nullptr, d_cell, d_acc, ld_acc, d_acc + D, ld_acc, nullptr, nullptr, d_grid_feat,
+                           d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, as_stream(stream));
+}
+
+int avl_builder_scatter_merge(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, const uint64_t* d_global_key,
+                              double* d_acc, int64_t ld_acc, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_scatter_merge: null handle");
+    hipStream_t st = as_stream(stream);
+    int64_t have = 0;
+    int rc = avl_builder_num_voxels(b, &have, stream);
+    if (rc != AVL_OK) return rc;
+    AVL_REQUIRE(n == have, "avl_builder_scatter_merge: n=%lld but the map holds %lld voxels", (long long)n, (long long)have);
+    AVL_REQUIRE(ld_acc >= b->D + 4, "avl_builder_scatter_merge: ld_acc must be >= D + 4");
+    if (b->key_bias != 0) {
+        set_error("avl_builder_scatter_merge: a builder seeded by avl_builder_import_map cannot take part in a multi-GPU merge");
+        return AVL_ERR_STATE;
+    }
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_row_of_slot && d_global_key && d_acc, "avl_builder_scatter_merge: null pointer");
+    int64_t blocks = (n + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(scatter_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, b->D, d_row_of_slot,
+                       reinterpret_cast<const unsigned long long*>(d_global_key), b->slot_key, b->sum_feat, b->sum_w4, b->first_feat,
+                       b->first_alpha, d_acc, ld_acc);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
 }
 
 int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
@@ -936,34 +1159,18 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
     AVL_HIP_CHECK(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
-    rc = launch_finalize(n, b->D, b->gs, b->vh, perm, b->slot_cell, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, d_grid_feat,
-                         d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, st);
+    rc = launch_finalize(n, b->D, b->gs, b->vh, 0, perm, b->slot_cell, b->sum_feat, b->D, b->sum_w4, 4, b->first_feat, b->first_alpha,
+                         d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, st);
     if (rc == AVL_OK && b->log.slot && b->key_bias == 0 && b->log_used > 0 && (d_weight || d_grid_rgb)) {
         // exact sequential weight / grid_rgb: stable sort of the key-ordered log by slot, then replay per voxel
-        const long long L = b->log_used;
-        uint32_t* sorted_slot = nullptr;
-        int32_t *liota = nullptr, *order = nullptr;
-        long long *seg_start = nullptr, *seg_end = nullptr;
-        void* tmp2 = nullptr;
-        size_t tmp2_bytes = 0;
-        AVL_HIP_CHECK(hipMallocAsync((void**)&sorted_slot, (size_t)L * sizeof(uint32_t), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&liota, (size_t)L * sizeof(int32_t), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&order, (size_t)L * sizeof(int32_t), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_start, (size_t)n * sizeof(long long), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_end, (size_t)n * sizeof(long long), st));
-        AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, (size_t)n * sizeof(long long), st));
-        AVL_HIP_CHECK(hipMemsetAsync(seg_end, 0, (size_t)n * sizeof(long long), st));
-        hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, liota, (int64_t)L);
-        AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp2_bytes, b->log.slot, sorted_slot, liota, order, (size_t)L, 0, 32, st));
-        AVL_HIP_CHECK(hipMallocAsync(&tmp2, tmp2_bytes ? tmp2_bytes : 16, st));
-        AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp2, tmp2_bytes, b->log.slot, sorted_slot, liota, order, (size_t)L, 0, 32, st));
-        hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((L + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
-                           L, (long long)n, seg_start, seg_end);
-        hipLaunchKernelGGL(replay_rgb_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
-                           (long long)b->n0 * b->gs, perm, keys_out, order, seg_start, seg_end, b->log, d_weight, d_grid_rgb);
-        if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
-        (void)hipFreeAsync(tmp2, st); (void)hipFreeAsync(seg_end, st); (void)hipFreeAsync(seg_start, st);
-        (void)hipFreeAsync(order, st); (void)hipFreeAsync(liota, st); (void)hipFreeAsync(sorted_slot, st);
+        LogSegments ls;
+        rc = ls.build(b, n, st);
+        if (rc == AVL_OK) {
+            hipLaunchKernelGGL(replay_rgb_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
+                               (long long)b->n0 * b->gs, perm, keys_out, ls.order, ls.seg_start, ls.seg_end, b->log, d_weight, d_grid_rgb);
+            if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
+        }
+        ls.release(st);
     }
     (void)hipFreeAsync(tmp, st);
     (void)hipFreeAsync(perm, st);
@@ -971,6 +1178,42 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
     (void)hipFreeAsync(keys_out, st);
     if (rc != AVL_OK) return rc;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
+    return AVL_OK;
+}
+
+int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
+                             void* stream) {
+    AVL_REQUIRE(b, "avl_builder_replay_chain: null handle");
+    hipStream_t st = as_stream(stream);
+    int64_t have = 0;
+    int rc = avl_builder_num_voxels(b, &have, stream);
+    if (rc != AVL_OK) return rc;
+    AVL_REQUIRE(n == have, "avl_builder_replay_chain: n=%lld but the map holds %lld voxels", (long long)n, (long long)have);
+    if (!b->log.slot || b->key_bias != 0) {
+        set_error("avl_builder_replay_chain: the builder has no replay log (avl_builder_enable_replay_log on a fresh builder)");
+        return AVL_ERR_STATE;
+    }
+    if (n == 0 || b->log_used == 0) return AVL_OK;
+    AVL_REQUIRE(d_row_of_slot && d_state, "avl_builder_replay_chain: null pointer");
+    LogSegments ls;
+    rc = ls.build(b, n, st);
+    if (rc == AVL_OK) {
+        hipLaunchKernelGGL(replay_chain_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
+                           (unsigned long long)grow_key, d_row_of_slot, ls.order, ls.seg_start, ls.seg_end, b->log,
+                           reinterpret_cast<ReplayState*>(d_state));
+        if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
+    }
+    ls.release(st);
+    return rc;
+}
+
+int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream) {
+    AVL_REQUIRE(n >= 0, "avl_replay_state_apply: bad n");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_state, "avl_replay_state_apply: null state");
+    hipLaunchKernelGGL(replay_apply_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, as_stream(stream), n,
+                       reinterpret_cast<const ReplayState*>(d_state), d_weight, d_grid_rgb);
+    AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
 
@@ -1005,6 +1248,7 @@ int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, 
         return AVL_ERR_INVALID;
     }
     b->key_bias = 1ull << 62;
+    b->vox_bound = n;
     return AVL_OK;
 }
 

@@ -3,12 +3,14 @@
 Per frame the reference runs LSeg, back-projects ~7.8 k sampled pixels and updates the map in a Python loop
 (vlmap_builder.py:102-183).  Here the per-point loop is three HIP launches (avl_builder_integrate_frame); the host
 keeps only what is inherently sequential and tiny: the float64 pose chain (one 4x4 per frame) and the reference's
-sampling order (np.random.shuffle on the GLOBAL NumPy state, so a seeded run samples the same pixels upstream and here).
+sampling order (np.random.shuffle on the GLOBAL NumPy state, so a seeded run samples the same pixels upstream and here --
+with several ranks too: rank r first draws and discards the shuffles of the frames before its shard, see shard_sampling).
 
 Feature extraction stays on PyTorch-ROCm: `feat_extractor(rgb_uint8_hwc) -> (Hf, Wf, D) float32 CUDA tensor`
 (channels-last, stays on the device).  A reference-style (1, D, Hf, Wf) array is accepted and transposed.
 With torch.distributed initialised (one process per GPU) frames are sharded contiguously over ranks and merged with one
-sparse RCCL reduce (avlmaps_amd.parallel.merge_raw); rank 0 writes the map file.
+sparse RCCL reduce (avlmaps_amd.parallel.merge_accumulator); rank 0 writes the map file.  A seeded N-rank build gives the
+map of the seeded single-process build: grid_pos / occupied_ids / grid_rgb / weight bit-exact, grid_feat to float64 rounding.
 """
 from __future__ import annotations
 
@@ -36,7 +38,8 @@ class VLMapBuilder:
         self.base_transform = base_transform
         self.feat_extractor = feat_extractor
         self.save_every = 100                      # vlmap_builder.py:181
-        self.capacity = None                       # voxels; default below
+        self.capacity = None                       # initial voxel capacity (default gs*gs like upstream); doubles on demand
+        self.max_capacity = None                   # growth limit (default: every cell of the grid); 0 = fixed capacity
         self.min_depth, self.max_depth = 0.1, 6    # vlmap_builder.py:129
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
@@ -44,6 +47,12 @@ class VLMapBuilder:
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
         self.skip_mapped_frames = False            # True: a resumed run skips the frames listed in the map file's
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
+        self.shard_sampling = "replay"             # several ranks: "replay" = every rank first consumes the global NumPy RNG
+                                                   # exactly as the frames before its shard would have (one discarded shuffle
+                                                   # per skipped frame, ~6 ms each at 720x1080), so that a seeded N-rank run
+                                                   # samples the pixels of the seeded single-process / reference run;
+                                                   # "independent" = start at once from the rank's own RNG state (an
+                                                   # unseeded production run: statistically the same map, not the same pixels)
 
     # ------------------------------------------------------------------ pose chain (host, float64)
     def frame_transforms(self, base_poses: np.ndarray) -> List[np.ndarray]:
@@ -67,14 +76,24 @@ class VLMapBuilder:
         np.random.shuffle(shuffle_mask)
         return shuffle_mask[::depth_sample_rate].astype(np.int32)
 
+    @staticmethod
+    def skip_pixel_shuffles(n_frames: int, n_pix: int) -> None:
+        """Advance the global NumPy RNG as `n_frames` calls of sample_pixels(n_pix, .) would (the draws of a shuffle depend
+        only on the array length): what rank r > 0 does for the frames [0, lo) of the other ranks' shards, so that its first
+        frame samples the pixels it samples in the single-process run.  All frames are taken to have n_pix pixels."""
+        scratch = np.arange(n_pix)
+        for _ in range(n_frames):
+            np.random.shuffle(scratch)
+
     # ------------------------------------------------------------------ frame sources (overridable for in-memory data)
     def load_frame(self, frame_i: int):
         rgb = load_rgb_png(self.rgb_paths[frame_i])
         depth = load_depth_npy(self.depth_paths[frame_i])
         return rgb, depth
 
-    def _frame_stream(self, lo: int, hi: int, depth_sample_rate: int):
-        """(frame_i, rgb, depth, samples) in frame order.  With prefetch_frames > 0 the PNG / npy decoding of the next
+    def _frame_stream(self, lo: int, hi: int, depth_sample_rate: int, skip_shuffles: int = 0):
+        """(frame_i, rgb, depth, samples) in frame order; before the first frame is sampled the RNG is advanced past
+        `skip_shuffles` frames (skip_pixel_shuffles).  With prefetch_frames > 0 the PNG / npy decoding of the next
         frames runs on host threads and ONE sampler thread draws the pixel shuffles, strictly in frame order, so the
         global NumPy RNG is consumed exactly as in the reference loop (vlmap_builder.py:275-277) - provided nothing else
         draws from np.random while the map is being built (upstream's loop does not).  Pillow, np.load and
@@ -83,6 +102,8 @@ class VLMapBuilder:
         if n <= 0 or hi - lo <= 1:
             for i in range(lo, hi):
                 rgb, depth = self.load_frame(i)
+                if i == lo and skip_shuffles:
+                    self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
                 yield i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
             return
         import queue
@@ -90,6 +111,16 @@ class VLMapBuilder:
         from concurrent.futures import ThreadPoolExecutor
         out = queue.Queue(maxsize=n)
         stop = threading.Event()
+
+        def put(item) -> bool:
+            """blocking put that gives up once the consumer has gone (never blocks forever on a full queue)"""
+            while not stop.is_set():
+                try:
+                    out.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def sampler(ex):
             try:
@@ -100,18 +131,13 @@ class VLMapBuilder:
                         futs[nxt] = ex.submit(self.load_frame, nxt)
                         nxt += 1
                     rgb, depth = futs.pop(i).result()
-                    item = (i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate))
-                    while not stop.is_set():
-                        try:
-                            out.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            continue
-                    if stop.is_set():
+                    if i == lo and skip_shuffles:
+                        self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
+                    if not put((i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate))):
                         return
-                out.put(None)
+                put(None)
             except BaseException as e:     # surfaced on the consuming thread
-                out.put(e)
+                put(e)
 
         with ThreadPoolExecutor(max_workers=min(n, 8), thread_name_prefix="avl-frame") as ex:
             th = threading.Thread(target=sampler, args=(ex,), name="avl-sampler", daemon=True)
@@ -177,21 +203,26 @@ class VLMapBuilder:
         acc = None
         mapped_iter_set = set()
         pending = []
-        for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate):
+        if self.shard_sampling not in ("replay", "independent"):
+            raise ValueError(f"shard_sampling must be 'replay' or 'independent', not {self.shard_sampling!r}")
+        skip = lo if (ws > 1 and self.shard_sampling == "replay") else 0
+        for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip):
             if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
                 continue        # the pixel shuffle of the skipped frame was still drawn, so later frames sample as upstream
             feat = self._features_hwc(rgb)
             if acc is None:
                 D = int(feat.shape[2])
                 self.clip_feat_dim = D
-                cap = self.capacity or max(gs * gs, 1 << 16)   # the reference starts at gs*gs rows and doubles
-                acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=cap)
+                # the reference starts at gs*gs rows and doubles (_reserve_map_space, vlmap_builder.py:286-311); so does
+                # the accumulator (max_capacity: every cell of the grid)
+                acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=self.capacity or max(gs * gs, 1 << 16), max_capacity=self.max_capacity)
                 mapped_iter_set = self._resume(acc, ws)
                 self._resumed_frames = frozenset(mapped_iter_set)
                 if self.skip_mapped_frames and frame_i in self._resumed_frames:
                     continue
-                if ws == 1 and not mapped_iter_set and self.exact_rgb:
-                    # per-sample log -> finalize replays the reference's sequential weight / uint8 colour exactly
+                if not mapped_iter_set and self.exact_rgb:
+                    # per-sample log -> finalize replays the reference's sequential weight / uint8 colour exactly (several
+                    # ranks: the replay state is chained through the ranks in frame order, parallel.merge_accumulator)
                     npix = depth.shape[0] * depth.shape[1]
                     acc.enable_replay_log((hi - lo) * ((npix + depth_sample_rate - 1) // depth_sample_rate))
             if self.batch_frames > 1:
@@ -208,7 +239,23 @@ class VLMapBuilder:
                 print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
                 self._save_3d_map(acc.finalize(), mapped_iter_set, background=True)
         if acc is None:
-            raise RuntimeError("no frames to map")
+            if ws == 1:
+                raise RuntimeError("no frames to map")
+            # an empty shard (fewer frames than ranks would fill) still takes part in the merge collectives
+            import torch
+            import torch.distributed as dist
+            d = torch.zeros(1, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)
+            if int(d.item()) <= 0:
+                raise RuntimeError("no frames to map")
+            acc = ops.VoxelAccumulator(gs, cs, vh, int(d.item()), capacity=1 << 10, max_capacity=0)
+            if self.exact_rgb:
+                acc.enable_replay_log(1)
+        elif ws > 1:
+            import torch
+            import torch.distributed as dist
+            d = torch.tensor([acc.D], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)
         self._flush(acc, pending, calib_mat, calib_inv, transforms)
         self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
 
@@ -247,12 +294,12 @@ class VLMapBuilder:
             self._save_3d_map(acc.finalize(), mapped_iter_set)
             return
         import torch.distributed as dist
-        merged = parallel.merge_raw(ops.export_raw_torch(acc), dst=0)
+        self.merge_timings = {}
+        fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=self.exact_rgb, timings=self.merge_timings)
         sets = [None] * ws
         dist.all_gather_object(sets, sorted(mapped_iter_set))
         if rank == 0:
-            fin = ops.finalize_raw(merged, acc.D, gs, vh)
-            self._save_3d_map(fin, set(i for s in sets for i in s))
+            self._save_3d_map({k: v.cpu().numpy() for k, v in fin.items()}, set(i for s in sets for i in s))
         dist.barrier()
 
     def _save_3d_map(self, arrays, mapped_iter_set, background: bool = False) -> None:

@@ -112,17 +112,35 @@ class VoxelAccumulator:
     inside VLMapBuilder.create_mobile_base_map (vlmap_builder.py:86-95), living in HBM.
     """
 
-    def __init__(self, gs, cs, vh, D, capacity=None, n_rows=None):
-        """grid (gs, gs, vh) -- or (n_rows, gs, vh) for the rectangular global multi-floor map"""
+    def __init__(self, gs, cs, vh, D, capacity=None, n_rows=None, max_capacity=None):
+        """grid (gs, gs, vh) -- or (n_rows, gs, vh) for the rectangular global multi-floor map.
+        capacity: voxels the accumulators hold initially (default gs * n_rows like the reference, vlmap_builder.py:202-206);
+        max_capacity: like the reference's _reserve_map_space (:286-311) the accumulators DOUBLE when the map outgrows them,
+        up to this many voxels (default: every cell of the grid, capped at 2^31 - 1); max_capacity=0 keeps the capacity fixed."""
         lib = _lib.load()
         _lib.require_gpu()
         self.gs, self.cs, self.vh, self.D = int(gs), float(cs), int(vh), int(D)
         self.n_rows = int(n_rows) if n_rows else self.gs
-        self.capacity = int(capacity) if capacity else min(self.n_rows * self.gs, self.n_rows * self.gs * self.vh)
+        ncell = self.n_rows * self.gs * self.vh
+        cap0 = int(capacity) if capacity else min(self.n_rows * self.gs, ncell)
         h = C.c_void_p()
-        _lib.check(lib.avl_builder_create_grid(C.byref(h), self.n_rows, self.gs, self.vh, self.cs, self.D, self.capacity),
+        _lib.check(lib.avl_builder_create_grid(C.byref(h), self.n_rows, self.gs, self.vh, self.cs, self.D, cap0),
                    "avl_builder_create_grid")
         self._h = h
+        self._has_log = False
+        if max_capacity is None:
+            max_capacity = min(ncell, (1 << 31) - 1)
+        if max_capacity and max_capacity > cap0:
+            _lib.check(lib.avl_builder_set_max_capacity(h, int(max_capacity)), "avl_builder_set_max_capacity")
+
+    @property
+    def capacity(self):
+        c = C.c_int64()
+        _lib.check(_lib.load().avl_builder_capacity(self._h, C.byref(c)), "avl_builder_capacity")
+        return c.value
+
+    def has_replay_log(self):
+        return self._has_log
 
     def close(self):
         if getattr(self, "_h", None):
@@ -137,6 +155,7 @@ class VoxelAccumulator:
     def enable_replay_log(self, max_samples):
         """log every sampled pixel so that finalize() replays the reference's sequential weight / grid_rgb exactly"""
         _lib.check(_lib.load().avl_builder_enable_replay_log(self._h, int(max_samples)), "avl_builder_enable_replay_log")
+        self._has_log = True
         return self
 
     def integrate_frame(self, depth, calib, pc_transform, sample_idx, feat_hwc, rgb, frame_idx, calib_inv=None,
@@ -263,10 +282,23 @@ class VoxelAccumulator:
         _lib.check(_lib.load().avl_builder_num_groups(self._h, C.byref(n), stream), "avl_builder_num_groups")
         return n.value
 
-    def finalize(self, stream=None, want_occupied=True, as_numpy=True):
-        """-> dict(grid_feat, grid_pos, weight, grid_rgb, occupied_ids) in the reference's voxel-id order."""
+    def finalize(self, stream=None, want_occupied=True, as_numpy=True, as_torch=False):
+        """-> dict(grid_feat, grid_pos, weight, grid_rgb, occupied_ids) in the reference's voxel-id order
+        (numpy arrays; DeviceArrays with as_numpy=False; torch CUDA tensors with as_torch=True)."""
         lib = _lib.load()
         n = self.num_voxels(stream)
+        if as_torch:
+            import torch
+            dev = torch.device("cuda", torch.cuda.current_device())
+            out = dict(grid_feat=torch.empty((n, self.D), dtype=torch.float32, device=dev),
+                       grid_pos=torch.empty((n, 3), dtype=torch.int32, device=dev),
+                       weight=torch.empty((n,), dtype=torch.float32, device=dev),
+                       grid_rgb=torch.empty((n, 3), dtype=torch.uint8, device=dev),
+                       occupied_ids=torch.empty((self.n_rows, self.gs, self.vh), dtype=torch.int32, device=dev) if want_occupied else None)
+            _lib.check(lib.avl_builder_finalize(self._h, n, out["grid_feat"].data_ptr(), out["grid_pos"].data_ptr(), out["weight"].data_ptr(),
+                                                out["grid_rgb"].data_ptr(),
+                                                out["occupied_ids"].data_ptr() if want_occupied else None, stream), "avl_builder_finalize")
+            return out
         gf = DeviceArray((n, self.D), np.float32)
         gp = DeviceArray((n, 3), np.int32)
         w = DeviceArray((n,), np.float32)
@@ -320,6 +352,24 @@ def finalize_raw(raw, D, gs, vh, stream=None, n_rows=None):
     rc = lib.avl_finalize_raw(n, D, gs, vh, dev["cell"][0], dev["sum_feat"][0], dev["sum_w4"][0], dev["first_feat"][0],
                               dev["first_alpha"][0], gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr, stream)
     _lib.check(rc, "avl_finalize_raw")
+    return dict(grid_feat=gf.numpy(stream), grid_pos=gp.numpy(stream), weight=w.numpy(stream), grid_rgb=rgb.numpy(stream),
+                occupied_ids=occ.numpy(stream))
+
+
+def finalize_merged(merged, D, gs, vh, stream=None, n_rows=None):
+    """Finalise accumulators merged by parallel.merge_raw / merge_raw_local: merged = dict(cell (M,) int32, acc (M, D+4) f64)
+    in voxel-id order with the first-touch term folded in (avl_finalize_merged).  numpy / torch in, numpy out."""
+    lib = _lib.load()
+    M = len(merged["cell"])
+    cp, _, k1 = as_device(merged["cell"], np.int32, stream)
+    ap, ashape, k2 = as_device(merged["acc"], np.float64, stream)
+    assert tuple(ashape) == (M, D + 4), ashape
+    gf, gp = DeviceArray((M, D), np.float32), DeviceArray((M, 3), np.int32)
+    w, rgb = DeviceArray((M,), np.float32), DeviceArray((M, 3), np.uint8)
+    occ = DeviceArray((n_rows or gs, gs, vh), np.int32)
+    _lib.check(lib.avl_memset(occ.ptr, 0xFF, occ.nbytes, stream))
+    _lib.check(lib.avl_finalize_merged(M, 0, D, gs, vh, cp, ap, D + 4, gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr, stream),
+               "avl_finalize_merged")
     return dict(grid_feat=gf.numpy(stream), grid_pos=gp.numpy(stream), weight=w.numpy(stream), grid_rgb=rgb.numpy(stream),
                 occupied_ids=occ.numpy(stream))
 

@@ -8,8 +8,9 @@ queries on one GPU (voxel rows shard across GPUs for N > 1, no data-path collect
 One step = one pass of the index hot path: scores = feat @ queries.T fused with the row argmax
 (VLMap.index_map, vlmap.py:104-125); the feature map is resident in HBM when the timed region starts.
 `--workload build` times map creation instead (configs[2]/[3]): one step = fusing one 720x1080 RGB-D
-frame (7 776 sampled pixels, 512-D channels-last features) into the voxel map; frames shard across GPUs
-and one sparse RCCL merge runs at the end (reported separately).
+frame (7 776 sampled pixels, 512-D channels-last features) into the voxel map.  STRONG scaling: the K frames
+of one sequence shard across the GPUs, and the merge (one sparse RCCL sum-reduce + chained colour replay) and
+the finalisation on rank 0 are INSIDE the timed region.  Feature extraction (LSeg) is not included.
 
 Prints ONE JSON line on rank 0.
 """
@@ -200,8 +201,7 @@ def run_index(args, torch, dist, lib, rank, ws):
                             "sim_stream_f16_kernel (fp16 hi/lo split MFMA, fp32 accumulate, query image streamed through LDS)")),
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                           traffic=load_pmc_traffic("index"), kernel_ms=ev_ms, algorithmic_bytes=alg_bytes,
-                           mfma_busy_frac=load_pmc_mfma_busy() if (D == 512 and Q == 64) else None)
+                           kernel_ms=ev_ms, algorithmic_bytes=alg_bytes, **pmc_lookup("index", dict(N=N, D=D, Q=Q)))
     if rank == 0:
         # what a kernel that ONLY reads the same 4.1 GB gets on this box (spec peak is 8 TB/s; boxes differ by ~15 %)
         g0, g1 = C.c_float(), C.c_float()
@@ -293,14 +293,8 @@ def run_index(args, torch, dist, lib, rank, ws):
                                        argmax_agreement_with_gpu=agree)
             out["extra"]["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             del feat_h
-            if not args.no_build_extra:
-                del sc
-                torch.cuda.empty_cache()
-                out["extra"]["map_build"] = run_build_core(args, torch, dist, lib, 0, 1, frames=args.build_frames, quiet=True)
-                args.build_batch = 16      # 16 frames per launch triple (avl_builder_integrate_batch)
-                out["extra"]["map_build_batched"] = run_build_core(args, torch, dist, lib, 0, 1, frames=args.build_frames * 4, quiet=True)
-                args.build_batch = 1
             if not args.no_build_extra and D == 512:
+                del sc
                 # BASELINE config 5 (fused multimodal index): 2M x (512 visual | 1024 audio) columns, 128 queries, one pass
                 try:
                     del feat
@@ -367,14 +361,19 @@ def pc_transforms(poses):
     return [inv_init @ (bt @ cvt_pose_vec2tf(p) @ inv_bt) @ bt @ b2c for p in poses]
 
 
-def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
+def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, batch=1, exact_rgb=True):
+    """STRONG scaling of map creation: `total_frames` frames of one sequence are sharded contiguously over the ranks; the
+    timed region is everything between the first fused frame and the finished map resident in rank 0's HBM:
+        fuse own shard (K1/K2/K3 per launch)  ->  [ws > 1: plan + scatter + ONE RCCL sum-reduce + chained colour replay]
+        -> finalize (first-touch-key sort, grid_feat / grid_pos / weight / grid_rgb / occupied_ids)
+    max over ranks.  Per-frame feature extraction (LSeg, 2 ViT-L crops per frame upstream) is NOT included: the pixel features
+    are resident in HBM, as the kernel boundary takes them."""
     from avlmaps_amd import ops, parallel
     H, W, Hf, Wf, D, rate = 720, 1080, 347, 520, 512, 100
     nbuf = 4
     depths, rgbs, feats = make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=99 + rank)
-    total = frames * ws
-    lo, hi = parallel.shard_frames(total, rank, ws)
-    Ts = pc_transforms(trajectory(total))
+    lo, hi = parallel.shard_frames(total_frames, rank, ws)
+    Ts = pc_transforms(trajectory(total_frames))
     calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
     rs = np.random.RandomState(5 + rank)
     samples = []
@@ -383,80 +382,106 @@ def run_build_core(args, torch, dist, lib, rank, ws, frames, quiet=False):
         rs.shuffle(m)
         samples.append(torch.from_numpy(m[::rate].astype(np.int32)).cuda())
     P = int(samples[0].numel())
-    cap = args.capacity or max(1_500_000, 300_000 + 800 * (hi - lo))
-    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=cap)
-
-    BATCH = max(1, int(args.build_batch))
-
-    def fuse(i):
-        b = i % nbuf
-        acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
-
+    nloc = hi - lo
+    warmup = min(warmup, nloc)
+    cap = args.capacity or max(1_500_000, 300_000 + 450 * nloc)
+    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=cap)       # doubles on demand like the reference's arrays
+    if exact_rgb:
+        acc.enable_replay_log(max(1, (nloc + warmup) * P))
+    BATCH = max(1, int(batch))
     plans = {}
 
-    def fuse_batch(i0, i1):
-        # the frame buffers form a ring of nbuf: the pointer table of a batch is resolved once per ring phase
-        idx = tuple(i % nbuf for i in range(i0, i1))
-        plan = plans.get(idx)
-        if plan is None:
-            plan = plans[idx] = acc.make_batch_plan([depths[b] for b in idx], [samples[b] for b in idx], [feats[b] for b in idx],
-                                                    [rgbs[b] for b in idx])
-        acc.integrate_batch(plan, calib, Ts[i0:i1], frame_idx0=i0)
+    def fuse(i0, i1):
+        if BATCH == 1:
+            for i in range(i0, i1):
+                b = i % nbuf
+                acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
+            return
+        for j0 in range(i0, i1, BATCH):
+            j1 = min(i1, j0 + BATCH)
+            # the frame buffers form a ring of nbuf: the pointer table of a batch is resolved once per ring phase
+            idx = tuple(i % nbuf for i in range(j0, j1))
+            plan = plans.get(idx)
+            if plan is None:
+                plan = plans[idx] = acc.make_batch_plan([depths[b] for b in idx], [samples[b] for b in idx], [feats[b] for b in idx],
+                                                        [rgbs[b] for b in idx])
+            acc.integrate_batch(plan, calib, Ts[j0:j1], frame_idx0=j0)
 
-    nwarm = min(args.warmup, hi - lo)
-    for i in range(lo, lo + nwarm):
-        fuse(i)
+    if warmup:
+        fuse(lo, lo + warmup)           # untimed: code objects loaded, pools warm; then start from an empty map
+        acc.num_voxels()
+        acc.reset()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    lib.avl_event_create(C.byref(e0))
+    lib.avl_event_create(C.byref(e1))
+    tim = {}
     barrier_sync(torch, dist, ws)
     t0 = time.perf_counter()
-    if BATCH == 1:
-        for i in range(lo + nwarm, hi):
-            fuse(i)
+    lib.avl_event_record(e0, None)
+    fuse(lo, hi)
+    lib.avl_event_record(e1, None)
+    if ws == 1:
+        fin = acc.finalize(as_torch=True)                      # sorts first-touch keys, emits the reference's arrays (device)
     else:
-        for i0 in range(lo + nwarm, hi, BATCH):
-            fuse_batch(i0, min(hi, i0 + BATCH))
+        fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=exact_rgb, timings=tim)
     torch.cuda.synchronize()
-    dt = max_over_ranks(torch, dist, ws, time.perf_counter() - t0)
-    timed = hi - lo - nwarm
-    nvox = acc.num_voxels()
-    npts = acc.num_points()
-    # merge (one sparse RCCL reduce) + finalize on rank 0
-    barrier_sync(torch, dist, ws)
-    t1 = time.perf_counter()
-    raw = ops.export_raw_torch(acc)
-    merged = parallel.merge_raw(raw, dst=0)
-    n_merged = None
-    if merged is not None:
-        fin = ops.finalize_raw({k: merged[k] for k in ("cell", "sum_feat", "sum_w4", "first_feat", "first_alpha")}, D, 1000, 30)
-        n_merged = int(fin["grid_pos"].shape[0])
-    torch.cuda.synchronize()
-    t_merge = max_over_ranks(torch, dist, ws, time.perf_counter() - t1)
-    timed_all = sum_over_ranks(torch, dist, ws, timed)
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(torch, dist, ws, dt_local)
+    ms = C.c_float()
+    lib.avl_event_elapsed_ms(e0, e1, C.byref(ms))
+    fuse_ms = ms.value
+    fuse_s = max_over_ranks(torch, dist, ws, fuse_ms * 1e-3)
+    lib.avl_event_destroy(e0)
+    lib.avl_event_destroy(e1)
+    nvox, npts, ngroups = acc.num_voxels(), acc.num_points(), acc.num_groups()
+    n_final = int(fin["grid_pos"].shape[0]) if fin is not None else None
+    single_gpu_merge = None
+    if ws == 1:
+        # what the merge path itself costs on this GPU at this map size (plan = key sort, scatter into the dense float64
+        # buffer, chained replay, finalize): everything of the N-GPU merge except the RCCL transfer.  Untimed extra.
+        del fin
+        torch.cuda.empty_cache()
+        single_gpu_merge = {}
+        parallel.merge_accumulator(acc, exact_rgb=exact_rgb, timings=single_gpu_merge)
+        t_fin = time.perf_counter()
+        acc.finalize(as_torch=True)
+        torch.cuda.synchronize()
+        single_gpu_merge["plain_finalize_s"] = time.perf_counter() - t_fin
     # algorithmic bytes per frame: every sample 4 B index + 4 B depth + 29 B record; every active sample 3 B rgb + D*4 B
     # feature gather + 29 B record re-read; every (frame, voxel) group one fp64 row store (D*8 B), plus a row load when
     # the voxel already existed, plus the first-touch feature row (D*4 B) when it is new
-    nfr = max(1, hi - lo)
-    pts_per_frame = npts / nfr
-    groups, newv = acc.num_groups() / nfr, nvox / nfr
+    nfr = max(1, nloc)
+    pts_per_frame, groups, newv = npts / nfr, ngroups / nfr, nvox / nfr
     alg_frame = P * (4 + 4 + 29) + pts_per_frame * (3 + D * 4 + 29) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
-    res = dict(frames_per_launch=BATCH, frames_per_s=timed_all / dt, ms_per_frame=dt / max(1, timed) * 1e3, frames_timed_per_gpu=timed,
-               sampled_px_per_frame=P, active_points_per_frame=pts_per_frame, voxel_groups_per_frame=groups,
-               new_voxels_per_frame=newv, voxels_local=nvox, voxels_merged=n_merged,
-               merge_finalize_s=t_merge, algorithmic_bytes_per_frame=alg_frame,
-               achieved_gbs=alg_frame * timed / dt / 1e9 if dt > 0 else None)
+    res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, frames_per_s=total_frames / dt,
+               seconds=dt, fuse_seconds_max_rank=fuse_s, merge_finalize_seconds=dt - fuse_s, exact_rgb_replay=bool(exact_rgb),
+               timed_region="fuse shard + merge (one RCCL sum-reduce, chained replay) + finalize on rank 0; no feature extraction",
+               ms_per_frame_fuse=fuse_ms / nfr, sampled_px_per_frame=P, active_points_per_frame=pts_per_frame,
+               voxel_groups_per_frame=groups, new_voxels_per_frame=newv, voxels_local=nvox, voxels_merged=n_final,
+               merge_breakdown=tim or None, single_gpu_merge_path=single_gpu_merge,
+               algorithmic_bytes_per_frame=alg_frame, fuse_achieved_gbs=alg_frame * nloc / (fuse_ms * 1e-3) / 1e9 if fuse_ms > 0 else None)
     acc.close()
+    del acc
+    torch.cuda.empty_cache()
     return res
 
 
 def run_build(args, torch, dist, lib, rank, ws):
-    r = run_build_core(args, torch, dist, lib, rank, ws, frames=args.steps + args.warmup)
+    r = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.steps, warmup=args.warmup, batch=args.build_batch,
+                       exact_rgb=not args.no_exact_rgb)
     out = dict(metric="map_build_frames_per_sec", value=r["frames_per_s"], unit="frames/s", n_gpus=ws, steps=args.steps,
-               warmup=args.warmup, ms_per_step=r["ms_per_frame"], higher_is_better=True, scaling="weak", vs_baseline=None,
-               dtype="f64", data="synthetic",
-               config=dict(workload="create_map kernels: 720x1080 RGB-D frame -> 7776 sampled px -> back-project + voxelise "
-                                    "+ fp64 feature fusion, 512-D channels-last features resident in HBM (LSeg not included)",
-                           parallelism=f"contiguous frame shards x{ws}, one sparse RCCL reduce at the end"))
-    out["roofline"] = dict(bound="hbm", achieved=r["achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                           frac=(r["achieved_gbs"] or 0) / HBM_PEAK_GBS, traffic=load_pmc_traffic("build"))
+               warmup=args.warmup, ms_per_step=r["seconds"] / max(1, args.steps) * 1e3, higher_is_better=True, scaling="strong",
+               vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=f"create_map: {args.steps} RGB-D frames 720x1080 of one sequence -> 7776 sampled px each -> "
+                                    "back-project + voxelise + fp64 feature fusion of 512-D channels-last pixel features resident in HBM "
+                                    "(feature extraction / LSeg NOT included), then merge + finalize INSIDE the timed region",
+                           total_frames=args.steps, frames_per_launch=r["frames_per_launch"],
+                           parallelism=f"contiguous frame shards x{ws}; one sparse RCCL sum-reduce + chained colour replay + "
+                                       "finalize on rank 0, all timed"))
+    out["roofline"] = dict(bound="hbm", achieved=r["fuse_achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                           frac=(r["fuse_achieved_gbs"] or 0) / HBM_PEAK_GBS, kernel="K1 bp_voxelize + K2 link + K3 fuse (per launch)",
+                           algorithmic_bytes=r["algorithmic_bytes_per_frame"] * max(1, r["frames_per_launch"]),
+                           **pmc_lookup("build", dict(frames_per_launch=r["frames_per_launch"])))
     out["extra"] = r
     if rank == 0 and ws == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_build_baseline()
@@ -486,27 +511,22 @@ def cpu_build_baseline(frames=12):
                        "(the reference's own Python loop measured ~5.2 frames/s, SURVEY.md section 6)")
 
 
-def load_pmc_traffic(which):
-    """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json, written by tools/publish_profiles.py
-    from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same command); None if absent."""
-    p = ROOT / "profiles" / "pmc_traffic.json"
+def pmc_lookup(which, shape):
+    """HBM bytes per launch (and, where collected, the matrix-pipe busy fraction) of the dominant kernel from the committed PMC
+    passes: profiles/pmc_traffic.json holds one entry per (workload, shape) that tools/publish_profiles.py derived from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / SQ-counter runs of this same command.  Only an entry whose shape matches
+    this run exactly is reported; otherwise traffic is null (never another shape's number)."""
+    out = dict(traffic=None, traffic_source=None, mfma_busy_frac=None)
     try:
-        return json.loads(p.read_text())[which]["total_bytes"]
+        entries = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["entries"]
     except Exception:
-        return None
-
-
-def load_pmc_mfma_busy():
-    """fraction of the kernel during which a SIMD's matrix pipe is busy, from the committed SQ counter pass
-    (SQ_VALU_MFMA_BUSY_CYCLES summed over 1024 SIMDs / (GRBM_GUI_ACTIVE summed over 8 XCDs / 8)); None if absent"""
-    try:
-        d = json.loads(sorted((ROOT / "profiles").glob("r*_pmc_index.json"))[-1].read_text())
-        for k, v in d.items():
-            if "sim_split_f16_kernel" in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
-                return v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * v["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
-    except Exception:
-        pass
-    return None
+        return out
+    for e in entries:
+        if e.get("workload") == which and all(e.get("shape", {}).get(k) == v for k, v in shape.items()):
+            out.update(traffic=e.get("total_bytes"), traffic_source=e.get("source"), mfma_busy_frac=e.get("mfma_busy_frac"),
+                       traffic_kernel=e.get("kernel"))
+            break
+    return out
 
 
 def main():
@@ -521,7 +541,9 @@ def main():
     ap.add_argument("--capacity", type=int, default=None,
                     help="voxel capacity of the builder (default: 1.5 M, grown with the frame count: config 3's 5 000 frames "
                          "create 2.1 M voxels)")
-    ap.add_argument("--build-frames", type=int, default=300)
+    ap.add_argument("--build-frames", type=int, default=10_000,
+                    help="index workload: total frames of the map-creation strong-scaling extra (north_star: a 10k-frame sequence)")
+    ap.add_argument("--no-exact-rgb", action="store_true", help="build without the per-sample replay log (no exact weight / colour)")
     ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch triple (avl_builder_integrate_batch)")
     ap.add_argument("--event-mode", choices=["pair", "each"], default="pair",
                     help="HIP events around the whole timed region (pair) or between every step (each)")
@@ -536,7 +558,7 @@ def main():
     if args.profile_run:
         args.no_cpu = args.no_build_extra = True
     if args.steps is None:
-        args.steps = 500 if args.workload == "index" else 500
+        args.steps = 500 if args.workload == "index" else 10_000     # build: north_star's 10k-frame sequence (config 4: --steps 40000)
     if args.warmup is None:
         args.warmup = 20
 
@@ -552,6 +574,19 @@ def main():
     _lib.check(lib.avl_set_device(local), "avl_set_device")
 
     out = run_index(args, torch, dist, lib, rank, ws) if args.workload == "index" else run_build(args, torch, dist, lib, rank, ws)
+    if args.workload == "index" and not args.no_build_extra:
+        # map creation next to the index line, at every N (all ranks take part: the merge is a collective): STRONG scaling of a
+        # fixed `--build-frames` sequence with merge + finalize inside the timed region (see run_build_core)
+        torch.cuda.empty_cache()
+        try:
+            r1 = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.build_frames, batch=1)
+            r16 = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.build_frames, batch=16)
+            if rank == 0:
+                out.setdefault("extra", {})["map_build_strong"] = r1
+                out["extra"]["map_build_strong_batched16"] = r16
+        except Exception as e:   # the extra must never break the benchmark line
+            if rank == 0:
+                out.setdefault("extra", {})["map_build_strong"] = dict(error=repr(e))
     if rank == 0:
         print(json.dumps(out))
     if ws > 1:

@@ -183,13 +183,33 @@ def test_edge_cases(ops):
     assert acc.num_voxels() == 0
     # capacity overflow is reported, not silently dropped
     depth = np.full((H, W), 1.0, np.float32)
-    small = ops.VoxelAccumulator(100, 0.05, 30, D, capacity=4)
+    small = ops.VoxelAccumulator(100, 0.05, 30, D, capacity=4, max_capacity=0)      # fixed capacity
     T2 = np.eye(4)
     T2[:3, :3] = [[0, 0, 1], [-1, 0, 0], [0, -1, 0]]   # camera z -> map x (forward), so points land in range
     T2[2, 3] = 0.5
     small.integrate_frame(depth, calib, T2, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
     with pytest.raises(AvlError, match="capacity"):
         small.num_voxels()
+    # growth limited below what the frame needs: reported at the launch that would overflow
+    capped = ops.VoxelAccumulator(100, 0.05, 30, D, capacity=4, max_capacity=8)
+    with pytest.raises(AvlError, match="capacity"):
+        capped.integrate_frame(depth, calib, T2, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
+
+
+def test_accumulators_double_like_reserve_map_space(ops, golden):
+    """the reference doubles its arrays when max_id reaches their length (vlmap_builder.py:286-311); a builder created far
+    too small grows between launches and produces the map of one created large enough, including the replayed colours"""
+    from oracle import avl_oracle as O
+    g = golden("g2a_builder_small.npz")
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    args = (ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"], g["rgbs"], g["feats"], g["samples"])
+    big = run_gpu_builder(*args, capacity=4000, replay=True)
+    tiny = run_gpu_builder(*args, capacity=8, replay=True)
+    assert big.capacity == 4000 and tiny.capacity >= tiny.num_voxels() == big.num_voxels() and tiny.capacity < 4000
+    a, b = big.finalize(), tiny.finalize()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(b["grid_pos"], g["grid_pos"]) and np.array_equal(b["grid_rgb"], g["grid_rgb"])
 
 
 def test_heatmap_matches_reference(ops, golden):
@@ -244,15 +264,28 @@ def test_sharded_build_merges_to_the_single_gpu_map(ops, golden):
                         frame_offset=k)
     raws = [ops.export_raw_torch(x) for x in (a, b)]
     merged = parallel.merge_raw_local(raws)
-    out = ops.finalize_raw({kk: v for kk, v in merged.items() if kk != "first_key"}, a.D, a.gs, a.vh)
+    out = ops.finalize_merged(merged, a.D, a.gs, a.vh)
     assert np.array_equal(out["grid_pos"], whole["grid_pos"]) and np.array_equal(out["occupied_ids"], whole["occupied_ids"])
     np.testing.assert_allclose(out["grid_feat"], whole["grid_feat"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(out["weight"], whole["weight"], rtol=1e-6)
     assert np.abs(out["grid_rgb"].astype(int) - whole["grid_rgb"].astype(int)).max() <= 1
-    # and the collective version degenerates to the same thing for one rank
-    one = parallel.merge_raw(ops.export_raw_torch(run_gpu_builder(ops, *args, Ts, g["depths"], g["rgbs"], g["feats"], g["samples"],
-                                                                   capacity=2000)))
+    # the collective version degenerates to the same thing for one rank, and the DEVICE merge (scatter + finalize kernels on
+    # the builder's own arrays, the product path) equals the torch-tensor merge of the exported accumulators bit for bit
+    full = run_gpu_builder(ops, *args, Ts, g["depths"], g["rgbs"], g["feats"], g["samples"], capacity=2000, replay=True)
+    one = parallel.merge_raw(ops.export_raw_torch(full))
     assert torch.equal(one["cell"].cpu(), merged["cell"].cpu())
+    ref1 = ops.finalize_merged({k: v for k, v in one.items()}, full.D, full.gs, full.vh)
+    tim = {}
+    dev = parallel.merge_accumulator(full, timings=tim)
+    assert tim["merged_voxels"] == len(whole["grid_pos"]) and tim["exact_rgb"] and tim["payload_bytes"] == tim["merged_voxels"] * (full.D + 4) * 8
+    fin = full.finalize()
+    for k in ("grid_feat", "grid_pos", "occupied_ids"):
+        assert np.array_equal(dev[k].cpu().numpy(), ref1[k]), k
+    # with the replay log the chained state gives the sequential weight / colour of the single-GPU finalize (= the reference)
+    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
+        assert np.array_equal(dev[k].cpu().numpy(), fin[k]), k
+    assert np.array_equal(dev["grid_rgb"].cpu().numpy(), g["grid_rgb"])
+    np.testing.assert_allclose(dev["grid_feat"].cpu().numpy(), fin["grid_feat"], rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("batch", [2, 3, 6])

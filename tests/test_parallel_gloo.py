@@ -37,6 +37,7 @@ def make_rank_raw(seed, D, cells, frame_lo):
 
 
 def expected_merge(raws):
+    """per cell: summed accumulators, the smallest first-touch key and ITS first-touch feature / alpha"""
     D = raws[0]["sum_feat"].shape[1]
     table = {}
     for r in raws:
@@ -58,19 +59,25 @@ def _worker(rank, ws, port, tmpdir):
     cellsets = [[5, 9, 100, 7, 42, 77], [9, 3, 77, 1000, 5]]
     raws = [make_rank_raw(10 + k, D, cellsets[k], frame_lo=1000 * k) for k in range(ws)]
     merged = parallel.merge_raw(raws[rank], dst=0)
+    plan = parallel.plan_merge(raws[rank]["cell"], raws[rank]["first_key"])      # collective: every rank calls it
+    cells, table = expected_merge(raws)
+    # the plan alone: every rank knows every voxel's final row
+    assert plan.M == len(cells) and plan.cell.tolist() == cells
+    assert [cells[r] for r in plan.row_of_slot.tolist()] == raws[rank]["cell"].tolist()
+    assert plan.grow_key(3) == table[cells[2]]["key"] and plan.grow_key(10 ** 6) == (1 << 64) - 1
     if rank == 0:
-        cells, table = expected_merge(raws)
         assert merged["cell"].tolist() == cells
+        assert set(merged) == {"cell", "first_key", "acc"} and merged["acc"].shape == (len(cells), D + 4)
         local = parallel.merge_raw_local(raws)                   # single-process variant: same result
         for k in merged:
-            assert torch.allclose(local[k].double(), merged[k].double(), rtol=1e-15, atol=1e-15), k
+            assert torch.allclose(local[k].double(), merged[k].double(), rtol=1e-14, atol=1e-14), k
         for i, c in enumerate(cells):
             e = table[c]
             assert int(merged["first_key"][i]) == e["key"]
-            np.testing.assert_allclose(merged["sum_feat"][i].numpy(), e["sf"], rtol=1e-15, atol=1e-15)
-            np.testing.assert_allclose(merged["sum_w4"][i].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
-            assert np.array_equal(merged["first_feat"][i].numpy(), e["ff"])
-            assert float(merged["first_alpha"][i]) == e["fa"]
+            # ONE reduce: the owner of the global first touch has already subtracted a1 (1 - a1) f1
+            want = e["sf"] - e["fa"] * (1.0 - e["fa"]) * e["ff"].astype(np.float64)
+            np.testing.assert_allclose(merged["acc"][i, :D].numpy(), want, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(merged["acc"][i, D:].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
         # rank 0's frames precede rank 1's: shared voxels must be owned by rank 0
         for c in set(cellsets[0]) & set(cellsets[1]):
             i = cells.index(c)
@@ -82,6 +89,16 @@ def _worker(rank, ws, port, tmpdir):
     merged = parallel.merge_raw(raws[0] if rank == 0 else empty, dst=0)
     if rank == 0:
         assert sorted(merged["cell"].tolist()) == sorted(cellsets[0])
+    # point-to-point chain of the replay state (24 B per voxel) as merge_accumulator does it
+    coll = parallel._Coll()
+    state = torch.zeros((4, 3), dtype=torch.int64)
+    if rank > 0:
+        coll.recv(state, rank - 1)
+    state += rank + 1
+    if rank < ws - 1:
+        coll.send(state, rank + 1)
+    else:
+        assert int(state[0, 0]) == ws * (ws + 1) // 2
     # row-sharded per-query top-1 with a cross-rank tie -> lowest global row wins
     vals = torch.tensor([[1.0, 5.0, 2.0], [4.0, 5.0, 0.5]])[rank]
     rows = torch.tensor([[3, 1, 2], [0, 4, 9]])[rank]
@@ -111,5 +128,54 @@ def test_single_process_merge_is_a_sort():
     perm = torch.tensor([2, 0, 1])
     shuffled = {k: v[perm] for k, v in raw.items()}
     merged = parallel.merge_raw(shuffled)
-    for k in raw:
-        assert torch.equal(merged[k], raw[k])
+    assert torch.equal(merged["cell"], raw["cell"]) and torch.equal(merged["first_key"], raw["first_key"])
+    a1 = raw["first_alpha"]
+    want = raw["sum_feat"] - (a1 * (1 - a1))[:, None] * raw["first_feat"].double()
+    assert torch.equal(merged["acc"][:, :4], want) and torch.equal(merged["acc"][:, 4:], raw["sum_w4"])
+
+
+def test_seeded_shards_sample_like_the_single_process_run():
+    """rank r fast-forwards the global NumPy RNG past the frames before its shard (VLMapBuilder.skip_pixel_shuffles):
+    its sample lists are the single-process (= reference, vlmap_builder.py:275-277) lists of the same frames"""
+    from avlmaps_amd.map.vlmap_builder import VLMapBuilder
+    n_pix, rate, n_frames = 48 * 64, 7, 7
+    np.random.seed(99)
+    whole = [VLMapBuilder.sample_pixels(n_pix, rate) for _ in range(n_frames)]
+    for ws in (2, 3, 8):
+        for rank in range(ws):
+            lo, hi = parallel.shard_frames(n_frames, rank, ws)
+            np.random.seed(99)
+            VLMapBuilder.skip_pixel_shuffles(lo, n_pix)
+            for i in range(lo, hi):
+                assert np.array_equal(VLMapBuilder.sample_pixels(n_pix, rate), whole[i]), (ws, rank, i)
+
+
+def test_frame_stream_skips_and_never_hangs_on_a_full_queue(tmp_path):
+    """_frame_stream(skip_shuffles=...) yields the reference's lists for a shard, inline and with the prefetch threads; a consumer
+    that stops early (exception) does not leave the sampler thread blocked on a full queue"""
+    import threading
+    from avlmaps_amd.map.vlmap_builder import VLMapBuilder
+    H, W, rate, n = 12, 16, 5, 9
+    b = VLMapBuilder(tmp_path, {}, None, [None] * n, [None] * n, np.eye(4), np.eye(4))
+    b.load_frame = lambda i: (np.zeros((H, W, 3), np.uint8), np.full((H, W), float(i), np.float32))
+    np.random.seed(5)
+    whole = [VLMapBuilder.sample_pixels(H * W, rate) for _ in range(n)]
+    for prefetch in (0, 3):
+        b.prefetch_frames = prefetch
+        np.random.seed(5)
+        got = list(b._frame_stream(4, 8, rate, skip_shuffles=4))
+        assert [g[0] for g in got] == [4, 5, 6, 7]
+        for i, _, depth, s in got:
+            assert depth[0, 0] == i and np.array_equal(s, whole[i])
+    b.prefetch_frames = 1
+    before = threading.active_count()
+    gen = b._frame_stream(0, n, rate)
+    next(gen)
+    gen.close()                                   # consumer gone with the queue full: the sampler must wind down
+    assert threading.active_count() <= before + 1
+
+    def boom(i):
+        raise OSError("disk gone")
+    b.load_frame = boom
+    with pytest.raises(OSError):
+        list(b._frame_stream(0, n, rate))
