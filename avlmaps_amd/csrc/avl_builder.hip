@@ -743,14 +743,12 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
 // per-slot arrays are reallocated at (at least) twice the size and copied device-to-device; cell_slot is indexed by cell and
 // does not change.  Called between launches only (stream drained first).
 static int grow_builder(avl_builder* b, int64_t want, hipStream_t st) {
+    // `want` is a worst-case bound (every sample of the next launch creates a voxel): grow as far as allowed; if the map
+    // really outgrows max_capacity the kernel's own overflow flag reports it (AVL_ERR_CAPACITY at the next counter read)
     int64_t cap = b->capacity;
     while (cap < want) cap *= 2;
     if (cap > b->max_capacity) cap = b->max_capacity;
-    if (cap < want) {
-        set_error("voxel capacity %lld exhausted and growth is limited to %lld: raise max_capacity", (long long)b->capacity,
-                  (long long)b->max_capacity);
-        return AVL_ERR_CAPACITY;
-    }
+    if (cap <= b->capacity) return AVL_OK;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     const size_t oc = (size_t)b->capacity, nc = (size_t)cap, D = (size_t)b->D;
     auto regrow = [&](void** p, size_t elem, int fill) -> hipError_t {
@@ -951,8 +949,10 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         rc = read_counter(b, 0, &have, st);
         if (rc != AVL_OK) return rc;
         b->vox_bound = have;
-        if (have + P > b->capacity) {
-            rc = grow_builder(b, have + P, st);
+        int64_t need = have + P;                       // a grid cannot hold more voxels than it has cells
+        if (need > (int64_t)b->ncell) need = (int64_t)b->ncell;
+        if (need > b->capacity) {
+            rc = grow_builder(b, need, st);
             if (rc != AVL_OK) return rc;
         }
     }

@@ -140,6 +140,10 @@ constexpr int kRowPadHalves = 8;  // +16 B per query row: consecutive rows shift
 // 8 waves per workgroup, one workgroup per CU (LDS-bound).  Measured alternatives on the config-2 shape: 12 or 16 waves
 // (0.81 / 1.37 ms vs 0.75 ms) and no register prefetch (1.10 ms) are slower.
 constexpr int kSplitThreads = 512;
+#ifndef AVL_RING
+#define AVL_RING 2
+#endif
+constexpr int kRing = AVL_RING;   // register buffers of the unrolled k loop (resident kernel)
 constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup iteration
 
 // One workgroup per (padded) query row: row max -> power-of-two scale 2^S with max|q|*2^S in [512, 1024)
@@ -231,13 +235,37 @@ __device__ __forceinline__ void split8(const f32x4 v0, const f32x4 v1, half8& hi
 #endif
 }
 
+// Range guard of the on-the-fly split (raw float32 maps).  The map operand is converted to fp16 hi/lo UNSCALED (a per-row scale
+// would need the row maximum before the first product), so a row is only as accurate as float32 when its largest |element|
+// lies in [kGuardLo, kGuardHi): below, the elements sink into the fp16 subnormal range (a voxel touched once from 4 m away
+// stores feat * exp(-r^2/1.2) ~ 1e-6, vlmap_builder.py:166-168) and above fp16 saturates.  Every lane tracks the maximum of
+// the 32 floats it loads per k step (v_max3_f32 with |.| modifiers: 16 VALU ops per step); the epilogue publishes one 32-bit
+// word per (wave, tile) with a bit per out-of-range / non-finite row, and sim_fixup_rows_kernel recomputes exactly those rows
+// in float32 (np.argmax semantics for NaN).  Prepared maps carry a per-row power-of-two scale instead (avl_sim_prepare_map).
+constexpr float kGuardLo = 0x1p-7f, kGuardHi = 0x1p15f;
+
+__device__ __forceinline__ void guard_max8(float& m, const f32x4 v0, const f32x4 v1) {
+#ifndef AVL_GUARD_BUILTIN
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v0.x), "v"(v0.y));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v0.z), "v"(v0.w));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v1.x), "v"(v1.y));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m) : "v"(v1.z), "v"(v1.w));
+#else
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v0.x)), __builtin_fabsf(v0.y));
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v0.z)), __builtin_fabsf(v0.w));
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v1.x)), __builtin_fabsf(v1.y));
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(v1.z)), __builtin_fabsf(v1.w));
+#endif
+}
+
 // epilogue shared by the split-fp16 kernels: this lane holds voxel `row`, queries q_base + t*32 + 8g + 4kg + e (g<4, e<4) in
 // acc[t][a][4g+e]; the NA partial accumulators are summed, scaled back by the per-query 2^-S, optionally stored, and reduced
 // to the row's first maximum (one cross-half shuffle); later query chunks chain through `best`
 template <int QT, int NA>
 __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], const float* isc, int q_base, int rows, int Q,
                                                float* __restrict__ scores, int32_t* __restrict__ argmax,
-                                               float* __restrict__ best, int64_t row, int64_t N, int kg, int first_chunk) {
+                                               float* __restrict__ best, int64_t row, int64_t N, int kg, int first_chunk,
+                                               float rscale = 1.f, uint32_t* __restrict__ flags = nullptr, float rmax = 1.f) {
     const int qend = q_base + rows;  // first query index NOT in this chunk
     float bv = -INFINITY;
     int bi = INT_MAX;
@@ -254,10 +282,10 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
             for (int a = 1; a < NA; ++a) {   // small cross-term sums first would be more accurate still; fp32 add suffices
                 r.x += acc[t][a][4 * g + 0]; r.y += acc[t][a][4 * g + 1]; r.z += acc[t][a][4 * g + 2]; r.w += acc[t][a][4 * g + 3];
             }
-            v.x = r.x * is4.x;
-            v.y = r.y * is4.y;
-            v.z = r.z * is4.z;
-            v.w = r.w * is4.w;
+            v.x = r.x * is4.x * rscale;   // rscale: the prepared map's per-row 2^-s (1 otherwise)
+            v.y = r.y * is4.y * rscale;
+            v.z = r.z * is4.z * rscale;
+            v.w = r.w * is4.w * rscale;
             if (scores && row < N) {
                 float* sp = scores + row * (int64_t)Q + qg;
                 if (qg + 3 < qend && (Q & 3) == 0) {
@@ -275,14 +303,23 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
             if (qg + 3 < qend && v.w > bv) { bv = v.w; bi = qg + 3; }
         }
     }
-    if (argmax || best) {
+    if (argmax || best || flags) {
         const float ov = __shfl_xor(bv, 32, 64);
         const int oi = __shfl_xor(bi, 32, 64);
         if (ov > bv || (ov == bv && oi < bi)) {
             bv = ov;
             bi = oi;
         }
-        if (kg == 0 && row < N) {
+        if (flags) {
+            // one word per 32-row unit: bit j = row j of the unit must be recomputed in float32 (largest |element| outside
+            // the range the unscaled fp16 split resolves, non-finite, or no score compared greater than -inf: NaN)
+            const float m = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+            const bool bad = row < N && (!(m == 0.f || (m >= kGuardLo && m < kGuardHi)) || bi == INT_MAX);
+            const unsigned long long mask = __ballot(bad);
+            const int64_t row0 = __shfl(row, 0, 64);
+            if ((threadIdx.x & 63) == 0 && row0 < N) flags[row0 >> 5] = (uint32_t)(mask | (mask >> 32));
+        }
+        if ((argmax || best) && kg == 0 && row < N) {
             if (bi == INT_MAX) bi = q_base;
             if (!first_chunk) {  // earlier chunks hold smaller indices: they win ties
                 const float pv = best[row];
@@ -298,19 +335,90 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
 }
 
 // in-place conversion of a float32 map to the split layout: group g of 8 floats (32 B) -> hi[8] fp16 (16 B) | lo[8] fp16 (16 B),
-// the same split8() the kernel applies on the fly, so prepared and raw maps give bit-identical scores
-__global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict__ feat, int64_t N, int D, int64_t ld) {
-    const int gpr = D >> 3;  // groups per row
-    const int64_t total = N * gpr;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / gpr;
-        const int g = (int)(i - row * gpr);
-        f32x4* p = reinterpret_cast<f32x4*>(feat + row * ld + 8 * g);
-        const f32x4 v0 = p[0], v1 = p[1];
-        half8 hi, lo;
-        split8(v0, v1, hi, lo);
-        p[0] = __builtin_bit_cast(f32x4, hi);
-        p[1] = __builtin_bit_cast(f32x4, lo);
+// the same split8() the kernel applies on the fly.  Wave per row.  With row_scale != nullptr the row is first multiplied by
+// the power of two 2^s that brings its largest |element| into [2^14, 2^15) -- exact, and it keeps EVERY row at the full
+// ~22 bits of the hi/lo pair whatever its magnitude (a voxel seen once from 5 m away holds feat * 1e-9) -- and 2^-s is stored
+// in row_scale[row] for the kernel's epilogue.  Without it (s = 0) prepared and raw maps give bit-identical scores.
+// Rows that are all zero or contain a non-finite value are left unscaled.
+__global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict__ feat, int64_t N, int D, int64_t ld,
+                                                              float* __restrict__ row_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int gpr = D >> 3;  // groups of 8 floats per row
+    for (int64_t row = wave0; row < N; row += nwaves) {
+        f32x4* p = reinterpret_cast<f32x4*>(feat + row * ld);
+        float scale = 1.f;
+        if (row_scale) {
+            unsigned mb = 0;   // max over |x| as integer bits: NaN / inf order above every finite value
+            for (int g = lane; g < 2 * gpr; g += 64) {
+                const f32x4 v = p[g];
+                mb = max(max(mb, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+                mb = max(max(mb, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+            }
+            for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
+            int sh = 0;
+            if (mb != 0 && mb < 0x7f800000u) sh = max(-100, min(100, 14 - ilogbf(__uint_as_float(mb))));
+            scale = ldexpf(1.f, sh);
+            if (lane == 0) row_scale[row] = ldexpf(1.f, -sh);
+        }
+        for (int g = lane; g < gpr; g += 64) {
+            f32x4 v0 = p[2 * g], v1 = p[2 * g + 1];
+            v0.x *= scale; v0.y *= scale; v0.z *= scale; v0.w *= scale;
+            v1.x *= scale; v1.y *= scale; v1.z *= scale; v1.w *= scale;
+            half8 hi, lo;
+            split8(v0, v1, hi, lo);
+            p[2 * g] = __builtin_bit_cast(f32x4, hi);
+            p[2 * g + 1] = __builtin_bit_cast(f32x4, lo);
+        }
+    }
+}
+
+// Recompute the rows the range guard flagged (one bit per row, one word per 32 rows) in float32 on the vector ALU, wave per
+// row: every score, and the row argmax with np.argmax semantics (first NaN wins, else first maximum).  Flagged rows are rare
+// on in-range maps (none at all on LSeg-scale rows), so this is a ~3 us scan of N/32 words; on a map full of tiny rows it is
+// the slow-but-correct path and the prepared map (per-row scale) is the fast one.
+__global__ __launch_bounds__(256) void sim_fixup_rows_kernel(const float* __restrict__ feat, int64_t N, int D, int64_t ld,
+                                                             const float* __restrict__ q, int Q, int64_t ldq,
+                                                             const uint32_t* __restrict__ flags, float* __restrict__ scores,
+                                                             int32_t* __restrict__ argmax, float* __restrict__ best) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t nwords = (N + 31) >> 5;
+    for (int64_t base = wave0 * 64; base < nwords; base += nwaves * 64) {
+        const uint32_t w = base + lane < nwords ? flags[base + lane] : 0u;
+        unsigned long long any = __ballot(w != 0u);
+        while (any) {
+            const int l = __ffsll((long long)any) - 1;
+            any &= any - 1;
+            uint32_t word = (uint32_t)__shfl((int)w, l, 64);
+            while (word) {
+                const int b = __ffs((int)word) - 1;
+                word &= word - 1;
+                const int64_t row = (base + l) * 32 + b;
+                if (row >= N) continue;
+                const float* a = feat + row * ld;
+                float bv = -INFINITY;
+                int bi = 0;
+                bool have = false, nan_seen = false;
+                for (int qi = 0; qi < Q; ++qi) {
+                    const float* qr = q + (int64_t)qi * ldq;
+                    float sum = 0.f;
+                    for (int d = lane; d < D; d += 64) sum = fmaf(a[d], qr[d], sum);
+                    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                    if (lane == 0 && scores) scores[row * (int64_t)Q + qi] = sum;
+                    if (!nan_seen) {
+                        if (sum != sum) { nan_seen = true; bv = sum; bi = qi; }
+                        else if (!have || sum > bv) { bv = sum; bi = qi; have = true; }
+                    }
+                }
+                if (lane == 0) {
+                    if (argmax) argmax[row] = bi;
+                    if (best) best[row] = bv;
+                }
+            }
+        }
     }
 }
 
@@ -325,7 +433,9 @@ template <int QT, int NSTEPS, bool PRE, bool FQ>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, const float* __restrict__ q_raw, int64_t ldq, int Qtot, int KC, int nkc, int q_base,
-    int rows, int Q, float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
+    int rows, int Q, float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk,
+    const float* __restrict__ row_scale, uint32_t* __restrict__ flags) {
+    // row_scale (PRE only, nullable): per-row 2^-s of a map prepared with scaling.  flags (!PRE): range-guard words, see kGuardLo.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NA = QT == 1 ? 3 : (QT == 2 ? 2 : 1);   // accumulator sets per tile (register budget: 16 VGPRs each)
     constexpr int X1 = NA > 1 ? 1 : 0, X2 = NA > 2 ? 2 : X1;
@@ -448,6 +558,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][a][e] = 0.f;
+        float rmax = 0.f;   // !PRE: largest |element| this lane has loaded of its row (range guard)
 
         for (int kc = 0; kc < nkc; ++kc) {
             if (nkc > 1) {
@@ -473,6 +584,9 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                         bh = __builtin_bit_cast(half8, b[2 * m]);
                         bl = __builtin_bit_cast(half8, b[2 * m + 1]);
                     } else {
+#ifndef AVL_ABL_NOGUARD
+                        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
+#endif
                         split8(b[2 * m], b[2 * m + 1], bh, bl);
                     }
                     const int off = (s * 64 + 8 * m) * 2;
@@ -502,16 +616,18 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                 }
             };
             if constexpr (NSTEPS > 0) {
-                // compile-time trip count, ring of 3 register buffers: the loads of steps s+1 and s+2 are in flight
-                // while step s is computed (24 KB per wave, 192 KB per CU), all waits are counted vmcnt
-                f32x4 ring[3][8];
-                load(ring[0], 0);
-                if (NSTEPS > 1) load(ring[1], 1);
+                // compile-time trip count, ring of kRing register buffers: the loads of the next kRing - 1 steps are in flight
+                // while step s is computed, all waits are counted vmcnt.  Rings of 2 and 3 measure the same (0.717 / 0.718 ms,
+                // DESIGN.md); 2 leaves the 32 VGPRs the range guard and the epilogue need without spilling.
+                f32x4 ring[kRing][8];
+#pragma unroll
+                for (int r = 0; r + 1 < kRing; ++r)
+                    if (r < NSTEPS) load(ring[r], r);
 #pragma unroll
                 for (int s = 0; s < NSTEPS; ++s) {
-                    if (s + 2 < NSTEPS) load(ring[(s + 2) % 3], s + 2);
+                    if (s + kRing - 1 < NSTEPS) load(ring[(s + kRing - 1) % kRing], s + kRing - 1);
                     __builtin_amdgcn_sched_barrier(0);   // keep the prefetch block ahead of the compute block
-                    compute(ring[s % 3], s);
+                    compute(ring[s % kRing], s);
                 }
             } else {
                 load(buf0, 0);
@@ -526,7 +642,11 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             }
         }
 
-        split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk);
+        float rscale = 1.f;
+        if constexpr (PRE) {
+            if (row_scale) rscale = row_scale[rowc];
+        }
+        split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax);
     }
 }
 
@@ -548,7 +668,8 @@ template <int QT, int SPC, bool PRE>
 __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
-    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk) {
+    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
+    uint32_t* __restrict__ flags) {
     static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 64 * SPC;
@@ -624,6 +745,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
         for (int t = 0; t < QT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][0][e] = 0.f;
+        float rmax = 0.f;
 
         for (int c = 0; c < nch; ++c) {
             const int cn = c + 1 < nch ? c + 1 : 0;
@@ -651,6 +773,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
                         bh = __builtin_bit_cast(half8, b[2 * m]);
                         bl = __builtin_bit_cast(half8, b[2 * m + 1]);
                     } else {
+                        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
                         split8(b[2 * m], b[2 * m + 1], bh, bl);
                     }
                     const int off = (s * 64 + 8 * m) * 2;
@@ -679,7 +802,11 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #endif
             cur ^= 1;
         }
-        split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk);
+        float rscale = 1.f;
+        if constexpr (PRE) {
+            if (row_scale) rscale = row_scale[row < N ? row : N - 1];
+        }
+        split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax);
     }
 }
 
@@ -1003,9 +1130,25 @@ static const void* pick_split_kernel(bool s8, bool fq) {
     return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, false>);
 }
 
+static int run_fixup(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq, const uint32_t* d_flags,
+                     float* d_scores, int32_t* d_argmax, float* d_best, hipStream_t st) {
+    const int64_t nwords = (N + 31) >> 5;
+    int64_t blocks = (nwords + 255) / 256;          // a wave scans 64 words: 4 x the waves needed, flagged rows spread out
+    const int64_t maxb = (int64_t)num_cus() * 8;
+    if (blocks > maxb) blocks = maxb;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sim_fixup_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_feat, N, D, ld, d_q, Q, ldq, d_flags, d_scores,
+                       d_argmax, d_best);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+// PRE: d_row_scale = per-row 2^-s of the prepared map (nullable).  !PRE: d_flags = (N + 31) / 32 range-guard words, written by
+// every launch and consumed by sim_fixup_rows_kernel at the end.
 template <bool PRE>
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
-                     float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, hipStream_t st) {
+                     float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, const float* d_row_scale,
+                     uint32_t* d_flags, hipStream_t st) {
     float* inv_scale = reinterpret_cast<float*>(d_ws);
     _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
     const bool fq = split_plan_is_fused(p, D);   // resident image built inside the kernel: no prep launch, no workspace
@@ -1025,11 +1168,12 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
             const _Float16* img_c = img;
             const float* isc_c = inv_scale;
             int Qtot = p.Qtot, nch = p.nkc, q_base = c.q_base, rows = c.rows, first = ci == 0 ? 1 : 0;
-            void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &nch, &q_base, &rows, &Q, &d_scores, &d_argmax, &d_best, &first};
+            void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &nch, &q_base, &rows, &Q, &d_scores, &d_argmax, &d_best, &first,
+                            &d_row_scale, &d_flags};
             AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
         }
         AVL_HIP_CHECK(hipGetLastError());
-        return AVL_OK;
+        return PRE ? AVL_OK : run_fixup(d_feat, N, D, ld, d_q, Q, ldq, d_flags, d_scores, d_argmax, d_best, st);
     }
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
@@ -1043,11 +1187,11 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
         const float* isc_c = inv_scale;
         int Qtot = p.Qtot, KC = p.KC, nkc = p.nkc, q_base = c.q_base, rows = c.rows, first = ci == 0 ? 1 : 0;
         void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &d_q, &ldq, &Qtot, &KC, &nkc, &q_base, &rows, &Q,
-                        &d_scores, &d_argmax, &d_best, &first};
+                        &d_scores, &d_argmax, &d_best, &first, &d_row_scale, &d_flags};
         AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
     }
     AVL_HIP_CHECK(hipGetLastError());
-    return AVL_OK;
+    return PRE ? AVL_OK : run_fixup(d_feat, N, D, ld, d_q, Q, ldq, d_flags, d_scores, d_argmax, d_best, st);
 }
 
 static int run_mfma_f32(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
@@ -1076,19 +1220,29 @@ using namespace avl;
 
 extern "C" {
 
+static size_t align_up(size_t b, size_t a) { return (b + a - 1) / a * a; }
+static size_t guard_bytes(int64_t N) { return align_up((size_t)((N + 31) >> 5) * sizeof(uint32_t), kHdrAlign); }
+
 int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes) {
     AVL_REQUIRE(h_bytes, "avl_sim_workspace_bytes: null output");
     SplitPlan p, r;
     size_t b = kHdrAlign;   // enough for either plan: the exact fp32-MFMA mode always uses the resident one
     if (make_split_plan(D, Q, p, true) && p.ws_bytes > b) b = p.ws_bytes;
     if (make_split_plan(D, Q, r, false) && r.ws_bytes > b) b = r.ws_bytes;
-    *h_bytes = b;
+    *h_bytes = align_up(b, kHdrAlign);
     return AVL_OK;
 }
 
-int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
-                      int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
-                      void* d_workspace, size_t workspace_bytes, void* stream) {
+int avl_sim_workspace_bytes_n(int64_t N, int D, int Q, size_t* h_bytes) {
+    AVL_REQUIRE(N >= 0, "avl_sim_workspace_bytes_n: bad N");
+    const int rc = avl_sim_workspace_bytes(D, Q, h_bytes);
+    if (rc == AVL_OK) *h_bytes += guard_bytes(N);
+    return rc;
+}
+
+static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat, const float* d_queries,
+                           int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
+                           void* d_workspace, size_t workspace_bytes, void* stream) {
     AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores: bad shape N=%lld D=%d Q=%d", (long long)N, D, Q);
     AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
     AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED, "avl_sim_scores: bad precision %d", precision);
@@ -1121,16 +1275,22 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     }
     int rc;
     if (use_split || use_f32_mfma) {
-        void* ws = d_workspace;
+        // workspace = [query image, only when the plan needs one][range-guard words, raw split path only]
+        const bool prepared = precision == AVL_SIM_PREPARED;
+        const bool needs_img = use_f32_mfma || !split_plan_is_fused(p, D);   // the fused-prep path keeps the query image in LDS only
+        const size_t img_bytes = needs_img ? align_up(p.ws_bytes, kHdrAlign) : 0;
+        const size_t flag_bytes = (use_split && !prepared) ? guard_bytes(N) : 0;
+        char* ws = static_cast<char*>(d_workspace);
         void* tmp_ws = nullptr;
-        const bool needs_ws = use_f32_mfma || !split_plan_is_fused(p, D);   // the fused-prep path keeps the query image in LDS only
-        if (needs_ws && (!ws || workspace_bytes < p.ws_bytes)) {
-            AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, p.ws_bytes, st));
-            ws = tmp_ws;
+        if (img_bytes + flag_bytes > 0 && (!ws || workspace_bytes < img_bytes + flag_bytes)) {
+            AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, img_bytes + flag_bytes, st));
+            ws = static_cast<char*>(tmp_ws);
         }
-        rc = use_split ? (precision == AVL_SIM_PREPARED
-                              ? run_split<true>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st)
-                              : run_split<false>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st))
+        uint32_t* flags = flag_bytes ? reinterpret_cast<uint32_t*>(ws + img_bytes) : nullptr;
+        rc = use_split ? (prepared ? run_split<true>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, d_row_scale,
+                                                     nullptr, st)
+                                   : run_split<false>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, nullptr,
+                                                      flags, st))
                        : run_mfma_f32(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st);
         if (tmp_ws) (void)hipFreeAsync(tmp_ws, st);
     } else {
@@ -1140,16 +1300,30 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
     return rc;
 }
 
-int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, void* stream) {
+int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
+                      int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
+                      void* d_workspace, size_t workspace_bytes, void* stream) {
+    return sim_scores_impl(d_feat, nullptr, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, d_best, precision, d_workspace,
+                           workspace_bytes, stream);
+}
+
+int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,
+                            const float* d_queries, int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best,
+                            void* d_workspace, size_t workspace_bytes, void* stream) {
+    return sim_scores_impl(d_feat, d_row_scale, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, d_best, AVL_SIM_PREPARED,
+                           d_workspace, workspace_bytes, stream);
+}
+
+int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, float* d_row_scale, void* stream) {
     AVL_REQUIRE(N >= 0 && D > 0 && ld_feat >= D, "avl_sim_prepare_map: bad shape");
     AVL_REQUIRE(D % 64 == 0 && ld_feat % 4 == 0 && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0,
                 "avl_sim_prepare_map: needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D, (long long)ld_feat);
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat, "avl_sim_prepare_map: null pointer");
-    int64_t blocks = (N * (D >> 3) + 255) / 256;
+    int64_t blocks = (N + 3) / 4;
     const int64_t maxb = (int64_t)num_cus() * 16;
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(sim_prepare_map_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_feat, N, D, ld_feat);
+    hipLaunchKernelGGL(sim_prepare_map_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_feat, N, D, ld_feat, d_row_scale);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }

@@ -68,17 +68,20 @@ class VLMap(Map):
     # ------------------------------------------------------------------ index
     def _device_feat(self):
         """grid_feat mirrored into HBM once (re-uploaded only if the host array object changes).  The private device copy
-        is converted to the split-fp16 layout the matrix-core kernel consumes directly (avl_sim_prepare_map: same bytes,
-        bit-identical scores, no per-query conversion work); self._sim_precision tells the kernels which form it has."""
+        is converted to the split-fp16 layout the matrix-core kernel consumes directly, every row with its own power-of-two
+        scale (avl_sim_prepare_map: same bytes, no per-query conversion work, and voxels observed once from far away --
+        rows of magnitude 1e-6 ... 1e-15, vlmap_builder.py:166-168 -- score as accurately as any other row);
+        self._sim_precision tells the kernels which form it has."""
         from .. import ops
         from ..device import DeviceArray
         if self._dev_feat is None or self._dev_feat_src is not self.grid_feat:
-            self._dev_feat = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_feat, dtype=np.float32))
+            dev = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_feat, dtype=np.float32))
             self._dev_feat_src = self.grid_feat
             self._sim_precision = "auto"
-            if self._dev_feat.shape[1] % 64 == 0 and self._dev_feat.shape[0] > 0:
-                ops.prepare_map(self._dev_feat)
+            if dev.shape[1] % 64 == 0 and dev.shape[0] > 0:
+                dev = ops.prepare_map(dev, scaled=True)
                 self._sim_precision = "prepared"
+            self._dev_feat = dev
         return self._dev_feat
 
     def _device_pos(self):

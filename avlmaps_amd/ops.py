@@ -22,6 +22,9 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
     """
     lib = _lib.load()
     _lib.require_gpu()
+    prepared = None
+    if isinstance(feat, PreparedMap):
+        prepared, feat, precision = feat, feat.feat, "prepared"
     if stream is None and _is_torch(feat):
         from .device import torch_stream_ptr
         stream = torch_stream_ptr()           # launch on torch's current stream so torch-side ordering holds
@@ -53,7 +56,11 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
         ap, ak = alloc((N,), np.int32, out_argmax)
     if want_best or out_best is not None:
         bp, bk = alloc((N,), np.float32, out_best)
-    rc = lib.avl_sim_scores(fptr, N, D, D, qptr, Q, D, sp, ap, bp, PRECISION[precision], stream)
+    if prepared is not None and prepared.row_scale is not None:
+        rs = prepared.row_scale
+        rc = lib.avl_sim_scores_prepared(fptr, rs.data_ptr() if _is_torch(rs) else rs.ptr, N, D, D, qptr, Q, D, sp, ap, bp, None, 0, stream)
+    else:
+        rc = lib.avl_sim_scores(fptr, N, D, D, qptr, Q, D, sp, ap, bp, PRECISION[precision], stream)
     _lib.check(rc, "avl_sim_scores")
     if isinstance(feat, np.ndarray):
         _lib.check(lib.avl_stream_sync(stream))
@@ -62,15 +69,37 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
     return sk, ak, bk
 
 
-def prepare_map(feat_dev, stream=None):
-    """Convert a DEVICE-resident float32 map in place into the split-fp16 layout (avl_sim_prepare_map); afterwards call
-    sim_scores(..., precision="prepared").  feat_dev: DeviceArray or torch CUDA tensor (N, D), D % 64 == 0."""
+class PreparedMap:
+    """a device-resident map converted in place by avl_sim_prepare_map: `feat` (N, D) now holds fp16 hi | lo groups,
+    `row_scale` (N,) float32 the per-row 2^-s (None: prepared without scaling).  Pass it to sim_scores as `feat`."""
+    __slots__ = ("feat", "row_scale", "shape")
+
+    def __init__(self, feat, row_scale, shape):
+        self.feat, self.row_scale, self.shape = feat, row_scale, tuple(shape)
+
+
+def prepare_map(feat_dev, scaled=True, stream=None):
+    """Convert a DEVICE-resident float32 map in place into the split-fp16 layout (avl_sim_prepare_map) and return a
+    PreparedMap for sim_scores.  scaled=True (default): every row gets its own power-of-two scale, so rows of any magnitude
+    -- e.g. voxels observed once from far away, feat * exp(-r^2/1.2) -- score with float32-class accuracy.  scaled=False:
+    scores bit-identical to the on-the-fly split of the raw map.  feat_dev: DeviceArray or torch CUDA tensor (N, D), D % 64 == 0."""
     lib = _lib.load()
     if isinstance(feat_dev, np.ndarray):
         raise TypeError("prepare_map works on a device-resident map (DeviceArray / torch CUDA tensor), not a host array")
+    if stream is None and _is_torch(feat_dev):
+        from .device import torch_stream_ptr
+        stream = torch_stream_ptr()
     fptr, fshape, _ = as_device(feat_dev, np.float32, stream)
-    _lib.check(lib.avl_sim_prepare_map(fptr, fshape[0], fshape[1], fshape[1], stream), "avl_sim_prepare_map")
-    return feat_dev
+    rs = None
+    if scaled:
+        if _is_torch(feat_dev):
+            import torch
+            rs = torch.empty((fshape[0],), dtype=torch.float32, device=feat_dev.device)
+        else:
+            rs = DeviceArray((fshape[0],), np.float32)
+    rptr = None if rs is None else (rs.data_ptr() if _is_torch(rs) else rs.ptr)
+    _lib.check(lib.avl_sim_prepare_map(fptr, fshape[0], fshape[1], fshape[1], rptr, stream), "avl_sim_prepare_map")
+    return PreparedMap(feat_dev, rs, fshape)
 
 
 def mask_from_argmax(argmax, cat_id, stream=None):

@@ -50,7 +50,7 @@ def init_distributed(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if ws > 1 and not dist.is_initialized():
+    if (ws > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:   # AVLMAPS_DIST_BACKEND=gloo lets several ranks share one GPU (testing the choreography)
@@ -63,8 +63,13 @@ def init_distributed(backend: Optional[str] = None):
 
 
 def _dist_on(group=None) -> bool:
+    """collectives are used with more than one rank -- or with ONE rank when AVLMAPS_FORCE_COLLECTIVES=1 (a single MI355X
+    box: RCCL refuses two ranks on one device, "Duplicate GPU detected", so this is how the real RCCL calls of the merge
+    -- float64 sum-reduce of the payload, int64 MIN all-reduce, all_gather -- are exercised there)"""
     import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1"
 
 
 class _Coll:

@@ -84,17 +84,25 @@ enum {
     AVL_SIM_AUTO = 0,      /* SPLIT_F16 when the shape allows it (D % 64 == 0, 16-byte aligned rows), else EXACT        */
     AVL_SIM_EXACT = 1,     /* float32 products and accumulation (an fmaf chain): v_mfma_f32_32x32x2_f32 on the matrix
                               cores when the shape allows it, otherwise the vector-ALU kernel (any N, D, Q, strides)     */
-    AVL_SIM_SPLIT_F16 = 2, /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q|, HBM-bound    */
+    AVL_SIM_SPLIT_F16 = 2, /* fp16 hi/lo split, 3 MFMA per product, fp32 accumulate: |err| <~ 1e-6*|a||q|, HBM-bound.
+                              Range-guarded: a row whose largest |element| is outside [2^-7, 2^15) -- where the unscaled
+                              fp16 pair would lose bits or saturate -- or non-finite is recomputed in float32 by a
+                              follow-up kernel (np.argmax semantics for NaN rows), so every row is float32-class.       */
     AVL_SIM_EXACT_VALU = 3,/* force the vector-ALU float32 kernel                                                        */
-    AVL_SIM_PREPARED = 4   /* d_feat was converted by avl_sim_prepare_map: SPLIT_F16 without the on-the-fly split,
-                              bit-identical scores                                                                       */
+    AVL_SIM_PREPARED = 4   /* d_feat was converted by avl_sim_prepare_map: SPLIT_F16 without the on-the-fly split        */
 };
 
 /* One-off, IN-PLACE conversion of a device-resident float32 map (N, D; D % 64 == 0, 16-byte aligned rows) into the split
  * layout the matrix-core kernel consumes directly: every group of 8 floats (32 bytes) becomes fp16 hi[8] | fp16 lo[8]
  * (same 4 bytes per element, same row stride).  Meant for a map that is indexed many times (VLMap keeps its private device
- * copy in this form); pass AVL_SIM_PREPARED to avl_sim_scores afterwards.  The float32 values are not recoverable exactly. */
-AVL_API int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, void* stream);
+ * copy in this form).  The float32 values are not recoverable exactly.
+ *   d_row_scale != NULL (N floats, out): every row is first scaled by the power of two that brings its largest |element| into
+ *     [2^14, 2^15) and 2^-s is stored here; pass it to avl_sim_scores_prepared.  Rows of any magnitude (a voxel observed once
+ *     from 5 m away stores feat * exp(-r^2/1.2) ~ 1e-9, vlmap_builder.py:166-168) keep the full ~22 bits: this is the form
+ *     VLMap uses.  Rows containing NaN / inf are left unscaled and score NaN (argmax 0).
+ *   d_row_scale == NULL: no scaling; avl_sim_scores(..., AVL_SIM_PREPARED) then gives scores bit-identical to the on-the-fly
+ *     split of the raw map (without its range guard: meant for maps known to be LSeg-scale). */
+AVL_API int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, float* d_row_scale, void* stream);
 
 /*
  * d_feat     (N, D) float32 row-major with row stride ld_feat (elements)  -- VLMap.grid_feat
@@ -108,12 +116,19 @@ AVL_API int avl_sim_scores(const float* d_feat, int64_t N, int D, int64_t ld_fea
                            int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
                            void* stream);
 
-/* Scratch the SPLIT_F16 path needs for the prepared query image; pass the same buffer to
- * avl_sim_scores_ws to avoid the internal allocation (used by the benchmark / graph capture). */
+/* Scratch of the matrix-core paths: the prepared query image (avl_sim_workspace_bytes: depends on D, Q only) and, for
+ * the raw split path, one range-guard word per 32 voxel rows (avl_sim_workspace_bytes_n = image + guard words).  Pass a
+ * buffer of that size to avl_sim_scores_ws to keep every allocation off the hot path (benchmark / graph capture); with a
+ * smaller or NULL workspace the library allocates from the stream-ordered pool. */
 AVL_API int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes);
+AVL_API int avl_sim_workspace_bytes_n(int64_t N, int D, int Q, size_t* h_bytes);
 AVL_API int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
                               int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
                               void* d_workspace, size_t workspace_bytes, void* stream);
+/* Scores of a map prepared WITH row scaling (d_row_scale from avl_sim_prepare_map; NULL = prepared without). */
+AVL_API int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,
+                                    const float* d_queries, int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax,
+                                    float* d_best, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Host-buffer convenience wrapper (synchronous): copies in, runs, copies out. */
 AVL_API int avl_sim_scores_host(const float* h_feat, int64_t N, int D, const float* h_queries, int Q,

@@ -190,10 +190,12 @@ def test_edge_cases(ops):
     small.integrate_frame(depth, calib, T2, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
     with pytest.raises(AvlError, match="capacity"):
         small.num_voxels()
-    # growth limited below what the frame needs: reported at the launch that would overflow
+    # growth limited below what the frame creates: grows as far as allowed, then reported the same way
     capped = ops.VoxelAccumulator(100, 0.05, 30, D, capacity=4, max_capacity=8)
+    capped.integrate_frame(depth, calib, T2, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
+    assert capped.capacity == 8
     with pytest.raises(AvlError, match="capacity"):
-        capped.integrate_frame(depth, calib, T2, np.arange(H * W, dtype=np.int32), feat, rgb, 0)
+        capped.num_voxels()
 
 
 def test_accumulators_double_like_reserve_map_space(ops, golden):

@@ -43,8 +43,7 @@ def test_golden_wide_queries(ops, golden, tag, precision):
     g = golden("g7_similarity_wide.npz")
     feat, q, ref = g[f"{tag}_feat"], g[f"{tag}_mean_feats"], g[f"{tag}_scores"]
     if precision == "prepared":
-        feat = DeviceArray.from_numpy(feat)
-        ops.prepare_map(feat)
+        feat = ops.prepare_map(DeviceArray.from_numpy(feat))          # per-row power-of-two scale (what VLMap keeps resident)
     sc, am, best = ops.sim_scores(feat, q, want_best=True, precision=precision)
     sc, am, best = (x.numpy() if hasattr(x, "numpy") and not isinstance(x, np.ndarray) else x for x in (sc, am, best))
     np.testing.assert_allclose(sc, ref, rtol=0, atol=1e-4)          # north_star tolerance
@@ -238,12 +237,65 @@ def test_prepared_map_gives_bit_identical_scores(ops):
         feat = (rng.standard_normal((N, D)) * np.exp(rng.uniform(-6, 2.5, (N, D)))).astype(np.float32)
         q = rng.standard_normal((Q, D)).astype(np.float32) / np.sqrt(D)
         sc0, am0, b0 = ops.sim_scores(feat, q, want_best=True, precision="split_f16")
-        dev = DeviceArray.from_numpy(feat)
-        ops.prepare_map(dev)
-        sc1, am1, b1 = ops.sim_scores(dev, q, want_best=True, precision="prepared")
+        dev = ops.prepare_map(DeviceArray.from_numpy(feat), scaled=False)
+        sc1, am1, b1 = ops.sim_scores(dev, q, want_best=True)
         assert np.array_equal(sc1.numpy(), sc0) and np.array_equal(am1.numpy(), am0) and np.array_equal(b1.numpy(), b0)
+        # with the per-row scale the scores differ in the last bits only (the row is split at another binary point)
+        sc2, am2, _ = ops.sim_scores(ops.prepare_map(DeviceArray.from_numpy(feat)), q)
+        ref = feat.astype(np.float64) @ q.astype(np.float64).T
+        bound = 3e-6 * (np.abs(feat).astype(np.float64) @ np.abs(q).astype(np.float64).T) + 1e-12
+        assert np.all(np.abs(sc2.numpy() - ref) <= bound) and np.mean(am2.numpy() == np.argmax(ref, axis=1)) > 0.999
     with pytest.raises(TypeError):
         ops.prepare_map(feat)
+
+
+@pytest.mark.parametrize("Q,D", [(2, 512), (64, 512), (65, 512), (100, 512), (128, 1536)])
+def test_rows_of_any_magnitude_rank_like_float64(ops, Q, D):
+    """A voxel touched by ONE sample stores feat * alpha with alpha = exp(-r^2 / 1.2) (vlmap_builder.py:166-168): 1e-7 ... 1e-15
+    at 4-6 m.  The unscaled fp16 hi/lo pair cannot hold such rows (and saturates above 6.5e4), so the raw split path guards its
+    range and recomputes out-of-range rows in float32, and the prepared map scales every row by its own power of two: in both,
+    every row -- 1e-14, 1, 1e5, all-zero, NaN, inf -- ranks its queries like the float64 product / like np.argmax."""
+    from avlmaps_amd.device import DeviceArray
+    rng = np.random.default_rng(77 + Q)
+    N = 3000
+    feat = rng.standard_normal((N, D)).astype(np.float32)
+    mag = np.ones(N)
+    mag[: N // 2] = 10.0 ** rng.uniform(-14, -2, N // 2)          # far single-touch voxels
+    mag[N // 2: N // 2 + 200] = 10.0 ** rng.uniform(4.9, 7, 200)    # beyond fp16
+    feat = (feat * mag[:, None]).astype(np.float32)
+    feat[5] = 0.0
+    q = (rng.standard_normal((Q, D)) / np.sqrt(D)).astype(np.float32)
+    if D == 1536:
+        q[: Q // 2, 512:] = 0
+        q[Q // 2:, :512] = 0
+    ref = feat.astype(np.float64) @ q.astype(np.float64).T
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 1e-4 * np.abs(ref).max(axis=1)      # rows whose winner float32 can resolve at all
+    clear[5] = True
+    f32 = np.argmax(feat @ q.T, axis=1)                                      # what the reference's sgemm ranks
+    for how in ("split_f16", "auto", "prepared"):
+        src = ops.prepare_map(DeviceArray.from_numpy(feat)) if how == "prepared" else feat
+        sc, am, best = ops.sim_scores(src, q, want_best=True, precision=how)
+        sc, am, best = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (sc, am, best))
+        assert np.array_equal(am[clear], np.argmax(ref, axis=1)[clear]), (how, np.flatnonzero(am[clear] != np.argmax(ref, axis=1)[clear])[:8])
+        assert np.mean(am == f32) >= np.mean(np.argmax(ref, axis=1) == f32) - 2e-3      # as close to the sgemm as float64 is
+        assert am[5] == 0 and np.all(sc[5] == 0)
+        rel = np.abs(sc - ref).max(axis=1) / (np.abs(feat).astype(np.float64) @ np.abs(q).astype(np.float64).T).max(axis=1).clip(1e-300)
+        assert rel.max() < 3e-6, (how, rel.argmax(), rel.max())
+        assert np.array_equal(am, np.argmax(sc, axis=1)) and np.array_equal(best, sc[np.arange(N), am])
+    # non-finite rows on the raw path: np.argmax semantics (first NaN wins; +inf is a maximum)
+    bad = feat.copy()
+    bad[7, 3] = np.nan
+    bad[9, 100] = np.inf
+    with np.errstate(invalid="ignore"):
+        want = bad @ q.T
+    sc, am, _ = ops.sim_scores(bad, q, precision="auto")
+    assert am[7] == np.argmax(want[7]) == 0 and np.all(np.isnan(sc[7]))
+    assert am[9] == np.argmax(want[9])
+    ok = np.ones(N, bool)
+    ok[[7, 9]] = False
+    sc0, am0, _ = ops.sim_scores(feat, q, precision="auto")
+    assert np.array_equal(am[ok], am0[ok]) and np.array_equal(sc[ok], sc0[ok])
 
 
 def test_large_map_64bit_offsets(ops):
