@@ -76,6 +76,10 @@ _SIGS = {
     "avl_finalize_merged": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),
     "avl_replay_state_apply": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "avl_pool_label_2d": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "avl_rgb_topdown": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "avl_obstacle_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "avl_obstacle_scatter": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "avl_heatmap_from_mask": (C.c_int, [_vp, _vp, _i64, _f64, _f64, _vp, _vp]),
 }
 

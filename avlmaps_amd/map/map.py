@@ -74,9 +74,8 @@ class Map:
     def generate_obstacle_map(self, h_min: float = 0, h_max: float = 1.5) -> np.ndarray:
         """(gs, gs) bool, True = free.  Reference: map.py:79-95 (note `> 0`: voxel id 0 does not count upstream)."""
         assert self.occupied_ids is not None, "map not loaded"
-        heights = np.arange(0, self.occupied_ids.shape[-1]) * self.cs
-        height_mask = np.logical_and(heights > h_min, heights < h_max)
-        self.obstacles_map = np.sum(self.occupied_ids[..., height_mask] > 0, axis=2) == 0
+        from .. import ops
+        self.obstacles_map = ops.obstacle_map(self.occupied_ids, self.cs, h_min, h_max)      # avl_obstacle_map
         self.generate_cropped_obstacle_map(self.obstacles_map)
         return self.obstacles_map
 
@@ -92,9 +91,8 @@ class Map:
         """Last voxel written per (row, col) wins, like the reference's sequential loop (map.py:106-113)."""
         assert self.grid_rgb is not None, "map not loaded"
         assert self.grid_pos is not None
-        rgb_topdown = np.zeros((self.gs, self.gs, 3))
-        rgb_topdown[self.grid_pos[:, 0], self.grid_pos[:, 1], :] = self.grid_rgb   # numpy keeps the last duplicate
-        return rgb_topdown.astype(np.uint8)
+        from .. import ops
+        return ops.rgb_topdown(self.grid_pos, self.grid_rgb, self.gs)                         # avl_rgb_topdown
 
     def init_categories(self, categories: List[str]) -> np.ndarray:
         return NotImplementedError

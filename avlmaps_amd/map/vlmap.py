@@ -144,4 +144,29 @@ class VLMap(Map):
         self.obstacles_new_cropped = self.obstacles_new_cropped == 0
 
     def get_pos(self, name: str):
-        raise NotImplementedError("contour extraction (vlmap.py:158-187) is navigator-side and not on the accelerated path")
+        """Contours, centres and bounding boxes of a category on the full map.  Reference: vlmap.py:158-187.  The per-voxel
+        work (argmax mask, top-down pooling) runs on the GPU; the 2-D morphology is the same SciPy calls as upstream; the
+        island extraction is utils/navigation_utils.get_segment_islands_pos (OpenCV when installed)."""
+        from scipy.ndimage import binary_closing, binary_dilation, gaussian_filter
+        from ..utils.navigation_utils import get_segment_islands_pos
+        from ..utils.visualize_utils import pool_3d_label_to_2d
+        assert self.categories
+        pc_mask = self.index_map(name, with_init_cat=True)
+        mask_2d = pool_3d_label_to_2d(pc_mask, self._device_pos(), self.gs)
+        mask_2d = mask_2d[self.rmin:self.rmax + 1, self.cmin:self.cmax + 1]
+        foreground = binary_closing(mask_2d, iterations=3)
+        foreground = gaussian_filter(foreground.astype(float), sigma=0.8, truncate=3)
+        foreground = foreground > 0.5
+        foreground = binary_dilation(foreground)
+        self._last_foreground = foreground
+        contours, centers, bbox_list, _ = get_segment_islands_pos(foreground, 1)
+        for i in range(len(contours)):          # whole-map positions (upstream adds rmin to both row bounds: kept)
+            centers[i][0] += self.rmin
+            centers[i][1] += self.cmin
+            bbox_list[i][0] += self.rmin
+            bbox_list[i][1] += self.rmin
+            bbox_list[i][2] += self.cmin
+            bbox_list[i][3] += self.cmin
+            contours[i][:, 0] += self.rmin
+            contours[i][:, 1] += self.cmin
+        return contours, centers, bbox_list

@@ -428,6 +428,73 @@ def heatmap_from_mask(grid_pos, mask, cell_size=0.05, decay_rate=0.01, stream=No
     return heat.numpy(stream) if isinstance(grid_pos, np.ndarray) else heat
 
 
+# ---------------------------------------------------------------------------------------- top-down 2-D products
+def _dev_u8(x, stream):
+    """bool / uint8 host array, DeviceArray or torch tensor -> uint8 device pointer"""
+    if isinstance(x, np.ndarray):
+        x = np.ascontiguousarray(x).astype(np.uint8, copy=False)
+    elif _is_torch(x):
+        import torch
+        if x.dtype == torch.bool:
+            x = x.to(torch.uint8)
+    return as_device(x, np.uint8, stream)
+
+
+def pool_label_2d(mask_3d, grid_pos, gs, stream=None):
+    """(gs, gs) bool: mask_2d[row, col] |= mask_3d[i]  (visualize_utils.py:77-83).  Inputs host or device-resident."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    pp, pshape, k1 = as_device(grid_pos, np.int32, stream)
+    mp, mshape, k2 = _dev_u8(mask_3d, stream)
+    out = DeviceArray((gs, gs), np.uint8)
+    _lib.check(lib.avl_pool_label_2d(pp, mp, pshape[0], int(gs), out.ptr, stream), "avl_pool_label_2d")
+    return out.numpy(stream).astype(bool)
+
+
+def rgb_topdown(grid_pos, grid_rgb, gs, stream=None):
+    """(gs, gs, 3) uint8 colour map, last voxel of a column wins  (map.py:106-113)"""
+    lib = _lib.load()
+    _lib.require_gpu()
+    pp, pshape, k1 = as_device(grid_pos, np.int32, stream)
+    rgb8 = np.ascontiguousarray(grid_rgb).astype(np.uint8) if isinstance(grid_rgb, np.ndarray) else grid_rgb
+    rp, _, k2 = as_device(rgb8, np.uint8, stream)
+    out = DeviceArray((gs, gs, 3), np.uint8)
+    _lib.check(lib.avl_rgb_topdown(pp, rp, pshape[0], int(gs), out.ptr, stream), "avl_rgb_topdown")
+    return out.numpy(stream)
+
+
+def obstacle_map(occupied_ids, cs, h_min=0, h_max=1.5, stream=None):
+    """(n0, n1) bool, True = free: no voxel id > 0 with h_min < height < h_max  (map.py:79-95)"""
+    lib = _lib.load()
+    _lib.require_gpu()
+    op, oshape, k1 = as_device(occupied_ids, np.int32, stream)
+    n0, n1, vh = oshape
+    heights = np.arange(0, vh) * cs                                     # float64, exactly as upstream
+    sel = np.flatnonzero(np.logical_and(heights > h_min, heights < h_max))
+    h0, h1 = (int(sel[0]), int(sel[-1]) + 1) if sel.size else (0, 0)   # heights ascend: the mask is one index range
+    out = DeviceArray((n0, n1), np.uint8)
+    _lib.check(lib.avl_obstacle_map(op, n0, n1, vh, h0, h1, out.ptr, stream), "avl_obstacle_map")
+    return out.numpy(stream).astype(bool)
+
+
+def obstacle_scatter(grid_pos, predict, obs_inds, n_classes, obstacles_cropped, rmin, cmin, stream=None):
+    """index_utils.py:163-177: cropped map, True = free, after marking the voxels whose class is in obs_inds.
+    predict may be the device-resident argmax of sim_scores."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    pp, pshape, k1 = as_device(grid_pos, np.int32, stream)
+    cp, cshape, k2 = as_device(predict, np.int32, stream)
+    crop = np.ascontiguousarray(np.asarray(obstacles_cropped) != 0).astype(np.uint8)
+    H, W = crop.shape
+    fp_, _, k3 = as_device(crop, np.uint8, stream)
+    table = np.zeros((int(n_classes),), dtype=np.uint8)
+    table[list(obs_inds)] = 1
+    out = DeviceArray((H, W), np.uint8)
+    _lib.check(lib.avl_obstacle_scatter(pp, cp, pshape[0], table.ctypes.data, int(n_classes), int(rmin), int(cmin), H, W, fp_, out.ptr,
+                                        stream), "avl_obstacle_scatter")
+    return out.numpy(stream).astype(bool)
+
+
 def export_raw_torch(acc: "VoxelAccumulator", device=None, stream=None):
     """VoxelAccumulator.export_raw into torch tensors on the GPU (input of parallel.merge_raw)."""
     import torch

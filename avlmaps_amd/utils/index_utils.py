@@ -26,28 +26,22 @@ def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstac
                                  precision="auto"):
     """Cropped top-down map, True = free, after keeping only voxels whose best class is one of `obstacle_classes`.
     Reference: avlmaps/utils/index_utils.py:138-184 -- the same matmul + argmax as index_map (:153-161), here the fused
-    similarity kernel (scores are never materialised), then a vectorised scatter instead of boolean Python loops.
+    similarity kernel (scores are never materialised), then one scatter kernel fed by the device-resident argmax.
     `grid_feat` may be a host array or a device-resident (N, D) array."""
     import numpy as np
     from .. import ops
     from .clip_utils import landmark_text_feats, _to_numpy
-    all_obstacles_mask = obstacles_cropped == 0
     if avg_mode != 0:
         from .clip_utils import get_lseg_score
         scores = get_lseg_score(clip_model, list(potential_obstacle_classes), grid_feat, clip_feat_dim,
                                 use_multiple_templates=use_multiple_templates, avg_mode=avg_mode, precision=precision)
-        predict = np.argmax(scores, axis=1)
+        predict = np.argmax(scores, axis=1).astype(np.int32)
     else:
         q, _ = landmark_text_feats(clip_model, list(potential_obstacle_classes), clip_feat_dim, use_multiple_templates, True)
         if isinstance(grid_feat, np.ndarray):
             grid_feat = np.ascontiguousarray(grid_feat, dtype=np.float32)
-        _, am, _ = ops.sim_scores(grid_feat, q, want_scores=False, want_argmax=True, precision=precision)
-        predict = _to_numpy(am)
+        _, predict, _ = ops.sim_scores(grid_feat, q, want_scores=False, want_argmax=True, precision=precision)   # stays in HBM
     obs_inds = [i for obs_name in obstacle_classes for i, po in enumerate(potential_obstacle_classes) if obs_name == po]
     print("obs_inds: ", obs_inds)
-    pts_mask = np.isin(predict, obs_inds)
-    new_obstacles = np.zeros_like(obstacles_cropped, dtype=bool)
-    obs_pts = np.asarray(grid_pos)[pts_mask]
-    new_obstacles[obs_pts[:, 0] - rmin, obs_pts[:, 1] - cmin] = 1
-    new_obstacles = np.logical_and(new_obstacles, all_obstacles_mask)
-    return np.logical_not(new_obstacles)
+    n_classes = len(potential_obstacle_classes) + (0 if potential_obstacle_classes[-1] == "other" else 1)
+    return ops.obstacle_scatter(grid_pos, predict, obs_inds, n_classes, obstacles_cropped, rmin, cmin)          # avl_obstacle_scatter

@@ -12,10 +12,11 @@ from typing import List, Optional, Sequence
 import numpy as np
 from scipy.spatial.transform import Rotation as R
 
-try:  # optional: the reference's on-disk format is HDF5
+try:  # the reference's on-disk format is HDF5, written with h5py
     import h5py  # type: ignore
 except Exception:  # pragma: no cover - absent in the build container
     h5py = None
+from . import h5lite   # the same files through the HDF5 C library (ctypes) where h5py is not installed
 
 MAP_DATASETS = ("mapped_iter_list", "grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")
 
@@ -66,20 +67,31 @@ def _npz_path(path) -> Path:
     return p.with_name(p.name + ".npz")
 
 
+def hdf5_backend() -> Optional[str]:
+    """'h5py' | 'h5lite' (libhdf5 through ctypes) | None"""
+    if h5py is not None:
+        return "h5py"
+    return "h5lite" if h5lite.available() else None
+
+
 def save_3d_map(save_path, grid_feat, grid_pos, weight, occupied_ids, mapped_iter_list, grid_rgb=None,
                 init_height_id=None) -> None:
-    """Write the six datasets of the reference's map file.  Reference: mapping_utils.py:469-505.
-    HDF5 (vlmaps.h5df) when h5py is importable, otherwise the same arrays in `<save_path>.npz`."""
+    """Write the datasets of the reference's map file, same names / dtypes / shapes (mapping_utils.py:469-505): an HDF5
+    file through h5py, or through the HDF5 C library (utils/h5lite.py) where h5py is missing.  Only if neither exists are the
+    same arrays written to `<save_path>.npz`."""
     data = dict(mapped_iter_list=np.array(sorted(mapped_iter_list), dtype=np.int32), grid_feat=np.asarray(grid_feat),
                 grid_pos=np.asarray(grid_pos), weight=np.asarray(weight), occupied_ids=np.asarray(occupied_ids))
     if init_height_id is not None:
         data["init_height_id"] = np.array(init_height_id, dtype=np.int32)
     if grid_rgb is not None:
         data["grid_rgb"] = np.asarray(grid_rgb)
-    if h5py is not None:
+    backend = hdf5_backend()
+    if backend == "h5py":
         with h5py.File(save_path, "w") as f:
             for k, v in data.items():
                 f.create_dataset(k, data=v)
+    elif backend == "h5lite":
+        h5lite.write_datasets(save_path, data)
     else:
         np.savez(_npz_path(save_path), **data)
 
@@ -89,12 +101,17 @@ def map_file_exists(map_path) -> bool:
 
 
 def load_3d_map(map_path):
-    """-> (mapped_iter_list, grid_feat, grid_pos, weight, occupied_ids, grid_rgb).  Reference: mapping_utils.py:508-541."""
+    """-> (mapped_iter_list, grid_feat, grid_pos, weight, occupied_ids, grid_rgb[, init_height_id]).
+    Reference: mapping_utils.py:508-541."""
     if Path(map_path).exists():
-        if h5py is None:
-            raise RuntimeError(f"{map_path} is an HDF5 map but h5py is not installed")
-        with h5py.File(map_path, "r") as f:
-            d = {k: f[k][:] for k in f.keys()}
+        backend = hdf5_backend()
+        if backend == "h5py":
+            with h5py.File(map_path, "r") as f:
+                d = {k: f[k][()] for k in f.keys()}
+        elif backend == "h5lite":
+            d = h5lite.read_datasets(map_path)
+        else:
+            raise RuntimeError(f"{map_path} is an HDF5 map but neither h5py nor the HDF5 C library (libhdf5) is available")
     else:
         with np.load(_npz_path(map_path)) as z:
             d = {k: z[k] for k in z.files}

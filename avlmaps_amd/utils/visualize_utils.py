@@ -15,8 +15,7 @@ def get_heatmap_from_mask_3d(pc: np.ndarray, mask: np.ndarray, cell_size: float 
 
 
 def pool_3d_label_to_2d(mask_3d: np.ndarray, grid_pos: np.ndarray, gs: int) -> np.ndarray:
-    """Top-down OR-pooling of a per-voxel mask.  Reference: visualize_utils.py:77-83 (Python loop upstream)."""
-    mask_2d = np.zeros((gs, gs), dtype=bool)
-    sel = np.asarray(mask_3d, dtype=bool)
-    mask_2d[grid_pos[sel, 0], grid_pos[sel, 1]] = True
-    return mask_2d
+    """Top-down OR-pooling of a per-voxel mask, (gs, gs) bool.  Reference: visualize_utils.py:77-83 (a Python loop over all
+    voxels upstream; here one scatter kernel, avl_pool_label_2d).  grid_pos / mask_3d may be device-resident."""
+    from .. import ops
+    return ops.pool_label_2d(mask_3d, grid_pos, int(gs))

@@ -315,6 +315,29 @@ AVL_API int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weig
 AVL_API int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d_mask, int64_t N, double cell_size,
                                   double decay_rate, float* d_heat, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (4) top-down 2-D products of the voxel map (the consumers that loop over all N voxels in Python upstream).
+ *     All take device pointers; images are row-major uint8 with 1 = true.  Synchronous (they report index errors).
+ *     Voxel positions index the image like NumPy does: negative values wrap once, anything else out of range is the
+ *     reference's IndexError -> AVL_ERR_INVALID.
+ * ------------------------------------------------------------------------------------------------ */
+/* avlmaps/utils/visualize_utils.py:77-83 pool_3d_label_to_2d: mask2d[row, col] |= mask[i].  d_mask2d (gs, gs) is cleared first. */
+AVL_API int avl_pool_label_2d(const int32_t* d_grid_pos, const uint8_t* d_mask, int64_t N, int gs, uint8_t* d_mask2d, void* stream);
+/* avlmaps/map/map.py:106-113 generate_rgb_topdown_map: rgb2d[row, col] = grid_rgb[i], the LAST voxel (largest i) of a
+ * column wins as in the sequential loop; untouched cells are 0.  d_rgb2d (gs, gs, 3). */
+AVL_API int avl_rgb_topdown(const int32_t* d_grid_pos, const uint8_t* d_grid_rgb, int64_t N, int gs, uint8_t* d_rgb2d, void* stream);
+/* avlmaps/map/map.py:79-95 generate_obstacle_map: free[r, c] = no voxel id > 0 among heights [h_begin, h_end) of
+ * occupied_ids (n0, n1, vh) -- the index range of `(heights > h_min) & (heights < h_max)`, which the host evaluates in
+ * float64 exactly as upstream.  Asynchronous. */
+AVL_API int avl_obstacle_map(const int32_t* d_occupied_ids, int n0, int n1, int vh, int h_begin, int h_end, uint8_t* d_free,
+                             void* stream);
+/* avlmaps/utils/index_utils.py:163-177 (body of get_dynamic_obstacles_map_3d after the argmax): voxels whose class
+ * d_class[i] (the similarity kernel's argmax, still on the device) has h_class_is_obstacle[class] != 0 mark
+ * (row - rmin, col - cmin) of the (H, W) crop; out_free = !(marked & (cropped_free == 0)). */
+AVL_API int avl_obstacle_scatter(const int32_t* d_grid_pos, const int32_t* d_class, int64_t N, const uint8_t* h_class_is_obstacle,
+                                 int Q, int rmin, int cmin, int H, int W, const uint8_t* d_cropped_free, uint8_t* d_out_free,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

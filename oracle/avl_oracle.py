@@ -316,3 +316,46 @@ def heatmap_from_mask(grid_pos, mask, cell_size=0.05, decay_rate=0.01):
     lib().avlo_heatmap_from_mask(_p(pos, C.c_int32), _p(mk, C.c_uint8), len(pos), cell_size, decay_rate,
                                  _p(heat, C.c_float))
     return heat
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# top-down 2-D products (restated sequentially / with NumPy; pinned against tests/golden/g8_map2d.npz)
+def pool_3d_label_to_2d(mask_3d, grid_pos, gs):
+    """avlmaps/utils/visualize_utils.py:77-83: mask_2d[row, col] = mask_3d[i] or mask_2d[row, col] over all voxels"""
+    mask_2d = np.zeros((gs, gs), dtype=bool)
+    for i in np.flatnonzero(np.asarray(mask_3d, dtype=bool)):
+        mask_2d[grid_pos[i, 0], grid_pos[i, 1]] = True
+    return mask_2d
+
+
+def obstacle_map(occupied_ids, cs, h_min=0, h_max=1.5):
+    """avlmaps/map/map.py:79-95: True = free; a column is an obstacle if a voxel id > 0 lies strictly inside the height band"""
+    heights = np.arange(0, occupied_ids.shape[-1]) * cs
+    height_mask = np.logical_and(heights > h_min, heights < h_max)
+    return np.sum(occupied_ids[..., height_mask] > 0, axis=2) == 0
+
+
+def crop_bounds(obstacle_map_):
+    """avlmaps/map/map.py:97-104: (rmin, rmax, cmin, cmax) of the obstacle cells"""
+    x, y = np.where(obstacle_map_ == 0)
+    return int(x.min()), int(x.max()), int(y.min()), int(y.max())
+
+
+def rgb_topdown(grid_pos, grid_rgb, gs):
+    """avlmaps/map/map.py:106-113: sequential loop, the last voxel written to a (row, col) wins"""
+    out = np.zeros((gs, gs, 3))
+    for rgb, pos in zip(grid_rgb, grid_pos):
+        out[pos[0], pos[1], :] = np.asarray(rgb).flatten()
+    return out.astype(np.uint8)
+
+
+def dynamic_obstacles(predict, potential, obstacle_names, grid_pos, rmin, cmin, obstacles_cropped):
+    """avlmaps/utils/index_utils.py:162-177 (after the argmax): True = free"""
+    obs_inds = [i for name in obstacle_names for i, po in enumerate(potential) if name == po]
+    pts_mask = np.zeros_like(predict, dtype=bool)
+    for k in obs_inds:
+        pts_mask |= predict == k
+    new_obstacles = np.zeros_like(obstacles_cropped, dtype=bool)
+    pts = grid_pos[pts_mask]
+    new_obstacles[pts[:, 0] - rmin, pts[:, 1] - cmin] = 1
+    return np.logical_not(np.logical_and(new_obstacles, obstacles_cropped == 0))

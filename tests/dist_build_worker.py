@@ -3,7 +3,7 @@
 Every rank seeds the global NumPy RNG like the reference run that produced the golden map, builds its contiguous frame
 shard from the golden frames and joins the merge; rank 0 writes <out>/vlmap/vlmaps.h5df (+ merge timings as JSON).
 
-    python -m torch.distributed.run --nproc-per-node 2 tests/dist_build_worker.py <golden.npz> <out_dir> <n_frames> [sampling]
+    python -m torch.distributed.run --nproc-per-node 2 tests/dist_build_worker.py <golden.npz> <out_dir> <n_frames> [sampling [seed]]
 """
 import json
 import sys
@@ -19,6 +19,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 def main():
     golden, out_dir, n_frames = sys.argv[1], Path(sys.argv[2]), int(sys.argv[3])
     sampling = sys.argv[4] if len(sys.argv) > 4 else "replay"
+    seed = int(sys.argv[5]) if len(sys.argv) > 5 else 1234
     from test_host_mirror import make_cfg
     from avlmaps_amd import parallel
     from avlmaps_amd.map.map import Map
@@ -60,7 +61,7 @@ def main():
     b._features_hwc = features_hwc
     b.capacity = 64                                           # forces the accumulators to double a few times
     b.shard_sampling = sampling
-    np.random.seed(1234)                                      # the state the reference run started from, on EVERY rank
+    np.random.seed(seed)                                      # the state the reference run started from, on EVERY rank
     b.create_mobile_base_map()
     if rank == 0:
         (out_dir / "merge_timings.json").write_text(json.dumps(getattr(b, "merge_timings", {})))

@@ -199,7 +199,17 @@ def test_cli_create_then_index_on_disk_dataset(tmp_path):
     assert it == list(range(6)) and gf.shape[1] == 64 and len(gp) > 500 and occ.shape == (400, 400, 30)
     assert (occ >= 0).sum() == len(gp) and np.array_equal(occ[gp[:, 0], gp[:, 1], gp[:, 2]], np.arange(len(gp)))
     heat = index_map.main(["--data-dir", str(scene), "--config", str(cfg), "--query", "sofa", "--text-model", "hash"])
-    assert heat.shape == (len(gp),) and heat.max() == 1.0 and 0 < (heat == 1.0).sum() < len(gp)
+    assert heat.shape == (len(gp),) and heat.max() == 1.0
+    # the voxels that match are the ones the float64 product ranks first -- including the many rows of magnitude 1e-7 this
+    # scene has (voxels seen once from far away, feat * exp(-r^2/1.2)): the unscaled fp16 split of round 1 flushed them to
+    # zero and called them "other"
+    from avlmaps_amd.apps.common import HashClip
+    from avlmaps_amd.utils.clip_utils import landmark_text_feats
+    q, _ = landmark_text_feats(HashClip(64), ["sofa"], 64, use_multiple_templates=True, add_other=True)
+    ref = gf.astype(np.float64) @ q.astype(np.float64).T
+    clear = np.abs(ref[:, 0] - ref[:, 1]) > 1e-5 * np.abs(ref).max(axis=1)
+    assert np.abs(gf).max(axis=1).min() < 1e-5 and clear.mean() > 0.9
+    assert np.array_equal((heat == 1.0)[clear], (ref.argmax(axis=1) == 0)[clear])
     # host-side pipelining (frame decode threads, sampler thread, batched launches) must not change a single bit:
     # the default above ran with prefetch 4; inline loading and 3-frame batches give the same file contents
     first = (it, gf, gp, w, occ, rgb)
@@ -330,8 +340,9 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
     from avlmaps_amd.utils.mapping_utils import load_3d_map
     GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
     one, many = tmp_path / "one", tmp_path / "many"
-    _run_ranks(1, [GOLDEN_DIR / name, one, n_frames], 29541)
-    _run_ranks(nproc, [GOLDEN_DIR / name, many, n_frames], 29542)
+    seed = 1234 if name.startswith("g2a") else 99              # what tools/gen_golden.py seeded the reference run with
+    _run_ranks(1, [GOLDEN_DIR / name, one, n_frames, "replay", seed], 29541)
+    _run_ranks(nproc, [GOLDEN_DIR / name, many, n_frames, "replay", seed], 29542)
     a = load_3d_map(one / "vlmap" / "vlmaps.h5df")
     b = load_3d_map(many / "vlmap" / "vlmaps.h5df")
     assert a[0] == b[0] == list(range(n_frames))
@@ -349,7 +360,7 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
     # without the RNG fast-forward the shards sample other pixels: the faithful mode is what makes the maps equal
     if nproc == 2 and n_frames == 6:
         ind = tmp_path / "independent"
-        _run_ranks(nproc, [GOLDEN_DIR / name, ind, n_frames, "independent"], 29543)
+        _run_ranks(nproc, [GOLDEN_DIR / name, ind, n_frames, "independent", seed], 29543)
         c = load_3d_map(ind / "vlmap" / "vlmaps.h5df")
         assert not (c[2].shape == a[2].shape and np.array_equal(c[2], a[2]))
 

@@ -386,7 +386,12 @@ def test_full_size_build_properties(ops):
     # two frame shards merged with the multi-GPU merge math
     raws = [ops.export_raw_torch(build(0, F // 2, replay=False)), ops.export_raw_torch(build(F // 2, F, replay=False))]
     merged = parallel.merge_raw_local(raws)
-    m = ops.finalize_raw({kk: v for kk, v in merged.items() if kk != "first_key"}, D, 1000, 30)
+    m = ops.finalize_merged(merged, D, 1000, 30)
     assert np.array_equal(m["grid_pos"], out["grid_pos"]) and np.array_equal(m["occupied_ids"], out["occupied_ids"])
     np.testing.assert_allclose(m["grid_feat"], out["grid_feat"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(m["weight"], out["weight"], rtol=1e-6)
+    # the device merge of the whole build (scatter + chained replay + finalize kernels): the single-GPU map again
+    dev = parallel.merge_accumulator(a)
+    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
+        assert np.array_equal(dev[k].cpu().numpy(), out[k]), k
+    np.testing.assert_allclose(dev["grid_feat"].cpu().numpy(), out["grid_feat"], rtol=1e-6, atol=1e-7)

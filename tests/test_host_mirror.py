@@ -88,13 +88,11 @@ def test_map_attribute_surface_and_obstacles():
     for a in ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb", "mapped_iter_list", "obstacles_map",
               "obstacles_cropped", "scores_mat", "categories"):
         assert getattr(m, a) is None
-    occ = -np.ones((20, 20, 30), np.int32)
-    occ[5, 6, 3] = 4
-    occ[9, 12, 10] = 7
-    occ[2, 2, 3] = 0          # voxel id 0 is NOT an obstacle upstream (`> 0`, map.py:92)
-    m.occupied_ids = occ
-    obs = m.generate_obstacle_map()
-    assert obs.shape == (20, 20) and not obs[5, 6] and not obs[9, 12] and obs[2, 2]
+    # generate_cropped_obstacle_map is host logic (map.py:97-104); generate_obstacle_map itself runs on the GPU
+    # (avl_obstacle_map) and is covered by tests/test_map2d_gpu.py against the reference's outputs
+    obs = np.ones((20, 20), bool)
+    obs[5, 6] = obs[9, 12] = False
+    m.generate_cropped_obstacle_map(obs)
     assert (m.rmin, m.rmax, m.cmin, m.cmax) == (5, 9, 6, 12) and m.obstacles_cropped.shape == (5, 7)
     with pytest.raises(Exception, match="Categories are not preloaded"):
         m.index_map("sofa", with_init_cat=True)
@@ -117,3 +115,78 @@ def test_get_lseg_feat_protocol_matches_reference(golden):
         np.testing.assert_allclose(f.numpy(), np.transpose(ref[0], (1, 2, 0)), rtol=1e-6, atol=1e-6)
         f2 = get_lseg_feat(FakeLSeg(), g[f"{name}_img"], ["example"], None, "cpu", crop, base, channels_last=False)
         np.testing.assert_allclose(f2.numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_map_file_is_the_reference_hdf5_layout(tmp_path):
+    """save_3d_map writes a real HDF5 file with the six dataset names / dtypes / shapes of the reference writer
+    (mapping_utils.py:499-505) -- through h5py, or through the HDF5 C library where h5py is missing -- and load_3d_map reads
+    it back as the reference reader does (:508-541); init_height_id is a 0-d int32 dataset like upstream's"""
+    import shutil
+    import subprocess
+    backend = mu.hdf5_backend()
+    if backend is None:
+        pytest.skip("neither h5py nor libhdf5 on this machine")
+    rng = np.random.default_rng(3)
+    n, D, gs, vh = 23, 16, 12, 5
+    arrays = dict(grid_feat=rng.standard_normal((n, D)).astype(np.float32), grid_pos=rng.integers(0, gs, (n, 3)).astype(np.int32),
+                  weight=rng.random(n).astype(np.float32), occupied_ids=-np.ones((gs, gs, vh), np.int32),
+                  grid_rgb=rng.integers(0, 255, (n, 3)).astype(np.uint8))
+    p = tmp_path / "vlmaps.h5df"
+    mu.save_3d_map(p, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"], {4, 1, 3}, arrays["grid_rgb"],
+                   init_height_id=7)
+    assert p.read_bytes()[:8] == b"\x89HDF\r\n\x1a\n"
+    assert not Path(str(p) + ".npz").exists()
+    from avlmaps_amd.utils import h5lite
+    if h5lite.available():
+        with h5lite.H5File(p) as f:
+            assert sorted(f.keys()) == sorted(mu.MAP_DATASETS + ("init_height_id",))
+            want = dict(mapped_iter_list=((3,), np.int32), grid_feat=((n, D), np.float32), grid_pos=((n, 3), np.int32),
+                        weight=((n,), np.float32), occupied_ids=((gs, gs, vh), np.int32), grid_rgb=((n, 3), np.uint8),
+                        init_height_id=((), np.int32))
+            for k, (shape, dt) in want.items():
+                assert f.shape_dtype(k) == (shape, np.dtype(dt)), k
+    out = mu.load_3d_map(p)
+    assert out[0] == [1, 3, 4] and int(out[6]) == 7
+    for a, b in zip(out[1:6], ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")):
+        assert np.array_equal(a, arrays[b]) and a.dtype == arrays[b].dtype
+    h5dump = shutil.which("h5dump") or ("/opt/conda/bin/h5dump" if Path("/opt/conda/bin/h5dump").exists() else None)
+    if h5dump:   # the HDF5 project's own tool agrees on types and extents
+        txt = subprocess.run([h5dump, "-H", str(p)], capture_output=True, text=True).stdout
+        for frag in ('DATASET "grid_feat"', "H5T_IEEE_F32LE", f"( {n}, {D} )", 'DATASET "grid_rgb"', "H5T_STD_U8LE",
+                     'DATASET "occupied_ids"', f"( {gs}, {gs}, {vh} )", "H5T_STD_I32LE"):
+            assert frag in txt, frag
+
+
+def test_h5lite_extendible_datasets_and_foreign_files(tmp_path):
+    from avlmaps_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((9, 6)).astype(np.float32)
+    occ = -np.ones((3, 4, 5), np.int32)
+    with h5lite.H5File(tmp_path / "x.h5", "w") as f:
+        f.create_dataset("a", data=a[:4], maxshape=(None, 6))
+        f.create_dataset("occ", data=occ)
+        f.create_dataset("empty", data=np.zeros((0, 3), np.uint8), maxshape=(None, 3))
+    with h5lite.H5File(tmp_path / "x.h5", "r+") as f:        # a later checkpoint: append rows, overwrite a few, poke cells
+        f.resize("a", 9)
+        f.write_rows("a", 4, a[4:])
+        f.write_scattered_rows("a", np.array([0, 2, 3, 8]), a[[0, 2, 3, 8]] + 1)
+        f.write_points("occ", np.array([[0, 0, 0], [2, 3, 4]]), np.array([5, 6]))
+        with pytest.raises(h5lite.H5Error):
+            f.write_rows("a", 8, a[:2])                        # beyond the extent
+    d = h5lite.read_datasets(tmp_path / "x.h5")
+    want = a.copy()
+    want[[0, 2, 3, 8]] += 1
+    assert np.array_equal(d["a"], want) and d["empty"].shape == (0, 3)
+    assert d["occ"][0, 0, 0] == 5 and d["occ"][2, 3, 4] == 6 and (d["occ"] == -1).sum() == occ.size - 2
+    with pytest.raises(KeyError):
+        h5lite.H5File(tmp_path / "x.h5").read("nope")
+    with pytest.raises(h5lite.H5Error):
+        h5lite.H5File(tmp_path / "missing.h5")
+    # a file written by other software (MATLAB v7.3 = HDF5 with a user block), shipped with SciPy's tests
+    import scipy.io
+    mat = Path(scipy.io.__file__).parent / "matlab" / "tests" / "data" / "testhdf5_7.4_GLNX86.mat"
+    if mat.exists():
+        with h5lite.H5File(mat) as f:
+            assert "testdouble" in f.keys() and f.read("testdouble").dtype == np.float64

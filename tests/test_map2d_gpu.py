@@ -1,0 +1,145 @@
+"""GPU tests of the top-down 2-D kernels (avl_map2d.hip) against outputs of the reference functions themselves (G8) and
+against the oracle at sizes the reference's Python loops would take minutes for."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+from test_host_mirror import Cfg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from avlmaps_amd import _lib, ops
+    _lib.load()
+    _lib.require_gpu()
+    return ops
+
+
+def _occ(g):
+    gs, vh = int(g["gs"]), int(g["vh"])
+    occ = -np.ones((gs, gs, vh), np.int32)
+    nz = g["occupied_ids_nz"]
+    occ[nz[:, 0], nz[:, 1], nz[:, 2]] = g["occupied_ids_vals"]
+    return occ
+
+
+def test_pool_obstacle_rgb_match_reference(ops, golden):
+    """visualize_utils.py:77-83, map.py:79-113 through the Map / visualize_utils mirrors (bit-exact images)"""
+    from avlmaps_amd.map.map import Map
+    from avlmaps_amd.utils.visualize_utils import pool_3d_label_to_2d
+    g = golden("g8_map2d.npz")
+    gs, cs, pos = int(g["gs"]), float(g["cs"]), g["grid_pos"]
+    for name in ("sparse", "dense", "none"):
+        got = pool_3d_label_to_2d(g[f"mask3d_{name}"], pos, gs)
+        assert got.dtype == bool and np.array_equal(got, g[f"mask2d_{name}"]), name
+    cfg = Cfg(map_type="vlmap", grid_size=gs, cell_size=cs,
+              pose_info=Cfg(camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1], base_forward_axis=[0, 0, -1],
+                            base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0]))
+    m = Map(cfg)
+    m.occupied_ids, m.grid_pos, m.grid_rgb = _occ(g), pos, g["grid_rgb"]
+    for tag, band in (("default", (0, 1.5)), ("band", (0.3, 1.0))):
+        om = m.generate_obstacle_map(*band)
+        assert om.dtype == bool and np.array_equal(om, g[f"obstacles_{tag}"]), tag
+        assert [m.rmin, m.rmax, m.cmin, m.cmax] == g[f"obstacles_{tag}_crop"].tolist()
+        assert np.array_equal(m.obstacles_cropped, g[f"obstacles_{tag}_cropped"])
+    top = m.generate_rgb_topdown_map()
+    assert top.dtype == np.uint8 and np.array_equal(top, g["rgb_topdown"])      # the LAST voxel of a column wins
+
+
+def test_dynamic_obstacles_and_get_pos_match_reference(ops, golden):
+    """index_utils.py:138-184 end to end (similarity kernel -> device argmax -> scatter kernel) and vlmap.py:158-187 up to
+    the contour call, through VLMap with the text features the reference run used"""
+    from avlmaps_amd.map.vlmap import VLMap
+    from avlmaps_amd.utils import clip_utils
+    from avlmaps_amd.utils.index_utils import get_dynamic_obstacles_map_3d
+    g = golden("g8_map2d.npz")
+    gs, cs, pos, D = int(g["gs"]), float(g["cs"]), g["grid_pos"], g["grid_feat"].shape[1]
+    potential, names = list(g["dyn_potential"]), list(g["dyn_obstacle_names"])
+    mean = {lm: v for lm, v in zip(potential, g["dyn_mean_feats"])}
+    orig = clip_utils.landmark_text_feats
+
+    def fake(clip_model, landmarks, clip_feat_dim, use_multiple_templates=False, add_other=True):
+        lms = list(landmarks)
+        if add_other and lms[-1] != "other":
+            lms = lms + ["other"]
+        return np.stack([mean[lm] for lm in lms]).astype(np.float32), lms
+    clip_utils.landmark_text_feats = fake
+    try:
+        rmin, _, cmin, _ = g["obstacles_default_crop"].tolist()
+        for feat in (g["grid_feat"], None):
+            if feat is None:                       # device-resident, prepared map (what VLMap passes)
+                from avlmaps_amd.device import DeviceArray
+                feat = ops.prepare_map(DeviceArray.from_numpy(g["grid_feat"])) if D % 64 == 0 else DeviceArray.from_numpy(g["grid_feat"])
+            got = get_dynamic_obstacles_map_3d(None, g["obstacles_default_cropped"], potential, names, feat, pos, rmin, cmin, D)
+            assert got.dtype == bool and np.array_equal(got, g["dyn_new_obstacles"])
+        cfg = Cfg(map_type="vlmap", grid_size=gs, cell_size=cs,
+                  pose_info=Cfg(camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1], base_forward_axis=[0, 0, -1],
+                                base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0]))
+        vm = VLMap(cfg)
+        vm.grid_feat, vm.grid_pos, vm.occupied_ids, vm.grid_rgb = g["grid_feat"], pos, _occ(g), g["grid_rgb"]
+        vm.clip_model, vm.clip_feat_dim = None, D
+        vm.generate_obstacle_map(0, 1.5)
+        import avlmaps_amd.map.vlmap as vlmap_mod
+        vlmap_mod.landmark_text_feats = fake
+        cats = list(g["get_pos_categories"])
+        sm = vm.init_categories(cats)
+        np.testing.assert_allclose(sm, g["get_pos_scores_mat"], rtol=0, atol=1e-4)
+        for name in ("wall", "table"):
+            contours, centers, bboxes = vm.get_pos(name)
+            assert np.array_equal(vm.index_map(name, with_init_cat=True), g[f"get_pos_{name}_mask3d"])
+            assert np.array_equal(vm._last_foreground, g[f"get_pos_{name}_foreground"])     # the mask the reference hands to cv2
+            # islands: bounding boxes cover exactly the foreground's 8-connected components
+            from scipy import ndimage
+            lab, n = ndimage.label(g[f"get_pos_{name}_foreground"], structure=np.ones((3, 3), int))
+            assert len(contours) == len(centers) == len(bboxes) == n
+            want = sorted([sl[0].start + vm.rmin, sl[0].stop - 1 + vm.rmin, sl[1].start + vm.cmin, sl[1].stop - 1 + vm.cmin]
+                          for sl in ndimage.find_objects(lab))
+            assert sorted([int(v) for v in b] for b in bboxes) == want
+    finally:
+        clip_utils.landmark_text_feats = orig
+        import avlmaps_amd.map.vlmap as vlmap_mod
+        vlmap_mod.landmark_text_feats = orig
+
+
+def test_large_maps_vs_oracle_and_index_errors(ops):
+    """2 M voxels on the default 1000 x 1000 x 30 grid (the reference's Python loops: minutes) vs the oracle's NumPy
+    restatements; out-of-range positions are reported like the reference's IndexError, negative ones wrap like NumPy"""
+    from avlmaps_amd._lib import AvlError
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(12)
+    gs, vh, N = 1000, 30, 2_000_000
+    lin = rng.choice(gs * gs * vh // 4, N, replace=False).astype(np.int64) * 4 + rng.integers(0, 4, N)
+    pos = np.stack([lin // (gs * vh), (lin // vh) % gs, lin % vh], 1).astype(np.int32)
+    mask = rng.random(N) < 0.1
+    want = np.zeros((gs, gs), bool)
+    want[pos[mask, 0], pos[mask, 1]] = True
+    assert np.array_equal(ops.pool_label_2d(mask, pos, gs), want)
+    rgb = rng.integers(0, 256, (N, 3)).astype(np.uint8)
+    ref = np.zeros((gs, gs, 3), np.uint8)
+    ref[pos[:, 0], pos[:, 1]] = rgb                     # NumPy keeps the last duplicate, like the sequential loop
+    assert np.array_equal(ops.rgb_topdown(pos, rgb, gs), ref)
+    occ = -np.ones((gs, gs, vh), np.int32)
+    occ[pos[:, 0], pos[:, 1], pos[:, 2]] = np.arange(N, dtype=np.int32)
+    for band in ((0, 1.5), (0.2, 0.9), (5, 6)):
+        assert np.array_equal(ops.obstacle_map(occ, 0.05, *band), O.obstacle_map(occ, 0.05, *band)), band
+    predict = rng.integers(0, 8, N).astype(np.int32)
+    free = O.obstacle_map(occ, 0.05, 0, 1.5)
+    rmin, rmax, cmin, cmax = O.crop_bounds(free)
+    crop = free[rmin:rmax + 1, cmin:cmax + 1]
+    potential = ["chair", "wall", "wall above the door", "table", "window", "floor", "stairs", "other"]
+    names = ["wall", "chair", "table", "window", "stairs", "other"]
+    obs_inds = [i for nme in names for i, po in enumerate(potential) if nme == po]
+    got = ops.obstacle_scatter(pos, predict, obs_inds, 8, crop, rmin, cmin)
+    assert np.array_equal(got, O.dynamic_obstacles(predict, potential, names, pos, rmin, cmin, crop))
+    # NumPy index semantics: one negative wrap is legal, anything else is the reference's IndexError
+    small = np.array([[2, 3, 0], [-1, -2, 0]], np.int32)
+    out = ops.pool_label_2d(np.array([True, True]), small, 8)
+    assert out[2, 3] and out[7, 6] and out.sum() == 2
+    with pytest.raises(AvlError, match="IndexError"):
+        ops.pool_label_2d(np.array([True]), np.array([[8, 0, 0]], np.int32), 8)
+    with pytest.raises(AvlError, match="IndexError"):
+        ops.rgb_topdown(np.array([[0, -9, 0]], np.int32), np.zeros((1, 3), np.uint8), 8)

@@ -150,3 +150,27 @@ def test_multi_floor_builder_matches_reference(golden):
     np.testing.assert_allclose(out["weight"], g["weight"], rtol=2e-7)
     np.testing.assert_allclose(out["grid_feat"], g["grid_feat"], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(out["grid_rgb"], g["grid_rgb"], rtol=1e-5, atol=1e-4)
+
+
+def test_oracle_map2d_matches_reference(golden):
+    """G8: the oracle's restatements of pool_3d_label_to_2d, generate_obstacle_map (+ crop), generate_rgb_topdown_map and the
+    scatter half of get_dynamic_obstacles_map_3d against outputs of the reference functions themselves"""
+    g = golden("g8_map2d.npz")
+    gs, vh, cs = int(g["gs"]), int(g["vh"]), float(g["cs"])
+    pos = g["grid_pos"]
+    occ = -np.ones((gs, gs, vh), np.int32)
+    nz = g["occupied_ids_nz"]
+    occ[nz[:, 0], nz[:, 1], nz[:, 2]] = g["occupied_ids_vals"]
+    for name in ("sparse", "dense", "none"):
+        assert np.array_equal(O.pool_3d_label_to_2d(g[f"mask3d_{name}"], pos, gs), g[f"mask2d_{name}"])
+    for tag, band in (("default", (0, 1.5)), ("band", (0.3, 1.0))):
+        om = O.obstacle_map(occ, cs, *band)
+        assert np.array_equal(om, g[f"obstacles_{tag}"])
+        assert list(O.crop_bounds(om)) == g[f"obstacles_{tag}_crop"].tolist()
+    assert np.array_equal(O.rgb_topdown(pos, g["grid_rgb"], gs), g["rgb_topdown"])
+    sc = O.sim_scores(g["grid_feat"], g["dyn_mean_feats"])
+    np.testing.assert_allclose(sc, g["dyn_scores"], rtol=0, atol=1e-5)
+    rmin, _, cmin, _ = g["obstacles_default_crop"].tolist()
+    got = O.dynamic_obstacles(g["dyn_predict"], list(g["dyn_potential"]), list(g["dyn_obstacle_names"]), pos, rmin, cmin,
+                              g["obstacles_default_cropped"])
+    assert np.array_equal(got, g["dyn_new_obstacles"])

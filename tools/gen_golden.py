@@ -13,6 +13,10 @@ Reference entry points exercised (file:line in /root/reference):
   G3  avlmaps/utils/clip_utils.py:196-242 get_lseg_score, avlmaps/map/vlmap.py:92-125
       VLMap.init_categories / index_map
   G4  avlmaps/utils/visualize_utils.py:29-49 get_heatmap_from_mask_3d
+  G8  the 2-D consumers of the map: avlmaps/utils/visualize_utils.py:77-83 pool_3d_label_to_2d,
+      avlmaps/map/map.py:79-113 Map.generate_obstacle_map / generate_cropped_obstacle_map / generate_rgb_topdown_map,
+      avlmaps/utils/index_utils.py:138-184 get_dynamic_obstacles_map_3d, avlmaps/map/vlmap.py:158-187 VLMap.get_pos
+      (up to the cv2.findContours call, which is stubbed: its input mask is recorded)
 """
 import os
 import sys
@@ -360,8 +364,102 @@ def gen_g4(m, rng):
     print("G4 written", len(pos), mask.sum())
 
 
+def gen_g8(m, rng):
+    """2-D consumers (see module docstring).  One synthetic map: unique cells, several voxels per (row, col) column, ids in
+    random spatial order (so 'last writer wins' in generate_rgb_topdown_map is not the spatially last voxel)."""
+    cu, iu, vu = m["clip_utils"], m["index_utils"], m["visualize_utils"]
+    Map, VLMap = m["map"].Map, m["vlmap"].VLMap
+    gs, vh, cs, D = 64, 30, 0.05, 64
+    cand = np.stack(np.meshgrid(np.arange(9, 52), np.arange(5, 61), np.arange(vh), indexing="ij"), -1).reshape(-1, 3)
+    keep = rng.random(len(cand)) < 0.045
+    # a few columns get many voxels, most get one or none
+    pos = cand[keep].astype(np.int32)
+    rng.shuffle(pos)
+    N = len(pos)
+    occ = -np.ones((gs, gs, vh), dtype=np.int32)
+    occ[pos[:, 0], pos[:, 1], pos[:, 2]] = np.arange(N, dtype=np.int32)
+    rgb = rng.integers(0, 256, (N, 3)).astype(np.uint8)
+    feat = rng.standard_normal((N, D)).astype(np.float32)
+    feat *= (rng.uniform(0.5, 14.2857, (N, 1)) / np.linalg.norm(feat, axis=1, keepdims=True)).astype(np.float32)
+    out = dict(gs=gs, vh=vh, cs=cs, grid_pos=pos, occupied_ids_nz=np.argwhere(occ >= 0).astype(np.int32),
+               occupied_ids_vals=occ[occ >= 0], grid_rgb=rgb, grid_feat=feat)
+    # pool_3d_label_to_2d
+    for name, frac in (("sparse", 0.03), ("dense", 0.5), ("none", 0.0)):
+        mask = rng.random(N) < frac
+        out[f"mask3d_{name}"] = mask
+        out[f"mask2d_{name}"] = vu.pool_3d_label_to_2d(mask, pos, gs)
+    # Map.generate_obstacle_map (+ crop) and rgb top-down
+    cfg = make_map_config(gs, cs, 1.5, [540, 0, 540, 0, 540, 360, 0, 0, 1], 100)
+    mp = Map(cfg)
+    mp.occupied_ids, mp.grid_pos, mp.grid_rgb = occ, pos, rgb
+    for tag, (h0, h1) in (("default", (0, 1.5)), ("band", (0.3, 1.0))):
+        om = mp.generate_obstacle_map(h0, h1)
+        out[f"obstacles_{tag}"] = om
+        out[f"obstacles_{tag}_crop"] = np.array([mp.rmin, mp.rmax, mp.cmin, mp.cmax], dtype=np.int64)
+        out[f"obstacles_{tag}_cropped"] = mp.obstacles_cropped
+    out["rgb_topdown"] = mp.generate_rgb_topdown_map()
+    # get_dynamic_obstacles_map_3d with deterministic text features
+    potential = ["chair", "wall", "wall above the door", "table", "window", "floor", "stairs", "other"]
+    obstacle_names = ["wall", "chair", "table", "window", "stairs", "other"]
+    table = {}
+
+    def fake_text_feats(in_text, clip_model, clip_feat_dim, batch_size=64):
+        r = np.zeros((len(in_text), clip_feat_dim), dtype=np.float32)
+        for i, t in enumerate(in_text):
+            if t not in table:
+                v = np.random.default_rng(abs(hash(t)) % (2 ** 32)).standard_normal(clip_feat_dim).astype(np.float32)
+                table[t] = v / np.linalg.norm(v)
+            r[i] = table[t]
+        return r
+
+    # deterministic across runs: derive the vectors from a seeded generator in registration order instead of hash()
+    reg = np.random.default_rng(808)
+    for lm in potential:
+        for t in cu.multiple_templates:
+            v = reg.standard_normal(D).astype(np.float32)
+            table[t.format(lm)] = v / np.linalg.norm(v)
+    cu.get_text_feats = fake_text_feats
+    iu.get_text_feats = fake_text_feats
+    iu.get_lseg_score = iu.get_lseg_score          # the module's own duplicate (index_utils.py:64-108) is what :150 calls
+    mp.generate_obstacle_map(0, 1.5)
+    new_obs = iu.get_dynamic_obstacles_map_3d(None, mp.obstacles_cropped, potential, obstacle_names, feat, pos, mp.rmin, mp.cmin, D)
+    out["dyn_potential"] = np.array(potential)
+    out["dyn_obstacle_names"] = np.array(obstacle_names)
+    out["dyn_mean_feats"] = np.stack([np.mean(np.stack([table[t.format(lm)] for t in cu.multiple_templates]), axis=0) for lm in potential])
+    out["dyn_new_obstacles"] = new_obs
+    sc = iu.get_lseg_score(None, potential, feat, D, use_multiple_templates=True, avg_mode=0)
+    out["dyn_scores"] = sc
+    out["dyn_predict"] = np.argmax(sc, axis=1).astype(np.int32)
+    # VLMap.get_pos up to cv2.findContours (navigation_utils.get_segment_islands_pos is stubbed and records its input)
+    vm = VLMap(cfg)
+    vm.grid_feat, vm.grid_pos, vm.occupied_ids, vm.grid_rgb = feat, pos, occ, rgb
+    vm.clip_model, vm.clip_feat_dim = None, D
+    m["vlmap"].get_lseg_score = cu.get_lseg_score
+    vm.generate_obstacle_map(0, 1.5)
+    cats = potential[:-1]
+    vm.init_categories(list(cats))
+    seen = {}
+
+    def fake_islands(segment_map, label_id, detect_internal_contours=False):
+        seen["foreground"] = np.array(segment_map, copy=True)
+        return [], [], [], None
+    m["vlmap"].get_segment_islands_pos = fake_islands
+    m["vlmap"].find_similar_category_id = lambda name, cats_: cats_.index(name)
+    for name in ("wall", "table"):
+        vm.get_pos(name)
+        out[f"get_pos_{name}_foreground"] = seen["foreground"]
+        out[f"get_pos_{name}_mask3d"] = vm.index_map(name, with_init_cat=True)
+    out["get_pos_categories"] = np.array(cats)
+    out["get_pos_scores_mat"] = vm.scores_mat
+    np.savez_compressed(OUT / "g8_map2d.npz", **out)
+    print("G8 written: N =", N, "obstacle cells", int((~out["obstacles_default"]).sum()), "dyn free", int(new_obs.sum()))
+
+
 def main():
     OUT.mkdir(parents=True, exist_ok=True)
+    if "--only-g8" in sys.argv:
+        gen_g8(import_reference(), np.random.default_rng(88))
+        return
     if "--only-g7" in sys.argv:
         gen_g7_wide(import_reference(), np.random.default_rng(77))
         return
@@ -370,6 +468,7 @@ def main():
     gen_g2(m, np.random.default_rng(22))
     gen_g3(m, np.random.default_rng(33))
     gen_g4(m, np.random.default_rng(44))
+    gen_g8(m, np.random.default_rng(88))
     gen_templates_hash(m)
     gen_g5_lseg_protocol()
     gen_g6_multi_floor(np.random.default_rng(66))
