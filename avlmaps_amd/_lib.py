@@ -43,6 +43,7 @@ _SIGS = {
     "avl_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "avl_sim_prepare_map": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp]),
     "avl_sim_workspace_bytes_n": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_sz)]),
+    "avl_sim_scores_blocks": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "avl_sim_scores_prepared": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_sim_scores": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp]),
     "avl_sim_workspace_bytes": (C.c_int, [C.c_int, C.c_int, C.POINTER(_sz)]),
@@ -68,6 +69,7 @@ _SIGS = {
     "avl_builder_num_points": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_num_groups": (C.c_int, [_vp, C.POINTER(_i64), _vp]),
     "avl_builder_finalize": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_builder_finalize_ex": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "avl_builder_export_raw": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_finalize_raw": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_set_max_capacity": (C.c_int, [_vp, _i64]),

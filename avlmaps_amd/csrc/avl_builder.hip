@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                                    double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                                   unsigned long long* __restrict__ slot_key) {
+                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
     const int lane = threadIdx.x & 63;
     const int s0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     if (s0 >= P) return;
@@ -364,7 +364,10 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
             slot_key[slot] = batch ? (batch[min_s / P_frame].frame_key | (unsigned)(min_s % P_frame)) : (frame_key | (unsigned)min_s);
         }
     }
-    if (lane == 0) head[slot] = -1;  // ready for the next launch
+    if (lane == 0) {
+        head[slot] = -1;  // ready for the next launch
+        dirty[slot] = 1;  // changed since the last checkpoint (avl_builder_finalize_ex)
+    }
 }
 
 // generic feature width: one 256-float chunk at a time, re-walking the (short) list per chunk
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigne
                                                            int32_t* __restrict__ head, const float* __restrict__ feat,
                                                            double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                            float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                                           unsigned long long* __restrict__ slot_key) {
+                                                           unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
     const int lane = threadIdx.x & 63;
     const int s0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (s0 >= P) return;
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigne
             slot_key[slot] = batch ? (batch[min_s / P_frame].frame_key | (unsigned)(min_s % P_frame)) : (frame_key | (unsigned)min_s);
         }
         head[slot] = -1;
+        dirty[slot] = 1;
     }
 }
 
@@ -599,6 +603,16 @@ __global__ __launch_bounds__(256) void replay_apply_kernel(int64_t n, const Repl
     }
 }
 
+// row_dirty[r] = the voxel in output row r was fused since the flags were last cleared
+__global__ void row_dirty_kernel(int64_t n, const int32_t* __restrict__ perm, uint8_t* __restrict__ dirty, uint8_t* __restrict__ row_dirty,
+                                 int clear) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t sl = perm[r];
+        row_dirty[r] = dirty[sl];
+        if (clear) dirty[sl] = 0;
+    }
+}
+
 __global__ void iota_kernel(int32_t* __restrict__ v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = (int32_t)i;
 }
@@ -683,6 +697,7 @@ struct avl_builder {
     float* first_feat = nullptr;
     double* first_alpha = nullptr;
     int32_t* head = nullptr;
+    uint8_t* dirty = nullptr;                // slot fused since the last clearing finalize (incremental checkpoints)
     unsigned long long* counters = nullptr;  // [0] slots handed out, [1] samples fused, [2] per-frame voxel groups fused
     int* err_flags = nullptr;
     char* recs_mem = nullptr;
@@ -766,6 +781,7 @@ static int grow_builder(avl_builder* b, int64_t want, hipStream_t st) {
     hipError_t e = regrow((void**)&b->slot_cell, sizeof(int32_t), 0xFF);
     if (e == hipSuccess) e = regrow((void**)&b->slot_key, sizeof(unsigned long long), 0xFF);
     if (e == hipSuccess) e = regrow((void**)&b->head, sizeof(int32_t), 0xFF);
+    if (e == hipSuccess) e = regrow((void**)&b->dirty, 1, 0);
     if (e == hipSuccess) e = regrow((void**)&b->sum_feat, D * sizeof(double), -1);
     if (e == hipSuccess) e = regrow((void**)&b->sum_w4, 4 * sizeof(double), -1);
     if (e == hipSuccess) e = regrow((void**)&b->first_feat, D * sizeof(float), -1);
@@ -818,6 +834,7 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     // sum_feat / sum_w4 / first_* need no clearing: a voxel's first fuse is store-only
     AVL_HIP_CHECK(hipMemsetAsync(b->cell_slot, 0xFF, b->ncell * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->head, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
+    AVL_HIP_CHECK(hipMemsetAsync(b->dirty, 0, (size_t)b->capacity, st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_cell, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_key, 0xFF, (size_t)b->capacity * sizeof(unsigned long long), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->counters, 0, 4 * sizeof(unsigned long long), st));
@@ -832,6 +849,7 @@ int avl_builder_destroy(avl_builder* b) {
     if (!b) return AVL_OK;
     (void)hipFree(b->cell_slot); (void)hipFree(b->slot_cell); (void)hipFree(b->slot_key); (void)hipFree(b->sum_feat);
     (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->head);
+    (void)hipFree(b->dirty);
     (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
     (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
     (void)hipFree(b->d_table);
@@ -859,6 +877,7 @@ int avl_builder_create_grid(avl_builder** h_out, int n0, int gs, int vh, double 
     alloc((void**)&b->first_feat, (size_t)capacity * D * sizeof(float));
     alloc((void**)&b->first_alpha, (size_t)capacity * sizeof(double));
     alloc((void**)&b->head, (size_t)capacity * sizeof(int32_t));
+    alloc((void**)&b->dirty, (size_t)capacity);
     alloc((void**)&b->counters, 4 * sizeof(unsigned long long));
     alloc((void**)&b->err_flags, sizeof(int));
     if (e != hipSuccess) {
@@ -1012,16 +1031,16 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     if (b->log.slot) b->log_used += P;
     if (b->D <= 256)
         hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
     else if (b->D <= 512)
         hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
     else if (b->D <= 1024)
         hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
     else
         hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat,
-                           b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key);
+                           b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
@@ -1136,6 +1155,11 @@ int avl_builder_scatter_merge(avl_builder* b, int64_t n, const int64_t* d_row_of
 
 int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
                          uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream) {
+    return avl_builder_finalize_ex(b, n, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, nullptr, 0, stream);
+}
+
+int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
+                            uint8_t* d_grid_rgb, int32_t* d_occupied_ids, uint8_t* d_row_dirty, int clear_dirty, void* stream) {
     AVL_REQUIRE(b, "avl_builder_finalize: null handle");
     hipStream_t st = as_stream(stream);
     int64_t have = 0;
@@ -1171,6 +1195,11 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
             if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
         }
         ls.release(st);
+    }
+    if (rc == AVL_OK && d_row_dirty) {
+        hipLaunchKernelGGL(row_dirty_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n, perm, b->dirty,
+                           d_row_dirty, clear_dirty);
+        if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
     }
     (void)hipFreeAsync(tmp, st);
     (void)hipFreeAsync(perm, st);

@@ -22,7 +22,9 @@
 //                         one lane).  The accumulator then holds, per lane, 16 queries of ONE voxel:
 //                         the row argmax is an in-register scan plus one cross-half exchange.
 #include <cfloat>
+#include <algorithm>
 #include <climits>
+#include <vector>
 
 #include "avl_common.h"
 
@@ -265,7 +267,11 @@ template <int QT, int NA>
 __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], const float* isc, int q_base, int rows, int Q,
                                                float* __restrict__ scores, int32_t* __restrict__ argmax,
                                                float* __restrict__ best, int64_t row, int64_t N, int kg, int first_chunk,
-                                               float rscale = 1.f, uint32_t* __restrict__ flags = nullptr, float rmax = 1.f) {
+                                               float rscale = 1.f, uint32_t* __restrict__ flags = nullptr, float rmax = 1.f,
+                                               const int32_t* __restrict__ qmap = nullptr) {
+    // qmap (column-block launches, avl_sim_scores_blocks): this launch's query rows are a gathered subset of the caller's;
+    // qmap[local row] = the caller's query index, ascending, so "first maximum" inside the launch is unchanged and only the
+    // published index / score column and the tie-break against earlier launches use the caller's numbering
     const int qend = q_base + rows;  // first query index NOT in this chunk
     float bv = -INFINITY;
     int bi = INT_MAX;
@@ -288,7 +294,13 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
             v.w = r.w * is4.w * rscale;
             if (scores && row < N) {
                 float* sp = scores + row * (int64_t)Q + qg;
-                if (qg + 3 < qend && (Q & 3) == 0) {
+                if (qmap) {
+                    float* sr = scores + row * (int64_t)Q;
+                    if (qg + 0 < qend) sr[qmap[qg + 0]] = v.x;
+                    if (qg + 1 < qend) sr[qmap[qg + 1]] = v.y;
+                    if (qg + 2 < qend) sr[qmap[qg + 2]] = v.z;
+                    if (qg + 3 < qend) sr[qmap[qg + 3]] = v.w;
+                } else if (qg + 3 < qend && (Q & 3) == 0) {
                     *reinterpret_cast<f32x4*>(sp) = v;
                 } else {
                     if (qg + 0 < qend) sp[0] = v.x;
@@ -304,6 +316,7 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
         }
     }
     if (argmax || best || flags) {
+        if (qmap && bi != INT_MAX) bi = qmap[bi];
         const float ov = __shfl_xor(bv, 32, 64);
         const int oi = __shfl_xor(bi, 32, 64);
         if (ov > bv || (ov == bv && oi < bi)) {
@@ -317,15 +330,19 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
             const bool bad = row < N && (!(m == 0.f || (m >= kGuardLo && m < kGuardHi)) || bi == INT_MAX);
             const unsigned long long mask = __ballot(bad);
             const int64_t row0 = __shfl(row, 0, 64);
-            if ((threadIdx.x & 63) == 0 && row0 < N) flags[row0 >> 5] = (uint32_t)(mask | (mask >> 32));
+            if ((threadIdx.x & 63) == 0 && row0 < N) {   // later launches of one call (other query chunks / column blocks) OR in
+                const uint32_t w = (uint32_t)(mask | (mask >> 32));
+                flags[row0 >> 5] = first_chunk ? w : (flags[row0 >> 5] | w);
+            }
         }
         if ((argmax || best) && kg == 0 && row < N) {
-            if (bi == INT_MAX) bi = q_base;
-            if (!first_chunk) {  // earlier chunks hold smaller indices: they win ties
+            if (bi == INT_MAX) bi = qmap ? qmap[q_base] : q_base;
+            if (!first_chunk) {  // an equal score keeps the lower query index (np.argmax: first maximum)
                 const float pv = best[row];
-                if (!(bv > pv)) {
+                const int pi = argmax ? argmax[row] : -1;
+                if (pv > bv || (pv == bv && pi < bi)) {
                     bv = pv;
-                    bi = argmax ? argmax[row] : bi;
+                    bi = argmax ? pi : bi;
                 }
             }
             if (argmax) argmax[row] = bi;
@@ -422,6 +439,16 @@ __global__ __launch_bounds__(256) void sim_fixup_rows_kernel(const float* __rest
     }
 }
 
+// column-block launches: out[r, 0:cols] = q[rows[r], col0 : col0 + cols]  (the gathered query rows of one support group)
+__global__ __launch_bounds__(256) void sim_gather_queries_kernel(const float* __restrict__ q, int64_t ldq, const int32_t* __restrict__ rows,
+                                                                 int nrows, int col0, int cols, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    if (r >= nrows) return;
+    const float* src = q + (int64_t)rows[r] * ldq + col0;
+    float* dst = out + (int64_t)r * cols;
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[c] = src[c];
+}
+
 // QT = number of 32-query MFMA tiles of this chunk (1..3); `rows` = valid query rows of the chunk (<= 32*QT):
 // only those rows are resident in LDS (lanes of a partial tile re-read the last valid row; their results are masked).
 // PRE: the map was converted in place by sim_prepare_map_kernel -- every 8 floats hold their fp16 hi[8] | lo[8] images, so
@@ -429,12 +456,12 @@ __global__ __launch_bounds__(256) void sim_fixup_rows_kernel(const float* __rest
 // FQ (needs nkc == 1 and D <= 512): the workgroup builds its LDS query image itself from the raw float32 query rows -- the
 // same arithmetic as sim_prep_queries_kernel, so the scores are bit-identical -- instead of copying a prepared image: no
 // prep launch and no workspace, which is ~8 us per query on maps of a few hundred thousand voxels.
-template <int QT, int NSTEPS, bool PRE, bool FQ>
+template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, const float* __restrict__ q_raw, int64_t ldq, int Qtot, int KC, int nkc, int q_base,
     int rows, int Q, float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk,
-    const float* __restrict__ row_scale, uint32_t* __restrict__ flags) {
+    const float* __restrict__ row_scale, uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
     // row_scale (PRE only, nullable): per-row 2^-s of a map prepared with scaling.  flags (!PRE): range-guard words, see kGuardLo.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NA = QT == 1 ? 3 : (QT == 2 ? 2 : 1);   // accumulator sets per tile (register budget: 16 VGPRs each)
@@ -646,7 +673,9 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         if constexpr (PRE) {
             if (row_scale) rscale = row_scale[rowc];
         }
-        split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax);
+        // QM (column-block launches) is a template parameter so that the dense kernels keep their register budget
+        split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax,
+                               QM ? qmap : nullptr);
     }
 }
 
@@ -664,13 +693,23 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kStreamFill = 9;   // 16-byte staging registers per thread: one LDS buffer <= 9 * 512 * 16 B = 72 KB
 
-template <int QT, int SPC, bool PRE>
+// TB = voxel tiles a workgroup carries through the chunk loop together (tile blocking).  A chunk's LDS residency -- its
+// staging traffic from L2 and the s_barrier that retires it, 11 % + 7 % of the kernel at TB = 1 -- is paid once per
+// TB tiles: the chunk's columns of tile 0, then of tile 1, ... are contracted against the same buffer into TB accumulator
+// sets.  Costs 16 * QT accumulator registers per extra tile, so TB = 4 for QT = 1, 2 for QT = 2 (3 spills), and 1 for QT >= 3.
+template <int QT>
+struct StreamTB {
+    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
+};
+
+template <int QT, int SPC, bool PRE, bool QM = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
-    uint32_t* __restrict__ flags) {
+    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
     static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
+    constexpr int TB = StreamTB<QT>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 64 * SPC;
     constexpr int row_b = (2 * KS + kRowPadHalves) * 2;   // bytes per query row of one chunk: hi[KS] | lo[KS] | pad
@@ -690,7 +729,8 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
             reinterpret_cast<uint32_t*>(smem + buf_b + rows * row_b)[i] = 0u;
         }
 
-    // the next chunk is staged in SPC slices, one per k step (registers: 5 x 16 B at SPC = 2, 3 x 16 B at SPC = 4)
+    // the next chunk is staged in SPC slices, one per k step of the block's FIRST tile (registers: 5 x 16 B at SPC = 2,
+    // 3 x 16 B at SPC = 4); the other tiles of the block only compute
     constexpr int NSTG = kStreamFill - ((SPC - 1) * kStreamFill) / SPC;
     f32x4 stg[NSTG];
     auto stage_load = [&](int c, int i0, int i1) {
@@ -710,7 +750,22 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
         }
     };
 
+    // work split: full rounds of interleaved TB-tile blocks (all workgroups sweep one compact window of the map), then what
+    // is left (< gridDim.x * TB tiles) dealt out evenly, at most TB tiles per workgroup
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    const int64_t G = gridDim.x;
+    const int64_t R = ntiles / (G * TB);
+    const int64_t rem0 = R * G * TB, rem = ntiles - rem0;
+    const int64_t ra = rem * blockIdx.x / G, rb = rem * (blockIdx.x + 1) / G;
+    auto block_of = [&](int64_t it, int64_t& tile0, int& cnt) {
+        if (it < R) {
+            tile0 = (it * G + blockIdx.x) * TB;
+            cnt = TB;
+        } else {
+            tile0 = rem0 + ra;
+            cnt = it == R ? (int)(rb - ra) : 0;
+        }
+    };
     auto tile_ptr = [&](int64_t tile) {
         const int64_t r = tile * kTileRows + wave * 32 + j;
         return feat + (r < N ? r : N - 1) * ld + 32 * kg;
@@ -721,7 +776,11 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = g[t];
     };
-    load(ring[0], tile_ptr(blockIdx.x));   // first tile, step 0: in flight while chunk 0 is brought in
+    int64_t tile0;
+    int cnt;
+    block_of(0, tile0, cnt);
+    if (cnt == 0) return;   // kernel-uniform per workgroup, before any barrier
+    load(ring[0], tile_ptr(tile0));   // first tile, step 0: in flight while chunk 0 is brought in
 #pragma unroll
     for (int s = 0; s < SPC; ++s) {
         stage_load(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
@@ -734,65 +793,80 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #pragma unroll
     for (int t = 0; t < QT; ++t) a_off[t] = min(t * 32 + j, rows - 1 + zrow) * row_b + kg * 64;
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row = tile * kTileRows + wave * 32 + j;
-        const float* rp = tile_ptr(tile);
-        const bool has_next = tile + gridDim.x < ntiles;
-        const float* p_next = has_next ? tile_ptr(tile + gridDim.x) : rp;
+    for (int64_t it = 0; cnt > 0; ++it) {
+        int64_t tile0_next;
+        int cnt_next;
+        block_of(it + 1, tile0_next, cnt_next);
+        const float* rp[TB];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) rp[b] = tile_ptr(tile0 + (b < cnt ? b : 0));
+        const float* p_next = cnt_next > 0 ? tile_ptr(tile0_next) : rp[0];
 
-        f32x16 acc[QT][1];
+        f32x16 acc[TB][QT][1];
+        float rmax[TB];
 #pragma unroll
-        for (int t = 0; t < QT; ++t)
+        for (int b = 0; b < TB; ++b) {
+            rmax[b] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][0][e] = 0.f;
-        float rmax = 0.f;
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][t][0][e] = 0.f;
+        }
 
         for (int c = 0; c < nch; ++c) {
             const int cn = c + 1 < nch ? c + 1 : 0;
             const char* ab = smem + cur * buf_b;
 #pragma unroll
-            for (int s = 0; s < SPC; ++s) {
-                const int i0 = (s * kStreamFill) / SPC, i1 = ((s + 1) * kStreamFill) / SPC;
+            for (int b = 0; b < TB; ++b) {
+                if (TB == 1 || b < cnt) {   // workgroup-uniform
+#pragma unroll
+                    for (int s = 0; s < SPC; ++s) {
+                        const int i0 = (s * kStreamFill) / SPC, i1 = ((s + 1) * kStreamFill) / SPC;
 #ifndef AVL_ABL_NOSTAGE
-                stage_load(cn, i0, i1);               // issued ahead of this step's voxel prefetch (older in vmcnt order)
+                        if (b == 0) stage_load(cn, i0, i1);   // issued ahead of this step's voxel prefetch (older in vmcnt order)
 #endif
-                const float* nxt = rp + 64 * (c * SPC + s + 1);
-                if (s + 1 < SPC) {
-                    load(ring[(s + 1) & 1], nxt);
-                } else if (c + 1 < nch) {
-                    load(ring[0], nxt);
-                } else if (has_next) {
-                    load(ring[0], p_next);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4(&b)[8] = ring[s & 1];
+                        // prefetch the next step in execution order: same tile, next tile of the block (same chunk), first tile
+                        // of the next chunk, first tile of the workgroup's next block
+                        if (s + 1 < SPC) {
+                            load(ring[(s + 1) & 1], rp[b] + 64 * (c * SPC + s + 1));
+                        } else if (b + 1 < TB && b + 1 < cnt) {
+                            load(ring[0], rp[b + 1 < TB ? b + 1 : b] + 64 * (c * SPC));
+                        } else if (c + 1 < nch) {
+                            load(ring[0], rp[0] + 64 * ((c + 1) * SPC));
+                        } else if (cnt_next > 0) {
+                            load(ring[0], p_next);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const f32x4(&v)[8] = ring[s & 1];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    half8 bh, bl;
-                    if constexpr (PRE) {
-                        bh = __builtin_bit_cast(half8, b[2 * m]);
-                        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
-                    } else {
-                        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
-                        split8(b[2 * m], b[2 * m + 1], bh, bl);
-                    }
-                    const int off = (s * 64 + 8 * m) * 2;
-                    half8 ah[QT], al[QT];
+                        for (int m = 0; m < 4; ++m) {
+                            half8 bh, bl;
+                            if constexpr (PRE) {
+                                bh = __builtin_bit_cast(half8, v[2 * m]);
+                                bl = __builtin_bit_cast(half8, v[2 * m + 1]);
+                            } else {
+                                guard_max8(rmax[b], v[2 * m], v[2 * m + 1]);
+                                split8(v[2 * m], v[2 * m + 1], bh, bl);
+                            }
+                            const int off = (s * 64 + 8 * m) * 2;
+                            half8 ah[QT], al[QT];
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) {
-                        ah[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off);
-                        al[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off + lo_b);
-                    }
+                            for (int t = 0; t < QT; ++t) {
+                                ah[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off);
+                                al[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off + lo_b);
+                            }
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][0], 0, 0, 0);
+                            for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[b][t][0], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][0], 0, 0, 0);
+                            for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[b][t][0], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][0], 0, 0, 0);
-                }
+                            for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[b][t][0], 0, 0, 0);
+                        }
 #ifndef AVL_ABL_NOSTAGE
-                stage_store(cur ^ 1, i0, i1);
+                        if (b == 0) stage_store(cur ^ 1, i0, i1);
 #endif
+                    }
+                }
             }
             // publish the next chunk / retire this one: LDS traffic only, the voxel prefetch stays in flight
 #ifndef AVL_ABL_NOBARRIER
@@ -802,11 +876,20 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #endif
             cur ^= 1;
         }
-        float rscale = 1.f;
-        if constexpr (PRE) {
-            if (row_scale) rscale = row_scale[row < N ? row : N - 1];
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+            if (TB == 1 || b < cnt) {
+                const int64_t row = (tile0 + b) * kTileRows + wave * 32 + j;
+                float rscale = 1.f;
+                if constexpr (PRE) {
+                    if (row_scale) rscale = row_scale[row < N ? row : N - 1];
+                }
+                split_epilogue<QT, 1>(acc[b], isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale,
+                                      PRE ? nullptr : flags, rmax[b], QM ? qmap : nullptr);
+            }
         }
-        split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax);
+        tile0 = tile0_next;
+        cnt = cnt_next;
     }
 }
 
@@ -1111,23 +1194,23 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     return AVL_OK;
 }
 
-template <int SPC, bool PRE>
+template <int SPC, bool PRE, bool QM>
 static const void* pick_stream_kernel(int QT) {
     switch (QT) {
-        case 1: return reinterpret_cast<const void*>(sim_stream_f16_kernel<1, SPC, PRE>);
-        case 2: return reinterpret_cast<const void*>(sim_stream_f16_kernel<2, SPC, PRE>);
-        case 3: return reinterpret_cast<const void*>(sim_stream_f16_kernel<3, SPC, PRE>);
-        default: return reinterpret_cast<const void*>(sim_stream_f16_kernel<4, SPC, PRE>);
+        case 1: return reinterpret_cast<const void*>(sim_stream_f16_kernel<1, SPC, PRE, QM>);
+        case 2: return reinterpret_cast<const void*>(sim_stream_f16_kernel<2, SPC, PRE, QM>);
+        case 3: return reinterpret_cast<const void*>(sim_stream_f16_kernel<3, SPC, PRE, QM>);
+        default: return reinterpret_cast<const void*>(sim_stream_f16_kernel<4, SPC, PRE, QM>);
     }
 }
 
 static bool split_plan_is_fused(const SplitPlan& p, int D) { return !p.stream && p.nkc == 1 && D <= 512; }
 
-template <int QT, bool PRE>
+template <int QT, bool PRE, bool QM>
 static const void* pick_split_kernel(bool s8, bool fq) {
-    if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, PRE, true>)
-                      : reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, true>);
-    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, false>);
+    if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, PRE, true, QM>)
+                      : reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, true, QM>);
+    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, PRE, false, QM>);
 }
 
 static int run_fixup(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq, const uint32_t* d_flags,
@@ -1143,17 +1226,19 @@ static int run_fixup(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     return AVL_OK;
 }
 
-// PRE: d_row_scale = per-row 2^-s of the prepared map (nullable).  !PRE: d_flags = (N + 31) / 32 range-guard words, written by
-// every launch and consumed by sim_fixup_rows_kernel at the end.
+// One column block of a similarity call: Qg gathered query rows x the map columns [feat, feat + D) (the whole call when
+// qmap == nullptr).  PRE: d_row_scale = per-row 2^-s of the prepared map (nullable).  !PRE: d_flags = (N + 31) / 32 range-guard
+// words, written by the first launch of the call and OR-ed into by the others; the caller runs sim_fixup_rows_kernel at the end.
+// Qs = row stride of d_scores (the caller's Q); qmap[local row] = the caller's query index (ascending), nullptr = identity.
 template <bool PRE>
-static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
+static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Qg, int64_t ldq, int Qs,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, const float* d_row_scale,
-                     uint32_t* d_flags, hipStream_t st) {
+                     uint32_t* d_flags, const int32_t* d_qmap, bool first_launch, hipStream_t st) {
     float* inv_scale = reinterpret_cast<float*>(d_ws);
     _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
     const bool fq = split_plan_is_fused(p, D);   // resident image built inside the kernel: no prep launch, no workspace
     if (!fq)
-        hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Q, D, ldq, inv_scale, img, p.Qtot, p.KC,
+        hipLaunchKernelGGL(sim_prep_queries_kernel, dim3(p.Qtot), dim3(256), 0, st, d_q, Qg, D, ldq, inv_scale, img, p.Qtot, p.KC,
                            p.nkc, p.stream ? 1 : 0);
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
     int64_t blocks = ntiles < num_cus() ? ntiles : num_cus();
@@ -1161,37 +1246,40 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     if (p.stream) {
         for (int ci = 0; ci < p.nchunks; ++ci) {
             const SplitChunk& c = p.chunks[ci];
-            const void* kern = p.SPC == 4 ? pick_stream_kernel<4, PRE>(c.QT) : pick_stream_kernel<2, PRE>(c.QT);
+            const void* kern = d_qmap ? (p.SPC == 4 ? pick_stream_kernel<4, PRE, true>(c.QT) : pick_stream_kernel<2, PRE, true>(c.QT))
+                                      : (p.SPC == 4 ? pick_stream_kernel<4, PRE, false>(c.QT) : pick_stream_kernel<2, PRE, false>(c.QT));
             const size_t lds = p.lds_bytes(c);
             int rc = ensure_dynamic_lds(kern, lds);
             if (rc != AVL_OK) return rc;
             const _Float16* img_c = img;
             const float* isc_c = inv_scale;
-            int Qtot = p.Qtot, nch = p.nkc, q_base = c.q_base, rows = c.rows, first = ci == 0 ? 1 : 0;
-            void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &nch, &q_base, &rows, &Q, &d_scores, &d_argmax, &d_best, &first,
-                            &d_row_scale, &d_flags};
+            int Qtot = p.Qtot, nch = p.nkc, q_base = c.q_base, rows = c.rows, first = (ci == 0 && first_launch) ? 1 : 0;
+            void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &nch, &q_base, &rows, &Qs, &d_scores, &d_argmax, &d_best, &first,
+                            &d_row_scale, &d_flags, &d_qmap};
             AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
         }
         AVL_HIP_CHECK(hipGetLastError());
-        return PRE ? AVL_OK : run_fixup(d_feat, N, D, ld, d_q, Q, ldq, d_flags, d_scores, d_argmax, d_best, st);
+        return AVL_OK;
     }
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
         const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
-        const void* kern = c.QT == 3 ? pick_split_kernel<3, PRE>(s8, fq)
-                                     : (c.QT == 2 ? pick_split_kernel<2, PRE>(s8, fq) : pick_split_kernel<1, PRE>(s8, fq));
+        const void* kern = d_qmap ? (c.QT == 3 ? pick_split_kernel<3, PRE, true>(s8, fq)
+                                               : (c.QT == 2 ? pick_split_kernel<2, PRE, true>(s8, fq) : pick_split_kernel<1, PRE, true>(s8, fq)))
+                                  : (c.QT == 3 ? pick_split_kernel<3, PRE, false>(s8, fq)
+                                               : (c.QT == 2 ? pick_split_kernel<2, PRE, false>(s8, fq) : pick_split_kernel<1, PRE, false>(s8, fq)));
         const size_t lds = p.lds_bytes(c);
         int rc = ensure_dynamic_lds(kern, lds);
         if (rc != AVL_OK) return rc;
         const _Float16* img_c = img;
         const float* isc_c = inv_scale;
-        int Qtot = p.Qtot, KC = p.KC, nkc = p.nkc, q_base = c.q_base, rows = c.rows, first = ci == 0 ? 1 : 0;
-        void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &d_q, &ldq, &Qtot, &KC, &nkc, &q_base, &rows, &Q,
-                        &d_scores, &d_argmax, &d_best, &first, &d_row_scale, &d_flags};
+        int Qtot = p.Qtot, KC = p.KC, nkc = p.nkc, q_base = c.q_base, rows = c.rows, first = (ci == 0 && first_launch) ? 1 : 0;
+        void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &d_q, &ldq, &Qtot, &KC, &nkc, &q_base, &rows, &Qs,
+                        &d_scores, &d_argmax, &d_best, &first, &d_row_scale, &d_flags, &d_qmap};
         AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
     }
     AVL_HIP_CHECK(hipGetLastError());
-    return PRE ? AVL_OK : run_fixup(d_feat, N, D, ld, d_q, Q, ldq, d_flags, d_scores, d_argmax, d_best, st);
+    return AVL_OK;
 }
 
 static int run_mfma_f32(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Q, int64_t ldq,
@@ -1222,6 +1310,7 @@ extern "C" {
 
 static size_t align_up(size_t b, size_t a) { return (b + a - 1) / a * a; }
 static size_t guard_bytes(int64_t N) { return align_up((size_t)((N + 31) >> 5) * sizeof(uint32_t), kHdrAlign); }
+static size_t blocks_bytes(int D, int Q);
 
 int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes) {
     AVL_REQUIRE(h_bytes, "avl_sim_workspace_bytes: null output");
@@ -1236,13 +1325,51 @@ int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes) {
 int avl_sim_workspace_bytes_n(int64_t N, int D, int Q, size_t* h_bytes) {
     AVL_REQUIRE(N >= 0, "avl_sim_workspace_bytes_n: bad N");
     const int rc = avl_sim_workspace_bytes(D, Q, h_bytes);
-    if (rc == AVL_OK) *h_bytes += guard_bytes(N);
+    if (rc == AVL_OK) *h_bytes += guard_bytes(N) + blocks_bytes(D, Q);
     return rc;
+}
+
+// Workspace layout of the matrix-core paths (every part aligned to kHdrAlign):
+//   [query image of the widest plan][range-guard words (raw split path)][gathered queries Q x D f32][query map Q x i32]
+// the last two only for column-block calls.
+static size_t blocks_bytes(int D, int Q) { return align_up((size_t)Q * D * sizeof(float), kHdrAlign) + align_up((size_t)Q * sizeof(int32_t), kHdrAlign); }
+
+struct ColGroup {
+    int col0, cols;
+    std::vector<int32_t> rows;   // the caller's query indices, ascending
+};
+
+// Column-support groups: queries whose non-zero columns lie in the same [begin, end) window (rounded outward to the 128-column
+// granularity of the streamed kernel) are scored together against just those columns of the map -- a text query never meets
+// the audio block of a fused visual | audio map (BASELINE config 5), which halves the matrix-core work per voxel byte while the
+// map is still read exactly once overall.  Groups are ordered by their first query so that ties resolve as in one dense pass.
+static void make_col_groups(int D, int Q, const int32_t* h_begin, const int32_t* h_end, std::vector<ColGroup>& groups) {
+    groups.clear();
+    std::vector<int> zero_rows;
+    for (int qi = 0; qi < Q; ++qi) {
+        int b = h_begin[qi] < 0 ? 0 : h_begin[qi], e = h_end[qi] > D ? D : h_end[qi];
+        if (e <= b) {   // an all-zero query scores 0 against any window: it joins the first group
+            zero_rows.push_back(qi);
+            continue;
+        }
+        b = (b / 128) * 128;
+        e = ((e + 127) / 128) * 128;
+        if (e > D) e = D;
+        size_t g = 0;
+        for (; g < groups.size(); ++g)
+            if (groups[g].col0 == b && groups[g].cols == e - b) break;
+        if (g == groups.size()) groups.push_back(ColGroup{b, e - b, {}});
+        groups[g].rows.push_back(qi);
+    }
+    if (groups.empty()) groups.push_back(ColGroup{0, 128 < D ? 128 : D, {}});
+    for (int qi : zero_rows) groups[0].rows.push_back(qi);
+    std::sort(groups[0].rows.begin(), groups[0].rows.end());   // rows ascend inside a group: "first maximum" stays the caller's
 }
 
 static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat, const float* d_queries,
                            int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
-                           void* d_workspace, size_t workspace_bytes, void* stream) {
+                           void* d_workspace, size_t workspace_bytes, void* stream, const int32_t* h_col_begin = nullptr,
+                           const int32_t* h_col_end = nullptr) {
     AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores: bad shape N=%lld D=%d Q=%d", (long long)N, D, Q);
     AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
     AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED, "avl_sim_scores: bad precision %d", precision);
@@ -1265,38 +1392,100 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
         use_split = true;
     } else use_split = can_split;   // ~1e-6 accurate and HBM-bound for every Q; EXACT remains the fallback / on request
 
-    // chaining query chunks needs a best-score buffer even if the caller does not want it
-    float* best = d_best;
-    float* tmp_best = nullptr;
-    const int nchunks = (use_split || use_f32_mfma) ? p.nchunks : (Q + kExactQB - 1) / kExactQB;
-    if (!best && d_argmax && nchunks > 1) {
-        AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_best), (size_t)N * sizeof(float), st));
-        best = tmp_best;
+    // column-support groups (only the split path exploits them; more than one group = block launches)
+    std::vector<ColGroup> groups;
+    std::vector<SplitPlan> gplans;
+    if (use_split && h_col_begin && h_col_end) {
+        make_col_groups(D, Q, h_col_begin, h_col_end, groups);
+        bool ok = groups.size() > 1 && groups.size() <= 16;
+        for (size_t g = 0; ok && g < groups.size(); ++g) {
+            SplitPlan gp;
+            ok = make_split_plan(groups[g].cols, (int)groups[g].rows.size(), gp, true);
+            gplans.push_back(gp);
+        }
+        if (!ok) { groups.clear(); gplans.clear(); }
     }
-    int rc;
+    const bool blocks = !groups.empty();
+
+    // chaining launches (query chunks, column blocks) needs best + argmax buffers even if the caller does not want them
+    float* best = d_best;
+    int32_t* amax = d_argmax;
+    float* tmp_best = nullptr;
+    int32_t* tmp_amax = nullptr;
+    int nlaunch = (use_split || use_f32_mfma) ? p.nchunks : (Q + kExactQB - 1) / kExactQB;
+    if (blocks) {
+        nlaunch = 0;
+        for (const SplitPlan& gp : gplans) nlaunch += gp.nchunks;
+    }
+    if (nlaunch > 1 && (d_argmax || d_best)) {
+        if (!best) {
+            AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_best), (size_t)N * sizeof(float), st));
+            best = tmp_best;
+        }
+        if (!amax && blocks) {   // blocks interleave the caller's query indices: the tie-break needs the previous index
+            AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp_amax), (size_t)N * sizeof(int32_t), st));
+            amax = tmp_amax;
+        }
+    }
+    int rc = AVL_OK;
     if (use_split || use_f32_mfma) {
-        // workspace = [query image, only when the plan needs one][range-guard words, raw split path only]
         const bool prepared = precision == AVL_SIM_PREPARED;
-        const bool needs_img = use_f32_mfma || !split_plan_is_fused(p, D);   // the fused-prep path keeps the query image in LDS only
-        const size_t img_bytes = needs_img ? align_up(p.ws_bytes, kHdrAlign) : 0;
+        size_t img_bytes = 0;
+        if (blocks) {
+            for (const SplitPlan& gp : gplans) img_bytes = img_bytes > gp.ws_bytes ? img_bytes : gp.ws_bytes;
+        } else if (use_f32_mfma || !split_plan_is_fused(p, D)) {   // the fused-prep path keeps the query image in LDS only
+            img_bytes = p.ws_bytes;
+        }
+        img_bytes = img_bytes ? align_up(img_bytes, kHdrAlign) : 0;
         const size_t flag_bytes = (use_split && !prepared) ? guard_bytes(N) : 0;
+        const size_t blk_bytes = blocks ? blocks_bytes(D, Q) : 0;
+        const size_t need = img_bytes + flag_bytes + blk_bytes;
         char* ws = static_cast<char*>(d_workspace);
         void* tmp_ws = nullptr;
-        if (img_bytes + flag_bytes > 0 && (!ws || workspace_bytes < img_bytes + flag_bytes)) {
-            AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, img_bytes + flag_bytes, st));
+        if (need > 0 && (!ws || workspace_bytes < need)) {
+            AVL_HIP_CHECK(hipMallocAsync(&tmp_ws, need, st));
             ws = static_cast<char*>(tmp_ws);
         }
         uint32_t* flags = flag_bytes ? reinterpret_cast<uint32_t*>(ws + img_bytes) : nullptr;
-        rc = use_split ? (prepared ? run_split<true>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, d_row_scale,
-                                                     nullptr, st)
-                                   : run_split<false>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, nullptr,
-                                                      flags, st))
-                       : run_mfma_f32(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, p, ws, st);
+        if (!use_split) {
+            rc = run_mfma_f32(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, amax, best, p, ws, st);
+        } else if (!blocks) {
+            rc = prepared ? run_split<true>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, Q, d_scores, amax, best, p, ws, d_row_scale, nullptr,
+                                            nullptr, true, st)
+                          : run_split<false>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, Q, d_scores, amax, best, p, ws, nullptr, flags,
+                                             nullptr, true, st);
+        } else {
+            float* qg = reinterpret_cast<float*>(ws + img_bytes + flag_bytes);
+            int32_t* qmap = reinterpret_cast<int32_t*>(ws + img_bytes + flag_bytes + align_up((size_t)Q * D * sizeof(float), kHdrAlign));
+            std::vector<int32_t> h_map;
+            h_map.reserve((size_t)Q);
+            for (const ColGroup& g : groups) h_map.insert(h_map.end(), g.rows.begin(), g.rows.end());
+            AVL_HIP_CHECK(hipMemcpyAsync(qmap, h_map.data(), (size_t)Q * sizeof(int32_t), hipMemcpyHostToDevice, st));   // pageable: staged
+            size_t row_off = 0, qg_off = 0;
+            for (size_t g = 0; g < groups.size() && rc == AVL_OK; ++g) {
+                const ColGroup& cg = groups[g];
+                const int Qg = (int)cg.rows.size();
+                float* qg_g = qg + qg_off;
+                const int32_t* qmap_g = qmap + row_off;
+                hipLaunchKernelGGL(sim_gather_queries_kernel, dim3((unsigned)Qg), dim3(256), 0, st, d_queries, ld_q, qmap_g, Qg, cg.col0,
+                                   cg.cols, qg_g);
+                const float* feat_g = d_feat + cg.col0;
+                rc = prepared ? run_split<true>(feat_g, N, cg.cols, ld_feat, qg_g, Qg, cg.cols, Q, d_scores, amax, best, gplans[g], ws,
+                                                d_row_scale, nullptr, qmap_g, g == 0, st)
+                              : run_split<false>(feat_g, N, cg.cols, ld_feat, qg_g, Qg, cg.cols, Q, d_scores, amax, best, gplans[g], ws, nullptr,
+                                                 flags, qmap_g, g == 0, st);
+                row_off += (size_t)Qg;
+                qg_off += (size_t)Qg * cg.cols;
+            }
+        }
+        if (rc == AVL_OK && use_split && !prepared)
+            rc = run_fixup(d_feat, N, D, ld_feat, d_queries, Q, ld_q, flags, d_scores, d_argmax, d_best, st);
         if (tmp_ws) (void)hipFreeAsync(tmp_ws, st);
     } else {
         rc = run_exact(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, best, st);
     }
     if (tmp_best) (void)hipFreeAsync(tmp_best, st);
+    if (tmp_amax) (void)hipFreeAsync(tmp_amax, st);
     return rc;
 }
 
@@ -1305,6 +1494,14 @@ int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, co
                       void* d_workspace, size_t workspace_bytes, void* stream) {
     return sim_scores_impl(d_feat, nullptr, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, d_best, precision, d_workspace,
                            workspace_bytes, stream);
+}
+
+int avl_sim_scores_blocks(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat, const float* d_queries,
+                          int Q, int64_t ld_q, const int32_t* h_col_begin, const int32_t* h_col_end, float* d_scores,
+                          int32_t* d_argmax, float* d_best, int precision, void* d_workspace, size_t workspace_bytes, void* stream) {
+    AVL_REQUIRE(h_col_begin && h_col_end, "avl_sim_scores_blocks: null column support");
+    return sim_scores_impl(d_feat, d_row_scale, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, d_best, precision, d_workspace,
+                           workspace_bytes, stream, h_col_begin, h_col_end);
 }
 
 int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,

@@ -21,7 +21,7 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from .. import ops, parallel
-from ..utils.mapping_utils import (cvt_pose_vec2tf, load_3d_map, load_depth_npy, load_rgb_png, map_file_exists,
+from ..utils.mapping_utils import (MapFileWriter, cvt_pose_vec2tf, load_3d_map, load_depth_npy, load_rgb_png, map_file_exists,
                                    save_3d_map)
 from .map import cfg_get
 
@@ -47,6 +47,8 @@ class VLMapBuilder:
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
         self.skip_mapped_frames = False            # True: a resumed run skips the frames listed in the map file's
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
+        self.incremental_checkpoints = True        # periodic saves write only the rows that changed + the new rows
+                                                   # (utils.mapping_utils.MapFileWriter); False = full rewrite like upstream
         self.shard_sampling = "replay"             # several ranks: "replay" = every rank first consumes the global NumPy RNG
                                                    # exactly as the frames before its shard would have (one discarded shuffle
                                                    # per skipped frame, ~6 ms each at 720x1080), so that a seeded N-rank run
@@ -237,7 +239,7 @@ class VLMapBuilder:
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
-                self._save_3d_map(acc.finalize(), mapped_iter_set, background=True)
+                self._save_3d_map(acc.finalize(want_dirty=self.incremental_checkpoints), mapped_iter_set, background=True)
         if acc is None:
             if ws == 1:
                 raise RuntimeError("no frames to map")
@@ -291,7 +293,7 @@ class VLMapBuilder:
 
     def _finish(self, acc, mapped_iter_set, rank, ws, gs, vh):
         if ws == 1:
-            self._save_3d_map(acc.finalize(), mapped_iter_set)
+            self._save_3d_map(acc.finalize(want_dirty=self.incremental_checkpoints), mapped_iter_set)
             return
         import torch.distributed as dist
         self.merge_timings = {}
@@ -316,10 +318,17 @@ class VLMapBuilder:
                 raise err
         iters = list(mapped_iter_set)
 
+        writer = getattr(self, "_map_writer", None)
+        if writer is None or writer.path != Path(self.map_save_path):
+            writer = self._map_writer = MapFileWriter(self.map_save_path)
+
         def write():
             try:
-                save_3d_map(self.map_save_path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"],
-                            iters, arrays["grid_rgb"])
+                if self.incremental_checkpoints:
+                    writer.save(arrays, iters, arrays.get("row_dirty"))
+                else:
+                    save_3d_map(self.map_save_path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"],
+                                iters, arrays["grid_rgb"])
             except BaseException as e:
                 self._save_error = e
                 if not background:

@@ -12,13 +12,26 @@ PRECISION = {"auto": _lib.SIM_AUTO, "exact": _lib.SIM_EXACT, "split_f16": _lib.S
              "prepared": _lib.SIM_PREPARED}
 
 
+def query_col_support(queries):
+    """(begin, end) int32 arrays: the non-zero column window of every row of a HOST query matrix"""
+    q = np.asarray(queries)
+    nz = q != 0
+    any_nz = nz.any(axis=1)
+    begin = np.where(any_nz, nz.argmax(axis=1), 0).astype(np.int32)
+    end = np.where(any_nz, q.shape[1] - nz[:, ::-1].argmax(axis=1), 0).astype(np.int32)
+    return begin, end
+
+
 def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=False, precision="auto", stream=None,
-               out_scores=None, out_argmax=None, out_best=None):
+               out_scores=None, out_argmax=None, out_best=None, col_support="auto"):
     """scores = feat @ queries.T (raw dot product, clip_utils.py:227-229) and argmax(axis=1) (vlmap.py:123).
 
     feat (N, D) float32, queries (Q, D) float32: numpy arrays, DeviceArrays or torch CUDA tensors.
     Returns (scores, argmax, best): numpy arrays for numpy inputs, otherwise device-side objects of
     the same kind as `feat` (entries are None when not requested).
+    col_support: (begin, end) per-query non-zero column windows for block-structured query sets (e.g. text queries living
+    in the visual columns and audio queries in the audio columns of a fused map): queries are then scored against their own
+    columns only (avl_sim_scores_blocks).  "auto" derives the windows when `queries` is a host array; None = dense.
     """
     lib = _lib.load()
     _lib.require_gpu()
@@ -56,9 +69,21 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
         ap, ak = alloc((N,), np.int32, out_argmax)
     if want_best or out_best is not None:
         bp, bk = alloc((N,), np.float32, out_best)
+    rsp = None
     if prepared is not None and prepared.row_scale is not None:
         rs = prepared.row_scale
-        rc = lib.avl_sim_scores_prepared(fptr, rs.data_ptr() if _is_torch(rs) else rs.ptr, N, D, D, qptr, Q, D, sp, ap, bp, None, 0, stream)
+        rsp = rs.data_ptr() if _is_torch(rs) else rs.ptr
+    if isinstance(col_support, str):
+        col_support = query_col_support(queries) if (col_support == "auto" and isinstance(queries, np.ndarray) and D > 128) else None
+    if col_support is not None and precision in ("auto", "split_f16", "prepared"):
+        cb = np.ascontiguousarray(col_support[0], dtype=np.int32)
+        ce = np.ascontiguousarray(col_support[1], dtype=np.int32)
+        if cb.shape != (Q,) or ce.shape != (Q,):
+            raise ValueError("col_support must be two (Q,) integer arrays")
+        rc = lib.avl_sim_scores_blocks(fptr, rsp, N, D, D, qptr, Q, D, cb.ctypes.data, ce.ctypes.data, sp, ap, bp, PRECISION[precision],
+                                       None, 0, stream)
+    elif rsp is not None:
+        rc = lib.avl_sim_scores_prepared(fptr, rsp, N, D, D, qptr, Q, D, sp, ap, bp, None, 0, stream)
     else:
         rc = lib.avl_sim_scores(fptr, N, D, D, qptr, Q, D, sp, ap, bp, PRECISION[precision], stream)
     _lib.check(rc, "avl_sim_scores")
@@ -311,9 +336,11 @@ class VoxelAccumulator:
         _lib.check(_lib.load().avl_builder_num_groups(self._h, C.byref(n), stream), "avl_builder_num_groups")
         return n.value
 
-    def finalize(self, stream=None, want_occupied=True, as_numpy=True, as_torch=False):
+    def finalize(self, stream=None, want_occupied=True, as_numpy=True, as_torch=False, want_dirty=False):
         """-> dict(grid_feat, grid_pos, weight, grid_rgb, occupied_ids) in the reference's voxel-id order
-        (numpy arrays; DeviceArrays with as_numpy=False; torch CUDA tensors with as_torch=True)."""
+        (numpy arrays; DeviceArrays with as_numpy=False; torch CUDA tensors with as_torch=True).
+        want_dirty: also 'row_dirty' (n,) uint8 = rows whose voxel was fused since the previous finalize(want_dirty=True)
+        (the flags are cleared): what an incremental checkpoint has to rewrite (avl_builder_finalize_ex)."""
         lib = _lib.load()
         n = self.num_voxels(stream)
         if as_torch:
@@ -333,9 +360,12 @@ class VoxelAccumulator:
         w = DeviceArray((n,), np.float32)
         rgb = DeviceArray((n, 3), np.uint8)
         occ = DeviceArray((self.n_rows, self.gs, self.vh), np.int32) if want_occupied else None
-        _lib.check(lib.avl_builder_finalize(self._h, n, gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr if occ else None, stream),
-                   "avl_builder_finalize")
+        dirty = DeviceArray((n,), np.uint8) if want_dirty else None
+        _lib.check(lib.avl_builder_finalize_ex(self._h, n, gf.ptr, gp.ptr, w.ptr, rgb.ptr, occ.ptr if occ else None,
+                                               dirty.ptr if dirty else None, 1 if want_dirty else 0, stream), "avl_builder_finalize")
         out = dict(grid_feat=gf, grid_pos=gp, weight=w, grid_rgb=rgb, occupied_ids=occ)
+        if want_dirty:
+            out["row_dirty"] = dirty
         if as_numpy:
             out = {k: (v.numpy(stream) if v is not None else None) for k, v in out.items()}
         return out

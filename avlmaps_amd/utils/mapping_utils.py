@@ -96,6 +96,58 @@ def save_3d_map(save_path, grid_feat, grid_pos, weight, occupied_ids, mapped_ite
         np.savez(_npz_path(save_path), **data)
 
 
+class MapFileWriter:
+    """Checkpointing writer of one map file.  The reference rewrites the whole file every 100 frames (vlmap_builder.py:180-183:
+    O(map) per checkpoint); voxel ids never change once assigned and new voxels are appended, so after the first save only
+    the rows that changed (row_dirty from VoxelAccumulator.finalize(want_dirty=True)) and the new rows are written, plus the few
+    new cells of occupied_ids.  The file stays the reference's layout -- the same six dataset names / dtypes, read back by
+    `f[name][:]` -- with the per-voxel datasets chunked and extendible instead of contiguous.  Needs the HDF5 C library
+    (utils/h5lite.py); otherwise every save is a full rewrite through save_3d_map."""
+
+    ROW_SETS = ("grid_feat", "grid_pos", "weight", "grid_rgb")
+
+    def __init__(self, path):
+        self.path = Path(path)
+        self.n_saved = None          # rows in the file, None = nothing written by this writer yet
+        self.stats = []              # per save: dict(mode, rows_written, rows_total)
+
+    def save(self, arrays, mapped_iter_list, row_dirty=None) -> None:
+        n = int(arrays["grid_pos"].shape[0])
+        iters = np.array(sorted(mapped_iter_list), dtype=np.int32)
+        incremental = (h5lite.available() and self.n_saved is not None and row_dirty is not None and n >= self.n_saved
+                       and self.path.exists())
+        if not h5lite.available():
+            save_3d_map(self.path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"], iters,
+                        arrays["grid_rgb"])
+            self.stats.append(dict(mode="full (no libhdf5)", rows_written=n, rows_total=n))
+            self.n_saved = n
+            return
+        if not incremental:
+            with h5lite.H5File(self.path, "w") as f:
+                f.create_dataset("mapped_iter_list", data=iters, maxshape=(None,))
+                for k in self.ROW_SETS:
+                    a = np.asarray(arrays[k])
+                    f.create_dataset(k, data=a, maxshape=(None,) + a.shape[1:])
+                f.create_dataset("occupied_ids", data=np.asarray(arrays["occupied_ids"]))
+            self.stats.append(dict(mode="full", rows_written=n, rows_total=n))
+            self.n_saved = n
+            return
+        n_old = self.n_saved
+        changed = np.flatnonzero(np.asarray(row_dirty[:n_old]))
+        rows = np.concatenate([changed, np.arange(n_old, n)]).astype(np.int64)
+        with h5lite.H5File(self.path, "r+") as f:
+            for k in self.ROW_SETS:
+                a = np.asarray(arrays[k])
+                f.resize(k, n)
+                f.write_scattered_rows(k, rows, a[rows])
+            new_pos = np.asarray(arrays["grid_pos"])[n_old:n]
+            f.write_points("occupied_ids", new_pos, np.arange(n_old, n, dtype=np.int32))
+            f.resize("mapped_iter_list", len(iters))
+            f.write_rows("mapped_iter_list", 0, iters)
+        self.stats.append(dict(mode="incremental", rows_written=int(rows.size), rows_total=n))
+        self.n_saved = n
+
+
 def map_file_exists(map_path) -> bool:
     return Path(map_path).exists() or _npz_path(map_path).exists()
 

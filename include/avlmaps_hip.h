@@ -118,13 +118,24 @@ AVL_API int avl_sim_scores(const float* d_feat, int64_t N, int D, int64_t ld_fea
 
 /* Scratch of the matrix-core paths: the prepared query image (avl_sim_workspace_bytes: depends on D, Q only) and, for
  * the raw split path, one range-guard word per 32 voxel rows (avl_sim_workspace_bytes_n = image + guard words).  Pass a
- * buffer of that size to avl_sim_scores_ws to keep every allocation off the hot path (benchmark / graph capture); with a
+ * buffer of that size (it also covers avl_sim_scores_blocks' gathered queries) to avl_sim_scores_ws to keep every allocation off the hot path (benchmark / graph capture); with a
  * smaller or NULL workspace the library allocates from the stream-ordered pool. */
 AVL_API int avl_sim_workspace_bytes(int D, int Q, size_t* h_bytes);
 AVL_API int avl_sim_workspace_bytes_n(int64_t N, int D, int Q, size_t* h_bytes);
 AVL_API int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_feat, const float* d_queries, int Q,
                               int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
                               void* d_workspace, size_t workspace_bytes, void* stream);
+/* Block-structured query sets: h_col_begin / h_col_end (Q host ints) give every query's non-zero column window [begin, end)
+ * (a superset is fine).  Queries with the same window (rounded out to 128 columns) are scored against just those columns of
+ * the map, one launch group per window: on a fused visual | audio map (BASELINE config 5: 512 + 1024 columns, every query
+ * living in one modality block) the map is still read once overall but the matrix cores do half the work.  Results equal the
+ * dense call (same products; zero products dropped); argmax ties still resolve to the lowest query index.  d_row_scale: see
+ * avl_sim_scores_prepared (NULL unless precision == AVL_SIM_PREPARED on a scaled map).  Falls back to the dense path when the
+ * windows do not split the queries or the shape does not allow it. */
+AVL_API int avl_sim_scores_blocks(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,
+                                  const float* d_queries, int Q, int64_t ld_q, const int32_t* h_col_begin,
+                                  const int32_t* h_col_end, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
+                                  void* d_workspace, size_t workspace_bytes, void* stream);
 /* Scores of a map prepared WITH row scaling (d_row_scale from avl_sim_prepare_map; NULL = prepared without). */
 AVL_API int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,
                                     const float* d_queries, int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax,
@@ -252,6 +263,14 @@ AVL_API int avl_builder_num_groups(avl_builder* b, int64_t* h_n, void* stream);
  */
 AVL_API int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
                                  uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream);
+
+/* avl_builder_finalize plus, for incremental checkpoints: d_row_dirty (n,) uint8 (nullable) receives 1 for every output row whose
+ * voxel was fused since the flags were last cleared, and clear_dirty != 0 clears them.  Voxel ids never change once assigned
+ * (new voxels are appended), so a checkpoint only has to rewrite the dirty rows and append rows >= the previous n -- upstream
+ * rewrites the whole file every 100 frames (vlmap_builder.py:180-183). */
+AVL_API int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
+                                    uint8_t* d_grid_rgb, int32_t* d_occupied_ids, uint8_t* d_row_dirty, int clear_dirty,
+                                    void* stream);
 
 /*
  * Multi-GPU merge support (frames sharded over ranks; the exchange itself runs in the host layer over

@@ -58,6 +58,36 @@ def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as, batch
     assert gf.dtype == np.float32 and w.dtype == np.float32 and rgb.dtype == np.uint8 and occ.dtype == np.int32
 
 
+def test_incremental_checkpoints_write_the_same_file(golden, tmp_path):
+    """save_every = 2 over the golden sequence: the first checkpoint is a full write, the later ones and the final save only
+    write changed + new rows (MapFileWriter); the finished file is the one a single full save produces = the reference's map"""
+    from avlmaps_amd.utils import h5lite
+    from avlmaps_amd.utils.mapping_utils import load_3d_map
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    g = golden("g2a_builder_small.npz")
+    files = {}
+    for mode in ("incremental", "full"):
+        d = tmp_path / mode
+        d.mkdir()
+        b = MemoryBuilder.make(g, d)
+        b.save_every = 2
+        b.incremental_checkpoints = mode == "incremental"
+        np.random.seed(1234)
+        b.create_mobile_base_map()
+        files[mode] = load_3d_map(d / "vlmap" / "vlmaps.h5df")
+        if mode == "incremental":
+            st = b._map_writer.stats
+            assert [s["mode"] for s in st] == ["full", "incremental", "incremental", "incremental"]     # 3 checkpoints + the final save
+            assert all(s["rows_written"] <= s["rows_total"] for s in st) and st[-1]["rows_written"] == 0    # nothing fused since
+            assert st[1]["rows_written"] < st[1]["rows_total"]
+    a, f = files["incremental"], files["full"]
+    assert a[0] == f[0] == list(range(len(g["depths"])))
+    for x, y, k in zip(a[1:], f[1:], ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")):
+        assert np.array_equal(x, y) and x.dtype == y.dtype, k
+    assert np.array_equal(a[2], g["grid_pos"]) and np.array_equal(a[5], g["grid_rgb"])
+
+
 def test_resume_appends_on_top_of_saved_map(golden, tmp_path):
     """second run finds the map file, imports it and fuses all frames again (upstream resume semantics)"""
     from avlmaps_amd.utils.mapping_utils import load_3d_map

@@ -32,6 +32,26 @@ def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samp
     return acc
 
 
+def check_scores_parity(ops, built_feat, ref_feat, seed=0, nq=9):
+    """END TO END: landmark scores of the HIP-BUILT map (HIP builder -> HIP similarity kernel) against the reference's scores of
+    the REFERENCE-built map, the same text features on both sides -- north_star's 1e-4 on the product of the two halves.
+    Queries are means of 63 unit template vectors, not re-normalised, like clip_utils.py:218-225 produces."""
+    rng = np.random.default_rng(1000 + seed)
+    D = ref_feat.shape[1]
+    base = rng.standard_normal((nq, 1, D))
+    t = base + 0.7 * rng.standard_normal((nq, 63, D))
+    t /= np.linalg.norm(t, axis=2, keepdims=True)
+    q = t.mean(axis=1).astype(np.float32)
+    want = np.asarray(ref_feat, dtype=np.float32) @ q.T                   # clip_utils.py:229 on the reference's grid_feat
+    got, am, _ = ops.sim_scores(np.ascontiguousarray(built_feat, dtype=np.float32), q)
+    err = float(np.abs(got - want).max())
+    assert err <= 1e-4, f"end-to-end score error {err:.3e} > 1e-4"
+    srt = np.sort(want, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-4
+    assert np.array_equal(am[clear], np.argmax(want, axis=1)[clear])
+    return err
+
+
 def compare_maps(out, ref, feat_scale, rgb_lsb=RGB_LSB):
     assert np.array_equal(out["grid_pos"], ref["grid_pos"])                 # bit-exact voxel indices + id order
     assert np.array_equal(out["occupied_ids"], ref["occupied_ids"])
@@ -58,6 +78,7 @@ def test_builder_matches_reference_golden(ops, golden, name):
                grid_rgb=np.floor(g["grid_rgb"]) if g["grid_rgb"].dtype != np.uint8 else g["grid_rgb"])
     # the growth fixture funnels ~16k points into 463 coarse voxels: many truncating updates per voxel upstream
     compare_maps(out, ref, 14.3, rgb_lsb=16 if "growth" in name else RGB_LSB)
+    check_scores_parity(ops, out["grid_feat"], g["grid_feat"], seed=len(name))        # build -> index vs the reference's pair
     # with the replay log, weight and grid_rgb follow the reference's sequential dtype semantics EXACTLY
     # (float32 running weight, truncating uint8 colour store, float64/float32 after the capacity doubling)
     acc2 = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"],
@@ -108,6 +129,7 @@ def test_builder_vs_sequential_oracle_medium(ops):
     assert acc.num_points() == om_points
     out = acc.finalize()
     compare_maps(out, ref, 14.3)
+    check_scores_parity(ops, out["grid_feat"], ref["grid_feat"], seed=7)
     accr = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000, replay=True)
     outr = accr.finalize()
     assert np.array_equal(outr["grid_rgb"], ref["grid_rgb"])            # sequential uint8 colour: bit exact
@@ -159,6 +181,8 @@ def test_builder_heavy_collisions(ops, seed, cs, batch):
     np.testing.assert_allclose(out["weight"], ref["weight"].astype(np.float32), rtol=2e-6)
     # the reference's float32 running mean drifts ~1e-7 per update from the exact weighted mean the GPU path returns
     np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=1e-4, atol=1e-4 * 14.3)
+    # ... and that drift stays inside the score tolerance: tens to hundreds of updates per voxel, end to end
+    check_scores_parity(ops, out["grid_feat"], ref["grid_feat"], seed=seed)
 
 
 def test_edge_cases(ops):

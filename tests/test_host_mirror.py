@@ -190,3 +190,46 @@ def test_h5lite_extendible_datasets_and_foreign_files(tmp_path):
     if mat.exists():
         with h5lite.H5File(mat) as f:
             assert "testdouble" in f.keys() and f.read("testdouble").dtype == np.float64
+
+
+def test_map_file_writer_incremental_checkpoints(tmp_path):
+    """MapFileWriter: after the first full save only dirty + new rows (and the new cells of occupied_ids) are written; the
+    file read back is always the complete current map in the reference's layout"""
+    from avlmaps_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    rng = np.random.default_rng(9)
+    gs, vh, D = 16, 6, 8
+    cells = rng.permutation(gs * gs * vh)[:300]
+    pos_all = np.stack([cells // (gs * vh), (cells // vh) % gs, cells % vh], 1).astype(np.int32)
+
+    def state(n, version):
+        r = np.random.default_rng(version)
+        feat = r.standard_normal((n, D)).astype(np.float32)
+        occ = -np.ones((gs, gs, vh), np.int32)
+        occ[pos_all[:n, 0], pos_all[:n, 1], pos_all[:n, 2]] = np.arange(n, dtype=np.int32)
+        return dict(grid_feat=feat, grid_pos=pos_all[:n].copy(), weight=r.random(n).astype(np.float32),
+                    grid_rgb=r.integers(0, 255, (n, 3)).astype(np.uint8), occupied_ids=occ)
+
+    w = mu.MapFileWriter(tmp_path / "vlmaps.h5df")
+    cur = state(100, 0)
+    w.save(cur, {0, 1}, None)
+    for step, n in enumerate((140, 140, 300), start=1):
+        new = state(n, step)
+        dirty = np.zeros(n, np.uint8)
+        keep = np.random.default_rng(100 + step).random(len(cur["grid_pos"])) < 0.7      # 70 % of the old rows did not change
+        for k in w.ROW_SETS:
+            new[k][: len(keep)][keep] = cur[k][keep]
+        dirty[: len(keep)][~keep] = 1
+        dirty[len(keep):] = 1
+        w.save(new, set(range(2 * step + 2)), dirty)
+        it, gf, gp, wt, occ, rgb = mu.load_3d_map(tmp_path / "vlmaps.h5df")
+        assert it == list(range(2 * step + 2))
+        for a, k in ((gf, "grid_feat"), (gp, "grid_pos"), (wt, "weight"), (occ, "occupied_ids"), (rgb, "grid_rgb")):
+            assert np.array_equal(a, new[k]) and a.dtype == new[k].dtype, (step, k)
+        cur = new
+    assert [s["mode"] for s in w.stats] == ["full", "incremental", "incremental", "incremental"]
+    assert w.stats[1]["rows_written"] < 0.6 * w.stats[1]["rows_total"] and w.stats[2]["rows_written"] < 0.5 * 140
+    # a map that shrank (or no dirty information) falls back to a full rewrite
+    w.save(state(50, 9), {0}, None)
+    assert w.stats[-1]["mode"] == "full" and len(mu.load_3d_map(tmp_path / "vlmaps.h5df")[2]) == 50

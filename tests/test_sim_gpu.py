@@ -318,3 +318,54 @@ def test_large_map_64bit_offsets(ops):
         ref = feat[idx].double() @ q.double().T
         assert torch.equal(ref.argmax(1), am[idx].long())
         assert (ref.max(1).values - best[idx].double()).abs().max().item() < 1e-4
+
+
+def test_column_block_launches_equal_the_dense_pass(ops, golden):
+    """avl_sim_scores_blocks: queries grouped by their non-zero column window are scored against just those columns -- same
+    scores as the dense pass (the dropped products are exact zeros), same argmax with ties going to the lowest caller index,
+    for sorted, interleaved and mixed supports, raw and prepared maps; and the reference's own fused-map golden (g7)"""
+    from avlmaps_amd.device import DeviceArray
+    g = golden("g7_similarity_wide.npz")
+    feat, q, ref = g["d1536_q128_feat"], g["d1536_q128_mean_feats"], g["d1536_q128_scores"]
+    cb, ce = ops.query_col_support(q)
+    assert set(zip(cb.tolist(), ce.tolist())) == {(0, 512), (512, 1536)}          # text / audio queries interleaved (qi % 2)
+    for src in (feat, ops.prepare_map(DeviceArray.from_numpy(feat))):
+        sc, am, best = ops.sim_scores(src, q, want_best=True)                      # host queries: windows derived automatically
+        sc, am, best = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (sc, am, best))
+        assert np.abs(sc - ref).max() < 3e-5 and np.array_equal(am, np.argmax(sc, axis=1)) and np.array_equal(best, sc.max(axis=1))
+        scd, amd, _ = ops.sim_scores(src, q, col_support=None)                     # the dense pass
+        scd, amd = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (scd, amd))
+        assert np.abs(sc - scd).max() < 1e-5 and np.mean(am == amd) > 0.995
+    rng = np.random.default_rng(21)
+    N, D = 2500, 1536
+    f = rng.standard_normal((N, D)).astype(np.float32)
+    for Q, layout in ((128, "halves"), (128, "interleaved"), (100, "three"), (7, "halves"), (160, "halves")):
+        qq = (rng.standard_normal((Q, D)) / 20).astype(np.float32)
+        for i in range(Q):
+            kind = {"halves": int(i >= Q // 2), "interleaved": i % 2, "three": i % 3}[layout]
+            if kind == 0:
+                qq[i, 512:] = 0
+            elif kind == 1:
+                qq[i, :512] = 0
+            else:
+                qq[i, :1024] = 0                                                   # a third window [1024, 1536)
+        qq[3] = 0                                                                  # an all-zero query
+        qq[5] = qq[4]                                                              # exact tie inside a group
+        if Q > 70:
+            qq[Q - 1, :] = 0
+            qq[Q - 1, :512] = qq[4, :512]                                          # and across launch chunks
+        want = f.astype(np.float64) @ qq.astype(np.float64).T
+        sc, am, best = ops.sim_scores(f, qq, want_best=True)
+        assert np.abs(sc - want).max() < 2e-5
+        assert np.array_equal(am, np.argmax(sc, axis=1)) and np.array_equal(best, sc[np.arange(N), am])
+        _, am_only, _ = ops.sim_scores(f, qq, want_scores=False)                   # argmax alone (no best buffer from the caller)
+        assert np.array_equal(am_only, am)
+        scd, amd, _ = ops.sim_scores(f, qq, col_support=None)
+        assert np.abs(sc - scd).max() < 1e-5          # same products, another summation grouping
+    # explicit windows with device-resident queries; a window may be a superset
+    import torch
+    qt = torch.from_numpy(qq).cuda()
+    ft = torch.from_numpy(f).cuda()
+    cb, ce = ops.query_col_support(qq)
+    sc2, am2, _ = ops.sim_scores(ft, qt, col_support=(cb, np.maximum(ce, 1)))
+    assert torch.equal(am2.cpu(), torch.from_numpy(am)) and float((sc2.cpu() - torch.from_numpy(sc)).abs().max()) == 0.0
