@@ -15,6 +15,30 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+void* scratch(size_t bytes) {
+    struct Slot { int dev; void* p; size_t bytes; };
+    static thread_local Slot slots[16] = {};
+    static thread_local int used = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Slot* s = nullptr;
+    for (int i = 0; i < used; ++i)
+        if (slots[i].dev == dev) s = &slots[i];
+    if (!s) {
+        if (used == 16) { set_error("scratch: more than 16 devices used from one thread"); return nullptr; }
+        s = &slots[used++];
+        *s = Slot{dev, nullptr, 0};
+    }
+    if (s->bytes < bytes) {
+        if (s->p) { (void)hipDeviceSynchronize(); (void)hipFree(s->p); s->p = nullptr; s->bytes = 0; }
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        hipError_t e = hipMalloc(&s->p, want);
+        if (e != hipSuccess) { set_error("scratch: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); s->p = nullptr; return nullptr; }
+        s->bytes = want;
+    }
+    return s->p;
+}
+
 int num_cus() {
     static thread_local int cached_dev = -1;
     static thread_local int cached = 256;

@@ -34,6 +34,11 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 // number of CUs of the current device (cached)
 int num_cus();
 
+// Small per-thread, per-device scratch buffer owned by the library (grown on demand, never shrunk): the SYNCHRONOUS entry
+// points that return host scalars (avl_argmax_f32, avl_topk_f32) keep their partial results here instead of allocating on
+// every call.  Valid until the calling thread's next scratch() call; returns nullptr (and sets the error) on failure.
+void* scratch(size_t bytes);
+
 constexpr int kWave = 64;
 
 }  // namespace avl

@@ -246,14 +246,109 @@ namespace avl {
 __global__ void iota64_kernel(int64_t* __restrict__ v, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = i;
 }
+
+// ---- wave-level top-k (k <= 64) ------------------------------------------------------------------------------------------
+// Order: value descending, equal values by ascending index, NaN last -- the order of np.argsort(-v, kind="stable").
+// key = order-preserving unsigned image of the float (+0 and -0 coincide, NaN -> 0 = below -inf).
+__device__ __forceinline__ uint32_t topk_key(float v) {
+    if (v != v) return 0u;
+    if (v == 0.f) v = 0.f;
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// A wave keeps its k best (key, index) pairs sorted, ONE PER LANE (lane i = rank i).  A chunk of 64 candidates is tested against
+// the current k-th entry with one compare + ballot -- after the first few chunks almost nothing passes -- and the few that do
+// are inserted by rank: rank = popcount(ballot(entry better than candidate)), lanes behind it shift up by one (one shuffle).
+struct WaveTopK {
+    uint32_t key;
+    int32_t idx;
+    __device__ void init() { key = 0u; idx = INT_MAX; }   // sentinel: worse than any real element (NaN has key 0, index < INT_MAX)
+    __device__ static bool better(uint32_t ka, int32_t ia, uint32_t kb, int32_t ib) { return ka > kb || (ka == kb && ia < ib); }
+    __device__ void offer(uint32_t ck, int32_t ci, bool valid, int k, int lane) {
+        uint32_t tk = (uint32_t)__shfl((int)key, k - 1, 64);
+        int32_t ti = __shfl(idx, k - 1, 64);
+        unsigned long long pass = __ballot(valid && better(ck, ci, tk, ti));
+        while (pass) {
+            const int src = __ffsll((long long)pass) - 1;
+            pass &= pass - 1;
+            const uint32_t k1 = (uint32_t)__shfl((int)ck, src, 64);
+            const int32_t i1 = __shfl(ci, src, 64);
+            if (!better(k1, i1, tk, ti)) continue;             // the threshold rose since the ballot
+            const int pos = __popcll(__ballot(lane < k && better(key, idx, k1, i1)));
+            const uint32_t upk = (uint32_t)__shfl_up((int)key, 1, 64);
+            const int32_t upi = __shfl_up(idx, 1, 64);
+            if (lane == pos) { key = k1; idx = i1; }
+            else if (lane > pos) { key = upk; idx = upi; }
+            tk = (uint32_t)__shfl((int)key, k - 1, 64);
+            ti = __shfl(idx, k - 1, 64);
+        }
+    }
+};
+
+// phase 1: every wave selects the k best of its strided share of the vector and writes them (64 slots per wave)
+__global__ __launch_bounds__(256) void topk_partial_kernel(const float* __restrict__ v, int64_t N, int k, uint32_t* __restrict__ ckey,
+                                                           int32_t* __restrict__ cidx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    WaveTopK t;
+    t.init();
+    for (int64_t base = wave * 64; base < N; base += nwaves * 64) {
+        const int64_t i = base + lane;
+        const bool valid = i < N;
+        t.offer(valid ? topk_key(v[i]) : 0u, valid ? (int32_t)i : INT_MAX, valid, k, lane);
+    }
+    ckey[wave * 64 + lane] = t.key;
+    cidx[wave * 64 + lane] = t.idx;
+}
+
+// phase 2: one wave merges the candidates of all waves and writes the final k (index, value)
+__global__ __launch_bounds__(64) void topk_merge_kernel(const float* __restrict__ v, const uint32_t* __restrict__ ckey,
+                                                        const int32_t* __restrict__ cidx, int64_t ncand, int k,
+                                                        int64_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    const int lane = threadIdx.x;
+    WaveTopK t;
+    t.init();
+    for (int64_t base = 0; base < ncand; base += 64) {
+        const int64_t i = base + lane;
+        const bool valid = i < ncand && cidx[i] != INT_MAX;
+        t.offer(valid ? ckey[i] : 0u, valid ? cidx[i] : INT_MAX, valid, k, lane);
+    }
+    if (lane < k) {
+        out_idx[lane] = t.idx;
+        out_val[lane] = t.idx != INT_MAX ? v[t.idx] : 0.f;
+    }
+}
 }  // namespace avl
 
-// k largest values of a float32 vector with their indices, descending; equal values keep ascending index order (the
-// order np.argsort(-v, kind="stable") gives).  The k = 1 case is the navigator's goal voxel (habitat_lang_robot.py:427-430).
+// k largest values of a float32 vector with their indices, descending; equal values keep ascending index order and NaN comes
+// last (the order np.argsort(-v, kind="stable") gives).  The k = 1 case is the navigator's goal voxel
+// (habitat_lang_robot.py:427-430).  k <= 64: wave-level selection, two small launches, no allocation (library scratch);
+// larger k: a full radix sort.
 extern "C" int avl_topk_f32(const float* d_vals, int64_t N, int k, int64_t* h_index, float* h_value, void* stream) {
     AVL_REQUIRE(d_vals && N > 0 && k > 0 && k <= N, "avl_topk_f32: bad arguments (N=%lld k=%d)", (long long)N, k);
     AVL_REQUIRE(N < (1ll << 31), "avl_topk_f32: N must fit 31 bits");
     hipStream_t st = as_stream(stream);
+    if (k <= 64) {
+        int64_t blocks = (N + 64 * 32 - 1) / (64 * 32) / 4;       // >= 32 chunks per wave, 4 waves per block
+        if (blocks > 256) blocks = 256;
+        if (blocks < 1) blocks = 1;
+        const int64_t nwaves = blocks * 4, ncand = nwaves * 64;
+        char* sc = static_cast<char*>(avl::scratch((size_t)ncand * 8 + 64 * 12));
+        if (!sc) return AVL_ERR_HIP;
+        uint32_t* ckey = reinterpret_cast<uint32_t*>(sc);
+        int32_t* cidx = reinterpret_cast<int32_t*>(sc + (size_t)ncand * 4);
+        int64_t* oidx = reinterpret_cast<int64_t*>(sc + (size_t)ncand * 8);
+        float* oval = reinterpret_cast<float*>(sc + (size_t)ncand * 8 + 64 * 8);
+        hipLaunchKernelGGL(avl::topk_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_vals, N, k, ckey, cidx);
+        hipLaunchKernelGGL(avl::topk_merge_kernel, dim3(1), dim3(64), 0, st, d_vals, ckey, cidx, ncand, k, oidx, oval);
+        AVL_HIP_CHECK(hipGetLastError());
+        if (h_index) AVL_HIP_CHECK(hipMemcpyAsync(h_index, oidx, (size_t)k * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        if (h_value) AVL_HIP_CHECK(hipMemcpyAsync(h_value, oval, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, st));
+        AVL_HIP_CHECK(hipStreamSynchronize(st));
+        return AVL_OK;
+    }
     float* keys_out = nullptr;
     int64_t *iota = nullptr, *order = nullptr;
     void* tmp = nullptr;

@@ -444,9 +444,10 @@ __global__ __launch_bounds__(256) void sim_gather_queries_kernel(const float* __
                                                                  int nrows, int col0, int cols, float* __restrict__ out) {
     const int r = blockIdx.x;
     if (r >= nrows) return;
-    const float* src = q + (int64_t)rows[r] * ldq + col0;
+    const int32_t sr = rows[r];                 // -1: a zero row
+    const float* src = q + (int64_t)(sr < 0 ? 0 : sr) * ldq + col0;
     float* dst = out + (int64_t)r * cols;
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[c] = src[c];
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) dst[c] = sr < 0 ? 0.f : src[c];
 }
 
 // QT = number of 32-query MFMA tiles of this chunk (1..3); `rows` = valid query rows of the chunk (<= 32*QT):
@@ -693,17 +694,167 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kStreamFill = 9;   // 16-byte staging registers per thread: one LDS buffer <= 9 * 512 * 16 B = 72 KB
 
-// TB = voxel tiles a workgroup carries through the chunk loop together (tile blocking).  A chunk's LDS residency -- its
-// staging traffic from L2 and the s_barrier that retires it, 11 % + 7 % of the kernel at TB = 1 -- is paid once per
-// TB tiles: the chunk's columns of tile 0, then of tile 1, ... are contracted against the same buffer into TB accumulator
-// sets.  Costs 16 * QT accumulator registers per extra tile, so TB = 4 for QT = 1, 2 for QT = 2 (3 spills), and 1 for QT >= 3.
+template <int QT, int SPC, bool PRE, bool QM = false>
+__global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
+    const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
+    const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
+    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
+    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
+    static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = 64 * SPC;
+    constexpr int row_b = (2 * KS + kRowPadHalves) * 2;   // bytes per query row of one chunk: hi[KS] | lo[KS] | pad
+    constexpr int lo_b = 2 * KS;                          // byte offset of the lo half inside a row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    // a partial last MFMA tile reads one extra all-zero row per buffer instead of re-reading a valid row: zeros toggle far
+    // fewer matrix-core bits, and at the power cap that is time
+    const int zrow = rows < 32 * QT ? 1 : 0;
+    const int buf_b = (rows + zrow) * row_b;              // one LDS buffer = the chunk's rows, a linear copy of the image
+    float* isc = reinterpret_cast<float*>(smem + 2 * buf_b);
+    if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    const int units = (rows * row_b) >> 4;
+    if (zrow)
+        for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
+            reinterpret_cast<uint32_t*>(smem + rows * row_b)[i] = 0u;
+            reinterpret_cast<uint32_t*>(smem + buf_b + rows * row_b)[i] = 0u;
+        }
+
+    // the next chunk is staged in SPC slices, one per k step (registers: 5 x 16 B at SPC = 2, 3 x 16 B at SPC = 4)
+    constexpr int NSTG = kStreamFill - ((SPC - 1) * kStreamFill) / SPC;
+    f32x4 stg[NSTG];
+    auto stage_load = [&](int c, int i0, int i1) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + ((int64_t)c * Qtot + q_base) * row_b);
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const int u = threadIdx.x + i * kSplitThreads;
+            if (u < units) stg[i - i0] = src[u];
+        }
+    };
+    auto stage_store = [&](int b, int i0, int i1) {
+        f32x4* dst = reinterpret_cast<f32x4*>(smem + b * buf_b);
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const int u = threadIdx.x + i * kSplitThreads;
+            if (u < units) dst[u] = stg[i - i0];
+        }
+    };
+
+    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    auto tile_ptr = [&](int64_t tile) {
+        const int64_t r = tile * kTileRows + wave * 32 + j;
+        return feat + (r < N ? r : N - 1) * ld + 32 * kg;
+    };
+    f32x4 ring[2][8];
+    auto load = [&](f32x4(&b)[8], const float* src) {
+        const f32x4* g = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[t] = g[t];
+    };
+    load(ring[0], tile_ptr(blockIdx.x));   // first tile, step 0: in flight while chunk 0 is brought in
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) {
+        stage_load(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
+        stage_store(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
+    }
+    __syncthreads();
+    int cur = 0;
+
+    int a_off[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) a_off[t] = min(t * 32 + j, rows - 1 + zrow) * row_b + kg * 64;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row = tile * kTileRows + wave * 32 + j;
+        const float* rp = tile_ptr(tile);
+        const bool has_next = tile + gridDim.x < ntiles;
+        const float* p_next = has_next ? tile_ptr(tile + gridDim.x) : rp;
+
+        f32x16 acc[QT][1];
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][0][e] = 0.f;
+        float rmax = 0.f;
+
+        for (int c = 0; c < nch; ++c) {
+            const int cn = c + 1 < nch ? c + 1 : 0;
+            const char* ab = smem + cur * buf_b;
+#pragma unroll
+            for (int s = 0; s < SPC; ++s) {
+                const int i0 = (s * kStreamFill) / SPC, i1 = ((s + 1) * kStreamFill) / SPC;
+#ifndef AVL_ABL_NOSTAGE
+                stage_load(cn, i0, i1);               // issued ahead of this step's voxel prefetch (older in vmcnt order)
+#endif
+                const float* nxt = rp + 64 * (c * SPC + s + 1);
+                if (s + 1 < SPC) {
+                    load(ring[(s + 1) & 1], nxt);
+                } else if (c + 1 < nch) {
+                    load(ring[0], nxt);
+                } else if (has_next) {
+                    load(ring[0], p_next);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4(&b)[8] = ring[s & 1];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    half8 bh, bl;
+                    if constexpr (PRE) {
+                        bh = __builtin_bit_cast(half8, b[2 * m]);
+                        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
+                    } else {
+                        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
+                        split8(b[2 * m], b[2 * m + 1], bh, bl);
+                    }
+                    const int off = (s * 64 + 8 * m) * 2;
+                    half8 ah[QT], al[QT];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        ah[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off);
+                        al[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off + lo_b);
+                    }
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][0], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][0], 0, 0, 0);
+                }
+#ifndef AVL_ABL_NOSTAGE
+                stage_store(cur ^ 1, i0, i1);
+#endif
+            }
+            // publish the next chunk / retire this one: LDS traffic only, the voxel prefetch stays in flight
+#ifndef AVL_ABL_NOBARRIER
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+#endif
+            cur ^= 1;
+        }
+        float rscale = 1.f;
+        if constexpr (PRE) {
+            if (row_scale) rscale = row_scale[row < N ? row : N - 1];
+        }
+        split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax,
+                              QM ? qmap : nullptr);
+    }
+}
+
+// Tile-blocked variant of the streamed kernel for QT <= 2.  TB = voxel tiles a workgroup carries through the chunk loop
+// together: a chunk's LDS residency -- its staging traffic from L2 and the s_barrier that retires it, 11 % + 7 % of the kernel
+// at one tile per chunk pass -- is paid once per TB tiles: the chunk's columns of tile 0, then of tile 1, ... are
+// contracted against the same buffer into TB accumulator sets (16 * QT registers per extra tile: TB = 2 for QT = 2, 3 spills).
+// Same-box A/B (2 M voxels): D = 1536, Q = 64: 2.40 -> 2.25 ms; config 5's column-block launches 2.51 -> 2.42 ms; with a
+// power-of-two row stride (D = 1024: 4 KiB) the two-tile walk is 5 % SLOWER (HBM channel camping), and for QT >= 3 the extra
+// bookkeeping costs 1-4 %, so the launcher only picks it for QT = 2 and row strides that are not a multiple of 4 KiB.
 template <int QT>
 struct StreamTB {
     static constexpr int value = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
 };
 
 template <int QT, int SPC, bool PRE, bool QM = false>
-__global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
+__global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
@@ -827,14 +978,15 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #endif
                         // prefetch the next step in execution order: same tile, next tile of the block (same chunk), first tile
                         // of the next chunk, first tile of the workgroup's next block
+                        // (the address is selected, the load itself is unconditional: a load inside a branch makes the compiler's
+                        // s_waitcnt bookkeeping fall back to vmcnt(0); the very last step of a workgroup re-reads its own line)
                         if (s + 1 < SPC) {
                             load(ring[(s + 1) & 1], rp[b] + 64 * (c * SPC + s + 1));
-                        } else if (b + 1 < TB && b + 1 < cnt) {
-                            load(ring[0], rp[b + 1 < TB ? b + 1 : b] + 64 * (c * SPC));
-                        } else if (c + 1 < nch) {
-                            load(ring[0], rp[0] + 64 * ((c + 1) * SPC));
-                        } else if (cnt_next > 0) {
-                            load(ring[0], p_next);
+                        } else {
+                            const float* nxt = p_next;
+                            if (b + 1 < TB && b + 1 < cnt) nxt = rp[b + 1 < TB ? b + 1 : b] + 64 * (c * SPC);
+                            else if (c + 1 < nch) nxt = rp[0] + 64 * ((c + 1) * SPC);
+                            load(ring[0], nxt);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         const f32x4(&v)[8] = ring[s & 1];
@@ -1195,7 +1347,8 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
 }
 
 template <int SPC, bool PRE, bool QM>
-static const void* pick_stream_kernel(int QT) {
+static const void* pick_stream_kernel(int QT, bool tile_block) {
+    if (tile_block && QT == 2) return reinterpret_cast<const void*>(sim_stream_tb_f16_kernel<2, SPC, PRE, QM>);
     switch (QT) {
         case 1: return reinterpret_cast<const void*>(sim_stream_f16_kernel<1, SPC, PRE, QM>);
         case 2: return reinterpret_cast<const void*>(sim_stream_f16_kernel<2, SPC, PRE, QM>);
@@ -1246,8 +1399,9 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     if (p.stream) {
         for (int ci = 0; ci < p.nchunks; ++ci) {
             const SplitChunk& c = p.chunks[ci];
-            const void* kern = d_qmap ? (p.SPC == 4 ? pick_stream_kernel<4, PRE, true>(c.QT) : pick_stream_kernel<2, PRE, true>(c.QT))
-                                      : (p.SPC == 4 ? pick_stream_kernel<4, PRE, false>(c.QT) : pick_stream_kernel<2, PRE, false>(c.QT));
+            const bool tb = (ld % 1024) != 0;   // tile blocking (QT = 2 only) loses on 4 KiB-multiple row strides, see the kernel
+            const void* kern = d_qmap ? (p.SPC == 4 ? pick_stream_kernel<4, PRE, true>(c.QT, tb) : pick_stream_kernel<2, PRE, true>(c.QT, tb))
+                                      : (p.SPC == 4 ? pick_stream_kernel<4, PRE, false>(c.QT, tb) : pick_stream_kernel<2, PRE, false>(c.QT, tb));
             const size_t lds = p.lds_bytes(c);
             int rc = ensure_dynamic_lds(kern, lds);
             if (rc != AVL_OK) return rc;
@@ -1585,18 +1739,16 @@ int avl_argmax_f32(const float* d_vals, int64_t N, int64_t* h_index, float* h_va
     AVL_REQUIRE(N > 0 && d_vals, "avl_argmax_f32: empty input");
     hipStream_t st = as_stream(stream);
     const int nb = 256;
-    float* d_pv = nullptr;
-    int64_t* d_pi = nullptr;
-    AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_pv), (nb + 1) * sizeof(float), st));
-    AVL_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&d_pi), (nb + 1) * sizeof(int64_t), st));
+    char* sc = static_cast<char*>(avl::scratch((size_t)(nb + 1) * (sizeof(float) + sizeof(int64_t)) + 64));   // no allocation per call
+    if (!sc) return AVL_ERR_HIP;
+    int64_t* d_pi = reinterpret_cast<int64_t*>(sc);
+    float* d_pv = reinterpret_cast<float*>(sc + (size_t)(nb + 1) * sizeof(int64_t));
     hipLaunchKernelGGL(argmax_partial_kernel, dim3(nb), dim3(256), 0, st, d_vals, N, d_pv, d_pi);
     float hv[nb];
     int64_t hi[nb];
     AVL_HIP_CHECK(hipMemcpyAsync(hv, d_pv, nb * sizeof(float), hipMemcpyDeviceToHost, st));
     AVL_HIP_CHECK(hipMemcpyAsync(hi, d_pi, nb * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     AVL_HIP_CHECK(hipStreamSynchronize(st));
-    (void)hipFreeAsync(d_pv, st);
-    (void)hipFreeAsync(d_pi, st);
     float bv = -INFINITY;
     int64_t bi = INT64_MAX;
     for (int b = 0; b < nb; ++b)

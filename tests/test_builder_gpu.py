@@ -257,6 +257,41 @@ def test_heatmap_matches_reference(ops, golden):
     assert np.array_equal(ti, want) and np.array_equal(tv, heat[want]) and ti[0] == idx
 
 
+def test_wave_level_topk_orders_like_stable_argsort(ops):
+    """avl_topk_f32, k <= 64 (wave-level selection): value descending, ties by ascending index, NaN last, -0.0 == 0.0 --
+    np.argsort(-v, kind="stable")[:k]; a heat vector has thousands of exact ties at 1.0"""
+    rng = np.random.default_rng(5)
+    cases = []
+    v = rng.random(2_000_003).astype(np.float32)
+    v[rng.integers(0, len(v), 5000)] = 1.0                      # many exact ties at the maximum
+    cases.append(v)
+    cases.append(np.sort(rng.standard_normal(100_000).astype(np.float32)))            # ascending: every chunk beats the threshold
+    cases.append(-np.sort(rng.standard_normal(70_001).astype(np.float32)))            # descending
+    w = rng.standard_normal(5000).astype(np.float32)
+    w[[3, 77, 4000]] = np.nan
+    w[[5, 9]] = [0.0, -0.0]
+    w[10:20] = np.inf
+    w[30] = -np.inf
+    cases.append(w)
+    cases.append(np.array([2.0, np.nan, 2.0, -1.0, 7.0], np.float32))                 # fewer than 64 elements
+    cases.append(np.zeros(1000, np.float32))
+    for v in cases:
+        order = np.argsort(-v, kind="stable")
+        for k in (1, 2, 5, 63, 64):
+            if k > len(v):
+                continue
+            idx, val = ops.topk_f32(v, k)
+            assert np.array_equal(idx, order[:k]), (len(v), k, idx[:8], order[:8])
+            assert np.array_equal(val, v[order[:k]], equal_nan=True)
+    # k > 64 keeps the full-sort path
+    idx, val = ops.topk_f32(cases[0], 100)
+    assert np.array_equal(idx, np.argsort(-cases[0], kind="stable")[:100])
+    # the navigator's argmax (first maximum), repeatedly: partial results live in the library's scratch, no allocation per call
+    for _ in range(3):
+        i, x = ops.argmax_f32(cases[0])
+        assert i == int(np.argmax(cases[0])) and x == 1.0
+
+
 def test_export_raw_and_finalize_raw_roundtrip(ops, golden):
     from oracle import avl_oracle as O
     g = golden("g2a_builder_small.npz")

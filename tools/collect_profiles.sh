@@ -1,32 +1,56 @@
 #!/bin/bash
-# GPU box: collect the rocprofv3 evidence for bench.py into gpurun_out/prof_<tag>/ (copy the summaries to profiles/ afterwards).
-# usage: tools/collect_profiles.sh <tag>
+# GPU box: collect the rocprofv3 evidence for bench.py into gpurun_out/prof_<tag>/ (tools/publish_profiles.py then copies the
+# judged summaries to profiles/<tag>_*).   usage: tools/collect_profiles.sh <tag>
+# Kernel traces (--kernel-trace --stats) and PMC passes (--pmc only) are separate runs: never combined with tracing flags.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 export TMPDIR=/tmp
 cd /tmp
-run() { timeout 300 "$@"; }
-run rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_index -o index -- python $R/bench.py --profile-run > $O/index_bench.log 2>&1
-cp /tmp/p_index/index_kernel_stats.csv $O/ 2>/dev/null
-run rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_build -o build -- python $R/bench.py --workload build --steps 500 --warmup 20 --no-cpu > $O/build_bench.log 2>&1
-cp /tmp/p_build/build_kernel_stats.csv $O/ 2>/dev/null
-# PMC passes: counters only, no tracing flags
-run rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -o fetch -- python $R/bench.py --steps 5 --warmup 2 --settle-steps 0 --profile-run > $O/pmc_fetch.log 2>&1
-run rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -o write -- python $R/bench.py --steps 5 --warmup 2 --settle-steps 0 --profile-run > $O/pmc_write.log 2>&1
-run rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetchb -o fetchb -- python $R/bench.py --workload build --steps 100 --warmup 5 --no-cpu > $O/pmc_fetch_build.log 2>&1
-run rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_writeb -o writeb -- python $R/bench.py --workload build --steps 100 --warmup 5 --no-cpu > $O/pmc_write_build.log 2>&1
-run rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_sq -o sq -- python $R/bench.py --steps 5 --warmup 2 --settle-steps 0 --profile-run > $O/pmc_sq.log 2>&1
-python $R/tools/summarize_prof.py $O/pmc_index.json /tmp/p_fetch /tmp/p_write /tmp/p_sq > /dev/null
-python $R/tools/summarize_prof.py $O/pmc_build.json /tmp/p_fetchb /tmp/p_writeb > /dev/null
-run rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -o c5 -- python $R/bench.py --feat-dim 1536 --queries 128 --steps 100 --profile-run > $O/config5_bench.log 2>&1
-cp /tmp/p_c5/c5_kernel_stats.csv $O/config5_kernel_stats.csv 2>/dev/null
-run rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_b64 -o b64 -- python $R/bench.py --workload build --steps 4000 --warmup 64 --build-batch 64 --no-cpu > $O/build_b64_bench.log 2>&1
-cp /tmp/p_b64/b64_kernel_stats.csv $O/build_b64_kernel_stats.csv 2>/dev/null
+run() { timeout 420 "$@"; }
+trace() {   # trace <name> <bench args...>
+  local name=$1; shift
+  run rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$name -o $name -- python $R/bench.py "$@" > $O/${name}_bench.log 2>&1
+  cp /tmp/p_$name/${name}_kernel_stats.csv $O/ 2>/dev/null
+}
+pmc() {     # pmc <name> "<counters>" <bench args...>
+  local name=$1; local cnt=$2; shift 2
+  run rocprofv3 --pmc $cnt --output-format csv -d /tmp/q_$name -o $name -- python $R/bench.py "$@" > $O/pmc_${name}.log 2>&1
+}
+SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
+# --- config 2 (headline): 2M x 512, 64 queries
+trace index --profile-run
+pmc index_fetch FETCH_SIZE --steps 5 --warmup 2 --settle-steps 0 --profile-run
+pmc index_write WRITE_SIZE --steps 5 --warmup 2 --settle-steps 0 --profile-run
+pmc index_sq "$SQ" --steps 5 --warmup 2 --settle-steps 0 --profile-run
+python $R/tools/summarize_prof.py $O/pmc_index.json /tmp/q_index_fetch /tmp/q_index_write /tmp/q_index_sq > /dev/null
+# --- config 5: 2M x 1536, 128 block-structured queries (column-block launches) and the dense single pass
+C5="--feat-dim 1536 --queries 128"
+trace config5 $C5 --steps 100 --profile-run
+trace config5_dense $C5 --steps 100 --profile-run --dense
+pmc c5_fetch FETCH_SIZE $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run
+pmc c5_write WRITE_SIZE $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run
+pmc c5_sq "$SQ" $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run
+python $R/tools/summarize_prof.py $O/pmc_config5.json /tmp/q_c5_fetch /tmp/q_c5_write /tmp/q_c5_sq > /dev/null
+# --- build: per-frame launches and 16 frames per launch, 10k frames, finalize inside the timed region
+trace build --workload build --steps 10000 --warmup 20 --no-cpu
+trace build_b16 --workload build --steps 10000 --warmup 20 --no-cpu --build-batch 16
+pmc build_fetch FETCH_SIZE --workload build --steps 200 --warmup 5 --no-cpu
+pmc build_write WRITE_SIZE --workload build --steps 200 --warmup 5 --no-cpu
+python $R/tools/summarize_prof.py $O/pmc_build.json /tmp/q_build_fetch /tmp/q_build_write > /dev/null
+pmc build16_fetch FETCH_SIZE --workload build --steps 320 --warmup 16 --no-cpu --build-batch 16
+pmc build16_write WRITE_SIZE --workload build --steps 320 --warmup 16 --no-cpu --build-batch 16
+python $R/tools/summarize_prof.py $O/pmc_build_b16.json /tmp/q_build16_fetch /tmp/q_build16_write > /dev/null
 cd $R
-(timeout 600 python bench.py) > $O/bench_default.log 2>&1
-(timeout 600 python bench.py --workload build --steps 5000 --warmup 20) > $O/build_config3.log 2>&1
+# --- plain runs (no profiler): the lines the judge reads
+(timeout 900 python bench.py) > $O/bench_default.log 2>&1
+(timeout 600 python bench.py $C5 --steps 200) > $O/config5_line.log 2>&1
+(timeout 600 python bench.py --workload build --steps 10000) > $O/build_10k.log 2>&1
+(timeout 600 python bench.py --workload build --steps 5000) > $O/build_config3.log 2>&1
+(timeout 600 python bench.py --workload build --steps 40000 --build-batch 16 --no-cpu) > $O/build_40k_b16.log 2>&1
+AVLMAPS_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 timeout 600 python bench.py --workload build --steps 10000 --build-batch 16 --no-cpu > $O/build_rccl_1rank.log 2>&1
+AVLMAPS_DIST_BACKEND=nccl timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --workload build --steps 2000 --no-cpu > $O/rccl_two_ranks_one_gpu.log 2>&1
 timeout 300 python tools/power_probe.py 3 2>&1 | grep -v '^/sys/class/drm\|amdgpu.ids' > $O/power_probe.txt
 ls -la $O
