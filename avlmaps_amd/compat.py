@@ -12,6 +12,7 @@ so `from avlmaps.utils.clip_utils import get_lseg_score` in avlmaps/map/vlmap.py
   avlmaps.utils.visualize_utils.get_heatmap_from_mask_3d (visualize_utils.py:29-49) -> heat kernels
   avlmaps.utils.visualize_utils.pool_3d_label_to_2d      (visualize_utils.py:77-83)
   avlmaps.map.vlmap_builder.VLMapBuilder.create_mobile_base_map (vlmap_builder.py:54-185) -> builder kernels
+  avlmaps.map.map.Map.generate_obstacle_map / generate_rgb_topdown_map (map.py:79-95, :106-113) -> top-down scatter kernels
 
 The upstream objects keep their classes, attributes and files (vlmaps.h5df): VLMap / AVLMap / the Habitat navigator run
 unchanged on top.  CLIP text encoding and LSeg stay the upstream PyTorch models.
@@ -52,6 +53,24 @@ def _builder_adapter():
     return create_mobile_base_map
 
 
+def _map_adapters():
+    def generate_obstacle_map(self, h_min: float = 0, h_max: float = 1.5):
+        """avlmaps.map.map.Map.generate_obstacle_map on avl_obstacle_map (same attributes set)"""
+        from . import ops
+        assert self.occupied_ids is not None, "map not loaded"
+        self.obstacles_map = ops.obstacle_map(self.occupied_ids, self.cs, h_min, h_max)
+        self.generate_cropped_obstacle_map(self.obstacles_map)
+        return self.obstacles_map
+
+    def generate_rgb_topdown_map(self):
+        """avlmaps.map.map.Map.generate_rgb_topdown_map on avl_rgb_topdown (the last voxel of a column wins)"""
+        from . import ops
+        assert self.grid_rgb is not None, "map not loaded"
+        assert self.grid_pos is not None
+        return ops.rgb_topdown(self.grid_pos, self.grid_rgb, self.gs)
+    return dict(generate_obstacle_map=generate_obstacle_map, generate_rgb_topdown_map=generate_rgb_topdown_map)
+
+
 def install(upstream: str = "avlmaps") -> Dict[str, int]:
     """Patch the upstream package (must be importable).  Returns {patched name: number of references re-pointed}."""
     if upstream in _INSTALLED:
@@ -90,6 +109,16 @@ def install(upstream: str = "avlmaps") -> Dict[str, int]:
             setattr(cls, "create_mobile_base_map", _builder_adapter())
             log.append((cls, "create_mobile_base_map", old))
             counts["map.vlmap_builder.VLMapBuilder.create_mobile_base_map"] = 1
+    except Exception:
+        pass
+    try:
+        mp = importlib.import_module(f"{upstream}.map.map")
+        for name, fn in _map_adapters().items():
+            old = mp.Map.__dict__.get(name)
+            if old is not None:
+                setattr(mp.Map, name, fn)
+                log.append((mp.Map, name, old))
+                counts[f"map.map.Map.{name}"] = 1
     except Exception:
         pass
     _INSTALLED[upstream] = log

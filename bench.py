@@ -385,7 +385,23 @@ def pc_transforms(poses):
     return [inv_init @ (bt @ cvt_pose_vec2tf(p) @ inv_bt) @ bt @ b2c for p in poses]
 
 
-def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, batch=1, exact_rgb=True):
+def make_vit_standin(torch):
+    """A random-weight ViT-L/16-shaped encoder (24 pre-norm layers, width 1024, 16 heads, MLP 4096) run in bf16 on the two
+    480x480 crops (900 tokens each) upstream's sliding-window LSeg evaluation feeds per 720x1080 frame (lseg_utils.py:61-102).
+    It is NOT LSeg -- no DPT decoder, no text head, no weights -- only a stand-in for the bulk of its per-frame cost, so that
+    the build line can also be quoted with a feature-extraction-sized load in front of every frame."""
+    layer = torch.nn.TransformerEncoderLayer(d_model=1024, nhead=16, dim_feedforward=4096, dropout=0.0, activation="gelu",
+                                             batch_first=True, norm_first=True)
+    enc = torch.nn.TransformerEncoder(layer, num_layers=24, enable_nested_tensor=False).cuda().to(torch.bfloat16).eval()
+    x = torch.randn((2, 900, 1024), device="cuda", dtype=torch.bfloat16)
+
+    def step():
+        with torch.no_grad():
+            return enc(x)
+    return step
+
+
+def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, batch=1, exact_rgb=True, feature_standin=None):
     """STRONG scaling of map creation: `total_frames` frames of one sequence are sharded contiguously over the ranks; the
     timed region is everything between the first fused frame and the finished map resident in rank 0's HBM:
         fuse own shard (K1/K2/K3 per launch)  ->  [ws > 1: plan + scatter + ONE RCCL sum-reduce + chained colour replay]
@@ -415,14 +431,21 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     BATCH = max(1, int(batch))
     plans = {}
 
+    extract = make_vit_standin(torch) if feature_standin == "vit-l16" else None
+
     def fuse(i0, i1):
         if BATCH == 1:
             for i in range(i0, i1):
                 b = i % nbuf
+                if extract is not None:
+                    extract()                                # same stream: the frame's fusion launches queue behind it
                 acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
             return
         for j0 in range(i0, i1, BATCH):
             j1 = min(i1, j0 + BATCH)
+            if extract is not None:
+                for _ in range(j0, j1):
+                    extract()
             # the frame buffers form a ring of nbuf: the pointer table of a batch is resolved once per ring phase
             idx = tuple(i % nbuf for i in range(j0, j1))
             plan = plans.get(idx)
@@ -479,7 +502,10 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     alg_frame = P * (4 + 4 + 29) + pts_per_frame * (3 + D * 4 + 29) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
     res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, frames_per_s=total_frames / dt,
                seconds=dt, fuse_seconds_max_rank=fuse_s, merge_finalize_seconds=dt - fuse_s, exact_rgb_replay=bool(exact_rgb),
-               timed_region="fuse shard + merge (one RCCL sum-reduce, chained replay) + finalize on rank 0; no feature extraction",
+               feature_standin=feature_standin,
+               timed_region="fuse shard + merge (one RCCL sum-reduce, chained replay) + finalize on rank 0; "
+                            + ("a random-weight ViT-L/16-shaped encoder (2 crops of 900 tokens, bf16) runs before every frame as a "
+                               "stand-in for LSeg's cost" if feature_standin else "no feature extraction"),
                ms_per_frame_fuse=fuse_ms / nfr, sampled_px_per_frame=P, active_points_per_frame=pts_per_frame,
                voxel_groups_per_frame=groups, new_voxels_per_frame=newv, voxels_local=nvox, voxels_merged=n_final,
                merge_breakdown=tim or None, single_gpu_merge_path=single_gpu_merge,
@@ -492,13 +518,16 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
 
 def run_build(args, torch, dist, lib, rank, ws):
     r = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.steps, warmup=args.warmup, batch=args.build_batch,
-                       exact_rgb=not args.no_exact_rgb)
+                       exact_rgb=not args.no_exact_rgb, feature_standin=args.feature_standin)
     out = dict(metric="map_build_frames_per_sec", value=r["frames_per_s"], unit="frames/s", n_gpus=ws, steps=args.steps,
                warmup=args.warmup, ms_per_step=r["seconds"] / max(1, args.steps) * 1e3, higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload=f"create_map: {args.steps} RGB-D frames 720x1080 of one sequence -> 7776 sampled px each -> "
                                     "back-project + voxelise + fp64 feature fusion of 512-D channels-last pixel features resident in HBM "
-                                    "(feature extraction / LSeg NOT included), then merge + finalize INSIDE the timed region",
+                                    + ("(a random-weight ViT-L/16-shaped encoder, 2 x 900 tokens bf16, runs before every frame as a stand-in "
+                                       "for LSeg's cost -- not LSeg)" if args.feature_standin else "(feature extraction / LSeg NOT included)")
+                                    + ", then merge + finalize INSIDE the timed region",
+                           feature_standin=args.feature_standin,
                            total_frames=args.steps, frames_per_launch=r["frames_per_launch"],
                            parallelism=f"contiguous frame shards x{ws}; one sparse RCCL sum-reduce + chained colour replay + "
                                        "finalize on rank 0, all timed"))
@@ -567,6 +596,9 @@ def main():
                          "create 2.1 M voxels)")
     ap.add_argument("--build-frames", type=int, default=10_000,
                     help="index workload: total frames of the map-creation strong-scaling extra (north_star: a 10k-frame sequence)")
+    ap.add_argument("--feature-standin", choices=["vit-l16"], default=None,
+                    help="build workload: run a random-weight ViT-L/16-shaped encoder (2 crops, bf16) before every frame as a "
+                         "stand-in for LSeg's per-frame cost (no weights exist here; it is NOT LSeg)")
     ap.add_argument("--no-exact-rgb", action="store_true", help="build without the per-sample replay log (no exact weight / colour)")
     ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch triple (avl_builder_integrate_batch)")
     ap.add_argument("--event-mode", choices=["pair", "each"], default="pair",

@@ -454,3 +454,47 @@ def test_full_size_build_properties(ops):
     for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
         assert np.array_equal(dev[k].cpu().numpy(), out[k]), k
     np.testing.assert_allclose(dev["grid_feat"].cpu().numpy(), out["grid_feat"], rtol=1e-6, atol=1e-7)
+
+
+def test_config3_sequence_5000_frames(ops):
+    """BASELINE config 3 at its full length: 5 000 frames of 720x1080 (7 776 samples each, 512-D features) through the
+    batched launches; the accumulators double on the way (the map outgrows the initial gs*gs = 1 M voxels, like upstream's
+    _reserve_map_space).  Size-independent properties on the device: ids dense, occupied_ids inverts grid_pos, weights
+    positive, features finite, and the device merge path (scatter + chained replay + finalize) reproduces the map."""
+    import torch
+    import bench
+    from avlmaps_amd import parallel
+    H, W, Hf, Wf, D, rate, F, B = 720, 1080, 347, 520, 512, 100, 5000, 16
+    nbuf = 4
+    depths, rgbs, feats = bench.make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=99)
+    Ts = bench.pc_transforms(bench.trajectory(F))
+    calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
+    rs = np.random.RandomState(5)
+    samples = []
+    for _ in range(nbuf):
+        m = np.arange(H * W)
+        rs.shuffle(m)
+        samples.append(torch.from_numpy(m[::rate].astype(np.int32)).cuda())
+    acc = ops.VoxelAccumulator(1000, 0.05, 30, D)                  # default capacity gs*gs = 1 M, doubles on demand
+    assert acc.capacity == 1_000_000
+    acc.enable_replay_log(F * 7776)
+    plans = {}
+    for i0 in range(0, F, B):
+        idx = tuple(i % nbuf for i in range(i0, min(F, i0 + B)))
+        plan = plans.get(idx)
+        if plan is None:
+            plan = plans[idx] = acc.make_batch_plan([depths[b] for b in idx], [samples[b] for b in idx], [feats[b] for b in idx],
+                                                    [rgbs[b] for b in idx])
+        acc.integrate_batch(plan, calib, Ts[i0:i0 + len(idx)], frame_idx0=i0)
+    n = acc.num_voxels()
+    assert n > 1_500_000 and acc.capacity >= n and acc.capacity > 1_000_000          # grew without dropping a voxel
+    out = acc.finalize(as_torch=True)
+    pos = out["grid_pos"].long()
+    assert out["grid_feat"].shape == (n, D) and bool(torch.isfinite(out["grid_feat"]).all()) and bool((out["weight"] > 0).all())
+    assert torch.equal(out["occupied_ids"][pos[:, 0], pos[:, 1], pos[:, 2]], torch.arange(n, dtype=torch.int32, device="cuda"))
+    assert int((out["occupied_ids"] >= 0).sum()) == n
+    tim = {}
+    dev = parallel.merge_accumulator(acc, timings=tim)
+    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
+        assert torch.equal(dev[k], out[k]), k
+    assert float((dev["grid_feat"] - out["grid_feat"]).abs().max()) <= 1e-5 and tim["merged_voxels"] == n and tim["exact_rgb"]

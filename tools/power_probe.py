@@ -58,7 +58,7 @@ def main():
     N, D, Q = 2_000_000, int(os.environ.get('PP_D', 512)), int(os.environ.get('PP_Q', 64))
     feat = torch.randn((N, D), device="cuda")
     prep = feat.clone()
-    assert lib.avl_sim_prepare_map(prep.data_ptr(), N, D, D, None) == 0
+    assert lib.avl_sim_prepare_map(prep.data_ptr(), N, D, D, None, None) == 0   # unscaled: bit-identical to the raw split
     q = torch.randn((Q, D), device="cuda"); q /= q.norm(dim=1, keepdim=True)
     am = torch.empty((N,), dtype=torch.int32, device="cuda")
     wsb = C.c_size_t(); lib.avl_sim_workspace_bytes(D, Q, C.byref(wsb))

@@ -64,14 +64,14 @@ def busy(d, match):
 # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
 # (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) -> doubled.  WRITE_SIZE is uncalibrated (atomics inflate it).
 entries = []
-SIM = ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_fixup_rows_kernel", "sim_gather_queries_kernel", "sim_prep_queries_kernel")
+SIM = ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel", "sim_fixup_rows_kernel", "sim_gather_queries_kernel", "sim_prep_queries_kernel")
 for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64), "index_bench"), ("pmc_config5", dict(N=2000000, D=1536, Q=128), "config5_bench")):
     if stem not in pmc:
         continue
     f, names = per_step(pmc[stem], SIM, "FETCH_SIZE")
     w, _ = per_step(pmc[stem], SIM, "WRITE_SIZE")
     if f:
-        b = busy(pmc[stem], ("sim_split_f16_kernel", "sim_stream_f16_kernel"))
+        b = busy(pmc[stem], ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel"))
         entries.append(dict(workload="index", shape=shape, kernel=" + ".join(sorted(set(n.split("avl")[-1] for n in names)))[:300],
                             read_bytes=2 * f * 1024, write_bytes=w * 1024, total_bytes=2 * f * 1024 + w * 1024,
                             mfma_busy_frac=(list(b.values())[0] if len(b) == 1 else (b or None)),
