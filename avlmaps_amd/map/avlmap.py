@@ -36,7 +36,13 @@ class AVLMap:
         from ..utils.clip_utils import landmark_text_feats
         vm = self.vlmap
         q, _ = landmark_text_feats(vm.clip_model, [object_name], vm.clip_feat_dim, use_multiple_templates=True, add_other=True)
-        _, am, _ = ops.sim_scores(vm._device_feat(), q, want_scores=False, want_argmax=True, precision=vm._sim_precision)
+        feat = vm._device_feat()
+        if vm._rows != (0, len(vm.grid_feat)):          # voxel rows sharded over ranks: gather the argmax, heat on the full map
+            mask = vm._score(q, want_scores=False)[1] == 0
+            if not mask.any():
+                raise ValueError("attempt to get argmin of an empty sequence")
+            return ops.heatmap_from_mask(vm._device_pos(), mask.astype(np.uint8), cs, decay_rate).numpy()
+        _, am, _ = ops.sim_scores(feat, q, want_scores=False, want_argmax=True, precision=vm._sim_precision)
         mask = ops.mask_from_argmax(am, 0)
         heat = ops.heatmap_from_mask(vm._device_pos(), mask, cs, decay_rate)
         if vm.grid_pos.shape[0] and ops.argmax_f32(heat)[1] < 1.0:      # a target voxel has heat exactly 1

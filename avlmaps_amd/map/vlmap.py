@@ -24,6 +24,8 @@ class VLMap(Map):
         self.categories = None
         self._dev_feat = None
         self._dev_feat_src = None
+        self.shard_index_rows = True      # with torch.distributed initialised (one process per GPU) every rank keeps and scores
+                                          # only its block of voxel rows; the per-voxel results are all-gathered (parallel.gather_rows)
 
     # ------------------------------------------------------------------ build / load
     def create_map(self, data_dir: Union[Path, str], feat_extractor=None) -> None:
@@ -72,10 +74,14 @@ class VLMap(Map):
         scale (avl_sim_prepare_map: same bytes, no per-query conversion work, and voxels observed once from far away --
         rows of magnitude 1e-6 ... 1e-15, vlmap_builder.py:166-168 -- score as accurately as any other row);
         self._sim_precision tells the kernels which form it has."""
-        from .. import ops
+        from .. import ops, parallel
         from ..device import DeviceArray
         if self._dev_feat is None or self._dev_feat_src is not self.grid_feat:
-            dev = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_feat, dtype=np.float32))
+            rank, ws = parallel.rank_world()
+            self._rows = (0, len(self.grid_feat))
+            if ws > 1 and self.shard_index_rows:
+                self._rows = parallel.shard_rows(len(self.grid_feat), rank, ws)
+            dev = DeviceArray.from_numpy(np.ascontiguousarray(self.grid_feat[self._rows[0]:self._rows[1]], dtype=np.float32))
             self._dev_feat_src = self.grid_feat
             self._sim_precision = "auto"
             if dev.shape[1] % 64 == 0 and dev.shape[0] > 0:
@@ -92,18 +98,28 @@ class VLMap(Map):
             self._dev_pos_src = self.grid_pos
         return self._dev_pos
 
+    def _score(self, q, want_scores: bool):
+        """(scores (N, Q) | None, argmax (N,)) as host arrays for ALL voxels: this rank's row block through the similarity
+        kernel, the other ranks' blocks through one all_gather of results when the rows are sharded"""
+        from .. import ops, parallel
+        feat = self._device_feat()
+        sc, am, _ = ops.sim_scores(feat, q, want_scores=want_scores, want_argmax=True, precision=self._sim_precision)
+        to_np = lambda x: None if x is None else (x if isinstance(x, np.ndarray) else x.numpy())
+        sc, am = to_np(sc), to_np(am)
+        n = len(self.grid_feat)
+        if self._rows != (0, n):
+            am = parallel.gather_rows(am, n)
+            sc = parallel.gather_rows(sc, n) if sc is not None else None
+        return sc, am
+
     def init_categories(self, categories: List[str]) -> np.ndarray:
         """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
-        from .. import ops
         self.categories = categories
-        feat = self._device_feat()
         q, _ = landmark_text_feats(self.clip_model, self.categories, self.clip_feat_dim, use_multiple_templates=True,
                                    add_other=True)
         # one launch gives scores_mat AND its row argmax (same values, first maximum wins like np.argmax), so index_map
         # does not have to rescan the (N, Q) host matrix per query as upstream does (vlmap.py:123)
-        sc, am, _ = ops.sim_scores(feat, q, want_scores=True, want_argmax=True, precision=self._sim_precision)
-        self.scores_mat = sc.numpy() if hasattr(sc, "numpy") and not isinstance(sc, np.ndarray) else np.asarray(sc)
-        self._argmax = am.numpy() if hasattr(am, "numpy") and not isinstance(am, np.ndarray) else np.asarray(am)
+        self.scores_mat, self._argmax = self._score(q, want_scores=True)
         self._argmax_src = self.scores_mat
         return self.scores_mat
 
@@ -122,9 +138,8 @@ class VLMap(Map):
         # fused path: scores never leave the GPU, only the (N,) argmax comes back
         q, _ = landmark_text_feats(self.clip_model, [language_desc], self.clip_feat_dim, use_multiple_templates=True,
                                    add_other=True)
-        feat = self._device_feat()
-        _, am, _ = ops.sim_scores(feat, q, want_scores=False, want_argmax=True, precision=self._sim_precision)
-        return am.numpy() == 0
+        _, am = self._score(q, want_scores=False)
+        return am == 0
 
     def customize_obstacle_map(self, potential_obstacle_names: List[str], obstacle_names: List[str], vis: bool = False):
         """Reference: vlmap.py:127-156.  The class scoring runs on the GPU; the 2-D smoothing (Map._dilate_map,
@@ -135,10 +150,14 @@ class VLMap(Map):
         if not hasattr(self, "clip_model"):
             print("init_clip in customize obstacle map")
             self._init_clip()
+        potential = list(cfg_get(self.map_config, "potential_obstacle_names"))
+        feat, predict = self._device_feat(), None
+        if self._rows != (0, len(self.grid_feat)):      # rows sharded over ranks: score here, hand the full argmax down
+            q, _ = landmark_text_feats(self.clip_model, potential, self.clip_feat_dim, use_multiple_templates=True, add_other=True)
+            predict = self._score(q, want_scores=False)[1]
         self.obstacles_new_cropped = get_dynamic_obstacles_map_3d(
-            self.clip_model, self.obstacles_cropped, list(cfg_get(self.map_config, "potential_obstacle_names")),
-            list(cfg_get(self.map_config, "obstacle_names")), self._device_feat(), self.grid_pos, self.rmin, self.cmin,
-            self.clip_feat_dim, vis=vis, precision=self._sim_precision)
+            self.clip_model, self.obstacles_cropped, potential, list(cfg_get(self.map_config, "obstacle_names")), feat,
+            self.grid_pos, self.rmin, self.cmin, self.clip_feat_dim, vis=vis, precision=self._sim_precision, predict=predict)
         self.obstacles_new_cropped = Map._dilate_map(self.obstacles_new_cropped == 0, cfg_get(self.map_config, "dilate_iter"),
                                                      cfg_get(self.map_config, "gaussian_sigma"))
         self.obstacles_new_cropped = self.obstacles_new_cropped == 0

@@ -80,18 +80,36 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
         ce = np.ascontiguousarray(col_support[1], dtype=np.int32)
         if cb.shape != (Q,) or ce.shape != (Q,):
             raise ValueError("col_support must be two (Q,) integer arrays")
+        wsp, wsb = _sim_workspace(lib, N, D, Q, stream)
         rc = lib.avl_sim_scores_blocks(fptr, rsp, N, D, D, qptr, Q, D, cb.ctypes.data, ce.ctypes.data, sp, ap, bp, PRECISION[precision],
-                                       None, 0, stream)
+                                       wsp, wsb, stream)
     elif rsp is not None:
-        rc = lib.avl_sim_scores_prepared(fptr, rsp, N, D, D, qptr, Q, D, sp, ap, bp, None, 0, stream)
+        wsp, wsb = _sim_workspace(lib, N, D, Q, stream)
+        rc = lib.avl_sim_scores_prepared(fptr, rsp, N, D, D, qptr, Q, D, sp, ap, bp, wsp, wsb, stream)
     else:
-        rc = lib.avl_sim_scores(fptr, N, D, D, qptr, Q, D, sp, ap, bp, PRECISION[precision], stream)
+        wsp, wsb = _sim_workspace(lib, N, D, Q, stream)
+        rc = lib.avl_sim_scores_ws(fptr, N, D, D, qptr, Q, D, sp, ap, bp, PRECISION[precision], wsp, wsb, stream)
     _lib.check(rc, "avl_sim_scores")
     if isinstance(feat, np.ndarray):
         _lib.check(lib.avl_stream_sync(stream))
         res = tuple(k.numpy(stream) if k is not None else None for k in (sk, ak, bk))
         return res
     return sk, ak, bk
+
+
+_WS_CACHE: dict = {}
+
+
+def _sim_workspace(lib, N, D, Q, stream):
+    """per-stream scratch of the similarity kernels (query image + range-guard words + column-block gather), grown on demand
+    and reused: the library then allocates nothing per call (avl_sim_workspace_bytes_n)"""
+    need = C.c_size_t()
+    _lib.check(lib.avl_sim_workspace_bytes_n(int(N), int(D), int(Q), C.byref(need)), "avl_sim_workspace_bytes_n")
+    key = int(stream or 0)
+    ws = _WS_CACHE.get(key)
+    if ws is None or ws.nbytes < need.value:
+        ws = _WS_CACHE[key] = DeviceArray((max(need.value, 1 << 20),), np.uint8)
+    return ws.ptr, ws.nbytes
 
 
 class PreparedMap:

@@ -290,6 +290,35 @@ def merge_accumulator(acc, dst: int = 0, group=None, exact_rgb: bool = True, tim
     return out
 
 
+def rank_world(group=None) -> Tuple[int, int]:
+    """(rank, world_size) of the process group, (0, 1) without torch.distributed"""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(group), dist.get_world_size(group)
+    except Exception:
+        pass
+    return 0, 1
+
+
+def gather_rows(local: np.ndarray, n_rows: int, group=None) -> np.ndarray:
+    """Row-sharded indexing: every rank holds the rows shard_rows(n_rows, rank, ws) of a per-voxel result (argmax (n,), scores
+    (n, Q), ...); returns the full (n_rows, ...) host array on every rank.  One all_gather of equally padded shards -- the only
+    exchange of the sharded index path, and it carries results (4 B per voxel and query), never features."""
+    import torch
+    rank, ws = rank_world(group)
+    if ws == 1:
+        return local
+    coll = _Coll(group)
+    per = (n_rows + ws - 1) // ws
+    pad = np.zeros((per,) + local.shape[1:], dtype=local.dtype)
+    pad[: local.shape[0]] = local
+    dev = "cuda" if (coll.dist.get_backend(group) == "nccl") else "cpu"
+    parts = coll.all_gather(torch.from_numpy(pad).to(dev))
+    out = np.concatenate([p.cpu().numpy() for p in parts], axis=0)
+    return out[:n_rows]
+
+
 def global_top1(best_val: "torch.Tensor", best_row: "torch.Tensor", row_offset: int, group=None):
     """Per-query best voxel over row shards: (Q,) local max values and local row indices -> global (value, row).
     Ties go to the lowest global row index (np.argmax semantics)."""

@@ -23,7 +23,7 @@ def find_similar_category_id(class_name: str, classes_list: List[str]) -> int:
 
 def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstacle_classes, obstacle_classes, grid_feat,
                                  grid_pos, rmin, cmin, clip_feat_dim, use_multiple_templates=True, avg_mode=0, vis=False,
-                                 precision="auto"):
+                                 precision="auto", predict=None):
     """Cropped top-down map, True = free, after keeping only voxels whose best class is one of `obstacle_classes`.
     Reference: avlmaps/utils/index_utils.py:138-184 -- the same matmul + argmax as index_map (:153-161), here the fused
     similarity kernel (scores are never materialised), then one scatter kernel fed by the device-resident argmax.
@@ -31,7 +31,9 @@ def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstac
     import numpy as np
     from .. import ops
     from .clip_utils import landmark_text_feats, _to_numpy
-    if avg_mode != 0:
+    if predict is not None:         # the caller already has the class argmax of every voxel (row-sharded VLMap)
+        predict = np.ascontiguousarray(predict, dtype=np.int32)
+    elif avg_mode != 0:
         from .clip_utils import get_lseg_score
         scores = get_lseg_score(clip_model, list(potential_obstacle_classes), grid_feat, clip_feat_dim,
                                 use_multiple_templates=use_multiple_templates, avg_mode=avg_mode, precision=precision)

@@ -395,6 +395,28 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
         assert not (c[2].shape == a[2].shape and np.array_equal(c[2], a[2]))
 
 
+def test_row_sharded_vlmap_indexing(golden, tmp_path):
+    """VLMap under 2 ranks: every rank keeps and scores only its block of voxel rows (prepared, per-row scaled), the per-voxel
+    results are all-gathered -- index_map / init_categories return what the single process and the reference return (g3)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    g = golden("g3_similarity.npz")
+    env = dict(os.environ, AVLMAPS_DIST_BACKEND="gloo")
+    out = tmp_path / "sharded.npz"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", str(root / "tests" / "dist_index_worker.py"), str(root / "tests" / "golden" / "g3_similarity.npz"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    z = np.load(out)
+    assert z["rows"].tolist() == [0, 512]
+    assert np.array_equal(z["mask"], g["index_map_sofa_mask"])
+    np.testing.assert_allclose(z["scores"], g["init_categories_scores"], rtol=0, atol=1e-4)
+    assert np.array_equal(z["m7"], np.argmax(z["scores"], axis=1) == 7)
+
+
 def test_bench_two_ranks_share_one_gpu():
     """the N > 1 launch path of bench.py (torch.distributed.run, one rank per process, barrier + max-over-ranks timing) with
     two ranks on this box's single GPU: gloo instead of RCCL via AVLMAPS_DIST_BACKEND, everything else as the driver runs it"""

@@ -99,6 +99,11 @@ def _worker(rank, ws, port, tmpdir):
         coll.send(state, rank + 1)
     else:
         assert int(state[0, 0]) == ws * (ws + 1) // 2
+    # row-sharded indexing: per-voxel results of every rank's row block -> the full array on every rank
+    full = np.arange(7 * 3, dtype=np.float32).reshape(7, 3)
+    lo, hi = parallel.shard_rows(7, rank, ws)
+    assert np.array_equal(parallel.gather_rows(full[lo:hi], 7), full)
+    assert np.array_equal(parallel.gather_rows(np.arange(7, dtype=np.int32)[lo:hi], 7), np.arange(7))
     # row-sharded per-query top-1 with a cross-rank tie -> lowest global row wins
     vals = torch.tensor([[1.0, 5.0, 2.0], [4.0, 5.0, 0.5]])[rank]
     rows = torch.tensor([[3, 1, 2], [0, 4, 9]])[rank]
