@@ -302,6 +302,38 @@ class H5File:
         finally:
             lib.H5Dclose(dset)
 
+    def write_row_runs(self, name: str, runs, array: np.ndarray):
+        """dset[r0:r1] = array[r0:r1] for every (r0, r1) of `runs`: the dataset is opened once and each run goes out as one
+        contiguous hyperslab straight from `array` (which holds ALL rows of the dataset's current extent)"""
+        lib = _lib()
+        array = np.ascontiguousarray(array)
+        dset = self._open(name)
+        try:
+            shape, dt = self._info(dset)
+            if array.dtype != dt or tuple(array.shape[1:]) != shape[1:] or array.shape[0] > shape[0]:
+                raise H5Error(f"write_row_runs({name}): array {array.shape} {array.dtype} does not fit dataset {shape} {dt}")
+            fspace = lib.H5Dget_space(dset)
+            mtype = _tid(_TYPES[dt][1])
+            row_bytes = int(np.prod(shape[1:], dtype=np.int64)) * dt.itemsize if len(shape) > 1 else dt.itemsize
+            try:
+                for r0, r1 in runs:
+                    r0, r1 = int(r0), int(r1)
+                    if r1 <= r0:
+                        continue
+                    if r1 > array.shape[0]:
+                        raise H5Error(f"write_row_runs({name}): run [{r0}, {r1}) beyond the array")
+                    start = _dims((r0,) + (0,) * (len(shape) - 1))
+                    count = _dims((r1 - r0,) + shape[1:])
+                    _ok(lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, None, count, None), "H5Sselect_hyperslab")
+                    mspace = lib.H5Screate_simple(len(shape), count, None)
+                    rc = lib.H5Dwrite(dset, mtype, mspace, fspace, 0, array.ctypes.data + r0 * row_bytes)
+                    lib.H5Sclose(mspace)
+                    _ok(rc, f"H5Dwrite({name}, rows {r0}:{r1})")
+            finally:
+                lib.H5Sclose(fspace)
+        finally:
+            lib.H5Dclose(dset)
+
     def write_scattered_rows(self, name: str, rows: np.ndarray, data: np.ndarray):
         """dset[rows[i]] = data[i] for ascending, distinct `rows`: consecutive runs go out as one hyperslab each"""
         rows = np.asarray(rows, dtype=np.int64)

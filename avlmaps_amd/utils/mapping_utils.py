@@ -105,6 +105,33 @@ class MapFileWriter:
     (utils/h5lite.py); otherwise every save is a full rewrite through save_3d_map."""
 
     ROW_SETS = ("grid_feat", "grid_pos", "weight", "grid_rgb")
+    MAX_RUNS = 2048      # one contiguous file write per run and dataset: scattered dirty rows are coalesced across small gaps
+                         # (the rows in between are rewritten with their unchanged values) so that a checkpoint never costs
+                         # more calls than this -- worst case (dirty rows everywhere) it degenerates to one full rewrite
+
+    @classmethod
+    def row_runs(cls, dirty_old: np.ndarray, n_old: int, n: int):
+        """[(r0, r1)] covering every dirty row below n_old and all rows [n_old, n), at most MAX_RUNS runs"""
+        d = np.flatnonzero(dirty_old)
+        starts, ends = [], []
+        if d.size:
+            cut = np.flatnonzero(np.diff(d) != 1) + 1
+            starts = d[np.concatenate([[0], cut])]
+            ends = d[np.concatenate([cut - 1, [d.size - 1]])] + 1
+            if n > n_old and ends[-1] == n_old:            # the last dirty run touches the appended block
+                ends[-1] = n
+            elif n > n_old:
+                starts, ends = np.append(starts, n_old), np.append(ends, n)
+        elif n > n_old:
+            starts, ends = np.array([n_old]), np.array([n])
+        starts, ends = np.asarray(starts, dtype=np.int64), np.asarray(ends, dtype=np.int64)
+        if starts.size > cls.MAX_RUNS:
+            gaps = starts[1:] - ends[:-1]
+            thr = np.partition(gaps, starts.size - cls.MAX_RUNS)[starts.size - cls.MAX_RUNS]     # merge every gap <= thr
+            keep = np.concatenate([[True], gaps > thr])
+            starts = starts[keep]
+            ends = np.concatenate([ends[:-1][keep[1:]], ends[-1:]])
+        return [(int(a), int(b)) for a, b in zip(starts, ends)]
 
     def __init__(self, path):
         self.path = Path(path)
@@ -133,18 +160,17 @@ class MapFileWriter:
             self.n_saved = n
             return
         n_old = self.n_saved
-        changed = np.flatnonzero(np.asarray(row_dirty[:n_old]))
-        rows = np.concatenate([changed, np.arange(n_old, n)]).astype(np.int64)
+        runs = self.row_runs(np.asarray(row_dirty[:n_old]), n_old, n)
         with h5lite.H5File(self.path, "r+") as f:
             for k in self.ROW_SETS:
-                a = np.asarray(arrays[k])
                 f.resize(k, n)
-                f.write_scattered_rows(k, rows, a[rows])
+                f.write_row_runs(k, runs, np.asarray(arrays[k]))
             new_pos = np.asarray(arrays["grid_pos"])[n_old:n]
             f.write_points("occupied_ids", new_pos, np.arange(n_old, n, dtype=np.int32))
             f.resize("mapped_iter_list", len(iters))
             f.write_rows("mapped_iter_list", 0, iters)
-        self.stats.append(dict(mode="incremental", rows_written=int(rows.size), rows_total=n))
+        self.stats.append(dict(mode="incremental", rows_written=int(sum(b - a for a, b in runs)), rows_total=n,
+                               rows_dirty=int(np.count_nonzero(row_dirty[:n_old])) + n - n_old, runs=len(runs)))
         self.n_saved = n
 
 
