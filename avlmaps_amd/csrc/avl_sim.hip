@@ -24,6 +24,7 @@
 #include <cfloat>
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <vector>
 
 #include "avl_common.h"
@@ -853,8 +854,11 @@ struct StreamTB {
     static constexpr int value = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
 };
 
-template <int QT, int SPC, bool PRE, bool QM = false>
-__global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
+// (NT: threads per workgroup.  Two co-resident 256-thread workgroups per CU with 128-column chunks -- so that one computes
+// while the other sits in its barrier -- measured 7.5 % SLOWER than one 512-thread workgroup with 256-column chunks: config 5
+// 2.54 vs 2.36 ms on one box; only the 512-thread form is launched.)
+template <int QT, int SPC, bool PRE, bool QM = false, int NT = kSplitThreads>
+__global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
@@ -875,7 +879,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
     if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
     const int units = (rows * row_b) >> 4;
     if (zrow)
-        for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
+        for (int i = threadIdx.x; i < row_b / 4; i += NT) {
             reinterpret_cast<uint32_t*>(smem + rows * row_b)[i] = 0u;
             reinterpret_cast<uint32_t*>(smem + buf_b + rows * row_b)[i] = 0u;
         }
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(img) + ((int64_t)c * Qtot + q_base) * row_b);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            const int u = threadIdx.x + i * kSplitThreads;
+            const int u = threadIdx.x + i * NT;
             if (u < units) stg[i - i0] = src[u];
         }
     };
@@ -896,14 +900,14 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
         f32x4* dst = reinterpret_cast<f32x4*>(smem + b * buf_b);
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
-            const int u = threadIdx.x + i * kSplitThreads;
+            const int u = threadIdx.x + i * NT;
             if (u < units) dst[u] = stg[i - i0];
         }
     };
 
     // work split: full rounds of interleaved TB-tile blocks (all workgroups sweep one compact window of the map), then what
     // is left (< gridDim.x * TB tiles) dealt out evenly, at most TB tiles per workgroup
-    const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    const int64_t ntiles = (N + (NT / 64 * 32) - 1) / (NT / 64 * 32);
     const int64_t G = gridDim.x;
     const int64_t R = ntiles / (G * TB);
     const int64_t rem0 = R * G * TB, rem = ntiles - rem0;
@@ -918,7 +922,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
         }
     };
     auto tile_ptr = [&](int64_t tile) {
-        const int64_t r = tile * kTileRows + wave * 32 + j;
+        const int64_t r = tile * (NT / 64 * 32) + wave * 32 + j;
         return feat + (r < N ? r : N - 1) * ld + 32 * kg;
     };
     f32x4 ring[2][8];
@@ -1031,7 +1035,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_tb_f16_kernel(
 #pragma unroll
         for (int b = 0; b < TB; ++b) {
             if (TB == 1 || b < cnt) {
-                const int64_t row = (tile0 + b) * kTileRows + wave * 32 + j;
+                const int64_t row = (tile0 + b) * (NT / 64 * 32) + wave * 32 + j;
                 float rscale = 1.f;
                 if constexpr (PRE) {
                     if (row_scale) rscale = row_scale[row < N ? row : N - 1];
