@@ -42,13 +42,22 @@ for name in ("rccl_two_ranks_one_gpu.log",):
         open(dst / f"{tag}_{name.replace('.log', '.txt')}", "w").writelines(keep[:6])
 
 
+def pretty(name):
+    """_ZN3avl20sim_split_f16_kernelILi2ELi8ELb0ELb1ELb0EEEv... -> sim_split_f16_kernel<2,8,0,1,0>; plain names pass through"""
+    import re
+    m = re.match(r"_ZN3avl\d+([A-Za-z0-9_]+?)I((?:L[ib]\d+E)+)E", name)
+    if m:
+        return m.group(1) + "<" + ",".join(re.findall(r"L[ib](\d+)E", m.group(2))) + ">"
+    return name.split("(")[0].replace("avl::", "").replace("void ", "")
+
+
 def per_step(d, match, counter, how="mean"):
     """sum over the kernels of one step (each is launched once per step) of a counter's per-launch mean"""
     tot, names = 0.0, []
     for k, v in d.items():
         if any(m in k for m in match) and counter in v:
             tot += v[counter][how]
-            names.append(k.split("(")[0][-60:])
+            names.append(pretty(k))
     return tot, names
 
 
@@ -72,7 +81,7 @@ for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64), "index_ben
     w, _ = per_step(pmc[stem], SIM, "WRITE_SIZE")
     if f:
         b = busy(pmc[stem], ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel"))
-        entries.append(dict(workload="index", shape=shape, kernel=" + ".join(sorted(set(n.split("avl")[-1] for n in names)))[:300],
+        entries.append(dict(workload="index", shape=shape, kernel=" + ".join(sorted(set(names)))[:300],
                             read_bytes=2 * f * 1024, write_bytes=w * 1024, total_bytes=2 * f * 1024 + w * 1024,
                             mfma_busy_frac=(list(b.values())[0] if len(b) == 1 else (b or None)),
                             source=f"profiles/{tag}_{stem}.json", note="sum over the kernels of one step; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> B"))
