@@ -849,9 +849,12 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 // Same-box A/B (2 M voxels): D = 1536, Q = 64: 2.40 -> 2.25 ms; config 5's column-block launches 2.51 -> 2.42 ms; with a
 // power-of-two row stride (D = 1024: 4 KiB) the two-tile walk is 5 % SLOWER (HBM channel camping), and for QT >= 3 the extra
 // bookkeeping costs 1-4 %, so the launcher only picks it for QT = 2 and row strides that are not a multiple of 4 KiB.
+#ifndef AVL_TB2
+#define AVL_TB2 2
+#endif
 template <int QT>
 struct StreamTB {
-    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? 2 : 1);
+    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? AVL_TB2 : 1);
 };
 
 // (NT: threads per workgroup.  Two co-resident 256-thread workgroups per CU with 128-column chunks -- so that one computes
