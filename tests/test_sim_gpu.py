@@ -362,6 +362,21 @@ def test_column_block_launches_equal_the_dense_pass(ops, golden):
         assert np.array_equal(am_only, am)
         scd, amd, _ = ops.sim_scores(f, qq, col_support=None)
         assert np.abs(sc - scd).max() < 1e-5          # same products, another summation grouping
+    # many queries per window (several launch chunks per group), overlapping windows (one is a superset of another), a window
+    # per query (more than 16 groups -> dense fallback): always the dense result
+    for Q, maker in ((300, lambda i: (0, 512) if i % 2 else (512, 1536)),
+                     (90, lambda i: (0, 1536) if i % 3 == 0 else ((0, 512) if i % 3 == 1 else (1024, 1536))),
+                     (40, lambda i: (128 * (i % 12), 128 * (i % 12) + 128))):
+        qq = (rng.standard_normal((Q, D)) / 20).astype(np.float32)
+        for i in range(Q):
+            lo, hi = maker(i)
+            qq[i, :lo] = 0
+            qq[i, hi:] = 0
+        qq[Q - 2] = qq[1]                                                           # a tie between distant indices
+        want = f.astype(np.float64) @ qq.astype(np.float64).T
+        sc, am, best = ops.sim_scores(f, qq, want_best=True)
+        assert np.abs(sc - want).max() < 2e-5 and np.array_equal(am, np.argmax(sc, axis=1)) and np.array_equal(best, sc[np.arange(N), am])
+        assert not np.any(am == Q - 2)                                              # the lower index of the tied pair wins
     # explicit windows with device-resident queries; a window may be a superset
     import torch
     qt = torch.from_numpy(qq).cuda()
