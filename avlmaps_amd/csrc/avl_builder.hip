@@ -296,15 +296,33 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
     if (!own) return;
     const bool is_new = slot_key[slot] == kNoKey;  // born in this launch: accumulators hold nothing yet
     const int h0 = head[slot];
+    double* sf = sum_feat + (size_t)slot * D;
 
-    double acc[CH][4];
+    double acc[CH][4], old[CH][4];
     float f1[CH][4];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[c][e] = 0.0; f1[c][e] = 0.f; }
-    double w4 = 0.0, a1 = 0.0;
+        for (int e = 0; e < 4; ++e) { acc[c][e] = 0.0; f1[c][e] = 0.f; old[c][e] = 0.0; }
+    double w4 = 0.0, a1 = 0.0, w4_old = 0.0;
     int min_s = INT_MAX;
+    // the voxel's accumulator row is requested NOW, together with the first feature row, instead of after the list walk: one
+    // memory round trip less on the wave's dependent chain (owner flag -> slot -> head / rows -> write)
+    if (!is_new) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = c * 256 + lane * 4;
+            if (d + 3 < D && (D & 1) == 0) {   // 16-byte aligned rows
+                const double2 q0 = *reinterpret_cast<const double2*>(sf + d), q1 = *reinterpret_cast<const double2*>(sf + d + 2);
+                old[c][0] = q0.x; old[c][1] = q0.y; old[c][2] = q1.x; old[c][3] = q1.y;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (d + e < D) old[c][e] = sf[d + e];
+            }
+        }
+        if (lane < 4) w4_old = sum_w4[(size_t)slot * 4 + lane];
+    }
 
     auto add = [&](int cur, double alpha, int32_t fpix, uint32_t rgbv) {
         const float* f = (batch ? batch[cur / P_frame].feat : feat) + (size_t)fpix * D;
@@ -338,18 +356,14 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
         cur = nxt;
     }
 
-    double* sf = sum_feat + (size_t)slot * D;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int d = c * 256 + lane * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (d + e < D) sf[d + e] = is_new ? acc[c][e] : sf[d + e] + acc[c][e];
+            if (d + e < D) sf[d + e] = is_new ? acc[c][e] : old[c][e] + acc[c][e];
     }
-    if (lane < 4) {
-        double* w = sum_w4 + (size_t)slot * 4 + lane;
-        *w = is_new ? w4 : *w + w4;
-    }
+    if (lane < 4) sum_w4[(size_t)slot * 4 + lane] = is_new ? w4 : w4_old + w4;
     if (is_new) {
         float* ff = first_feat + (size_t)slot * D;
 #pragma unroll
