@@ -3,8 +3,10 @@
     python -m avlmaps_amd.apps.create_map --data-dir <scene> [--config cfg.yaml] [--features lseg|hash] [--seed N]
 
 <scene>/ holds rgb/*.png, depth/*.npy (float32 metres) and poses.txt (x y z qx qy qz qw per line), the layout of the
-reference's dataset/README.md:76-93; the map goes to <scene>/vlmap/vlmaps.h5df (HDF5 if h5py is installed, else .npz).
-Multi-GPU: launch with torchrun; frames are sharded over ranks and merged with one sparse RCCL reduce."""
+reference's dataset/README.md:76-93; the map goes to <scene>/vlmap/vlmaps.h5df (a real HDF5 file: through h5py, or through
+the HDF5 C library where h5py is missing).
+Multi-GPU: launch with torchrun; frames are sharded over ranks and merged with one sparse RCCL reduce; with --seed the N-rank
+map equals the single-process map (every rank replays the RNG draws of the frames before its shard)."""
 from __future__ import annotations
 
 import argparse
@@ -24,6 +26,9 @@ def main(argv=None):
     ap.add_argument("--capacity", type=int, default=None, help="voxel capacity (default gs*gs)")
     ap.add_argument("--prefetch", type=int, default=None, help="frames decoded ahead on host threads (default 4, 0 = inline)")
     ap.add_argument("--batch-frames", type=int, default=None, help="frames fused per launch triple (default 1)")
+    ap.add_argument("--shard-sampling", choices=["replay", "independent"], default=None,
+                    help="several ranks: replay = sample the pixels of the single-process run (default); independent = do not "
+                         "fast-forward the RNG past the other ranks' frames (unseeded runs)")
     args = ap.parse_args(argv)
 
     from avlmaps_amd import parallel
@@ -35,7 +40,7 @@ def main(argv=None):
         np.random.seed(args.seed)
     extractor = HashFeatureExtractor(args.feat_dim) if args.features == "hash" else None
     avlmap = AVLMap(cfg, data_dir=args.data_dir)
-    if args.capacity or args.prefetch is not None or args.batch_frames:
+    if args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling:
         import avlmaps_amd.map.vlmap_builder as vb
         orig = vb.VLMapBuilder.__init__
 
@@ -47,6 +52,8 @@ def main(argv=None):
                 self.prefetch_frames = args.prefetch
             if args.batch_frames:
                 self.batch_frames = args.batch_frames
+            if args.shard_sampling:
+                self.shard_sampling = args.shard_sampling
         vb.VLMapBuilder.__init__ = patched
     t0 = time.perf_counter()
     avlmap.create_map(args.data_dir, feat_extractor=extractor)
