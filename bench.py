@@ -456,6 +456,13 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
 
     if warmup:
         fuse(lo, lo + warmup)           # untimed: code objects loaded, pools warm; then start from an empty map
+    # the warm-up covers the tail of the path too: the first merge of a process pays for torch's sort / unique kernels, RCCL's
+    # lazily created point-to-point communicators and the allocator's first large blocks (tens to hundreds of ms, once)
+    if ws > 1:
+        parallel.merge_accumulator(acc, dst=0, exact_rgb=exact_rgb)      # every rank, also one without warm-up frames
+    elif warmup:
+        acc.finalize(as_torch=True)
+    if warmup or ws > 1:
         acc.num_voxels()
         acc.reset()
     e0, e1 = C.c_void_p(), C.c_void_p()
