@@ -18,7 +18,7 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from .. import ops
-from ..utils.mapping_utils import h5py, load_rgb_png
+from ..utils.mapping_utils import load_rgb_png, read_map_datasets, write_map_datasets
 from .map import cfg_get
 from .vlmap_builder import VLMapBuilder
 
@@ -121,22 +121,11 @@ class VLMapBuilderMultiFloor:
                     grid_pos=arrays["grid_pos"], weight=arrays["weight"], occupied_ids=arrays["occupied_ids"],
                     grid_rgb=arrays["grid_rgb"], pcd_min=self.pcd_min, pcd_max=self.pcd_max,
                     cs=np.array(cfg_get(self.map_config, "cell_size")))
-        if h5py is not None:
-            with h5py.File(self.map_save_path, "w") as f:
-                for k, v in data.items():
-                    f.create_dataset(k, data=v)
-        else:
-            np.savez(self.map_save_path.with_name(self.map_save_path.name + ".npz"), **data)
+        write_map_datasets(self.map_save_path, {k: np.asarray(v) for k, v in data.items()})
 
     @staticmethod
     def load_3d_map(map_path):
         """-> (mapped_iter_list, grid_feat, grid_pos, weight, occupied_ids, grid_rgb, pcd_min, pcd_max, cs). Reference: :244-256."""
-        map_path = Path(map_path)
-        if map_path.exists() and h5py is not None:
-            with h5py.File(map_path, "r") as f:
-                d = {k: f[k][()] for k in f.keys()}
-        else:
-            with np.load(map_path.with_name(map_path.name + ".npz")) as z:
-                d = {k: z[k] for k in z.files}
+        d = read_map_datasets(Path(map_path))
         return (d["mapped_iter_list"].tolist(), d["grid_feat"], d["grid_pos"], d["weight"], d["occupied_ids"], d["grid_rgb"],
                 d["pcd_min"], d["pcd_max"], float(d["cs"]))

@@ -74,6 +74,33 @@ def hdf5_backend() -> Optional[str]:
     return "h5lite" if h5lite.available() else None
 
 
+def write_map_datasets(save_path, data: dict) -> None:
+    """{name: array} -> one HDF5 file (h5py, else libhdf5 through ctypes); `<save_path>.npz` only if neither exists"""
+    backend = hdf5_backend()
+    if backend == "h5py":
+        with h5py.File(save_path, "w") as f:
+            for k, v in data.items():
+                f.create_dataset(k, data=v)
+    elif backend == "h5lite":
+        h5lite.write_datasets(save_path, data)
+    else:
+        np.savez(_npz_path(save_path), **data)
+
+
+def read_map_datasets(map_path) -> dict:
+    """every dataset of a map file as {name: array}; an .h5df without an HDF5 backend fails loudly"""
+    if Path(map_path).exists():
+        backend = hdf5_backend()
+        if backend == "h5py":
+            with h5py.File(map_path, "r") as f:
+                return {k: f[k][()] for k in f.keys()}
+        if backend == "h5lite":
+            return h5lite.read_datasets(map_path)
+        raise RuntimeError(f"{map_path} is an HDF5 map but neither h5py nor the HDF5 C library (libhdf5) is available")
+    with np.load(_npz_path(map_path)) as z:
+        return {k: z[k] for k in z.files}
+
+
 def save_3d_map(save_path, grid_feat, grid_pos, weight, occupied_ids, mapped_iter_list, grid_rgb=None,
                 init_height_id=None) -> None:
     """Write the datasets of the reference's map file, same names / dtypes / shapes (mapping_utils.py:469-505): an HDF5
@@ -181,18 +208,7 @@ def map_file_exists(map_path) -> bool:
 def load_3d_map(map_path):
     """-> (mapped_iter_list, grid_feat, grid_pos, weight, occupied_ids, grid_rgb[, init_height_id]).
     Reference: mapping_utils.py:508-541."""
-    if Path(map_path).exists():
-        backend = hdf5_backend()
-        if backend == "h5py":
-            with h5py.File(map_path, "r") as f:
-                d = {k: f[k][()] for k in f.keys()}
-        elif backend == "h5lite":
-            d = h5lite.read_datasets(map_path)
-        else:
-            raise RuntimeError(f"{map_path} is an HDF5 map but neither h5py nor the HDF5 C library (libhdf5) is available")
-    else:
-        with np.load(_npz_path(map_path)) as z:
-            d = {k: z[k] for k in z.files}
+    d = read_map_datasets(map_path)
     out = (d["mapped_iter_list"].tolist(), d["grid_feat"], d["grid_pos"], d["weight"], d["occupied_ids"], d.get("grid_rgb"))
     if "init_height_id" in d:
         return out + (d["init_height_id"],)
