@@ -143,3 +143,21 @@ def test_large_maps_vs_oracle_and_index_errors(ops):
         ops.pool_label_2d(np.array([True]), np.array([[8, 0, 0]], np.int32), 8)
     with pytest.raises(AvlError, match="IndexError"):
         ops.rgb_topdown(np.array([[0, -9, 0]], np.int32), np.zeros((1, 3), np.uint8), 8)
+
+
+def test_get_lseg_score_avg_mode_1_matches_reference(ops, golden):
+    """clip_utils.py:231-240: every template is scored separately and the SCORES are averaged (not the features); the
+    reference's own result on the g8 map with the template vectors it used"""
+    from avlmaps_amd.utils import clip_utils
+    from avlmaps_amd.utils.clip_utils import get_lseg_score, multiple_templates
+    g = golden("g8_map2d.npz")
+    lms = [str(x) for x in g["avg1_landmarks"]]
+    table = {t.format(lm): g["avg1_template_feats"][i, k] for i, lm in enumerate(lms) for k, t in enumerate(multiple_templates)}
+    orig = clip_utils.get_text_feats
+    clip_utils.get_text_feats = lambda texts, clip_model, dim, batch_size=64: np.stack([table[t] for t in texts]).astype(np.float32)
+    try:
+        sc = get_lseg_score(None, lms[:-1], g["grid_feat"], g["grid_feat"].shape[1], use_multiple_templates=True, avg_mode=1)
+    finally:
+        clip_utils.get_text_feats = orig
+    assert sc.shape == g["avg1_scores"].shape
+    np.testing.assert_allclose(sc, g["avg1_scores"], rtol=0, atol=1e-4)

@@ -430,6 +430,11 @@ def gen_g8(m, rng):
     sc = iu.get_lseg_score(None, potential, feat, D, use_multiple_templates=True, avg_mode=0)
     out["dyn_scores"] = sc
     out["dyn_predict"] = np.argmax(sc, axis=1).astype(np.int32)
+    # get_lseg_score with avg_mode=1 (average of the per-template SCORES instead of the features, clip_utils.py:231-240)
+    lms3 = potential[:3]
+    out["avg1_landmarks"] = np.array(lms3 + ["other"])
+    out["avg1_template_feats"] = np.stack([np.stack([table[t.format(lm)] for t in cu.multiple_templates]) for lm in lms3 + ["other"]])
+    out["avg1_scores"] = cu.get_lseg_score(None, list(lms3), feat, D, use_multiple_templates=True, avg_mode=1)
     # VLMap.get_pos up to cv2.findContours (navigation_utils.get_segment_islands_pos is stubbed and records its input)
     vm = VLMap(cfg)
     vm.grid_feat, vm.grid_pos, vm.occupied_ids, vm.grid_rgb = feat, pos, occ, rgb
