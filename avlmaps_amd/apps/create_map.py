@@ -26,6 +26,8 @@ def main(argv=None):
     ap.add_argument("--capacity", type=int, default=None, help="voxel capacity (default gs*gs)")
     ap.add_argument("--prefetch", type=int, default=None, help="frames decoded ahead on host threads (default 4, 0 = inline)")
     ap.add_argument("--batch-frames", type=int, default=None, help="frames fused per launch triple (default 1)")
+    ap.add_argument("--deferred-fuse", action="store_true",
+                    help="frame-by-frame fusion in one launch per frame (the extractor must return a new tensor per frame)")
     ap.add_argument("--shard-sampling", choices=["replay", "independent"], default=None,
                     help="several ranks: replay = sample the pixels of the single-process run (default); independent = do not "
                          "fast-forward the RNG past the other ranks' frames (unseeded runs)")
@@ -40,7 +42,7 @@ def main(argv=None):
         np.random.seed(args.seed)
     extractor = HashFeatureExtractor(args.feat_dim) if args.features == "hash" else None
     avlmap = AVLMap(cfg, data_dir=args.data_dir)
-    if args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling:
+    if args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling or args.deferred_fuse:
         import avlmaps_amd.map.vlmap_builder as vb
         orig = vb.VLMapBuilder.__init__
 
@@ -54,6 +56,8 @@ def main(argv=None):
                 self.batch_frames = args.batch_frames
             if args.shard_sampling:
                 self.shard_sampling = args.shard_sampling
+            if args.deferred_fuse:
+                self.deferred_fuse = True
         vb.VLMapBuilder.__init__ = patched
     t0 = time.perf_counter()
     avlmap.create_map(args.data_dir, feat_extractor=extractor)

@@ -89,6 +89,7 @@ struct Recs {
 constexpr int kEmpty = -1, kPending = -2;
 constexpr int kAggregateSamples = 32768;   // launches at least this large allocate slots per workgroup instead of per wave
 constexpr unsigned long long kNoKey = ~0ull;
+constexpr int kMaxPendingSpins = 1 << 18;   // link step of a deferred-fuse launch: polls of a cell that is being created
 
 __device__ __forceinline__ long long py_int(double v) {
     // Python int(): truncate toward zero.  Saturate far-out values (they are out of range anyway).
@@ -101,17 +102,26 @@ __device__ __forceinline__ double gemv3(const double* a, double x0, double x1, d
     return fma(a[2], x2, fma(a[0], x0, a[1] * x1));
 }
 
-__global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const float* depth, const int32_t* __restrict__ sample_idx,
-                                                          const uint8_t* rgb, int32_t* __restrict__ cell_slot,
-                                                          int32_t* __restrict__ slot_cell, Recs recs,
-                                                          unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
+// what K1 leaves in registers for a fused K2 (deferred-fuse launches run both in one kernel)
+struct SampleRec {
+    double alpha;
+    int32_t cell, fpix;
+    uint32_t rgbv;
+};
+
+// K1 body: block `blk` of a launch over fp.P samples.  Slots are published with agent-scope atomic stores so that a
+// K2 running in the SAME kernel (other workgroups, other XCDs) can wait for them.
+__device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams& fp, const float* depth,
+                                                      const int32_t* __restrict__ sample_idx, const uint8_t* rgb,
+                                                      int32_t* __restrict__ cell_slot, int32_t* __restrict__ slot_cell, const Recs& recs,
+                                                      unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
     // slots are allocated per workgroup: creators are counted in LDS and ONE device atomic per 256 samples reserves the
     // block's range (a single hot device word only sustains ~90 atomics/us)
     __shared__ unsigned blk_new;
     __shared__ unsigned long long blk_base;
     if (threadIdx.x == 0) blk_new = 0;
     __syncthreads();
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;   // global sample index: frame-major within a batch
+    const int s = blk * blockDim.x + threadIdx.x;   // global sample index: frame-major within a batch
     const bool valid = s < fp.P;
     double alpha = 0.0;
     int32_t cell = -1, fpix = 0;
@@ -210,10 +220,11 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
         const unsigned long long slot = base + __popcll(cmask & ((1ull << lane) - 1ull));
         if ((long long)slot >= fp.capacity) {
             atomicOr(err_flags, 1);
-            cell_slot[cell] = kEmpty;  // give the cell back; its samples are dropped in K2
+            // give the cell back; its samples are dropped in K2
+            __hip_atomic_store(&cell_slot[cell], kEmpty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            cell_slot[cell] = (int32_t)slot;
             slot_cell[slot] = cell;
+            __hip_atomic_store(&cell_slot[cell], (int32_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (valid) {
@@ -222,6 +233,14 @@ __global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const 
         recs.fpix[s] = fpix;
         recs.rgb[s] = rgbv;
     }
+    return SampleRec{alpha, cell, fpix, rgbv};
+}
+
+__global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const float* depth, const int32_t* __restrict__ sample_idx,
+                                                          const uint8_t* rgb, int32_t* __restrict__ cell_slot,
+                                                          int32_t* __restrict__ slot_cell, Recs recs,
+                                                          unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
+    (void)bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
 }
 
 // optional per-sample log for the exact sequential replay of weight / grid_rgb at finalisation (position = key order)
@@ -232,23 +251,42 @@ struct ReplayLog {
     uint32_t* rgb;
 };
 
-__global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
-                                                   Recs recs, unsigned long long* __restrict__ counters, ReplayLog log,
-                                                   long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
-                                                   int P_frame) {
+// K2 body.  SAME_KERNEL: runs right behind K1 in one kernel (deferred-fuse launches): the sample comes in registers and a
+// cell another workgroup is still creating (kPending) is waited for.  That cannot deadlock: a creator publishes its slot
+// without waiting for anybody but its own workgroup's barrier, which every wave of the workgroup reaches before it spins.
+template <bool SAME_KERNEL>
+__device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
+                                          const Recs& recs, unsigned long long* __restrict__ counters, const ReplayLog& log,
+                                          long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                          int P_frame, const SampleRec& in, int* __restrict__ err_flags) {
     // statistics counters are aggregated per workgroup in LDS: a single hot device word sustains only ~90 atomics/us,
     // which at one atomic per wave was most of this kernel's time in batched launches
     __shared__ unsigned blk_cnt[2];
     if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = blk * blockDim.x + threadIdx.x;
     const bool valid = s < P;
     int32_t slot = -1, next = -1;
     uint8_t owner = 0;
     if (valid) {
-        const int32_t cell = recs.cell[s];
+        const int32_t cell = SAME_KERNEL ? in.cell : recs.cell[s];
         if (cell >= 0) {
-            slot = cell_slot[cell];
+            if constexpr (SAME_KERNEL) {
+                slot = __hip_atomic_load(&cell_slot[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the creator needs one counter atomic and one store (~1-2 us); the cap (~0.2 s) turns a wait that should be
+                // impossible into AVL_ERR_STATE at the next flag check instead of a hung device
+                for (int spins = 0; slot == kPending; ++spins) {
+                    if (spins >= kMaxPendingSpins) {
+                        atomicOr(err_flags, 16);
+                        slot = -1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    slot = __hip_atomic_load(&cell_slot[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                slot = cell_slot[cell];
+            }
             if (slot >= 0) {
                 next = atomicExch(&head[slot], s);  // LIFO push; whoever finds the list empty owns it this launch
                 owner = next == -1;
@@ -269,12 +307,19 @@ __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restr
             const long long i = log_base + s;
             log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
             log.key[i] = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
-            log.alpha[i] = recs.alpha[s];
-            log.rgb[i] = recs.rgb[s];
+            log.alpha[i] = SAME_KERNEL ? in.alpha : recs.alpha[s];
+            log.rgb[i] = SAME_KERNEL ? in.rgbv : recs.rgb[s];
         }
     }
     __syncthreads();
     if (threadIdx.x < 2 && blk_cnt[threadIdx.x]) atomicAdd(&counters[1 + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
+                                                   Recs recs, unsigned long long* __restrict__ counters, ReplayLog log,
+                                                   long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                                   int P_frame) {
+    link_body<false>(blockIdx.x, P, cell_slot, head, recs, counters, log, log_base, frame_key, batch, P_frame, SampleRec{}, nullptr);
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
@@ -282,13 +327,13 @@ __global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restr
 // index is wave-uniform) together with the owner flag, and its feature row, the list head and the accumulator row go out in
 // the next round trip; the rest of the list (1.3 samples per group on average) is walked from the head down to s0.
 template <int CH>
-__global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
-                                                   int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
-                                                   double* __restrict__ sum_feat, double* __restrict__ sum_w4,
-                                                   float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+__device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                          int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
+                                          double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                          float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                          unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
     const int lane = threadIdx.x & 63;
-    const int s0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
     if (s0 >= P) return;
     const uint8_t own = recs.owner[s0];
     const int32_t slot = recs.slot[s0];
@@ -352,7 +397,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
         if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
     };
     add(s0, alpha0, fpix0, rgb0);
-    for (int cur = h0; cur != s0;) {
+    for (int cur = h0; cur != s0 && (unsigned)cur < (unsigned)P;) {   // the owner is the tail: the range test never fires
         const int nxt = recs.next[cur];
         add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
         cur = nxt;
@@ -383,6 +428,45 @@ __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long l
     if (lane == 0) {
         head[slot] = -1;  // ready for the next launch
         dirty[slot] = 1;  // changed since the last checkpoint (avl_builder_finalize_ex)
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                                   int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
+                                                   double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                                   float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+    fuse_body<CH>(blockIdx.x, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty);
+}
+
+// Deferred-fuse launch (avl_builder_set_deferred_fuse): ONE kernel per frame.  Workgroups [0, pb) run K1 + K2 of the NEW frame
+// (records into recs / lists into head), the others run K3 of the PREVIOUS frame (prev_recs / prev_head, the other halves of
+// the double buffers).  The two touch disjoint state: K1/K2 use cell_slot, slot_cell, the slot counter and the new frame's
+// buffers; K3 uses the accumulators, slot_key, dirty and the previous frame's buffers.
+struct FusePrev {
+    int P;                       // 0: nothing pending
+    unsigned long long frame_key;
+    Recs recs;
+    int32_t* head;
+    const float* feat;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void pipe_kernel(FrameParams fp, int pb, const float* depth, const int32_t* __restrict__ sample_idx,
+                                                   const uint8_t* rgb, int32_t* __restrict__ cell_slot, int32_t* __restrict__ slot_cell,
+                                                   Recs recs, int32_t* __restrict__ head, unsigned long long* __restrict__ counters,
+                                                   int* __restrict__ err_flags, ReplayLog log, long long log_base,
+                                                   unsigned long long frame_key, FusePrev prev, int D, double* __restrict__ sum_feat,
+                                                   double* __restrict__ sum_w4, float* __restrict__ first_feat,
+                                                   double* __restrict__ first_alpha, unsigned long long* __restrict__ slot_key,
+                                                   uint8_t* __restrict__ dirty) {
+    if ((int)blockIdx.x < pb) {
+        const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+        link_body<true>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
+    } else {
+        fuse_body<CH>((int)blockIdx.x - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
+                      first_feat, first_alpha, slot_key, dirty);
     }
 }
 
@@ -712,13 +796,21 @@ struct avl_builder {
     double* sum_w4 = nullptr;
     float* first_feat = nullptr;
     double* first_alpha = nullptr;
-    int32_t* head = nullptr;
+    int32_t* head = nullptr;                 // lists of the launch being linked
+    int32_t* head_alt = nullptr;             // deferred fuse: lists of the frame whose K3 is still pending (the two swap per frame)
     uint8_t* dirty = nullptr;                // slot fused since the last clearing finalize (incremental checkpoints)
     unsigned long long* counters = nullptr;  // [0] slots handed out, [1] samples fused, [2] per-frame voxel groups fused
     int* err_flags = nullptr;
     char* recs_mem = nullptr;
-    Recs recs{};
+    Recs recs{}, recs_alt{};                 // recs_alt: records of the pending frame (deferred fuse), swapped like head
     int recs_cap = 0;
+    // deferred fuse (avl_builder_set_deferred_fuse): K3 of a frame runs inside the NEXT frame's launch
+    int deferred = 0;
+    struct Pending {
+        int P = 0;                           // 0: nothing pending
+        unsigned long long frame_key = 0;
+        const float* feat = nullptr;
+    } pend;
     unsigned long long key_bias = 0;  // set after import_map so that imported voxels order before new ones
     ReplayLog log{};
     long long log_cap = 0, log_used = 0;
@@ -740,6 +832,10 @@ static int builder_check_flags(avl_builder* b, hipStream_t st) {
         set_error("a sampled point projected outside the RGB image (the reference raises IndexError here)");
         return AVL_ERR_INVALID;
     }
+    if (flags & 16) {
+        set_error("internal error: a voxel under creation was never published to the samples waiting for it (deferred fuse)");
+        return AVL_ERR_STATE;
+    }
     return AVL_OK;   // bit 8 (global mode: samples outside the pass-1 bounding box were dropped) is informational
 }
 
@@ -751,21 +847,29 @@ static int read_counter(avl_builder* b, int which, int64_t* h_n, hipStream_t st)
     return AVL_OK;
 }
 
+static int flush_pending(avl_builder* b, hipStream_t st);
+
 static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     if (P <= b->recs_cap) return AVL_OK;
+    int rc = flush_pending(b, st);   // the pending frame's records live in the buffers about to be freed
+    if (rc != AVL_OK) return rc;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     if (b->recs_mem) AVL_HIP_CHECK(hipFree(b->recs_mem));
     b->recs_mem = nullptr;
     const size_t cap = ((size_t)P + P / 4 + 1024 + 63) / 64 * 64;
-    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, cap * (8 + 4 * 5 + 1) + 256));
-    char* p = b->recs_mem;
-    b->recs.alpha = reinterpret_cast<double*>(p); p += cap * 8;
-    b->recs.cell = reinterpret_cast<int32_t*>(p); p += cap * 4;
-    b->recs.slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
-    b->recs.fpix = reinterpret_cast<int32_t*>(p); p += cap * 4;
-    b->recs.rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
-    b->recs.next = reinterpret_cast<int32_t*>(p); p += cap * 4;
-    b->recs.owner = reinterpret_cast<uint8_t*>(p);
+    const size_t one = (cap * (8 + 4 * 5 + 1) + 255) / 256 * 256;
+    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one));
+    auto carve = [&](Recs& r, char* p) {
+        r.alpha = reinterpret_cast<double*>(p); p += cap * 8;
+        r.cell = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        r.slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        r.fpix = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        r.rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+        r.next = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        r.owner = reinterpret_cast<uint8_t*>(p);
+    };
+    carve(b->recs, b->recs_mem);
+    carve(b->recs_alt, b->recs_mem + one);
     b->recs_cap = (int)cap;
     return AVL_OK;
 }
@@ -780,6 +884,8 @@ static int grow_builder(avl_builder* b, int64_t want, hipStream_t st) {
     while (cap < want) cap *= 2;
     if (cap > b->max_capacity) cap = b->max_capacity;
     if (cap <= b->capacity) return AVL_OK;
+    int rcf = flush_pending(b, st);
+    if (rcf != AVL_OK) return rcf;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     const size_t oc = (size_t)b->capacity, nc = (size_t)cap, D = (size_t)b->D;
     auto regrow = [&](void** p, size_t elem, int fill) -> hipError_t {
@@ -797,6 +903,7 @@ static int grow_builder(avl_builder* b, int64_t want, hipStream_t st) {
     hipError_t e = regrow((void**)&b->slot_cell, sizeof(int32_t), 0xFF);
     if (e == hipSuccess) e = regrow((void**)&b->slot_key, sizeof(unsigned long long), 0xFF);
     if (e == hipSuccess) e = regrow((void**)&b->head, sizeof(int32_t), 0xFF);
+    if (e == hipSuccess) e = regrow((void**)&b->head_alt, sizeof(int32_t), 0xFF);
     if (e == hipSuccess) e = regrow((void**)&b->dirty, 1, 0);
     if (e == hipSuccess) e = regrow((void**)&b->sum_feat, D * sizeof(double), -1);
     if (e == hipSuccess) e = regrow((void**)&b->sum_w4, 4 * sizeof(double), -1);
@@ -873,6 +980,43 @@ struct LogSegments {
     }
 };
 
+// K3 over one launch's records (CH = 256-float register chunks of a feature row)
+static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, const BatchEntry* batch, int P_frame, const Recs& recs,
+                       int32_t* head, const float* d_feat, hipStream_t st) {
+    const unsigned wb = (unsigned)((P + 3) / 4);
+    if (b->D <= 256)
+        hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    else if (b->D <= 512)
+        hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    else if (b->D <= 1024)
+        hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    else
+        hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,
+                           b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+// deferred fuse: run the K3 that is still owed (on `st`, which must be the stream the frame was integrated on)
+static int flush_pending(avl_builder* b, hipStream_t st) {
+    if (b->pend.P == 0) return AVL_OK;
+    const int P = b->pend.P;
+    b->pend.P = 0;
+    return launch_fuse(b, P, b->pend.frame_key, nullptr, P, b->recs_alt, b->head_alt, b->pend.feat, st);
+}
+
+template <int CH>
+static void launch_pipe(avl_builder* b, const FrameParams& fp, unsigned pb, const void* d_depth, const int32_t* d_sample_idx,
+                        const uint8_t* d_rgb, unsigned long long frame_key, const FusePrev& prev, hipStream_t st) {
+    const unsigned wb = prev.P ? (unsigned)((prev.P + 3) / 4) : 0u;
+    hipLaunchKernelGGL(pipe_kernel<CH>, dim3(pb + wb), dim3(256), 0, st, fp, (int)pb, reinterpret_cast<const float*>(d_depth), d_sample_idx,
+                       d_rgb, b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, prev,
+                       b->D, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+}
+
 extern "C" {
 
 int avl_builder_reset(avl_builder* b, void* stream) {
@@ -881,6 +1025,8 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     // sum_feat / sum_w4 / first_* need no clearing: a voxel's first fuse is store-only
     AVL_HIP_CHECK(hipMemsetAsync(b->cell_slot, 0xFF, b->ncell * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->head, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
+    AVL_HIP_CHECK(hipMemsetAsync(b->head_alt, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
+    b->pend = avl_builder::Pending{};   // a pending frame is dropped with the rest of the map
     AVL_HIP_CHECK(hipMemsetAsync(b->dirty, 0, (size_t)b->capacity, st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_cell, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_key, 0xFF, (size_t)b->capacity * sizeof(unsigned long long), st));
@@ -896,6 +1042,7 @@ int avl_builder_destroy(avl_builder* b) {
     if (!b) return AVL_OK;
     (void)hipFree(b->cell_slot); (void)hipFree(b->slot_cell); (void)hipFree(b->slot_key); (void)hipFree(b->sum_feat);
     (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->head);
+    (void)hipFree(b->head_alt);
     (void)hipFree(b->dirty);
     (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
     (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
@@ -924,6 +1071,7 @@ int avl_builder_create_grid(avl_builder** h_out, int n0, int gs, int vh, double 
     alloc((void**)&b->first_feat, (size_t)capacity * D * sizeof(float));
     alloc((void**)&b->first_alpha, (size_t)capacity * sizeof(double));
     alloc((void**)&b->head, (size_t)capacity * sizeof(int32_t));
+    alloc((void**)&b->head_alt, (size_t)capacity * sizeof(int32_t));
     alloc((void**)&b->dirty, (size_t)capacity);
     alloc((void**)&b->counters, 4 * sizeof(unsigned long long));
     alloc((void**)&b->err_flags, sizeof(int));
@@ -1070,26 +1218,45 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         set_error("replay log full (%lld samples): enable it with a larger max_samples", b->log_cap);
         return AVL_ERR_CAPACITY;
     }
-    const unsigned pb = (unsigned)((P + 255) / 256), wb = (unsigned)((P + 3) / 4);
+    const unsigned pb = (unsigned)((P + 255) / 256);
+    if (b->deferred && B == 0 && b->D <= 1024) {
+        // ONE launch: K1 + K2 of this frame next to K3 of the previous one; this frame's K3 rides in the next launch (or a flush)
+        const FusePrev prev{b->pend.P, b->pend.frame_key, b->recs_alt, b->head_alt, b->pend.feat};
+        if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        else launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        if (b->log.slot) b->log_used += P;
+        b->pend.P = P;
+        b->pend.frame_key = frame_key;
+        b->pend.feat = d_feat;
+        std::swap(b->recs, b->recs_alt);
+        std::swap(b->head, b->head_alt);
+        AVL_HIP_CHECK(hipGetLastError());
+        return AVL_OK;
+    }
+    rc = flush_pending(b, st);
+    if (rc != AVL_OK) return rc;
     hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb, b->cell_slot,
                        b->slot_cell, b->recs, b->counters, b->err_flags);
     hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters, b->log, b->log_used,
                        frame_key, fp.batch, P_frame);
     if (b->log.slot) b->log_used += P;
-    if (b->D <= 256)
-        hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else if (b->D <= 512)
-        hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else if (b->D <= 1024)
-        hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else
-        hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat,
-                           b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    AVL_HIP_CHECK(hipGetLastError());
+    return launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st);
+}
+
+int avl_builder_set_deferred_fuse(avl_builder* b, int on, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_set_deferred_fuse: null handle");
+    if (!on) {
+        int rc = flush_pending(b, as_stream(stream));
+        if (rc != AVL_OK) return rc;
+    }
+    b->deferred = on ? 1 : 0;
     return AVL_OK;
+}
+
+int avl_builder_flush(avl_builder* b, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_flush: null handle");
+    return flush_pending(b, as_stream(stream));
 }
 
 int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int W, const double* h_calib,
@@ -1123,7 +1290,9 @@ int avl_builder_integrate_batch(avl_builder* b, int B, const float* const* h_dep
 
 int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_voxels: null argument");
-    int rc = builder_check_flags(b, as_stream(stream));
+    int rc = flush_pending(b, as_stream(stream));
+    if (rc != AVL_OK) return rc;
+    rc = builder_check_flags(b, as_stream(stream));
     if (rc != AVL_OK) return rc;
     rc = read_counter(b, 0, h_n, as_stream(stream));
     if (rc == AVL_OK && *h_n > b->capacity) *h_n = b->capacity;
@@ -1132,11 +1301,13 @@ int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream) {
 
 int avl_builder_num_points(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_points: null argument");
+    if (int rc = flush_pending(b, as_stream(stream)); rc != AVL_OK) return rc;
     return read_counter(b, 1, h_n, as_stream(stream));
 }
 
 int avl_builder_num_groups(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_groups: null argument");
+    if (int rc = flush_pending(b, as_stream(stream)); rc != AVL_OK) return rc;
     return read_counter(b, 2, h_n, as_stream(stream));
 }
 

@@ -44,6 +44,10 @@ class VLMapBuilder:
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
         self.batch_frames = 1                      # >1: fuse that many frames per launch triple (same map, fewer launches)
+        self.deferred_fuse = False                 # frame-by-frame runs: ONE launch per frame (the feature fusion of frame i
+                                                   # runs inside the launch of frame i + 1; same map bit for bit).  Opt-in: the
+                                                   # extractor must hand out a NEW feature tensor per frame (LSeg on PyTorch
+                                                   # does; one that refills a single buffer would be read one frame late)
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
         self.skip_mapped_frames = False            # True: a resumed run skips the frames listed in the map file's
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
@@ -217,7 +221,8 @@ class VLMapBuilder:
                 self.clip_feat_dim = D
                 # the reference starts at gs*gs rows and doubles (_reserve_map_space, vlmap_builder.py:286-311); so does
                 # the accumulator (max_capacity: every cell of the grid)
-                acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=self.capacity or max(gs * gs, 1 << 16), max_capacity=self.max_capacity)
+                acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=self.capacity or max(gs * gs, 1 << 16), max_capacity=self.max_capacity,
+                                           deferred_fuse=self.deferred_fuse and self.batch_frames <= 1)
                 mapped_iter_set = self._resume(acc, ws)
                 self._resumed_frames = frozenset(mapped_iter_set)
                 if self.skip_mapped_frames and frame_i in self._resumed_frames:

@@ -184,11 +184,13 @@ class VoxelAccumulator:
     inside VLMapBuilder.create_mobile_base_map (vlmap_builder.py:86-95), living in HBM.
     """
 
-    def __init__(self, gs, cs, vh, D, capacity=None, n_rows=None, max_capacity=None):
+    def __init__(self, gs, cs, vh, D, capacity=None, n_rows=None, max_capacity=None, deferred_fuse=False):
         """grid (gs, gs, vh) -- or (n_rows, gs, vh) for the rectangular global multi-floor map.
         capacity: voxels the accumulators hold initially (default gs * n_rows like the reference, vlmap_builder.py:202-206);
         max_capacity: like the reference's _reserve_map_space (:286-311) the accumulators DOUBLE when the map outgrows them,
-        up to this many voxels (default: every cell of the grid, capped at 2^31 - 1); max_capacity=0 keeps the capacity fixed."""
+        up to this many voxels (default: every cell of the grid, capped at 2^31 - 1); max_capacity=0 keeps the capacity fixed.
+        deferred_fuse: frame-by-frame calls take ONE launch each (avl_builder_set_deferred_fuse): the features of a frame are
+        read by the NEXT call's launch, so this object keeps them alive until then; same map, bit for bit."""
         lib = _lib.load()
         _lib.require_gpu()
         self.gs, self.cs, self.vh, self.D = int(gs), float(cs), int(vh), int(D)
@@ -204,6 +206,29 @@ class VoxelAccumulator:
             max_capacity = min(ncell, (1 << 31) - 1)
         if max_capacity and max_capacity > cap0:
             _lib.check(lib.avl_builder_set_max_capacity(h, int(max_capacity)), "avl_builder_set_max_capacity")
+        if deferred_fuse:
+            self.set_deferred_fuse(True)
+
+    def _calib_pair(self, calib, calib_inv):
+        """(K, inv(K)) as contiguous float64; the inverse of an unchanged calibration is computed once (np.linalg.inv is
+        ~8 us, most of the host cost of a frame-by-frame call)"""
+        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
+        if calib_inv is not None:
+            return K, np.ascontiguousarray(np.asarray(calib_inv, dtype=np.float64).reshape(3, 3))
+        key = K.tobytes()
+        c = getattr(self, "_kinv_cache", None)
+        if c is None or c[0] != key:
+            c = self._kinv_cache = (key, np.ascontiguousarray(np.linalg.inv(K)))
+        return K, c[1]
+
+    def set_deferred_fuse(self, on, stream=None):
+        _lib.check(_lib.load().avl_builder_set_deferred_fuse(self._h, int(bool(on)), stream), "avl_builder_set_deferred_fuse")
+        return self
+
+    def flush(self, stream=None):
+        """run the feature fusion a deferred-fuse accumulator still owes (every read of the map does this by itself)"""
+        _lib.check(_lib.load().avl_builder_flush(self._h, stream), "avl_builder_flush")
+        return self
 
     @property
     def capacity(self):
@@ -241,8 +266,7 @@ class VoxelAccumulator:
         sp, sshape, k4 = as_device(sample_idx, np.int32, stream)
         if len(dshape) != 2 or len(fshape) != 3 or fshape[2] != self.D or tuple(rshape) != (dshape[0], dshape[1], 3):
             raise ValueError(f"bad frame shapes depth {dshape} feat {fshape} rgb {rshape}")
-        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
-        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
+        K, Kinv = self._calib_pair(calib, calib_inv)
         T = np.ascontiguousarray(np.asarray(pc_transform, dtype=np.float64).reshape(4, 4))
         rc = lib.avl_builder_integrate_frame(self._h, dp, dshape[0], dshape[1], K.ctypes.data, Kinv.ctypes.data, T.ctypes.data,
                                              sp, int(np.prod(sshape)), fp_, fshape[0], fshape[1], rp, int(frame_idx),
@@ -289,8 +313,7 @@ class VoxelAccumulator:
     def _integrate_plan(self, plan, calib, pc_transforms, frame_idx0, calib_inv, min_depth, max_depth, sigma_sq, stream):
         lib = _lib.load()
         B = plan.B
-        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
-        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
+        K, Kinv = self._calib_pair(calib, calib_inv)
         T = np.ascontiguousarray(np.asarray(pc_transforms, dtype=np.float64).reshape(B, 16))
         rc = lib.avl_builder_integrate_batch(self._h, B, plan.depth, plan.H, plan.W, K.ctypes.data, Kinv.ctypes.data, T.ctypes.data,
                                              plan.samples, plan.P, plan.feat, plan.Hf, plan.Wf, plan.rgb, int(frame_idx0),
@@ -313,8 +336,7 @@ class VoxelAccumulator:
         fp_, fshape, k2 = as_device(feat_hwc, np.float32, stream)
         rp, rshape, k3 = as_device(rgb, np.uint8, stream)
         sp, sshape, k4 = as_device(sample_idx, np.int32, stream)
-        K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
-        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64))
+        K, Kinv = self._calib_pair(calib, calib_inv)
         T = np.ascontiguousarray(np.asarray(transform, dtype=np.float64).reshape(4, 4))
         pm = np.ascontiguousarray(pcd_min, dtype=np.float64)
         rc = lib.avl_builder_integrate_frame_global(self._h, dp, int(is_u16), float(depth_div), dshape[0], dshape[1], K.ctypes.data,

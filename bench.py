@@ -401,7 +401,8 @@ def make_vit_standin(torch):
     return step
 
 
-def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, batch=1, exact_rgb=True, feature_standin=None):
+def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, batch=1, exact_rgb=True, feature_standin=None,
+                   deferred=False):
     """STRONG scaling of map creation: `total_frames` frames of one sequence are sharded contiguously over the ranks; the
     timed region is everything between the first fused frame and the finished map resident in rank 0's HBM:
         fuse own shard (K1/K2/K3 per launch)  ->  [ws > 1: plan + scatter + ONE RCCL sum-reduce + chained colour replay]
@@ -425,7 +426,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     nloc = hi - lo
     warmup = min(warmup, nloc)
     cap = args.capacity or max(1_500_000, 300_000 + 450 * nloc)
-    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=cap)       # doubles on demand like the reference's arrays
+    # doubles on demand like the reference's arrays; deferred: one launch per frame (K1 + K2 of frame i next to K3 of frame i - 1)
+    acc = ops.VoxelAccumulator(1000, 0.05, 30, D, capacity=cap, deferred_fuse=bool(deferred) and int(batch) <= 1)
     if exact_rgb:
         acc.enable_replay_log(max(1, (nloc + warmup) * P))
     BATCH = max(1, int(batch))
@@ -473,6 +475,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     t0 = time.perf_counter()
     lib.avl_event_record(e0, None)
     fuse(lo, hi)
+    acc.flush()                                                # deferred fuse: the last frame's K3 belongs to the fuse time
     lib.avl_event_record(e1, None)
     if ws == 1:
         fin = acc.finalize(as_torch=True)                      # sorts first-touch keys, emits the reference's arrays (device)
@@ -507,7 +510,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     nfr = max(1, nloc)
     pts_per_frame, groups, newv = npts / nfr, ngroups / nfr, nvox / nfr
     alg_frame = P * (4 + 4 + 29) + pts_per_frame * (3 + D * 4 + 29) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
-    res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, frames_per_s=total_frames / dt,
+    res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, deferred_fuse=bool(deferred) and BATCH == 1,
+               frames_per_s=total_frames / dt,
                seconds=dt, fuse_seconds_max_rank=fuse_s, merge_finalize_seconds=dt - fuse_s, exact_rgb_replay=bool(exact_rgb),
                feature_standin=feature_standin,
                timed_region="fuse shard + merge (one RCCL sum-reduce, chained replay) + finalize on rank 0; "
@@ -525,7 +529,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
 
 def run_build(args, torch, dist, lib, rank, ws):
     r = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.steps, warmup=args.warmup, batch=args.build_batch,
-                       exact_rgb=not args.no_exact_rgb, feature_standin=args.feature_standin)
+                       exact_rgb=not args.no_exact_rgb, feature_standin=args.feature_standin, deferred=args.deferred_fuse)
     out = dict(metric="map_build_frames_per_sec", value=r["frames_per_s"], unit="frames/s", n_gpus=ws, steps=args.steps,
                warmup=args.warmup, ms_per_step=r["seconds"] / max(1, args.steps) * 1e3, higher_is_better=True, scaling="strong",
                vs_baseline=None, dtype="f64", data="synthetic",
@@ -608,6 +612,8 @@ def main():
                          "stand-in for LSeg's per-frame cost (no weights exist here; it is NOT LSeg)")
     ap.add_argument("--no-exact-rgb", action="store_true", help="build without the per-sample replay log (no exact weight / colour)")
     ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch triple (avl_builder_integrate_batch)")
+    ap.add_argument("--deferred-fuse", action="store_true",
+                    help="frame-by-frame build with one launch per frame (avl_builder_set_deferred_fuse); ignored with --build-batch > 1")
     ap.add_argument("--event-mode", choices=["pair", "each"], default="pair",
                     help="HIP events around the whole timed region (pair) or between every step (each)")
     ap.add_argument("--settle-steps", type=int, default=80,
@@ -644,9 +650,11 @@ def main():
         torch.cuda.empty_cache()
         try:
             r1 = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.build_frames, batch=1)
+            r1d = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.build_frames, batch=1, deferred=True)
             r64 = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.build_frames, batch=64)
             if rank == 0:
                 out.setdefault("extra", {})["map_build_strong"] = r1
+                out["extra"]["map_build_strong_deferred_fuse"] = r1d      # frame by frame, ONE launch per frame
                 out["extra"]["map_build_strong_batched64"] = r64
         except Exception as e:   # the extra must never break the benchmark line
             if rank == 0:

@@ -179,6 +179,17 @@ AVL_API int avl_builder_reset(avl_builder* b, void* stream);
  * voxels instead of failing with AVL_ERR_CAPACITY; 0 (the default after create) keeps the capacity fixed. */
 AVL_API int avl_builder_set_max_capacity(avl_builder* b, int64_t max_capacity);
 AVL_API int avl_builder_capacity(avl_builder* b, int64_t* h_capacity);
+/* Deferred fuse: frame-by-frame integration in ONE launch per frame instead of three dependent ones.  With on != 0,
+ * avl_builder_integrate_frame / _frame_global run the geometry + list linking of the frame they are given next to the feature
+ * fusion of the PREVIOUS frame (disjoint state, same kernel); the frame's own fusion rides in the next call's launch or in
+ * avl_builder_flush.  The map that results is the same, bit for bit.  What changes for the caller: the d_feat buffer of a
+ * frame is read by the launch of the NEXT integrate / flush / finalize / num_* / export call, so it must stay valid and
+ * unmodified until that call has been enqueued (all on one stream).  d_depth, d_sample_idx and d_rgb are consumed by the
+ * call they are passed to, as before.  Every entry point that reads the map flushes first; batched calls flush and then run
+ * the three-launch path.  The reference's loop (vlmap_builder.py:102-183) has the same shape: features of frame i are
+ * produced, then fused, one frame at a time. */
+AVL_API int avl_builder_set_deferred_fuse(avl_builder* b, int on, void* stream);
+AVL_API int avl_builder_flush(avl_builder* b, void* stream);
 
 /* Optional: keep a 24-byte log entry per sampled pixel (up to max_samples in total) so that avl_builder_finalize can
  * REPLAY the reference's sequential weight / grid_rgb updates exactly -- float32 weight accumulation and the truncating

@@ -39,11 +39,14 @@ class MemoryBuilder:
         return b
 
 
-@pytest.mark.parametrize("feats_as,batch", [("numpy_chw", 1), ("torch_hwc", 1), ("torch_hwc", 4), ("numpy_chw", 2)])
+@pytest.mark.parametrize("feats_as,batch", [("numpy_chw", 1), ("torch_hwc", 1), ("torch_hwc", 4), ("numpy_chw", 2),
+                                            ("torch_hwc", "deferred"), ("numpy_chw", "deferred")])
 def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as, batch):
     from avlmaps_amd.utils.mapping_utils import load_3d_map
     g = golden("g2a_builder_small.npz")
     b = MemoryBuilder.make(g, tmp_path, feats_as)
+    if batch == "deferred":                  # one launch per frame; checkpoints (save_every) flush the pending fusion
+        b.deferred_fuse, b.save_every, batch = True, 3, 1
     b.batch_frames = batch
     np.random.seed(1234)                     # same global-RNG state the reference run had
     b.create_mobile_base_map()

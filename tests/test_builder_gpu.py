@@ -20,10 +20,10 @@ def ops():
 
 
 def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samples, capacity=None, frame_offset=0,
-                    replay=False):
+                    replay=False, deferred=False):
     D = feats_chw.shape[1]
     vh = int(cam_h / cs)
-    acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=capacity)
+    acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=capacity, deferred_fuse=deferred)
     if replay:
         acc.enable_replay_log(sum(len(s) for s in samples))
     for i in range(len(depths)):
@@ -370,6 +370,82 @@ def test_batched_fusion_equals_frame_by_frame(ops, golden, batch):
     assert np.array_equal(out["grid_pos"], g["grid_pos"]) and np.array_equal(out["occupied_ids"], ref["occupied_ids"])
     assert np.array_equal(out["grid_rgb"], ref["grid_rgb"]) and np.array_equal(out["weight"], ref["weight"])
     np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=1e-6, atol=1e-6)
+
+
+def _same_map(a, b):
+    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight", "grid_feat"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("name", ["g2a_builder_small.npz", "g2b_builder_growth.npz"])
+def test_deferred_fuse_is_the_same_map_bit_for_bit(ops, golden, name):
+    """avl_builder_set_deferred_fuse: one launch per frame (K1 + K2 of frame i next to K3 of frame i - 1), same arithmetic in
+    the same order -> every output identical, also through a capacity doubling and with the replay log"""
+    from oracle import avl_oracle as O
+    g = golden(name)
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    args = (ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"], g["rgbs"], g["feats"], g["samples"])
+    for replay in (False, True):
+        for cap in (2000, 16):                                                       # 16: the accumulators double several times
+            ref = run_gpu_builder(*args, capacity=cap, replay=replay)
+            acc = run_gpu_builder(*args, capacity=cap, replay=replay, deferred=True)
+            assert acc.num_voxels() == ref.num_voxels() == int(g["max_id"]) and acc.num_points() == ref.num_points()
+            assert acc.num_groups() == ref.num_groups()
+            _same_map(acc.finalize(), ref.finalize())
+    assert np.array_equal(acc.finalize()["grid_pos"], g["grid_pos"])
+
+
+def test_deferred_fuse_heavy_collisions_and_mixed_calls(ops):
+    """long per-voxel lists and hot cells (a sample may wait for a cell another workgroup is still creating); batched calls,
+    explicit flushes and switching the mode off in the middle of a sequence"""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(11)
+    H, W, Hf, Wf, D, nfr = 120, 160, 59, 79, 64, 9
+    gs, cam_h, cs = 60, 1.6, 0.3
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(5)
+    samples = [O.sample_indices(rs, H * W, 1) for _ in range(nfr)]                    # every pixel: 19 200 samples per frame
+    fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
+    vh = int(cam_h / cs)
+
+    def build(plan, deferred):
+        acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=64, deferred_fuse=deferred)
+        acc.enable_replay_log(nfr * H * W)
+        i = 0
+        for step in plan:
+            if step == "flush":
+                acc.flush()
+            elif step == "off":
+                acc.set_deferred_fuse(False)
+            elif step == "on":
+                acc.set_deferred_fuse(True)
+            elif step == 1:
+                acc.integrate_frame(depths[i], calib, Ts[i], samples[i], fs[i], rgbs[i], frame_idx=i)
+                i += 1
+            else:
+                sl = slice(i, i + step)
+                acc.integrate_batch(list(depths[sl]), calib, Ts[sl], samples[sl], fs[sl], list(rgbs[sl]), frame_idx0=i)
+                i += step
+        assert i == nfr
+        return acc
+
+    ref = build([1] * nfr, False)
+    n, pts = ref.num_voxels(), ref.num_points()
+    assert pts > 10 * n > 0
+    want = ref.finalize()
+    for plan in ([1] * nfr, [1, 1, "flush", 1, 1, 1, "flush", "flush", 1, 1, 1, 1], [1, 1, 1, "off", 1, 1, "on", 1, 1, 1, 1]):
+        acc = build(plan, True)
+        assert acc.num_voxels() == n and acc.num_points() == pts
+        _same_map(acc.finalize(), want)
+    # a batched call in the middle groups the samples of its frames per voxel: same ids / colour / weight, features to rounding
+    acc = build([1, 1, 3, 1, 2, 1], True)
+    out = acc.finalize()
+    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
+        assert np.array_equal(out[k], want[k]), k
+    np.testing.assert_allclose(out["grid_feat"], want["grid_feat"], rtol=1e-6, atol=1e-6)
 
 
 def test_full_size_build_properties(ops):
