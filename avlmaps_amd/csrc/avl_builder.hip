@@ -22,17 +22,20 @@
 //   grid_feat = (sum_feat - a1*(1-a1)*first_feat) / sum_alpha,  weight = sum_alpha
 // so the accumulation itself is commutative; only the first-touch point (smallest key) is special.
 //
-// Per frame three launches on the caller's stream, none of them serial:
-//   K1 bp_voxelize  thread per sampled pixel: fp64 geometry; an empty cell is created by the CAS winner
-//                   (slot = atomicAdd on the voxel counter)
-//   K2 link         thread per sampled pixel: push the sample on its voxel's list (atomicExch on head);
-//                   the first pusher becomes the voxel's owner for this frame
+// Per launch (one frame, or the B frames of a batch) two kernels on the caller's stream, none of them serial:
+//   voxelize_link_kernel, thread per sampled pixel:
+//     K1 bp_voxelize  fp64 geometry; an empty cell is created by the CAS winner (slot = atomicAdd on the voxel counter)
+//     K2 link         push the sample on its voxel's list (atomicExch on head); the first pusher becomes the voxel's owner
+//                     for this launch.  A sample whose cell is being created by another workgroup polls for the slot
+//                     (bounded; the creator needs one atomic and one store) -- K1 and K2 used to be two launches
+//   fuse_kernel:
 //   K3 fuse         wave per sampled pixel, owners only: walk the list, gather each member's channels-last
 //                   feature row (2 KB contiguous at D=512), accumulate alpha*f in fp64 REGISTERS, then ONE plain
 //                   read-modify-write of the voxel row (store-only for a voxel born this frame).  No floating-point
 //                   atomics: an earlier version used 512 fp64 atomics per point and was bound by the L2 atomic rate
 //                   (36 us/frame, 47 MB of write traffic for 11 MB of algorithmic RMW).  The owner also finds the
 //                   voxel's first-touch sample (smallest position) when the voxel is new.
+// Deferred fuse (avl_builder_set_deferred_fuse): pipe_kernel = voxelize_link of frame i + fuse of frame i - 1 in one launch.
 // Slots are handed out in arrival order, so finalisation sorts the first-touch keys (rocPRIM radix sort) to emit
 // rows in the reference's voxel-id order; the sort is a once-per-save cost.
 #include <algorithm>
@@ -78,8 +81,7 @@ struct FrameParams {
 // per-frame sample records (structure of arrays, sized for the largest P seen)
 struct Recs {
     double* alpha;
-    int32_t* cell;    // -1 = inactive
-    int32_t* slot;
+    int32_t* slot;    // -1 = the sample updates no voxel
     int32_t* fpix;    // py*Wf + px into the (Hf, Wf, D) feature map
     uint32_t* rgb;    // r | g<<8 | b<<16
     int32_t* next;    // next sample of the same voxel in this frame, -1 = end
@@ -107,6 +109,7 @@ struct SampleRec {
     double alpha;
     int32_t cell, fpix;
     uint32_t rgbv;
+    int32_t slot;   // >= 0: the voxel's slot is already known (cell seen occupied, or created by this sample); else -1
 };
 
 // K1 body: block `blk` of a launch over fp.P samples.  Slots are published with agent-scope atomic stores so that a
@@ -196,7 +199,14 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     }
     // create the voxel if the cell is empty: the CAS winner takes the next slot.  One counter atomic per wave:
     // winners are ranked with a ballot (a single hot word only sustains ~90 atomics/us).
-    const bool creator = ok && cell_slot[cell] == kEmpty && atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
+    // cell states only move forward (empty -> pending -> slot), so a slot read here is final even if the line is old
+    int32_t known = -1;
+    bool creator = false;
+    if (ok) {
+        const int32_t seen = cell_slot[cell];
+        if (seen == kEmpty) creator = atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
+        else if (seen >= 0) known = seen;
+    }
     const unsigned long long cmask = __ballot(creator);
     const int lane = threadIdx.x & 63;
     unsigned long long base = 0;
@@ -225,22 +235,15 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         } else {
             slot_cell[slot] = cell;
             __hip_atomic_store(&cell_slot[cell], (int32_t)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            known = (int32_t)slot;
         }
     }
     if (valid) {
         recs.alpha[s] = alpha;
-        recs.cell[s] = cell;
         recs.fpix[s] = fpix;
         recs.rgb[s] = rgbv;
     }
-    return SampleRec{alpha, cell, fpix, rgbv};
-}
-
-__global__ __launch_bounds__(256) void bp_voxelize_kernel(FrameParams fp, const float* depth, const int32_t* __restrict__ sample_idx,
-                                                          const uint8_t* rgb, int32_t* __restrict__ cell_slot,
-                                                          int32_t* __restrict__ slot_cell, Recs recs,
-                                                          unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
-    (void)bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+    return SampleRec{alpha, cell, fpix, rgbv, known};
 }
 
 // optional per-sample log for the exact sequential replay of weight / grid_rgb at finalisation (position = key order)
@@ -251,10 +254,9 @@ struct ReplayLog {
     uint32_t* rgb;
 };
 
-// K2 body.  SAME_KERNEL: runs right behind K1 in one kernel (deferred-fuse launches): the sample comes in registers and a
-// cell another workgroup is still creating (kPending) is waited for.  That cannot deadlock: a creator publishes its slot
-// without waiting for anybody but its own workgroup's barrier, which every wave of the workgroup reaches before it spins.
-template <bool SAME_KERNEL>
+// K2 body.  Runs right behind K1 in the same kernel: the sample comes in registers, and a cell another workgroup is still
+// creating (kPending) is waited for.  That cannot deadlock: a creator publishes its slot without waiting for anybody but
+// its own workgroup's barrier (batched launches), which every wave of the workgroup reaches before it spins.
 __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
                                           const Recs& recs, unsigned long long* __restrict__ counters, const ReplayLog& log,
                                           long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
@@ -269,10 +271,11 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
     int32_t slot = -1, next = -1;
     uint8_t owner = 0;
     if (valid) {
-        const int32_t cell = SAME_KERNEL ? in.cell : recs.cell[s];
+        const int32_t cell = in.cell;
         if (cell >= 0) {
-            if constexpr (SAME_KERNEL) {
-                slot = __hip_atomic_load(&cell_slot[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {
+                // most samples hit a voxel of an earlier frame: K1 has read its slot already
+                slot = in.slot >= 0 ? in.slot : __hip_atomic_load(&cell_slot[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // the creator needs one counter atomic and one store (~1-2 us); the cap (~0.2 s) turns a wait that should be
                 // impossible into AVL_ERR_STATE at the next flag check instead of a hung device
                 for (int spins = 0; slot == kPending; ++spins) {
@@ -284,8 +287,6 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
                     __builtin_amdgcn_s_sleep(2);
                     slot = __hip_atomic_load(&cell_slot[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            } else {
-                slot = cell_slot[cell];
             }
             if (slot >= 0) {
                 next = atomicExch(&head[slot], s);  // LIFO push; whoever finds the list empty owns it this launch
@@ -307,19 +308,23 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
             const long long i = log_base + s;
             log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
             log.key[i] = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
-            log.alpha[i] = SAME_KERNEL ? in.alpha : recs.alpha[s];
-            log.rgb[i] = SAME_KERNEL ? in.rgbv : recs.rgb[s];
+            log.alpha[i] = in.alpha;
+            log.rgb[i] = in.rgbv;
         }
     }
     __syncthreads();
     if (threadIdx.x < 2 && blk_cnt[threadIdx.x]) atomicAdd(&counters[1 + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
 }
 
-__global__ __launch_bounds__(256) void link_kernel(int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
-                                                   Recs recs, unsigned long long* __restrict__ counters, ReplayLog log,
-                                                   long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
-                                                   int P_frame) {
-    link_body<false>(blockIdx.x, P, cell_slot, head, recs, counters, log, log_base, frame_key, batch, P_frame, SampleRec{}, nullptr);
+// K1 + K2 of one launch (a frame, or the B frames of a batch) in ONE kernel: the record stays in registers between the two
+// steps, and a sample whose cell is being created by another workgroup waits for the slot instead of for a kernel boundary
+__global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, const float* depth, const int32_t* __restrict__ sample_idx,
+                                                            const uint8_t* rgb, int32_t* __restrict__ cell_slot,
+                                                            int32_t* __restrict__ slot_cell, Recs recs, int32_t* __restrict__ head,
+                                                            unsigned long long* __restrict__ counters, int* __restrict__ err_flags,
+                                                            ReplayLog log, long long log_base, unsigned long long frame_key) {
+    const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+    link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags);
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
@@ -354,7 +359,9 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
     double w4 = 0.0, a1 = 0.0, w4_old = 0.0;
     int min_s = INT_MAX;
     // the voxel's accumulator row is requested NOW, together with the first feature row, instead of after the list walk: one
-    // memory round trip less on the wave's dependent chain (owner flag -> slot -> head / rows -> write)
+    // memory round trip less on the wave's dependent chain (owner flag -> slot -> head / rows -> write).  Requesting it
+    // before slot_key is known (reading the row of a new voxel too, discarding it) was measured slower: 12.5 vs 12.1 us per
+    // frame, 260 vs 236 us per 64-frame launch -- the scalar loads of slot_key / head are not what the wave waits for.
     if (!is_new) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(FrameParams fp, int pb, const
                                                    uint8_t* __restrict__ dirty) {
     if ((int)blockIdx.x < pb) {
         const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
-        link_body<true>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
+        link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
     } else {
         fuse_body<CH>((int)blockIdx.x - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
                       first_feat, first_alpha, slot_key, dirty);
@@ -857,11 +864,10 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     if (b->recs_mem) AVL_HIP_CHECK(hipFree(b->recs_mem));
     b->recs_mem = nullptr;
     const size_t cap = ((size_t)P + P / 4 + 1024 + 63) / 64 * 64;
-    const size_t one = (cap * (8 + 4 * 5 + 1) + 255) / 256 * 256;
+    const size_t one = (cap * (8 + 4 * 4 + 1) + 255) / 256 * 256;
     AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one));
     auto carve = [&](Recs& r, char* p) {
         r.alpha = reinterpret_cast<double*>(p); p += cap * 8;
-        r.cell = reinterpret_cast<int32_t*>(p); p += cap * 4;
         r.slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
         r.fpix = reinterpret_cast<int32_t*>(p); p += cap * 4;
         r.rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
@@ -1236,10 +1242,8 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     }
     rc = flush_pending(b, st);
     if (rc != AVL_OK) return rc;
-    hipLaunchKernelGGL(bp_voxelize_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb, b->cell_slot,
-                       b->slot_cell, b->recs, b->counters, b->err_flags);
-    hipLaunchKernelGGL(link_kernel, dim3(pb), dim3(256), 0, st, P, b->cell_slot, b->head, b->recs, b->counters, b->log, b->log_used,
-                       frame_key, fp.batch, P_frame);
+    hipLaunchKernelGGL(voxelize_link_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb,
+                       b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key);
     if (b->log.slot) b->log_used += P;
     return launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st);
 }

@@ -504,12 +504,12 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         acc.finalize(as_torch=True)
         torch.cuda.synchronize()
         single_gpu_merge["plain_finalize_s"] = time.perf_counter() - t_fin
-    # algorithmic bytes per frame: every sample 4 B index + 4 B depth + 29 B record; every active sample 3 B rgb + D*4 B
-    # feature gather + 29 B record re-read; every (frame, voxel) group one fp64 row store (D*8 B), plus a row load when
+    # algorithmic bytes per frame: every sample 4 B index + 4 B depth + 25 B record; every active sample 3 B rgb + D*4 B
+    # feature gather + 25 B record re-read; every (frame, voxel) group one fp64 row store (D*8 B), plus a row load when
     # the voxel already existed, plus the first-touch feature row (D*4 B) when it is new
     nfr = max(1, nloc)
     pts_per_frame, groups, newv = npts / nfr, ngroups / nfr, nvox / nfr
-    alg_frame = P * (4 + 4 + 29) + pts_per_frame * (3 + D * 4 + 29) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
+    alg_frame = P * (4 + 4 + 25) + pts_per_frame * (3 + D * 4 + 25) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
     res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, deferred_fuse=bool(deferred) and BATCH == 1,
                frames_per_s=total_frames / dt,
                seconds=dt, fuse_seconds_max_rank=fuse_s, merge_finalize_seconds=dt - fuse_s, exact_rgb_replay=bool(exact_rgb),
@@ -543,7 +543,7 @@ def run_build(args, torch, dist, lib, rank, ws):
                            parallelism=f"contiguous frame shards x{ws}; one sparse RCCL sum-reduce + chained colour replay + "
                                        "finalize on rank 0, all timed"))
     out["roofline"] = dict(bound="hbm", achieved=r["fuse_achieved_gbs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                           frac=(r["fuse_achieved_gbs"] or 0) / HBM_PEAK_GBS, kernel="K1 bp_voxelize + K2 link + K3 fuse (per launch)",
+                           frac=(r["fuse_achieved_gbs"] or 0) / HBM_PEAK_GBS, kernel="K1+K2 voxelize_link + K3 fuse (per launch pair; deferred fuse: one pipe_kernel)",
                            algorithmic_bytes=r["algorithmic_bytes_per_frame"] * max(1, r["frames_per_launch"]),
                            **pmc_lookup("build", dict(frames_per_launch=r["frames_per_launch"])))
     out["extra"] = r

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Builds an experiment variant of the library: avl_sim.hip recompiled with extra -D flags, linked with the stock objects.
+"""Builds an experiment variant of the library: one source (default avl_sim.hip) recompiled with extra -D flags, linked with
+the stock objects.
 
-  python tools/build_variant.py NAME -DAVL_ABL_NOMFMA ...   ->  variants/libavlmaps_hip_NAME.so
+  python tools/build_variant.py NAME [--src avl_builder.hip] -DAVL_ABL_NOMFMA ...   ->  variants/libavlmaps_hip_NAME.so
 Select it at run time with AVLMAPS_HIP_LIB=variants/libavlmaps_hip_NAME.so (same-box A/B runs; box-to-box spread is ~10 %)."""
 import subprocess
 import sys
@@ -14,13 +15,18 @@ from avlmaps_amd import build as B  # noqa: E402
 
 def main():
     name, flags = sys.argv[1], sys.argv[2:]
+    src = "avl_sim.hip"
+    if "--src" in flags:
+        i = flags.index("--src")
+        src = flags[i + 1]
+        del flags[i:i + 2]
     B.build()
     out = ROOT / "variants"
     out.mkdir(exist_ok=True)
-    obj = out / f"avl_sim_{name}.o"
-    cmd = [B._hipcc(), *B.COMMON, *flags, "-c", str(B.CSRC / "avl_sim.hip"), "-o", str(obj)]
+    obj = out / f"{Path(src).stem}_{name}.o"
+    cmd = [B._hipcc(), *B.COMMON, *B.SOURCES[src], *flags, "-c", str(B.CSRC / src), "-o", str(obj)]
     subprocess.run(cmd, check=True)
-    objs = [str(obj)] + [str(B.PKG / "build" / (Path(s).stem + ".o")) for s in B.SOURCES if s != "avl_sim.hip"]
+    objs = [str(obj)] + [str(B.PKG / "build" / (Path(s).stem + ".o")) for s in B.SOURCES if s != src]
     lib = out / f"libavlmaps_hip_{name}.so"
     subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-o", str(lib), *objs], check=True)
     print(lib)

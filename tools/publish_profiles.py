@@ -85,14 +85,14 @@ for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64), "index_ben
                             read_bytes=2 * f * 1024, write_bytes=w * 1024, total_bytes=2 * f * 1024 + w * 1024,
                             mfma_busy_frac=(list(b.values())[0] if len(b) == 1 else (b or None)),
                             source=f"profiles/{tag}_{stem}.json", note="sum over the kernels of one step; FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KB -> B"))
-BUILD = ("bp_voxelize_kernel", "link_kernel", "fuse_kernel", "fuse_generic_kernel")
+BUILD = ("voxelize_link_kernel", "pipe_kernel", "fuse_kernel", "fuse_generic_kernel")
 for stem, fpl in (("pmc_build", 1), ("pmc_build_b16", 16)):
     if stem not in pmc:
         continue
     f, names = per_step(pmc[stem], BUILD, "FETCH_SIZE")
     w, _ = per_step(pmc[stem], BUILD, "WRITE_SIZE")
     if f:
-        entries.append(dict(workload="build", shape=dict(frames_per_launch=fpl), kernel="bp_voxelize + link + fuse (one launch triple)",
+        entries.append(dict(workload="build", shape=dict(frames_per_launch=fpl), kernel="voxelize_link + fuse (one launch pair)",
                             read_bytes=2 * f * 1024, write_bytes=w * 1024, total_bytes=2 * f * 1024 + w * 1024, mfma_busy_frac=None,
                             source=f"profiles/{tag}_{stem}.json",
                             note="FETCH_SIZE x2 is calibrated for wide coalesced reads only; gathers may differ; mean over the launches of the run"))
