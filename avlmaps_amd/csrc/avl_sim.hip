@@ -357,7 +357,7 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
 // the power of two 2^s that brings its largest |element| into [2^14, 2^15) -- exact, and it keeps EVERY row at the full
 // ~22 bits of the hi/lo pair whatever its magnitude (a voxel seen once from 5 m away holds feat * 1e-9) -- and 2^-s is stored
 // in row_scale[row] for the kernel's epilogue.  Without it (s = 0) prepared and raw maps give bit-identical scores.
-// Rows that are all zero or contain a non-finite value are left unscaled.
+// Rows that are all zero or contain a non-finite value are left unscaled; the latter get row_scale = NaN (all their scores are NaN).
 __global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict__ feat, int64_t N, int D, int64_t ld,
                                                               float* __restrict__ row_scale) {
     const int lane = threadIdx.x & 63;
@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict_
             int sh = 0;
             if (mb != 0 && mb < 0x7f800000u) sh = max(-100, min(100, 14 - ilogbf(__uint_as_float(mb))));
             scale = ldexpf(1.f, sh);
-            if (lane == 0) row_scale[row] = ldexpf(1.f, -sh);
+            // a row with a non-finite element scores NaN against EVERY query, as in NumPy (0 * nan = nan): also against the
+            // queries of a column-block launch whose window does not contain the element
+            if (lane == 0) row_scale[row] = mb >= 0x7f800000u ? __uint_as_float(0x7fc00000u) : ldexpf(1.f, -sh);
         }
         for (int g = lane; g < gpr; g += 64) {
             f32x4 v0 = p[2 * g], v1 = p[2 * g + 1];
@@ -857,6 +859,10 @@ struct StreamTB {
     static constexpr int value = QT == 1 ? 4 : (QT == 2 ? AVL_TB2 : 1);
 };
 
+// (Tried and dropped, round 2: ONE pass over several column windows -- the chunk loop switching query rows / running the
+// epilogue at window ends, so that config 5 reads whole 6 KB rows once instead of 2 KB + 4 KB pieces in two launches.  Same-box
+// A/B at 2 M x 1536: 2.40 / 2.37 / 2.41 ms against 2.39 / 2.39 / 2.43 ms for the two launches (Q = 64 and 96: the same within
+// 1 %).  The kernel is bound by the package power the three MFMAs per product draw, not by how the rows are walked.)
 // (NT: threads per workgroup.  Two co-resident 256-thread workgroups per CU with 128-column chunks -- so that one computes
 // while the other sits in its barrier -- measured 7.5 % SLOWER than one 512-thread workgroup with 256-column chunks: config 5
 // 2.54 vs 2.36 ms on one box; only the 512-thread form is launched.)

@@ -384,3 +384,48 @@ def test_column_block_launches_equal_the_dense_pass(ops, golden):
     cb, ce = ops.query_col_support(qq)
     sc2, am2, _ = ops.sim_scores(ft, qt, col_support=(cb, np.maximum(ce, 1)))
     assert torch.equal(am2.cpu(), torch.from_numpy(am)) and float((sc2.cpu() - torch.from_numpy(sc)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("windows,counts,D", [
+    (((0, 512), (512, 1536)), (64, 64), 1536),              # BASELINE config 5: text | audio
+    (((0, 512), (512, 1024), (1024, 1536)), (40, 64, 24), 1536),
+    (((256, 768), (768, 1280)), (33, 50), 1536),            # the windows do not start at column 0 nor end at D
+    (((0, 384), (384, 1152)), (20, 30), 1280),              # 128-column granularity
+    (((512, 1536), (0, 512)), (64, 64), 1536),              # the first queries own the LAST columns
+])
+def test_column_windows_with_ties_zero_queries_and_bad_rows(ops, windows, counts, D):
+    """avl_sim_scores_blocks on windows that tile a column range: float64 scores / np.argmax semantics with a maximum in the
+    last window, all-zero queries, rows outside the fp16 range and a NaN row (0 * nan = nan: the row is NaN against EVERY
+    query, also those whose window does not contain the element), on raw and on prepared maps"""
+    from avlmaps_amd.device import DeviceArray
+    rng = np.random.default_rng(5 + D + len(windows))
+    N, Q = 2500 + 37, sum(counts)
+    f = rng.standard_normal((N, D)).astype(np.float32)
+    q = np.zeros((Q, D), np.float32)
+    q0 = 0
+    for (lo, hi), n in zip(windows, counts):
+        q[q0:q0 + n, lo:hi] = rng.standard_normal((n, hi - lo)) / 20
+        q0 += n
+    q[1] = 0                                                 # an all-zero query (scores 0 everywhere)
+    q[Q - 1] = 0
+    lo, hi = windows[-1]
+    q[Q - 1, lo:lo + 128] = 0.05
+    f[7, :] = 0
+    f[7, lo:lo + 128] = 1.0                                  # row 7: the last query scores 6.4, everything else 0
+    f[11] *= 1e5                                             # outside the unscaled fp16 range: float32 fix-up (raw maps)
+    f[13] *= 1e-9                                            # far below it
+    f[17, 3] = np.nan
+    want = f.astype(np.float64) @ q.astype(np.float64).T
+    cb, ce = ops.query_col_support(q)
+    ok = np.ones(N, bool)
+    ok[17] = False
+    scale = np.maximum(1.0, np.abs(want[ok]).max(axis=1, keepdims=True))
+    for name, src in (("raw", f), ("prepared", ops.prepare_map(DeviceArray.from_numpy(f)))):
+        sc, am, best = ops.sim_scores(src, q, want_best=True, col_support=(cb, np.maximum(ce, 1)))
+        sc, am, best = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (sc, am, best))
+        _, am_only, _ = ops.sim_scores(src, q, want_scores=False, col_support=(cb, np.maximum(ce, 1)))
+        am_only = am_only.numpy() if not isinstance(am_only, np.ndarray) else am_only
+        assert (np.abs(sc[ok] - want[ok]) / scale).max() < 2e-5, name
+        assert np.array_equal(am[ok], np.argmax(sc[ok], axis=1)) and np.array_equal(best[ok], sc[ok, am[ok]]), name
+        assert np.array_equal(am_only, am), name
+        assert am[7] == Q - 1 and np.isnan(sc[17]).all() and am[17] == 0, name       # np.argmax of an all-NaN row is 0
