@@ -25,7 +25,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=None, help="seed of the global NumPy RNG that orders the pixel sampling")
     ap.add_argument("--capacity", type=int, default=None, help="voxel capacity (default gs*gs)")
     ap.add_argument("--prefetch", type=int, default=None, help="frames decoded ahead on host threads (default 4, 0 = inline)")
-    ap.add_argument("--batch-frames", type=int, default=None, help="frames fused per launch triple (default 1)")
+    ap.add_argument("--batch-frames", type=int, default=None, help="frames fused per launch pair (default 1)")
     ap.add_argument("--deferred-fuse", action="store_true",
                     help="frame-by-frame fusion in one launch per frame (the extractor must return a new tensor per frame)")
     ap.add_argument("--shard-sampling", choices=["replay", "independent"], default=None,

@@ -43,7 +43,7 @@ class VLMapBuilder:
         self.min_depth, self.max_depth = 0.1, 6    # vlmap_builder.py:129
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
-        self.batch_frames = 1                      # >1: fuse that many frames per launch triple (same map, fewer launches)
+        self.batch_frames = 1                      # >1: fuse that many frames per launch pair (same map, fewer launches)
         self.deferred_fuse = False                 # frame-by-frame runs: ONE launch per frame (the feature fusion of frame i
                                                    # runs inside the launch of frame i + 1; same map bit for bit).  Opt-in: the
                                                    # extractor must hand out a NEW feature tensor per frame (LSeg on PyTorch
@@ -267,7 +267,7 @@ class VLMapBuilder:
         self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
 
     def _flush(self, acc, pending, calib_mat, calib_inv, transforms):
-        """fuse the buffered frames (consecutive indices, equal shapes) with one launch triple"""
+        """fuse the buffered frames (consecutive indices, equal shapes) with one launch pair"""
         if not pending:
             return
         i0 = pending[0][0]

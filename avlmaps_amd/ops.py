@@ -277,7 +277,7 @@ class VoxelAccumulator:
 
     def integrate_batch(self, depths, calib, pc_transforms, sample_idxs=None, feats_hwc=None, rgbs=None, frame_idx0=0, calib_inv=None,
                         min_depth=0.1, max_depth=6.0, sigma_sq=0.6, stream=None):
-        """Fuse len(depths) consecutive frames with one launch triple (avl_builder_integrate_batch).  Arguments are lists of
+        """Fuse len(depths) consecutive frames with one launch pair (avl_builder_integrate_batch).  Arguments are lists of
         per-frame arrays (numpy / DeviceArray / torch CUDA) with identical shapes; results equal frame-by-frame fusion."""
         if isinstance(depths, BatchPlan):
             plan = depths

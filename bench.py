@@ -611,7 +611,7 @@ def main():
                     help="build workload: run a random-weight ViT-L/16-shaped encoder (2 crops, bf16) before every frame as a "
                          "stand-in for LSeg's per-frame cost (no weights exist here; it is NOT LSeg)")
     ap.add_argument("--no-exact-rgb", action="store_true", help="build without the per-sample replay log (no exact weight / colour)")
-    ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch triple (avl_builder_integrate_batch)")
+    ap.add_argument("--build-batch", type=int, default=1, help="frames fused per launch pair (avl_builder_integrate_batch)")
     ap.add_argument("--deferred-fuse", action="store_true",
                     help="frame-by-frame build with one launch per frame (avl_builder_set_deferred_fuse); ignored with --build-batch > 1")
     ap.add_argument("--event-mode", choices=["pair", "each"], default="pair",

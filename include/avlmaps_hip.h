@@ -219,7 +219,7 @@ AVL_API int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, in
                                         double max_depth, double sigma_sq, void* stream);
 
 /*
- * Fuse B consecutive frames (frame_idx0 .. frame_idx0 + B - 1) with ONE launch triple.  Same semantics and results as B calls
+ * Fuse B consecutive frames (frame_idx0 .. frame_idx0 + B - 1) with ONE launch pair.  Same semantics and results as B calls
  * of avl_builder_integrate_frame; the samples of a voxel coming from different frames share one list, so the voxel row is
  * read-modified-written once per batch instead of once per frame, and the per-launch latencies are amortised.
  * All frames share H, W, P, Hf, Wf and the camera matrix.  h_*_ptrs are HOST arrays of B DEVICE pointers

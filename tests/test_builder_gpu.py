@@ -351,7 +351,7 @@ def test_sharded_build_merges_to_the_single_gpu_map(ops, golden):
 
 @pytest.mark.parametrize("batch", [2, 3, 6])
 def test_batched_fusion_equals_frame_by_frame(ops, golden, batch):
-    """avl_builder_integrate_batch: several frames per launch triple, same map (ids and colour exact, features to rounding)"""
+    """avl_builder_integrate_batch: several frames per launch pair, same map (ids and colour exact, features to rounding)"""
     from oracle import avl_oracle as O
     g = golden("g2a_builder_small.npz")
     Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])

@@ -37,6 +37,8 @@ python $R/tools/summarize_prof.py $O/pmc_config5.json /tmp/q_c5_fetch /tmp/q_c5_
 # --- build: per-frame launches and 16 frames per launch, 10k frames, finalize inside the timed region
 trace build --workload build --steps 10000 --warmup 20 --no-cpu
 trace build_b16 --workload build --steps 10000 --warmup 20 --no-cpu --build-batch 16
+trace build_b64 --workload build --steps 10000 --warmup 64 --no-cpu --build-batch 64
+trace build_deferred --workload build --steps 10000 --warmup 20 --no-cpu --deferred-fuse
 pmc build_fetch FETCH_SIZE --workload build --steps 200 --warmup 5 --no-cpu
 pmc build_write WRITE_SIZE --workload build --steps 200 --warmup 5 --no-cpu
 python $R/tools/summarize_prof.py $O/pmc_build.json /tmp/q_build_fetch /tmp/q_build_write > /dev/null
@@ -49,6 +51,8 @@ cd $R
 (timeout 600 python bench.py $C5 --steps 200) > $O/config5_line.log 2>&1
 (timeout 600 python bench.py --workload build --steps 10000) > $O/build_10k.log 2>&1
 (timeout 600 python bench.py --workload build --steps 5000) > $O/build_config3.log 2>&1
+(timeout 600 python bench.py --workload build --steps 10000 --deferred-fuse --no-cpu) > $O/build_10k_deferred.log 2>&1
+(timeout 600 python bench.py --workload build --steps 10000 --build-batch 64 --no-cpu) > $O/build_10k_b64.log 2>&1
 (timeout 600 python bench.py --workload build --steps 40000 --build-batch 16 --no-cpu) > $O/build_40k_b16.log 2>&1
 AVLMAPS_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 timeout 600 python bench.py --workload build --steps 10000 --build-batch 16 --no-cpu > $O/build_rccl_1rank.log 2>&1
 AVLMAPS_DIST_BACKEND=nccl timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --workload build --steps 2000 --no-cpu > $O/rccl_two_ranks_one_gpu.log 2>&1
