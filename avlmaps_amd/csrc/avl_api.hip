@@ -96,7 +96,7 @@ using namespace avl;
 extern "C" {
 
 const char* avl_last_error(void) { return g_err; }
-int avl_version(void) { return 200; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change)
+int avl_version(void) { return 201; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush added
 
 int avl_device_count(int* h_count) {
     AVL_REQUIRE(h_count, "avl_device_count: null output");
