@@ -179,7 +179,7 @@ AVL_API int avl_builder_reset(avl_builder* b, void* stream);
  * voxels instead of failing with AVL_ERR_CAPACITY; 0 (the default after create) keeps the capacity fixed. */
 AVL_API int avl_builder_set_max_capacity(avl_builder* b, int64_t max_capacity);
 AVL_API int avl_builder_capacity(avl_builder* b, int64_t* h_capacity);
-/* Deferred fuse: frame-by-frame integration in ONE launch per frame instead of three dependent ones.  With on != 0,
+/* Deferred fuse: frame-by-frame integration in ONE launch per frame instead of two dependent ones.  With on != 0,
  * avl_builder_integrate_frame / _frame_global run the geometry + list linking of the frame they are given next to the feature
  * fusion of the PREVIOUS frame (disjoint state, same kernel); the frame's own fusion rides in the next call's launch or in
  * avl_builder_flush.  The map that results is the same, bit for bit.  What changes for the caller: the d_feat buffer of a
