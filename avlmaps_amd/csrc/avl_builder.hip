@@ -404,7 +404,9 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
         if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
     };
     add(s0, alpha0, fpix0, rgb0);
-    for (int cur = h0; cur != s0 && (unsigned)cur < (unsigned)P;) {   // the owner is the tail: the range test never fires
+    // the owner is the tail of a simple chain of at most P samples: the range test and the step cap never fire, they only
+    // make sure that no corrupted list can keep a wave (and with it the device) busy forever
+    for (int cur = h0, steps = 0; cur != s0 && (unsigned)cur < (unsigned)P && steps < P; ++steps) {
         const int nxt = recs.next[cur];
         add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
         cur = nxt;
