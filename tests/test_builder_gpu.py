@@ -141,6 +141,49 @@ def test_builder_vs_sequential_oracle_medium(ops):
     assert np.mean(out2["grid_feat"] == out["grid_feat"]) > 0.9999
 
 
+@pytest.mark.parametrize("D", [5, 30, 257, 768, 1024, 1536])
+def test_builder_feature_widths(ops, D):
+    """every register-chunk variant of K3 (D <= 256 / 512 / 1024), rows that are not 16-byte multiples, and the generic kernel
+    (D > 1024: a fused visual | audio map is built at D = 1536) against the sequential oracle -- frame by frame, deferred,
+    batched; the three GPU modes give the same ids / colour / weight and the same features to fp64 rounding"""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(100 + D)
+    H, W, Hf, Wf, nfr, rate = 48, 64, 23, 31, 5, 2
+    gs, cs, cam_h = 200, 0.1, 1.5
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(D)
+    samples = [O.sample_indices(rs, H * W, rate) for _ in range(nfr)]
+    om = O.OracleMap(gs, cs, cam_h, D)
+    pts = sum(om.integrate(depths[i], calib, Ts[i], samples[i], feats[i], rgbs[i]) for i in range(nfr))
+    ref = om.export()
+    assert pts > len(ref["grid_pos"]) > 100
+    outs = {}
+    for mode in ("frames", "deferred", "batch"):
+        if mode == "batch":
+            vh = int(cam_h / cs)
+            acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=20_000)
+            acc.enable_replay_log(sum(len(x) for x in samples))
+            fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
+            acc.integrate_batch(list(depths[:3]), calib, Ts[:3], samples[:3], fs[:3], list(rgbs[:3]), frame_idx0=0)
+            acc.integrate_batch(list(depths[3:]), calib, Ts[3:], samples[3:], fs[3:], list(rgbs[3:]), frame_idx0=3)
+        else:
+            acc = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=20_000, replay=True,
+                                  deferred=mode == "deferred")
+        assert acc.num_voxels() == len(ref["grid_pos"]) and acc.num_points() == pts, mode
+        out = outs[mode] = acc.finalize()
+        assert np.array_equal(out["grid_pos"], ref["grid_pos"]) and np.array_equal(out["occupied_ids"], ref["occupied_ids"]), mode
+        assert np.array_equal(out["grid_rgb"], ref["grid_rgb"]), mode
+        np.testing.assert_allclose(out["weight"], ref["weight"].astype(np.float32), rtol=2e-6, err_msg=mode)
+        np.testing.assert_allclose(out["grid_feat"], ref["grid_feat"], rtol=2e-5, atol=2e-5 * 14.3, err_msg=mode)
+    _same_map(outs["frames"], outs["deferred"])
+    for k in ("grid_pos", "grid_rgb", "weight"):
+        assert np.array_equal(outs["batch"][k], outs["frames"][k]), k
+    np.testing.assert_allclose(outs["batch"]["grid_feat"], outs["frames"]["grid_feat"], rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("seed,cs,batch", [(1, 0.4, 1), (2, 0.25, 1), (3, 0.4, 3), (4, 0.8, 6)])
 def test_builder_heavy_collisions(ops, seed, cs, batch):
     """coarse cells and every pixel sampled: tens to hundreds of samples per voxel per frame (long per-voxel lists, hot
