@@ -1001,6 +1001,9 @@ static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, cons
     else if (b->D <= 1024)
         hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    else if (b->D <= 1536)   // a fused visual | audio map (512 + 1024 columns, BASELINE config 5)
+        hipLaunchKernelGGL(fuse_kernel<6>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
     else
         hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,
                            b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
@@ -1227,12 +1230,13 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         return AVL_ERR_CAPACITY;
     }
     const unsigned pb = (unsigned)((P + 255) / 256);
-    if (b->deferred && B == 0 && b->D <= 1024) {
+    if (b->deferred && B == 0 && b->D <= 1536) {
         // ONE launch: K1 + K2 of this frame next to K3 of the previous one; this frame's K3 rides in the next launch (or a flush)
         const FusePrev prev{b->pend.P, b->pend.frame_key, b->recs_alt, b->head_alt, b->pend.feat};
         if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
-        else launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        else if (b->D <= 1024) launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        else launch_pipe<6>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         if (b->log.slot) b->log_used += P;
         b->pend.P = P;
         b->pend.frame_key = frame_key;

@@ -241,7 +241,10 @@ class VoxelAccumulator:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.load().avl_builder_destroy(self._h)
+            try:
+                _lib.load().avl_builder_destroy(self._h)
+            except Exception:      # interpreter shutdown: the module globals are already gone, the driver frees the memory
+                pass
             self._h = None
 
     __del__ = close
