@@ -1,4 +1,5 @@
 """End-to-end GPU tests through the reference-shaped Python API (VLMapBuilder / VLMap / AVLMap)."""
+import os
 import sys
 from pathlib import Path
 
@@ -449,3 +450,14 @@ def test_bench_two_ranks_share_one_gpu():
         assert ex["merge_finalize_seconds"] >= mb["scatter_reduce_s"] > 0
         if metric.startswith("map_build"):
             assert d["scaling"] == "strong" and abs(d["value"] - 4 / ex["seconds"]) < 1e-6 * d["value"]
+
+
+def test_randomised_parity_sweep():
+    """tools/fuzz_parity.py with a fixed seed and case count: random similarity shapes / strides / modes / column windows against
+    float64, random builder scenes frame-by-frame vs deferred vs batched vs the sequential oracle (the long form runs for minutes;
+    2 x 2 699 cases were clean at the end of round 2)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "2", "120"], capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert r.returncode == 0 and "0 failures" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
