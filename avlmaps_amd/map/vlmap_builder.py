@@ -45,7 +45,7 @@ class VLMapBuilder:
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
         self.batch_frames = 1                      # >1: fuse that many frames per launch pair (same map, fewer launches)
         self.deferred_fuse = False                 # frame-by-frame runs: ONE launch per frame (the feature fusion of frame i
-                                                   # runs inside the launch of frame i + 1; same map bit for bit).  Opt-in: the
+                                                   # runs inside the launch of frame i + 1; same map).  Opt-in: the
                                                    # extractor must hand out a NEW feature tensor per frame (LSeg on PyTorch
                                                    # does; one that refills a single buffer would be read one frame late)
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)

@@ -416,14 +416,20 @@ def test_batched_fusion_equals_frame_by_frame(ops, golden, batch):
 
 
 def _same_map(a, b):
-    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight", "grid_feat"):
+    """ids, colour and weight identical; features identical up to the order in which the samples of ONE voxel are summed inside
+    ONE launch (the list order is the arrival order of the atomics): fp64 sums rounded once to float32, i.e. what two runs of the
+    same mode guarantee each other (test_builder_vs_sequential_oracle_medium) -- a randomised sweep saw one differing map in 10 000"""
+    for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
         assert np.array_equal(a[k], b[k]), k
+    assert np.mean(a["grid_feat"] == b["grid_feat"]) > 0.9999
+    np.testing.assert_allclose(a["grid_feat"], b["grid_feat"], rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("name", ["g2a_builder_small.npz", "g2b_builder_growth.npz"])
-def test_deferred_fuse_is_the_same_map_bit_for_bit(ops, golden, name):
+def test_deferred_fuse_is_the_same_map(ops, golden, name):
     """avl_builder_set_deferred_fuse: one launch per frame (K1 + K2 of frame i next to K3 of frame i - 1), same arithmetic in
-    the same order -> every output identical, also through a capacity doubling and with the replay log"""
+    the same order per frame -> same map (ids / colour / weight identical, features to the last bit except for the summation
+    order inside a voxel's per-launch list), also through a capacity doubling and with the replay log"""
     from oracle import avl_oracle as O
     g = golden(name)
     Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
