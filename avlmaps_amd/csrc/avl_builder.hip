@@ -403,14 +403,55 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
         }
         if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
     };
+#ifdef AVL_ABL_K3_LIST_ORDER   // ablation: sum the members in list (= atomic arrival) order, as before round 2
     add(s0, alpha0, fpix0, rgb0);
-    // the owner is the tail of a simple chain of at most P samples: the range test and the step cap never fire, they only
-    // make sure that no corrupted list can keep a wave (and with it the device) busy forever
     for (int cur = h0, steps = 0; cur != s0 && (unsigned)cur < (unsigned)P && steps < P; ++steps) {
         const int nxt = recs.next[cur];
         add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
         cur = nxt;
     }
+#else
+    if (h0 == s0) {
+        add(s0, alpha0, fpix0, rgb0);   // one sample for this voxel in this launch: 70 % of the groups of a single frame
+    } else {
+        // Several samples: sum them in ASCENDING SAMPLE ORDER (the reference's order), not in the order in which their atomics
+        // happened to arrive -- fp64 addition is not associative, and with the arrival order two runs of the same build could
+        // differ in the last bit of a feature (seen in 1 map of 10 000).  Lane i keeps the i-th member met on the walk (the
+        // owner, the tail, is member 0) and fetches its record; ranks come from n wave-wide compares; up to 64 members are
+        // ordered, what is beyond (all-pixel sampling into coarse cells) is added in list order.
+        // The range test and the step caps never fire: a list is a simple chain of at most P samples; they only make sure
+        // that no corrupted list can keep a wave (and with it the device) busy forever.
+        int my = lane == 0 ? s0 : INT_MAX;
+        int n = 1, cur = h0;
+        while (cur != s0 && n < 64 && (unsigned)cur < (unsigned)P) {
+            if (lane == n) my = cur;
+            ++n;
+            cur = recs.next[cur];
+        }
+        double a_l = 0.0;
+        int32_t fp_l = 0;
+        uint32_t rgb_l = 0;
+        if (lane < n) {
+            a_l = recs.alpha[my];
+            fp_l = recs.fpix[my];
+            rgb_l = recs.rgb[my];
+        }
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(my, j) < my ? 1 : 0;
+        const int a_lo = __double2loint(a_l), a_hi = __double2hiint(a_l);
+        for (int k = 0; k < n; ++k) {
+            const unsigned long long m = __ballot(lane < n && rank == k);
+            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+            const double al = __hiloint2double(__builtin_amdgcn_readlane(a_hi, l), __builtin_amdgcn_readlane(a_lo, l));
+            add(__builtin_amdgcn_readlane(my, l), al, __builtin_amdgcn_readlane(fp_l, l), (uint32_t)__builtin_amdgcn_readlane((int)rgb_l, l));
+        }
+        for (int steps = 0; cur != s0 && (unsigned)cur < (unsigned)P && steps < P; ++steps) {   // members beyond the 64th
+            const int nxt = recs.next[cur];
+            add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
+            cur = nxt;
+        }
+    }
+#endif
 
 #pragma unroll
     for (int c = 0; c < CH; ++c) {

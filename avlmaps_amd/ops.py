@@ -190,8 +190,8 @@ class VoxelAccumulator:
         max_capacity: like the reference's _reserve_map_space (:286-311) the accumulators DOUBLE when the map outgrows them,
         up to this many voxels (default: every cell of the grid, capped at 2^31 - 1); max_capacity=0 keeps the capacity fixed.
         deferred_fuse: frame-by-frame calls take ONE launch each (avl_builder_set_deferred_fuse): the features of a frame are
-        read by the NEXT call's launch, so this object keeps them alive until then; same map (ids / colour / weight identical,
-        features equal up to the summation order inside a voxel's per-launch list, like two runs of any mode)."""
+        read by the NEXT call's launch, so this object keeps them alive until then; same map, bit for bit (K3 sums a voxel's
+        samples in ascending sample order in either mode)."""
         lib = _lib.load()
         _lib.require_gpu()
         self.gs, self.cs, self.vh, self.D = int(gs), float(cs), int(vh), int(D)

@@ -182,9 +182,9 @@ AVL_API int avl_builder_capacity(avl_builder* b, int64_t* h_capacity);
 /* Deferred fuse: frame-by-frame integration in ONE launch per frame instead of two dependent ones.  With on != 0,
  * avl_builder_integrate_frame / _frame_global run the geometry + list linking of the frame they are given next to the feature
  * fusion of the PREVIOUS frame (disjoint state, same kernel); the frame's own fusion rides in the next call's launch or in
- * avl_builder_flush.  The map that results is the same (ids, colour, weight identical; features equal up to the order in which
- * the samples of one voxel are summed inside one launch, the guarantee two runs of any mode have).  What changes for the
- * caller: the d_feat buffer of a
+ * avl_builder_flush.  The map that results is the same, bit for bit (the samples of a voxel are summed in ascending sample
+ * order in either mode; only a voxel that receives more than 64 samples in ONE launch may differ in the last feature bit, as
+ * it may between two runs of any mode).  What changes for the caller: the d_feat buffer of a
  * frame is read by the launch of the NEXT integrate / flush / finalize / num_* / export call, so it must stay valid and
  * unmodified until that call has been enqueued (all on one stream).  d_depth, d_sample_idx and d_rgb are consumed by the
  * call they are passed to, as before.  Every entry point that reads the map flushes first; batched calls flush and then run

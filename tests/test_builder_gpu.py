@@ -416,9 +416,8 @@ def test_batched_fusion_equals_frame_by_frame(ops, golden, batch):
 
 
 def _same_map(a, b):
-    """ids, colour and weight identical; features identical up to the order in which the samples of ONE voxel are summed inside
-    ONE launch (the list order is the arrival order of the atomics): fp64 sums rounded once to float32, i.e. what two runs of the
-    same mode guarantee each other (test_builder_vs_sequential_oracle_medium) -- a randomised sweep saw one differing map in 10 000"""
+    """ids, colour and weight identical; features identical too unless a voxel got more than 64 samples in one launch (K3 orders
+    up to 64 members of a list by sample index; the rest is summed in arrival order) -- then equal to fp64 summation order"""
     for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
         assert np.array_equal(a[k], b[k]), k
     assert np.mean(a["grid_feat"] == b["grid_feat"]) > 0.9999
@@ -442,6 +441,30 @@ def test_deferred_fuse_is_the_same_map(ops, golden, name):
             assert acc.num_groups() == ref.num_groups()
             _same_map(acc.finalize(), ref.finalize())
     assert np.array_equal(acc.finalize()["grid_pos"], g["grid_pos"])
+
+
+def test_builder_is_bitwise_reproducible(ops):
+    """K3 sums the samples of a voxel in ascending sample order (up to 64 per voxel and launch), not in the arrival order of
+    their atomics: repeated runs, the deferred mode and the frame-by-frame mode give the same bits in every output"""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(23)
+    H, W, Hf, Wf, D, nfr, rate = 90, 120, 44, 59, 512, 6, 3
+    gs, cam_h, cs = 80, 1.6, 0.25
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(9)
+    samples = [O.sample_indices(rs, H * W, rate) for _ in range(nfr)]
+    runs = []
+    for deferred in (False, False, True, False, True):
+        acc = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=50_000, replay=True, deferred=deferred)
+        runs.append(acc.finalize())
+        pts, groups = acc.num_points(), acc.num_groups()
+    assert 2.5 < pts / groups < 30, pts / groups                       # the point of the test: several samples per voxel and frame
+    for r in runs[1:]:
+        for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight", "grid_feat"):
+            assert np.array_equal(r[k], runs[0][k]), k
 
 
 def test_deferred_fuse_heavy_collisions_and_mixed_calls(ops):
