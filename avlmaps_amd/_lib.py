@@ -31,10 +31,13 @@ _SIGS = {
     "avl_stream_sync": (C.c_int, [_vp]),
     "avl_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
     "avl_free": (C.c_int, [_vp]),
+    "avl_host_alloc": (C.c_int, [C.POINTER(_vp), _sz]),
+    "avl_host_free": (C.c_int, [_vp]),
     "avl_memset": (C.c_int, [_vp, C.c_int, _sz, _vp]),
     "avl_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
     "avl_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
     "avl_memcpy_d2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "avl_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "avl_hbm_read_probe": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _vp]),
     "avl_event_create": (C.c_int, [C.POINTER(_vp)]),
     "avl_event_destroy": (C.c_int, [_vp]),

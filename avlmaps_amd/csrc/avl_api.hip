@@ -96,7 +96,7 @@ using namespace avl;
 extern "C" {
 
 const char* avl_last_error(void) { return g_err; }
-int avl_version(void) { return 201; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush added
+int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc
 
 int avl_device_count(int* h_count) {
     AVL_REQUIRE(h_count, "avl_device_count: null output");
@@ -158,6 +158,17 @@ int avl_free(void* d_ptr) {
     return AVL_OK;
 }
 
+int avl_host_alloc(void** h_ptr_out, size_t bytes) {
+    AVL_REQUIRE(h_ptr_out, "avl_host_alloc: null output");
+    AVL_HIP_CHECK(hipHostMalloc(h_ptr_out, bytes ? bytes : 1, hipHostMallocDefault));
+    return AVL_OK;
+}
+
+int avl_host_free(void* h_ptr) {
+    if (h_ptr) AVL_HIP_CHECK(hipHostFree(h_ptr));
+    return AVL_OK;
+}
+
 int avl_memset(void* d_ptr, int value, size_t bytes, void* stream) {
     AVL_HIP_CHECK(hipMemsetAsync(d_ptr, value, bytes, as_stream(stream)));
     return AVL_OK;
@@ -176,6 +187,48 @@ int avl_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream) {
 
 int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream) {
     AVL_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return AVL_OK;
+}
+
+// dst row i = src row rows[i]; one wave per row when rows are 16-byte multiples at 16-byte aligned bases, bytes otherwise
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const uint4* __restrict__ src, int64_t row_u4, const int64_t* __restrict__ rows,
+                                                            int64_t n, uint4* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < n; i += nwaves) {
+        const uint4* s = src + rows[i] * row_u4;
+        uint4* d = dst + i * row_u4;
+        for (int64_t k = lane; k < row_u4; k += 64) d[k] = s[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const unsigned char* __restrict__ src, int64_t row_bytes,
+                                                                const int64_t* __restrict__ rows, int64_t n, unsigned char* __restrict__ dst) {
+    const int64_t total = n * row_bytes;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / row_bytes, k = t - i * row_bytes;
+        dst[t] = src[rows[i] * row_bytes + k];
+    }
+}
+
+int avl_gather_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, void* stream) {
+    AVL_REQUIRE(row_bytes > 0 && n >= 0, "avl_gather_rows: bad shape");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_src && d_rows && d_dst, "avl_gather_rows: null pointer");
+    hipStream_t st = as_stream(stream);
+    const bool wide = row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0;
+    if (wide) {
+        int64_t blocks = (n + 3) / 4;
+        if (blocks > (int64_t)avl::num_cus() * 16) blocks = (int64_t)avl::num_cus() * 16;
+        hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_src), row_bytes / 16,
+                           d_rows, n, reinterpret_cast<uint4*>(d_dst));
+    } else {
+        int64_t blocks = (n * row_bytes + 255) / 256;
+        if (blocks > (int64_t)avl::num_cus() * 16) blocks = (int64_t)avl::num_cus() * 16;
+        hipLaunchKernelGGL(gather_rows_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const unsigned char*>(d_src),
+                           row_bytes, d_rows, n, reinterpret_cast<unsigned char*>(d_dst));
+    }
+    AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
 

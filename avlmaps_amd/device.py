@@ -88,6 +88,41 @@ class DeviceArray:
             pass
 
 
+class PinnedBuffer:
+    """Reusable page-locked host buffer (avl_host_alloc).  view(nbytes-offset, shape, dtype) hands out NumPy arrays that ALIAS
+    it: they are valid until the buffer is reused or freed."""
+
+    def __init__(self):
+        self.ptr, self.nbytes = 0, 0
+
+    def reserve(self, nbytes: int) -> None:
+        if nbytes <= self.nbytes:
+            return
+        self.free()
+        p = C.c_void_p()
+        cap = max(int(nbytes * 1.25), 1 << 20)
+        _lib.check(_lib.load().avl_host_alloc(C.byref(p), cap), "avl_host_alloc")
+        self.ptr, self.nbytes = p.value or 0, cap
+
+    def view(self, offset: int, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        assert offset + n <= self.nbytes
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr + offset)
+        a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        return a
+
+    def free(self) -> None:
+        if self.ptr:
+            try:
+                _lib.load().avl_host_free(self.ptr)
+            except Exception:
+                pass
+            self.ptr, self.nbytes = 0, 0
+
+    __del__ = free
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 

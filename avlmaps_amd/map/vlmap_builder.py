@@ -244,7 +244,7 @@ class VLMapBuilder:
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
-                self._save_3d_map(acc.finalize(want_dirty=self.incremental_checkpoints), mapped_iter_set, background=True)
+                self._checkpoint(acc, mapped_iter_set)
         if acc is None:
             if ws == 1:
                 raise RuntimeError("no frames to map")
@@ -298,7 +298,7 @@ class VLMapBuilder:
 
     def _finish(self, acc, mapped_iter_set, rank, ws, gs, vh):
         if ws == 1:
-            self._save_3d_map(acc.finalize(want_dirty=self.incremental_checkpoints), mapped_iter_set)
+            self._checkpoint(acc, mapped_iter_set, background=False)
             return
         import torch.distributed as dist
         self.merge_timings = {}
@@ -309,18 +309,52 @@ class VLMapBuilder:
             self._save_3d_map({k: v.cpu().numpy() for k, v in fin.items()}, set(i for s in sets for i in s))
         dist.barrier()
 
+    def _checkpoint(self, acc, mapped_iter_set, background: bool = True) -> None:
+        """Save while frames keep coming (and the final save of a single-process run).  After the first full write only the rows
+        that changed and the new rows cross PCIe (VoxelAccumulator.finalize_rows -> MapFileWriter.save_packed, which patches its
+        host mirror of the map and the file): at 2 M voxels a full copy costs 0.3-0.5 s on this thread, as much as the feature
+        extractor needs for the 100 frames between two checkpoints."""
+        from ..utils import h5lite
+        self._join_save()
+        writer = getattr(self, "_map_writer", None)
+        lean_ok = (self.incremental_checkpoints and h5lite.available() and writer is not None and writer.n_saved is not None
+                   and writer.mirror is not None and writer.path == Path(self.map_save_path) and writer.path.exists())
+        if not lean_ok:
+            self._save_3d_map(acc.finalize(want_dirty=self.incremental_checkpoints), mapped_iter_set, background=background)
+            return
+        lean = acc.finalize_rows(writer.n_saved)
+        iters = list(mapped_iter_set)
+
+        def write():
+            try:
+                writer.save_packed(lean, iters)
+            except BaseException as e:
+                self._save_error = e
+        if background and self.prefetch_frames:
+            import threading
+            self._save_error = None
+            self._save_thread = threading.Thread(target=write, name="avl-save", daemon=False)
+            self._save_thread.start()
+        else:
+            write()
+            self._join_save()
+            self.last_map = writer.current_map()
+
+    def _join_save(self) -> None:
+        prev = getattr(self, "_save_thread", None)
+        if prev is not None:
+            prev.join()
+            self._save_thread = None
+        if getattr(self, "_save_error", None) is not None:
+            err, self._save_error = self._save_error, None
+            raise err
+
     def _save_3d_map(self, arrays, mapped_iter_set, background: bool = False) -> None:
         """Reference: vlmap_builder.py:313-327 -> mapping_utils.save_3d_map.  The periodic checkpoints (every
         `save_every` frames upstream rewrites the whole file) are written by a host thread while fusion continues; the
         final save, and any save that follows an unfinished one, waits."""
         self.last_map = arrays
-        prev = getattr(self, "_save_thread", None)
-        if prev is not None:
-            prev.join()
-            self._save_thread = None
-            if getattr(self, "_save_error", None) is not None:
-                err, self._save_error = self._save_error, None
-                raise err
+        self._join_save()
         iters = list(mapped_iter_set)
 
         writer = getattr(self, "_map_writer", None)

@@ -137,8 +137,9 @@ class MapFileWriter:
                          # more calls than this -- worst case (dirty rows everywhere) it degenerates to one full rewrite
 
     @classmethod
-    def row_runs(cls, dirty_old: np.ndarray, n_old: int, n: int):
-        """[(r0, r1)] covering every dirty row below n_old and all rows [n_old, n), at most MAX_RUNS runs"""
+    def row_runs(cls, dirty_old: np.ndarray, n_old: int, n: int, max_runs=None):
+        """[(r0, r1)] covering every dirty row below n_old and all rows [n_old, n), at most max_runs (default MAX_RUNS) runs"""
+        max_runs = cls.MAX_RUNS if max_runs is None else int(max_runs)
         d = np.flatnonzero(dirty_old)
         starts, ends = [], []
         if d.size:
@@ -152,9 +153,9 @@ class MapFileWriter:
         elif n > n_old:
             starts, ends = np.array([n_old]), np.array([n])
         starts, ends = np.asarray(starts, dtype=np.int64), np.asarray(ends, dtype=np.int64)
-        if starts.size > cls.MAX_RUNS:
+        if starts.size > max_runs:
             gaps = starts[1:] - ends[:-1]
-            thr = np.partition(gaps, starts.size - cls.MAX_RUNS)[starts.size - cls.MAX_RUNS]     # merge every gap <= thr
+            thr = np.partition(gaps, starts.size - max_runs)[starts.size - max_runs]     # merge every gap <= thr
             keep = np.concatenate([[True], gaps > thr])
             starts = starts[keep]
             ends = np.concatenate([ends[:-1][keep[1:]], ends[-1:]])
@@ -164,6 +165,9 @@ class MapFileWriter:
         self.path = Path(path)
         self.n_saved = None          # rows in the file, None = nothing written by this writer yet
         self.stats = []              # per save: dict(mode, rows_written, rows_total)
+        self.mirror = None           # host copy of the per-voxel datasets as last saved (adopted from a full save, patched by
+                                     # save_packed): what lets a checkpoint ship only its changed rows across PCIe
+        self._occ_shape = None
 
     def save(self, arrays, mapped_iter_list, row_dirty=None) -> None:
         n = int(arrays["grid_pos"].shape[0])
@@ -185,9 +189,10 @@ class MapFileWriter:
                 f.create_dataset("occupied_ids", data=np.asarray(arrays["occupied_ids"]))
             self.stats.append(dict(mode="full", rows_written=n, rows_total=n))
             self.n_saved = n
+            self._adopt(arrays)
             return
         n_old = self.n_saved
-        runs = self.row_runs(np.asarray(row_dirty[:n_old]), n_old, n)
+        runs = self.row_runs(np.asarray(row_dirty[:n_old]), n_old, n, self.MAX_RUNS)
         with h5lite.H5File(self.path, "r+") as f:
             for k in self.ROW_SETS:
                 f.resize(k, n)
@@ -199,6 +204,58 @@ class MapFileWriter:
         self.stats.append(dict(mode="incremental", rows_written=int(sum(b - a for a, b in runs)), rows_total=n,
                                rows_dirty=int(np.count_nonzero(row_dirty[:n_old])) + n - n_old, runs=len(runs)))
         self.n_saved = n
+        self._adopt(arrays)
+
+    def _adopt(self, arrays) -> None:
+        """the arrays of a save that had the whole map on the host become the mirror (no copy)"""
+        self.mirror = {k: np.asarray(arrays[k]) for k in self.ROW_SETS}
+        self._occ_shape = tuple(np.asarray(arrays["occupied_ids"]).shape)
+
+
+    def save_packed(self, lean, mapped_iter_list) -> None:
+        """incremental save from VoxelAccumulator.finalize_rows(self.n_saved): only the changed and the new rows reached the
+        host.  They are folded into the writer's host mirror of the map (the arrays of the last full save: what the reference
+        keeps as its working state), and the file is patched from the mirror in at most MAX_RUNS contiguous runs."""
+        n, idx, rows = int(lean["n"]), np.asarray(lean["idx"], dtype=np.int64), lean["rows"]
+        n_old = self.n_saved
+        if n_old is None or self.mirror is None or not h5lite.available() or n < n_old or not self.path.exists():
+            raise RuntimeError("MapFileWriter.save_packed needs a file this writer has already written in full")
+        if int(lean.get("n_saved", n_old)) != n_old:
+            raise RuntimeError(f"finalize_rows was called for {lean.get('n_saved')} saved rows, the file holds {n_old}")
+        iters = np.array(sorted(mapped_iter_list), dtype=np.int32)
+        for k in self.ROW_SETS:
+            m = self.mirror[k]
+            if n > m.shape[0]:                               # grow like the reference's arrays: double, copy once
+                grown = np.empty((max(n, 2 * m.shape[0]),) + m.shape[1:], m.dtype)
+                grown[:n_old] = m[:n_old]
+                m = self.mirror[k] = grown
+            m[idx] = rows[k]
+        dirty = np.zeros(n_old, np.uint8)
+        dirty[idx[idx < n_old]] = 1
+        runs = self.row_runs(dirty, n_old, n, self.MAX_RUNS)
+        with h5lite.H5File(self.path, "r+") as f:
+            for k in self.ROW_SETS:
+                f.resize(k, n)
+                f.write_row_runs(k, runs, self.mirror[k][:n])
+            if n > n_old:
+                f.write_points("occupied_ids", self.mirror["grid_pos"][n_old:n], np.arange(n_old, n, dtype=np.int32))
+            f.resize("mapped_iter_list", len(iters))
+            f.write_rows("mapped_iter_list", 0, iters)
+        self.stats.append(dict(mode="incremental", rows_written=int(sum(b - a for a, b in runs)), rows_total=n, rows_dirty=int(idx.size),
+                               runs=len(runs), host_bytes=int(sum(np.asarray(v).nbytes for v in rows.values()))))
+        self.n_saved = n
+
+    def current_map(self):
+        """the writer's host mirror as the dict a full finalize() returns (views of n_saved rows; occupied_ids rebuilt)"""
+        if self.mirror is None or self.n_saved is None:
+            return None
+        n = self.n_saved
+        out = {k: self.mirror[k][:n] for k in self.ROW_SETS}
+        occ = -np.ones(self._occ_shape, np.int32)
+        gp = out["grid_pos"]
+        occ[gp[:, 0], gp[:, 1], gp[:, 2]] = np.arange(n, dtype=np.int32)
+        out["occupied_ids"] = occ
+        return out
 
 
 def map_file_exists(map_path) -> bool:

@@ -53,10 +53,18 @@ AVL_API int avl_stream_sync(void* stream);
 /* device memory helpers so that hosts without a GPU array library can drive the ABI */
 AVL_API int avl_malloc(void** h_ptr_out, size_t bytes);
 AVL_API int avl_free(void* d_ptr);
+/* page-locked host memory (hipHostMalloc): device-to-host copies into it run at PCIe rate (~50 GB/s) instead of the ~6 GB/s of a
+ * pageable destination; used as the staging buffer of the checkpoint rows */
+AVL_API int avl_host_alloc(void** h_ptr_out, size_t bytes);
+AVL_API int avl_host_free(void* h_ptr);
 AVL_API int avl_memset(void* d_ptr, int value, size_t bytes, void* stream);
 AVL_API int avl_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 AVL_API int avl_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
+/* dst row i = src row d_rows[i] (rows of row_bytes bytes, int64 indices): packs the rows an incremental checkpoint has to
+ * write (the changed and the new voxels, avl_builder_finalize_ex's d_row_dirty) so that only they cross PCIe -- the reference
+ * rewrites the whole map file every 100 frames (vlmap_builder.py:180-183). */
+AVL_API int avl_gather_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, void* stream);
 /* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32.
  * pattern bit 0: 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk;
  * pattern bit 1: 0 = best GB/s of `iters` individually synchronised passes (burst rate),

@@ -443,6 +443,39 @@ def test_deferred_fuse_is_the_same_map(ops, golden, name):
     assert np.array_equal(acc.finalize()["grid_pos"], g["grid_pos"])
 
 
+def test_finalize_rows_ships_only_changed_and_new_rows(ops, golden):
+    """lean checkpoint transfer: after a checkpoint at frame k, finalize_rows(n_saved) brings over exactly the rows fused since
+    plus the new rows (device gather into a page-locked staging buffer) and they equal the full finalisation"""
+    from oracle import avl_oracle as O
+    g = golden("g2b_builder_growth.npz")
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    D = g["feats"].shape[1]
+    acc = ops.VoxelAccumulator(int(g["gs"]), float(g["cs"]), int(float(g["camera_height"]) / float(g["cs"])), D, capacity=64)
+    acc.enable_replay_log(sum(len(x) for x in g["samples"]))
+    nfr = len(g["depths"])
+    fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in g["feats"]]
+    half = nfr // 2
+    for i in range(half):
+        acc.integrate_frame(g["depths"][i], g["calib"], Ts[i], g["samples"][i], fs[i], g["rgbs"][i], frame_idx=i)
+    first = acc.finalize(want_dirty=True)
+    n0 = len(first["grid_pos"])
+    assert first["row_dirty"].all()
+    assert len(acc.finalize_rows(n0)["idx"]) == 0                                   # nothing fused since
+    for i in range(half, nfr):
+        acc.integrate_frame(g["depths"][i], g["calib"], Ts[i], g["samples"][i], fs[i], g["rgbs"][i], frame_idx=i)
+    lean = acc.finalize_rows(n0)
+    rows = {k: v.copy() for k, v in lean["rows"].items()}                           # they alias the staging buffer
+    full = acc.finalize()
+    n = lean["n"]
+    assert n == len(full["grid_pos"]) == int(g["max_id"]) and np.array_equal(lean["idx"][-(n - n0):], np.arange(n0, n))
+    changed = np.zeros(n, bool)
+    changed[lean["idx"]] = True
+    for k in ("grid_feat", "grid_pos", "weight", "grid_rgb"):
+        assert np.array_equal(rows[k], full[k][lean["idx"]]), k
+        assert np.array_equal(full[k][:n0][~changed[:n0]], first[k][~changed[:n0]]), k      # rows not shipped did not change
+    assert 0 < changed[:n0].sum() < n0
+
+
 def test_builder_is_bitwise_reproducible(ops):
     """K3 sums the samples of a voxel in ascending sample order (up to 64 per voxel and launch), not in the arrival order of
     their atomics: repeated runs, the deferred mode and the frame-by-frame mode give the same bits in every output"""

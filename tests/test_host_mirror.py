@@ -230,6 +230,34 @@ def test_map_file_writer_incremental_checkpoints(tmp_path):
         cur = new
     assert [s["mode"] for s in w.stats] == ["full", "incremental", "incremental", "incremental"]
     assert w.stats[1]["rows_written"] < 0.6 * w.stats[1]["rows_total"] and w.stats[2]["rows_written"] < 0.5 * 140
+    # the lean form (VoxelAccumulator.finalize_rows): only the changed rows reach the writer; it patches its host mirror of the
+    # map and writes the file from there in coalesced runs
+    new = state(300, 7)
+    keep = np.random.default_rng(77).random(300) < 0.8
+    for k in w.ROW_SETS:
+        new[k][keep] = cur[k][keep]
+    idx = np.flatnonzero(~keep)
+    w.MAX_RUNS, saved_max = 5, w.MAX_RUNS                                  # forces coalescing across small gaps
+    w.save_packed(dict(n=300, n_saved=300, idx=idx, rows={k: new[k][idx] for k in w.ROW_SETS}), set(range(9)))
+    w.MAX_RUNS = saved_max
+    it, gf, gp, wt, occ, rgb = mu.load_3d_map(tmp_path / "vlmaps.h5df")
+    assert it == list(range(9)) and w.stats[-1]["mode"] == "incremental" and w.stats[-1]["runs"] <= 5
+    assert w.stats[-1]["rows_dirty"] == len(idx) <= w.stats[-1]["rows_written"] < 300
+    for a, k in ((gf, "grid_feat"), (gp, "grid_pos"), (wt, "weight"), (occ, "occupied_ids"), (rgb, "grid_rgb")):
+        assert np.array_equal(a, new[k]) and a.dtype == new[k].dtype, k
+    # ... and with appended rows: the mirror grows, the new cells of occupied_ids come from the new grid_pos rows
+    small = {k: v[:280].copy() for k, v in new.items() if k != "occupied_ids"}
+    w.save(dict(small, occupied_ids=state(280, 0)["occupied_ids"]), {0}, None)                     # full rewrite at 280 rows
+    idx = np.array([3, 4, 100] + list(range(280, 300)))
+    w.save_packed(dict(n=300, n_saved=280, idx=idx, rows={k: new[k][idx] for k in w.ROW_SETS}), {0, 1})
+    it, gf, gp, wt, occ, rgb = mu.load_3d_map(tmp_path / "vlmaps.h5df")
+    for a, k in ((gf, "grid_feat"), (gp, "grid_pos"), (wt, "weight"), (occ, "occupied_ids"), (rgb, "grid_rgb")):
+        assert np.array_equal(a, new[k]), k
+    cm = w.current_map()
+    for k in ("grid_feat", "grid_pos", "weight", "grid_rgb", "occupied_ids"):
+        assert np.array_equal(cm[k], new[k]), k
+    with pytest.raises(RuntimeError):
+        w.save_packed(dict(n=300, n_saved=280, idx=idx, rows={k: new[k][idx] for k in w.ROW_SETS}), {0})   # stale n_saved
     # a map that shrank (or no dirty information) falls back to a full rewrite
     w.save(state(50, 9), {0}, None)
     assert w.stats[-1]["mode"] == "full" and len(mu.load_3d_map(tmp_path / "vlmaps.h5df")[2]) == 50
