@@ -28,6 +28,9 @@ def main(argv=None):
     ap.add_argument("--batch-frames", type=int, default=None, help="frames fused per launch pair (default 1)")
     ap.add_argument("--deferred-fuse", action="store_true",
                     help="frame-by-frame fusion in one launch per frame (the extractor must return a new tensor per frame)")
+    ap.add_argument("--pixel-sampling", choices=["reference", "uniform"], default=None,
+                    help="reference = np.random.shuffle on the global RNG like upstream (6 ms per 720x1080 frame, serial); uniform = "
+                         "the same distribution from per-frame generators (0.25 ms, other pixels than a seeded upstream run)")
     ap.add_argument("--shard-sampling", choices=["replay", "independent"], default=None,
                     help="several ranks: replay = sample the pixels of the single-process run (default); independent = do not "
                          "fast-forward the RNG past the other ranks' frames (unseeded runs)")
@@ -42,7 +45,7 @@ def main(argv=None):
         np.random.seed(args.seed)
     extractor = HashFeatureExtractor(args.feat_dim) if args.features == "hash" else None
     avlmap = AVLMap(cfg, data_dir=args.data_dir)
-    if args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling or args.deferred_fuse:
+    if args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling or args.deferred_fuse or args.pixel_sampling:
         import avlmaps_amd.map.vlmap_builder as vb
         orig = vb.VLMapBuilder.__init__
 
@@ -58,6 +61,8 @@ def main(argv=None):
                 self.shard_sampling = args.shard_sampling
             if args.deferred_fuse:
                 self.deferred_fuse = True
+            if args.pixel_sampling:
+                self.pixel_sampling = args.pixel_sampling
         vb.VLMapBuilder.__init__ = patched
     t0 = time.perf_counter()
     avlmap.create_map(args.data_dir, feat_extractor=extractor)

@@ -53,6 +53,13 @@ class VLMapBuilder:
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
         self.incremental_checkpoints = True        # periodic saves write only the rows that changed + the new rows
                                                    # (utils.mapping_utils.MapFileWriter); False = full rewrite like upstream
+        self.pixel_sampling = "reference"          # "reference": np.random.shuffle(arange(H*W))[::rate] on the global RNG, the pixels a
+                                                   # seeded upstream run samples (6 ms per 720x1080 frame, serial by nature: it
+                                                   # caps the pipeline at ~165 frames/s); "uniform": the same distribution -- an
+                                                   # ordered uniform sample without replacement -- from a per-frame generator
+                                                   # seeded by ONE draw of the global RNG and the frame index (0.25 ms; not the
+                                                   # reference's pixels, but reproducible under np.random.seed and independent
+                                                   # of how the frames are sharded over ranks)
         self.shard_sampling = "replay"             # several ranks: "replay" = every rank first consumes the global NumPy RNG
                                                    # exactly as the frames before its shard would have (one discarded shuffle
                                                    # per skipped frame, ~6 ms each at 720x1080), so that a seeded N-rank run
@@ -82,6 +89,13 @@ class VLMapBuilder:
         np.random.shuffle(shuffle_mask)
         return shuffle_mask[::depth_sample_rate].astype(np.int32)
 
+    def _draw_samples(self, frame_i: int, n_pix: int, depth_sample_rate: int) -> np.ndarray:
+        if self.pixel_sampling == "reference":
+            return self.sample_pixels(n_pix, depth_sample_rate)
+        k = (n_pix + depth_sample_rate - 1) // depth_sample_rate
+        gen = np.random.default_rng([self._uniform_seed, int(frame_i)])
+        return gen.choice(n_pix, size=k, replace=False, shuffle=True).astype(np.int32)
+
     @staticmethod
     def skip_pixel_shuffles(n_frames: int, n_pix: int) -> None:
         """Advance the global NumPy RNG as `n_frames` calls of sample_pixels(n_pix, .) would (the draws of a shuffle depend
@@ -105,12 +119,17 @@ class VLMapBuilder:
         draws from np.random while the map is being built (upstream's loop does not).  Pillow, np.load and
         np.random.shuffle release the GIL, so all of this overlaps with the GPU work of the current frame."""
         n = int(self.prefetch_frames or 0)
+        if self.pixel_sampling not in ("reference", "uniform"):
+            raise ValueError(f"pixel_sampling must be 'reference' or 'uniform', not {self.pixel_sampling!r}")
+        if self.pixel_sampling == "uniform":
+            self._uniform_seed = int(np.random.randint(0, 2**31 - 1))     # the one draw from the global RNG (np.random.seed applies)
+            skip_shuffles = 0                                             # per-frame generators: nothing to fast-forward
         if n <= 0 or hi - lo <= 1:
             for i in range(lo, hi):
                 rgb, depth = self.load_frame(i)
                 if i == lo and skip_shuffles:
                     self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
-                yield i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate)
+                yield i, rgb, depth, self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate)
             return
         import queue
         import threading
@@ -139,7 +158,7 @@ class VLMapBuilder:
                     rgb, depth = futs.pop(i).result()
                     if i == lo and skip_shuffles:
                         self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
-                    if not put((i, rgb, depth, self.sample_pixels(depth.shape[0] * depth.shape[1], depth_sample_rate))):
+                    if not put((i, rgb, depth, self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate))):
                         return
                 put(None)
             except BaseException as e:     # surfaced on the consuming thread

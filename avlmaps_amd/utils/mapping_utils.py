@@ -132,6 +132,9 @@ class MapFileWriter:
     (utils/h5lite.py); otherwise every save is a full rewrite through save_3d_map."""
 
     ROW_SETS = ("grid_feat", "grid_pos", "weight", "grid_rgb")
+    FEAT_CHUNK_ROWS = 64  # rows per HDF5 chunk of grid_feat (128 KB at D = 512).  An incremental save only ever writes WHOLE chunks
+                          # of it (from the host mirror): a partial-chunk write makes the library read the chunk first, and with
+                          # the 1 MiB chunks of the first version a checkpoint that changed 20 % of the rows cost twice a full rewrite
     MAX_RUNS = 2048      # one contiguous file write per run and dataset: scattered dirty rows are coalesced across small gaps
                          # (the rows in between are rewritten with their unchanged values) so that a checkpoint never costs
                          # more calls than this -- worst case (dirty rows everywhere) it degenerates to one full rewrite
@@ -167,9 +170,18 @@ class MapFileWriter:
         self.stats = []              # per save: dict(mode, rows_written, rows_total)
         self.mirror = None           # host copy of the per-voxel datasets as last saved (adopted from a full save, patched by
                                      # save_packed): what lets a checkpoint ship only its changed rows across PCIe
-        self._occ_shape = None
+        self.mirror_occ = None       # ... and of occupied_ids
 
     def save(self, arrays, mapped_iter_list, row_dirty=None) -> None:
+        import time
+        t0 = time.perf_counter()
+        try:
+            self._save(arrays, mapped_iter_list, row_dirty)
+        finally:
+            if self.stats:
+                self.stats[-1].setdefault("seconds", time.perf_counter() - t0)
+
+    def _save(self, arrays, mapped_iter_list, row_dirty=None) -> None:
         n = int(arrays["grid_pos"].shape[0])
         iters = np.array(sorted(mapped_iter_list), dtype=np.int32)
         incremental = (h5lite.available() and self.n_saved is not None and row_dirty is not None and n >= self.n_saved
@@ -185,37 +197,68 @@ class MapFileWriter:
                 f.create_dataset("mapped_iter_list", data=iters, maxshape=(None,))
                 for k in self.ROW_SETS:
                     a = np.asarray(arrays[k])
-                    f.create_dataset(k, data=a, maxshape=(None,) + a.shape[1:])
+                    chunks = (self.FEAT_CHUNK_ROWS,) + a.shape[1:] if k == "grid_feat" else None
+                    f.create_dataset(k, data=a, maxshape=(None,) + a.shape[1:], chunks=chunks)
                 f.create_dataset("occupied_ids", data=np.asarray(arrays["occupied_ids"]))
             self.stats.append(dict(mode="full", rows_written=n, rows_total=n))
             self.n_saved = n
             self._adopt(arrays)
             return
         n_old = self.n_saved
-        runs = self.row_runs(np.asarray(row_dirty[:n_old]), n_old, n, self.MAX_RUNS)
-        with h5lite.H5File(self.path, "r+") as f:
-            for k in self.ROW_SETS:
-                f.resize(k, n)
-                f.write_row_runs(k, runs, np.asarray(arrays[k]))
-            new_pos = np.asarray(arrays["grid_pos"])[n_old:n]
-            f.write_points("occupied_ids", new_pos, np.arange(n_old, n, dtype=np.int32))
-            f.resize("mapped_iter_list", len(iters))
-            f.write_rows("mapped_iter_list", 0, iters)
+        runs = self._patch_file(n_old, n, np.asarray(row_dirty[:n_old]), {k: np.asarray(arrays[k]) for k in self.ROW_SETS}, iters)
         self.stats.append(dict(mode="incremental", rows_written=int(sum(b - a for a, b in runs)), rows_total=n,
                                rows_dirty=int(np.count_nonzero(row_dirty[:n_old])) + n - n_old, runs=len(runs)))
         self.n_saved = n
         self._adopt(arrays)
 
+    def _patch_file(self, n_old: int, n: int, dirty_old: np.ndarray, src, iters):
+        """Bring the file from n_old rows to the n rows of `src` (arrays holding the WHOLE current map): grid_feat -- 99 % of the
+        bytes -- is written in runs of whole chunks that contain a changed or new row, the small per-voxel datasets (19 B per voxel
+        together) are rewritten, occupied_ids gets its new cells.  -> the grid_feat runs [(r0, r1)]"""
+        C = self.FEAT_CHUNK_ROWS
+        full_old = n_old // C                                   # chunks that lie completely below the old end of the file
+        cd = np.zeros(full_old, np.uint8)
+        d = np.flatnonzero(dirty_old[: full_old * C])
+        if d.size:
+            cd[np.unique(d // C)] = 1
+        n_chunks = (n + C - 1) // C
+        if n == n_old and not np.any(dirty_old[full_old * C:]):
+            n_chunks = full_old                                 # nothing new and the partial last chunk is clean
+        cruns = self.row_runs(cd, full_old, n_chunks, self.MAX_RUNS)
+        runs = [(a * C, min(b * C, n)) for a, b in cruns]
+        with h5lite.H5File(self.path, "r+") as f:
+            for k in self.ROW_SETS:
+                f.resize(k, n)
+                if k == "grid_feat":
+                    f.write_row_runs(k, runs, src[k][:n])
+                elif n:
+                    f.write_rows(k, 0, src[k][:n])
+            if n > n_old:
+                # the new cells of occupied_ids: whole grid rows (gs * vh cells, contiguous in the file) that contain one, from the
+                # host mirror of the grid -- a point selection of 100 k scattered cells costs seconds in the HDF5 library
+                new_pos = np.asarray(src["grid_pos"][n_old:n])
+                self.mirror_occ[new_pos[:, 0], new_pos[:, 1], new_pos[:, 2]] = np.arange(n_old, n, dtype=np.int32)
+                touched = np.unique(new_pos[:, 0])
+                cut = np.flatnonzero(np.diff(touched) != 1) + 1
+                for a, b in zip(np.concatenate([[0], cut]), np.concatenate([cut, [touched.size]])):
+                    r0, r1 = int(touched[a]), int(touched[b - 1]) + 1
+                    f.write_rows("occupied_ids", r0, self.mirror_occ[r0:r1])
+            f.resize("mapped_iter_list", len(iters))
+            f.write_rows("mapped_iter_list", 0, iters)
+        return runs
+
     def _adopt(self, arrays) -> None:
         """the arrays of a save that had the whole map on the host become the mirror (no copy)"""
         self.mirror = {k: np.asarray(arrays[k]) for k in self.ROW_SETS}
-        self._occ_shape = tuple(np.asarray(arrays["occupied_ids"]).shape)
+        self.mirror_occ = np.asarray(arrays["occupied_ids"])
 
 
     def save_packed(self, lean, mapped_iter_list) -> None:
         """incremental save from VoxelAccumulator.finalize_rows(self.n_saved): only the changed and the new rows reached the
         host.  They are folded into the writer's host mirror of the map (the arrays of the last full save: what the reference
         keeps as its working state), and the file is patched from the mirror in at most MAX_RUNS contiguous runs."""
+        import time
+        t0 = time.perf_counter()
         n, idx, rows = int(lean["n"]), np.asarray(lean["idx"], dtype=np.int64), lean["rows"]
         n_old = self.n_saved
         if n_old is None or self.mirror is None or not h5lite.available() or n < n_old or not self.path.exists():
@@ -232,29 +275,20 @@ class MapFileWriter:
             m[idx] = rows[k]
         dirty = np.zeros(n_old, np.uint8)
         dirty[idx[idx < n_old]] = 1
-        runs = self.row_runs(dirty, n_old, n, self.MAX_RUNS)
-        with h5lite.H5File(self.path, "r+") as f:
-            for k in self.ROW_SETS:
-                f.resize(k, n)
-                f.write_row_runs(k, runs, self.mirror[k][:n])
-            if n > n_old:
-                f.write_points("occupied_ids", self.mirror["grid_pos"][n_old:n], np.arange(n_old, n, dtype=np.int32))
-            f.resize("mapped_iter_list", len(iters))
-            f.write_rows("mapped_iter_list", 0, iters)
+        t_mirror = time.perf_counter() - t0
+        runs = self._patch_file(n_old, n, dirty, self.mirror, iters)
         self.stats.append(dict(mode="incremental", rows_written=int(sum(b - a for a, b in runs)), rows_total=n, rows_dirty=int(idx.size),
-                               runs=len(runs), host_bytes=int(sum(np.asarray(v).nbytes for v in rows.values()))))
+                               runs=len(runs), host_bytes=int(sum(np.asarray(v).nbytes for v in rows.values())),
+                               seconds=time.perf_counter() - t0, mirror_seconds=t_mirror))
         self.n_saved = n
 
     def current_map(self):
-        """the writer's host mirror as the dict a full finalize() returns (views of n_saved rows; occupied_ids rebuilt)"""
+        """the writer's host mirror as the dict a full finalize() returns (views of the n_saved rows)"""
         if self.mirror is None or self.n_saved is None:
             return None
         n = self.n_saved
         out = {k: self.mirror[k][:n] for k in self.ROW_SETS}
-        occ = -np.ones(self._occ_shape, np.int32)
-        gp = out["grid_pos"]
-        occ[gp[:, 0], gp[:, 1], gp[:, 2]] = np.arange(n, dtype=np.int32)
-        out["occupied_ids"] = occ
+        out["occupied_ids"] = self.mirror_occ
         return out
 
 

@@ -60,7 +60,10 @@ def main():
         return feats(rgb)
     b._features_hwc = features_hwc
     b.capacity = 64                                           # forces the accumulators to double a few times
-    b.shard_sampling = sampling
+    if sampling == "uniform":
+        b.pixel_sampling = "uniform"                          # per-frame generators: the sharding does not matter
+    else:
+        b.shard_sampling = sampling
     np.random.seed(seed)                                      # the state the reference run started from, on EVERY rank
     b.create_mobile_base_map()
     if rank == 0:

@@ -84,7 +84,7 @@ def test_incremental_checkpoints_write_the_same_file(golden, tmp_path):
             st = b._map_writer.stats
             assert [s["mode"] for s in st] == ["full", "incremental", "incremental", "incremental"]     # 3 checkpoints + the final save
             assert all(s["rows_written"] <= s["rows_total"] for s in st) and st[-1]["rows_written"] == 0    # nothing fused since
-            assert st[1]["rows_written"] < st[1]["rows_total"]
+            assert st[1]["rows_written"] <= st[1]["rows_total"] and st[1]["rows_dirty"] < st[1]["rows_total"]   # whole 64-row chunks go out
     a, f = files["incremental"], files["full"]
     assert a[0] == f[0] == list(range(len(g["depths"])))
     for x, y, k in zip(a[1:], f[1:], ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")):
@@ -397,6 +397,41 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
         _run_ranks(nproc, [GOLDEN_DIR / name, ind, n_frames, "independent", seed], 29543)
         c = load_3d_map(ind / "vlmap" / "vlmaps.h5df")
         assert not (c[2].shape == a[2].shape and np.array_equal(c[2], a[2]))
+
+
+def test_uniform_pixel_sampling(golden, tmp_path):
+    """pixel_sampling = "uniform": ceil(H*W / rate) distinct pixels per frame from a generator seeded by one draw of the global
+    RNG and the frame index -- reproducible under np.random.seed, other pixels than the reference's shuffle, and the same map
+    whether the frames are built by one rank or by two (no RNG fast-forward needed)"""
+    from avlmaps_amd.utils.mapping_utils import load_3d_map
+    GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+    g = golden("g2a_builder_small.npz")
+    maps = []
+    for rep in range(2):
+        d = tmp_path / f"rep{rep}"
+        d.mkdir()
+        b = MemoryBuilder.make(g, d)
+        b.pixel_sampling = "uniform"
+        drawn = []
+        orig = b._draw_samples
+        b._draw_samples = lambda i, n, r: drawn.append(orig(i, n, r)) or drawn[-1]
+        np.random.seed(1234)
+        b.create_mobile_base_map()
+        maps.append(load_3d_map(d / "vlmap" / "vlmaps.h5df"))
+        H, W = g["depths"][0].shape
+        for s in drawn:
+            assert s.dtype == np.int32 and len(s) == len(g["samples"][0]) == len(set(s.tolist())) and 0 <= s.min() and s.max() < H * W
+    for x, y in zip(maps[0][1:], maps[1][1:]):
+        assert np.array_equal(x, y)                                                   # seeded -> reproducible
+    assert not (maps[0][2].shape == g["grid_pos"].shape and np.array_equal(maps[0][2], g["grid_pos"]))      # not the shuffle's pixels
+    n_frames = len(g["depths"])
+    one, two = tmp_path / "one", tmp_path / "two"
+    _run_ranks(1, [GOLDEN_DIR / "g2a_builder_small.npz", one, n_frames, "uniform", 1234], 29545)
+    _run_ranks(2, [GOLDEN_DIR / "g2a_builder_small.npz", two, n_frames, "uniform", 1234], 29546)
+    a, c = load_3d_map(one / "vlmap" / "vlmaps.h5df"), load_3d_map(two / "vlmap" / "vlmaps.h5df")
+    for i in (2, 3, 4, 5):
+        assert np.array_equal(a[i], c[i]), i
+    np.testing.assert_allclose(c[1], a[1], rtol=1e-6, atol=1e-7)
 
 
 def test_row_sharded_vlmap_indexing(golden, tmp_path):

@@ -212,6 +212,7 @@ def test_map_file_writer_incremental_checkpoints(tmp_path):
                     grid_rgb=r.integers(0, 255, (n, 3)).astype(np.uint8), occupied_ids=occ)
 
     w = mu.MapFileWriter(tmp_path / "vlmaps.h5df")
+    w.FEAT_CHUNK_ROWS = 1                                   # row granularity first; chunk-aligned runs further down
     cur = state(100, 0)
     w.save(cur, {0, 1}, None)
     for step, n in enumerate((140, 140, 300), start=1):
@@ -258,6 +259,25 @@ def test_map_file_writer_incremental_checkpoints(tmp_path):
         assert np.array_equal(cm[k], new[k]), k
     with pytest.raises(RuntimeError):
         w.save_packed(dict(n=300, n_saved=280, idx=idx, rows={k: new[k][idx] for k in w.ROW_SETS}), {0})   # stale n_saved
+    # whole-chunk writes: with 8-row chunks a save only writes runs of complete chunks (the last one may be partial) that contain
+    # a changed or a new row -- and the file is still the complete current map
+    w8 = mu.MapFileWriter(tmp_path / "chunked.h5df")
+    w8.FEAT_CHUNK_ROWS = 8
+    base = state(203, 20)
+    w8.save(base, {0}, None)
+    nxt = state(230, 21)
+    for k in w8.ROW_SETS:
+        nxt[k][:203] = base[k]
+    changed = np.array([5, 6, 90, 201])
+    for k in w8.ROW_SETS:
+        nxt[k][changed] = state(230, 22)[k][changed]
+    w8.save_packed(dict(n=230, n_saved=203, idx=np.concatenate([changed, np.arange(203, 230)]),
+                        rows={k: nxt[k][np.concatenate([changed, np.arange(203, 230)])] for k in w8.ROW_SETS}), {0, 1})
+    st = w8.stats[-1]
+    assert st["rows_written"] == 8 + 8 + (230 - 200) and st["runs"] == 3               # chunks 0, 11 and 25..28 (rows 200..229)
+    got = mu.load_3d_map(tmp_path / "chunked.h5df")
+    for a, k in zip(got[1:], ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb")):
+        assert np.array_equal(a, nxt[k]), k
     # a map that shrank (or no dirty information) falls back to a full rewrite
     w.save(state(50, 9), {0}, None)
     assert w.stats[-1]["mode"] == "full" and len(mu.load_3d_map(tmp_path / "vlmaps.h5df")[2]) == 50
