@@ -96,7 +96,7 @@ using namespace avl;
 extern "C" {
 
 const char* avl_last_error(void) { return g_err; }
-int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc
+int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc, avl_mt19937_skip_shuffles
 
 int avl_device_count(int* h_count) {
     AVL_REQUIRE(h_count, "avl_device_count: null output");
@@ -155,6 +155,82 @@ int avl_malloc(void** h_ptr_out, size_t bytes) {
 
 int avl_free(void* d_ptr) {
     if (d_ptr) AVL_HIP_CHECK(hipFree(d_ptr));
+    return AVL_OK;
+}
+
+// ---- host-only helper: fast-forward NumPy's legacy global RNG past pixel shuffles ------------------------------------------
+// np.random.shuffle(arange(n)) (vlmap_builder.py:275-277) draws, for i = n-1 .. 1, one bounded integer j <= i with the legacy
+// masked-rejection rule (numpy/random/_legacy: random_interval): mask = smallest 2^k - 1 >= i, 32-bit Mersenne-twister outputs
+// are drawn until (x & mask) <= i.  The number of draws is data dependent, so skipping a shuffle means drawing them -- but only
+// drawing: no 6 MB index array is permuted.  A rank of a sharded build uses this to reach the RNG state its first frame has in
+// the single-process run (VLMapBuilder.skip_pixel_shuffles): ~1.7 ms instead of ~7 ms per skipped 720x1080 frame.
+namespace {
+struct Mt19937 {
+    uint32_t* key;   // 624 words, NumPy's layout (np.random.get_state()[1])
+    int pos;         // next word to hand out, 624 = regenerate first
+    void regen() {
+        constexpr uint32_t kUpper = 0x80000000u, kLower = 0x7fffffffu, kMat = 0x9908b0dfu;
+        int i = 0;
+        for (; i < 624 - 397; ++i) {
+            const uint32_t y = (key[i] & kUpper) | (key[i + 1] & kLower);
+            key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1u) ? kMat : 0u);
+        }
+        for (; i < 623; ++i) {
+            const uint32_t y = (key[i] & kUpper) | (key[i + 1] & kLower);
+            key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? kMat : 0u);
+        }
+        const uint32_t y = (key[623] & kUpper) | (key[0] & kLower);
+        key[623] = key[396] ^ (y >> 1) ^ ((y & 1u) ? kMat : 0u);
+        pos = 0;
+    }
+    inline uint32_t next() {
+        if (pos >= 624) regen();
+        uint32_t y = key[pos++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        return y;
+    }
+};
+}  // namespace
+
+int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t n_shuffles) {
+    AVL_REQUIRE(h_key624 && h_pos, "avl_mt19937_skip_shuffles: null state");
+    AVL_REQUIRE(*h_pos >= 0 && *h_pos <= 624 && n_items >= 0 && n_shuffles >= 0, "avl_mt19937_skip_shuffles: bad arguments");
+    AVL_REQUIRE(n_items <= 0xffffffffll, "avl_mt19937_skip_shuffles: arrays beyond 2^32 items draw 64-bit integers (not implemented)");
+    Mt19937 g{h_key624, *h_pos};
+    uint32_t out[624];                       // tempered outputs of the current state block (filled in one vectorisable sweep)
+    auto temper_block = [&]() {
+        for (int k = 0; k < 624; ++k) {
+            uint32_t y = g.key[k];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            out[k] = y;
+        }
+    };
+    if (g.pos < 624) temper_block();
+    for (int64_t s = 0; s < n_shuffles; ++s) {
+        uint32_t mask = 0;
+        if (n_items >= 2) {
+            mask = (uint32_t)(n_items - 1);
+            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        }
+        for (uint32_t i = (uint32_t)(n_items > 0 ? n_items - 1 : 0); i >= 1; --i) {
+            if (i <= (mask >> 1)) mask >>= 1;             // smallest 2^k - 1 >= i, tracked instead of recomputed
+            uint32_t x;
+            do {
+                if (g.pos >= 624) {
+                    g.regen();
+                    temper_block();
+                }
+                x = out[g.pos++] & mask;
+            } while (x > i);
+        }
+    }
+    *h_pos = g.pos;
     return AVL_OK;
 }
 

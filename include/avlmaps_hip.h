@@ -55,6 +55,11 @@ AVL_API int avl_malloc(void** h_ptr_out, size_t bytes);
 AVL_API int avl_free(void* d_ptr);
 /* page-locked host memory (hipHostMalloc): device-to-host copies into it run at PCIe rate (~50 GB/s) instead of the ~6 GB/s of a
  * pageable destination; used as the staging buffer of the checkpoint rows */
+/* Host only (no GPU needed): advance a NumPy legacy Mersenne-twister state (np.random.get_state(): key[624], pos) as n_shuffles
+ * calls of np.random.shuffle on an array of n_items elements would (vlmap_builder.py:275-277 shuffles arange(H*W) once per
+ * frame) -- the draws only, nothing is permuted.  A rank of a sharded build fast-forwards past the frames of the ranks before
+ * it with this, so that a seeded N-rank run samples the pixels of the seeded single-process run. */
+AVL_API int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t n_shuffles);
 AVL_API int avl_host_alloc(void** h_ptr_out, size_t bytes);
 AVL_API int avl_host_free(void* h_ptr);
 AVL_API int avl_memset(void* d_ptr, int value, size_t bytes, void* stream);
