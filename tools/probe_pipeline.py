@@ -28,8 +28,9 @@ cfg = Cfg(map_type="vlmap", grid_size=1000, cell_size=0.05, depth_sample_rate=10
           pose_info=Cfg(pose_type="mobile_base", camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1],
                         base_forward_axis=[0, 0, -1], base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0]))
 CASES = (("reference", False, 100), ("uniform", False, 100), ("uniform", True, 100), ("reference", False, 0), ("uniform", True, 0))
-if os.environ.get("PROBE_ONLY"):
-    CASES = tuple(c for c in CASES if c[0] == os.environ["PROBE_ONLY"] and not c[1])
+if os.environ.get("PROBE_CASE"):                      # e.g. PROBE_CASE=uniform,1,0 = sampling, deferred fuse, save_every
+    a, b_, c_ = os.environ["PROBE_CASE"].split(",")
+    CASES = ((a, bool(int(b_)), int(c_)),)
 for sampling, deferred, save_every in CASES:
     with tempfile.TemporaryDirectory() as tmp:
         tmp = Path(tmp)
