@@ -527,6 +527,53 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     return res
 
 
+def run_pipeline_probe(torch, frames=300):
+    """The product's whole host + device pipeline (VLMapBuilder.create_mobile_base_map: frame queue, pixel sampling, host-to-device
+    copies, the kernels, checkpoints every 100 frames through the incremental HDF5 writer) around a FREE feature extractor, single
+    process: what the pipeline itself sustains.  Reference pixel sampling is one serial np.random.shuffle of H*W indices per frame."""
+    import tempfile
+    from pathlib import Path
+    from avlmaps_amd.map.map import Map
+    from avlmaps_amd.map.vlmap_builder import VLMapBuilder
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    H, W, Hf, Wf, D, nbuf = 720, 1080, 347, 520, 512, 4
+    depths, rgbs, feats = make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=7)
+    depths_h, rgbs_h = [d.cpu().numpy() for d in depths], [r.cpu().numpy() for r in rgbs]
+    cfg = Cfg(map_type="vlmap", grid_size=1000, cell_size=0.05, depth_sample_rate=100, cam_calib_mat=[540, 0, 540, 0, 540, 360, 0, 0, 1],
+              pose_info=Cfg(pose_type="mobile_base", camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1],
+                            base_forward_axis=[0, 0, -1], base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0]))
+    res = {}
+    for sampling in ("reference", "uniform"):
+        with tempfile.TemporaryDirectory() as tmp:
+            tmp = Path(tmp)
+            m = Map(cfg)
+            np.savetxt(tmp / "poses.txt", trajectory(frames))
+            k = [0]
+
+            def extractor(rgb):
+                k[0] += 1
+                return feats[k[0] % nbuf]
+            b = VLMapBuilder(tmp, cfg, tmp / "poses.txt", [None] * frames, [None] * frames, m.base2cam_tf, m.base_transform,
+                             feat_extractor=extractor)
+            b.load_frame = lambda i: (rgbs_h[i % nbuf], depths_h[i % nbuf])
+            b.pixel_sampling = sampling
+            np.random.seed(0)
+            import contextlib
+            import io
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):          # "Temporarily saving ..." lines of the checkpoints
+                b.create_mobile_base_map()
+            dt = time.perf_counter() - t0
+            res[f"{sampling}_pixel_sampling"] = dict(frames_per_s=frames / dt, ms_per_frame=1e3 * dt / frames,
+                                                     voxels=int(len(b.last_map["grid_pos"])), checkpoints=len(b._map_writer.stats))
+    res["what"] = (f"VLMapBuilder.create_mobile_base_map over {frames} in-memory 720x1080 frames, free feature extractor, checkpoints every "
+                   "100 frames, one process; reference sampling = np.random.shuffle(arange(H*W)) per frame on the global RNG (serial)")
+    return res
+
+
 def run_build(args, torch, dist, lib, rank, ws):
     r = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.steps, warmup=args.warmup, batch=args.build_batch,
                        exact_rgb=not args.no_exact_rgb, feature_standin=args.feature_standin, deferred=args.deferred_fuse)
@@ -656,6 +703,8 @@ def main():
                 out.setdefault("extra", {})["map_build_strong"] = r1
                 out["extra"]["map_build_strong_deferred_fuse"] = r1d      # frame by frame, ONE launch per frame
                 out["extra"]["map_build_strong_batched64"] = r64
+                if ws == 1:
+                    out["extra"]["vlmapbuilder_pipeline"] = run_pipeline_probe(torch)
         except Exception as e:   # the extra must never break the benchmark line
             if rank == 0:
                 out.setdefault("extra", {})["map_build_strong"] = dict(error=repr(e))
