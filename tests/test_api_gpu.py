@@ -493,6 +493,6 @@ def test_randomised_parity_sweep():
     2 x 2 699 cases were clean at the end of round 2)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "2", "120"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "120", "2", "80"], capture_output=True, text=True,
                        timeout=300, cwd=root)
     assert r.returncode == 0 and "0 failures" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

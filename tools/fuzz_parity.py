@@ -1,6 +1,7 @@
 """GPU box: randomised parity sweep (time-boxed).  fuzz_parity.py [seconds] [seed] [max cases per kind]
   sim:     random N / D / Q / row strides / precision modes / column windows / prepared maps against float64 NumPy
   builder: random frame shapes / grids / widths / sample rates, frame-by-frame vs deferred vs batched vs the sequential oracle
+  aux:     heat decay, argmax / top-k, pool_3d_label_to_2d, rgb top-down, obstacle map on random maps against the oracle (bit exact)
 Prints one line per failure with the configuration that reproduces it; exit status 1 if anything failed."""
 import os
 import sys
@@ -151,17 +152,59 @@ def builder_case(i):
             fails.append((dict(cfg, mode="deferred-vs-frames"), "grid_feat differs beyond fp64 summation order"))
 
 
+def aux_case(i):
+    gs = int(rng.choice([16, 50, 128, 300]))
+    vh = int(rng.choice([4, 12, 30]))
+    ncell = gs * gs * vh
+    N = int(min(ncell, rng.choice([1, 5, 64, 1000, 20000])))
+    cells = rng.choice(ncell, size=N, replace=False)
+    pos = np.stack([cells // (gs * vh), (cells // vh) % gs, cells % vh], 1).astype(np.int32)
+    cfg = dict(kind="aux", i=i, gs=gs, vh=vh, N=N)
+    mask = rng.random(N) < float(rng.choice([0.001, 0.05, 0.5] if N <= 1000 else [0.001, 0.02]))   # the oracle's heat is O(N * targets)
+    if not mask.any():
+        mask[int(rng.integers(0, N))] = True
+    cs, decay = float(rng.choice([0.05, 0.1])), float(rng.choice([0.01, 0.05, 0.3]))
+    heat = ops.heatmap_from_mask(pos, mask, cs, decay)
+    heat = heat.numpy() if not isinstance(heat, np.ndarray) else heat
+    if not np.array_equal(heat, O.heatmap_from_mask(pos, mask, cs, decay)):
+        fails.append((cfg, "heat differs"))
+    idx, val = ops.argmax_f32(heat)
+    if idx != int(np.argmax(heat)) or val != heat[idx]:
+        fails.append((cfg, "argmax_f32 differs"))
+    vals = rng.standard_normal(N).astype(np.float32)
+    vals[rng.integers(0, N, size=max(1, N // 10))] = vals[0]                  # ties
+    k = int(min(N, rng.choice([1, 3, 17, 64, 100])))
+    ti, tv = ops.topk_f32(vals, k)
+    order = np.argsort(-vals, kind="stable")[:k]
+    if not (np.array_equal(np.asarray(ti), order) and np.array_equal(np.asarray(tv), vals[order])):
+        fails.append((cfg, f"topk k={k} differs"))
+    if not np.array_equal(np.asarray(ops.pool_label_2d(mask, pos, gs)), O.pool_3d_label_to_2d(mask, pos, gs)):
+        fails.append((cfg, "pool_label_2d differs"))
+    rgb = rng.integers(0, 256, (N, 3), dtype=np.uint8)
+    if not np.array_equal(np.asarray(ops.rgb_topdown(pos, rgb, gs)), O.rgb_topdown(pos, rgb, gs)):
+        fails.append((cfg, "rgb_topdown differs"))
+    occ = -np.ones((gs, gs, vh), np.int32)
+    occ[pos[:, 0], pos[:, 1], pos[:, 2]] = np.arange(N, dtype=np.int32)
+    h_min, h_max = float(rng.choice([0.0, 0.1, -1.0])), float(rng.choice([0.3, 1.5, 100.0]))
+    if not np.array_equal(np.asarray(ops.obstacle_map(occ, cs, h_min, h_max)), O.obstacle_map(occ, cs, h_min, h_max)):
+        fails.append((cfg, "obstacle_map differs"))
+
+
 t0 = time.time()
-n_sim = n_b = 0
+n_sim = n_b = n_aux = 0
 while time.time() - t0 < budget and n_b < max_cases:
     before = len(fails)
-    if (n_sim + n_b) % 2 == 0:
+    which = (n_sim + n_b + n_aux) % 3
+    if which == 0:
         sim_case(n_sim)
         n_sim += 1
-    else:
+    elif which == 1:
         builder_case(n_b)
         n_b += 1
+    else:
+        aux_case(n_aux)
+        n_aux += 1
     for cfg, msg in fails[before:]:
         print("FAIL", cfg, msg, flush=True)
-print(f"fuzz: {n_sim} similarity cases, {n_b} builder cases, {len(fails)} failures, seed {seed}")
+print(f"fuzz: {n_sim} similarity cases, {n_b} builder cases, {n_aux} auxiliary cases, {len(fails)} failures, seed {seed}")
 sys.exit(1 if fails else 0)
