@@ -24,6 +24,7 @@ _SIGS = {
     "avl_version": (C.c_int, []),
     "avl_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "avl_set_device": (C.c_int, [C.c_int]),
+    "avl_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "avl_device_name": (C.c_int, [C.c_int, C.c_char_p, _sz]),
     "avl_device_sync": (C.c_int, []),
     "avl_stream_create": (C.c_int, [C.POINTER(_vp)]),

@@ -111,6 +111,12 @@ int avl_device_count(int* h_count) {
     return AVL_OK;
 }
 
+int avl_get_device(int* h_device) {
+    AVL_REQUIRE(h_device, "avl_get_device: null output");
+    AVL_HIP_CHECK(hipGetDevice(h_device));
+    return AVL_OK;
+}
+
 int avl_set_device(int device) {
     AVL_HIP_CHECK(hipSetDevice(device));
     return AVL_OK;

@@ -20,6 +20,7 @@ _POOL: dict = {}
 _POOL_BYTES = [0]
 _POOL_LIMIT = 2 << 30
 _POOL_MAX_ITEM = 256 << 20
+_H2D_PIECE = 64 << 20
 
 
 def _pool_alloc(nbytes: int) -> int:
@@ -62,8 +63,12 @@ class DeviceArray:
         a = np.ascontiguousarray(a)
         d = cls(a.shape, a.dtype)
         if a.nbytes:
-            _lib.check(_lib.load().avl_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes, stream), "avl_memcpy_h2d")
-            _lib.check(_lib.load().avl_stream_sync(stream), "avl_stream_sync")   # source may be a temporary
+            lib, src = _lib.load(), a.ctypes.data
+            # in pieces: one pageable copy of several GB keeps the process's memory map locked while its pages are pinned, which
+            # stalls every other thread of the process that allocates or frees (seen: 0.8 s of a map upload on a worker thread)
+            for off in range(0, a.nbytes, _H2D_PIECE):
+                _lib.check(lib.avl_memcpy_h2d(d.ptr + off, src + off, min(_H2D_PIECE, a.nbytes - off), stream), "avl_memcpy_h2d")
+            _lib.check(lib.avl_stream_sync(stream), "avl_stream_sync")   # source may be a temporary
         return d
 
     def zero_(self, stream=None):

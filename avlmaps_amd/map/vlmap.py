@@ -17,6 +17,18 @@ CLIP_FEAT_DIM = {"RN50": 1024, "RN101": 512, "RN50x4": 640, "RN50x16": 768, "RN5
                  "ViT-B/16": 512, "ViT-L/14": 768}
 
 
+_UPLOADS = []       # map-upload threads still running: joined at interpreter exit so that the process never tears HIP down mid-copy
+
+
+def _join_uploads():
+    for th in list(_UPLOADS):
+        th.join(timeout=30)
+
+
+import atexit  # noqa: E402
+atexit.register(_join_uploads)
+
+
 class VLMap(Map):
     def __init__(self, map_config, data_dir: str = ""):
         super().__init__(map_config, data_dir=data_dir)
@@ -24,6 +36,11 @@ class VLMap(Map):
         self.categories = None
         self._dev_feat = None
         self._dev_feat_src = None
+        import threading
+        self._dev_lock = threading.RLock()
+        self.prefetch_device = True       # load_map starts the one-off upload + conversion of grid_feat (1.1 s at 2 M voxels: 4 GB over
+                                          # PCIe from pageable memory) on a host thread, so that it overlaps with whatever the
+                                          # caller does next (upstream: loading CLIP, seconds) instead of sitting in the first query
         self.shard_index_rows = True      # with torch.distributed initialised (one process per GPU) every rank keeps and scores
                                           # only its block of voxel rows; the per-voxel results are all-gathered (parallel.gather_rows)
 
@@ -51,7 +68,37 @@ class VLMap(Map):
         (self.mapped_iter_list, self.grid_feat, self.grid_pos, self.weight, self.occupied_ids,
          self.grid_rgb) = load_3d_map(self.map_save_path)[:6]
         self._dev_feat = None
+        self._start_device_prefetch()
         return True
+
+    def _start_device_prefetch(self) -> None:
+        if not self.prefetch_device or self.grid_feat is None or len(self.grid_feat) == 0:
+            return
+        import sys
+        import threading
+        # the device the CALLING thread works on (HIP keeps the current device per thread).  Asking HIP itself would initialise the
+        # runtime right here (~0.8 s): torch knows it if it has initialised the GPU, otherwise nothing has selected a device yet
+        dev = 0
+        t = sys.modules.get("torch")
+        try:
+            if t is not None and t.cuda.is_initialized():
+                dev = int(t.cuda.current_device())
+        except Exception:
+            dev = 0
+
+        def work():
+            try:
+                from .. import _lib
+                lib = _lib.load()
+                _lib.require_gpu()                                         # first HIP call of the process: runtime start-up
+                _lib.check(lib.avl_set_device(dev), "avl_set_device")
+                self._device_feat()
+            except Exception:             # no GPU / no library / upload failed: the query path repeats it on the calling thread
+                pass                      # and reports the error there
+        th = threading.Thread(target=work, name="avl-map-upload", daemon=True)
+        th.start()
+        _UPLOADS.append(th)
+        del _UPLOADS[:-8]
 
     def _init_clip(self, clip_version="ViT-B/32"):
         """Reference: vlmap.py:67-90."""
@@ -76,6 +123,10 @@ class VLMap(Map):
         self._sim_precision tells the kernels which form it has."""
         from .. import ops, parallel
         from ..device import DeviceArray
+        with self._dev_lock:
+            return self._device_feat_locked(ops, parallel, DeviceArray)
+
+    def _device_feat_locked(self, ops, parallel, DeviceArray):
         if self._dev_feat is None or self._dev_feat_src is not self.grid_feat:
             rank, ws = parallel.rank_world()
             self._rows = (0, len(self.grid_feat))

@@ -45,6 +45,7 @@ AVL_API const char* avl_last_error(void);
 AVL_API int avl_version(void);                       /* major*10000 + minor*100 + patch */
 AVL_API int avl_device_count(int* h_count);
 AVL_API int avl_set_device(int device);
+AVL_API int avl_get_device(int* h_device);           /* the calling THREAD's current device (HIP keeps it per thread) */
 AVL_API int avl_device_name(int device, char* h_buf, size_t buf_len);
 AVL_API int avl_device_sync(void);
 AVL_API int avl_stream_create(void** h_stream_out);

@@ -48,9 +48,13 @@ with tempfile.TemporaryDirectory() as tmp:
     timed("save_3d_map (4.2 GB)", lambda: save_3d_map(d / "vlmaps.h5df", feat, pos, np.ones(N, np.float32), occ, list(range(10)),
                                                       np.zeros((N, 3), np.uint8)))
     m = AVLMap(cfg, data_dir=tmp)
+    if os.environ.get("PROBE_NO_PREFETCH"):
+        m.vlmap.prefetch_device = False
     timed("AVLMap.load_map", lambda: m.load_map(tmp))
     vm = m.vlmap
     vm.clip_feat_dim, vm.clip_model = D, HashClip(D)
+    if os.environ.get("PROBE_GAP"):       # what upstream does between load_map and the first query: load CLIP (seconds)
+        timed(f"(host-side work for {os.environ['PROBE_GAP']} s, e.g. loading CLIP)", lambda: sum(i * i for i in range(int(2e7 * float(os.environ["PROBE_GAP"])))))
     timed("index_map('sofa', no categories)  first call (upload + prepare)", lambda: vm.index_map("sofa", with_init_cat=False))
     for _ in range(2):
         timed("index_map('chair', no categories)", lambda: vm.index_map("chair", with_init_cat=False))
