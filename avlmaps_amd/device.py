@@ -26,8 +26,13 @@ _H2D_PIECE = 64 << 20
 def _pool_alloc(nbytes: int) -> int:
     lst = _POOL.get(nbytes)
     if lst:
-        _POOL_BYTES[0] -= nbytes
-        return lst.pop()
+        try:
+            ptr = lst.pop()               # another thread (map upload, checkpoint writer) may have taken the last one
+        except IndexError:
+            ptr = None
+        if ptr is not None:
+            _POOL_BYTES[0] -= nbytes
+            return ptr
     p = C.c_void_p()
     _lib.check(_lib.load().avl_malloc(C.byref(p), nbytes), "avl_malloc")
     return p.value or 0
