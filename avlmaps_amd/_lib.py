@@ -33,6 +33,7 @@ _SIGS = {
     "avl_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
     "avl_free": (C.c_int, [_vp]),
     "avl_mt19937_skip_shuffles": (C.c_int, [_vp, C.POINTER(C.c_int), _i64, _i64]),
+    "avl_mt19937_shuffle_sample": (C.c_int, [_vp, C.POINTER(C.c_int), _i64, _i64, _vp, _vp]),
     "avl_host_alloc": (C.c_int, [C.POINTER(_vp), _sz]),
     "avl_host_free": (C.c_int, [_vp]),
     "avl_memset": (C.c_int, [_vp, C.c_int, _sz, _vp]),

@@ -96,7 +96,7 @@ using namespace avl;
 extern "C" {
 
 const char* avl_last_error(void) { return g_err; }
-int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc, avl_mt19937_skip_shuffles
+int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc, avl_get_device, avl_mt19937_skip_shuffles / _shuffle_sample
 
 int avl_device_count(int* h_count) {
     AVL_REQUIRE(h_count, "avl_device_count: null output");
@@ -201,11 +201,13 @@ struct Mt19937 {
 };
 }  // namespace
 
-int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t n_shuffles) {
-    AVL_REQUIRE(h_key624 && h_pos, "avl_mt19937_skip_shuffles: null state");
-    AVL_REQUIRE(*h_pos >= 0 && *h_pos <= 624 && n_items >= 0 && n_shuffles >= 0, "avl_mt19937_skip_shuffles: bad arguments");
-    AVL_REQUIRE(n_items <= 0xffffffffll, "avl_mt19937_skip_shuffles: arrays beyond 2^32 items draw 64-bit integers (not implemented)");
-    Mt19937 g{h_key624, *h_pos};
+extern "C++" {
+namespace {
+// n_shuffles legacy shuffles of n_items elements on generator g.  The loop consumes one tempered output per iteration and is
+// branch-free inside: a rejected draw (x & mask) > i leaves i where it is (and, with SWAP, swaps arr[i] with itself) -- the
+// rejection branch of the textbook form mispredicts on a quarter of the draws and cost more than the generator.
+template <bool SWAP>
+void run_shuffles(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t* arr) {
     uint32_t out[624];                       // tempered outputs of the current state block (filled in one vectorisable sweep)
     auto temper_block = [&]() {
         for (int k = 0; k < 624; ++k) {
@@ -219,24 +221,54 @@ int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, i
     };
     if (g.pos < 624) temper_block();
     for (int64_t s = 0; s < n_shuffles; ++s) {
-        uint32_t mask = 0;
-        if (n_items >= 2) {
-            mask = (uint32_t)(n_items - 1);
-            mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
-        }
-        for (uint32_t i = (uint32_t)(n_items > 0 ? n_items - 1 : 0); i >= 1; --i) {
-            if (i <= (mask >> 1)) mask >>= 1;             // smallest 2^k - 1 >= i, tracked instead of recomputed
-            uint32_t x;
-            do {
-                if (g.pos >= 624) {
-                    g.regen();
-                    temper_block();
+        if (n_items < 2) continue;
+        uint32_t i = (uint32_t)(n_items - 1), mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        while (i >= 1) {
+            if (g.pos >= 624) {
+                g.regen();
+                temper_block();
+            }
+            const int avail = 624 - g.pos;
+            int k = 0;
+            for (; k < avail && i >= 1; ++k) {
+                mask >>= (i <= (mask >> 1)) ? 1 : 0;      // smallest 2^m - 1 >= i: i falls by at most one per draw
+                const uint32_t x = out[g.pos + k] & mask;
+                const uint32_t acc = x <= i ? 1u : 0u;
+                if (SWAP) {
+                    const uint32_t jj = acc ? x : i;
+                    const int32_t t = arr[i];
+                    arr[i] = arr[jj];
+                    arr[jj] = t;
                 }
-                x = out[g.pos++] & mask;
-            } while (x > i);
+                i -= acc;
+            }
+            g.pos += k;
         }
     }
+}
+}  // namespace
+}  // extern "C++"
+
+int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t n_shuffles) {
+    AVL_REQUIRE(h_key624 && h_pos, "avl_mt19937_skip_shuffles: null state");
+    AVL_REQUIRE(*h_pos >= 0 && *h_pos <= 624 && n_items >= 0 && n_shuffles >= 0, "avl_mt19937_skip_shuffles: bad arguments");
+    AVL_REQUIRE(n_items <= 0x7fffffffll, "avl_mt19937_skip_shuffles: arrays beyond 2^31 items are not supported");
+    Mt19937 g{h_key624, *h_pos};
+    run_shuffles<false>(g, n_items, n_shuffles, nullptr);
     *h_pos = g.pos;
+    return AVL_OK;
+}
+
+int avl_mt19937_shuffle_sample(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t rate, int32_t* h_scratch, int32_t* h_out) {
+    AVL_REQUIRE(h_key624 && h_pos && h_scratch && h_out, "avl_mt19937_shuffle_sample: null pointer");
+    AVL_REQUIRE(*h_pos >= 0 && *h_pos <= 624 && n_items >= 0 && rate >= 1, "avl_mt19937_shuffle_sample: bad arguments");
+    AVL_REQUIRE(n_items <= 0x7fffffffll, "avl_mt19937_shuffle_sample: arrays beyond 2^31 items are not supported");
+    for (int64_t k = 0; k < n_items; ++k) h_scratch[k] = (int32_t)k;
+    Mt19937 g{h_key624, *h_pos};
+    run_shuffles<true>(g, n_items, 1, h_scratch);
+    *h_pos = g.pos;
+    for (int64_t k = 0, o = 0; k < n_items; k += rate, ++o) h_out[o] = h_scratch[k];
     return AVL_OK;
 }
 

@@ -61,6 +61,11 @@ AVL_API int avl_free(void* d_ptr);
  * frame) -- the draws only, nothing is permuted.  A rank of a sharded build fast-forwards past the frames of the ranks before
  * it with this, so that a seeded N-rank run samples the pixels of the seeded single-process run. */
 AVL_API int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t n_shuffles);
+/* Host only: h_out[k] = perm[k * rate] of the permutation np.random.shuffle(np.arange(n_items)) produces from this state
+ * (vlmap_builder.py:275-277: shuffle_mask[::depth_sample_rate]); the state advances exactly as the shuffle advances it.
+ * h_scratch: n_items int32 of work space, h_out: ceil(n_items / rate) int32.  Same result as NumPy, about twice as fast (int32
+ * indices, branch-free rejection): the serial part of a pixel-faithful build. */
+AVL_API int avl_mt19937_shuffle_sample(uint32_t* h_key624, int* h_pos, int64_t n_items, int64_t rate, int32_t* h_scratch, int32_t* h_out);
 AVL_API int avl_host_alloc(void** h_ptr_out, size_t bytes);
 AVL_API int avl_host_free(void* h_ptr);
 AVL_API int avl_memset(void* d_ptr, int value, size_t bytes, void* stream);

@@ -301,3 +301,25 @@ def test_skip_pixel_shuffles_fast_forwards_the_global_rng_like_the_shuffles():
         got = np.random.get_state()
         assert np.array_equal(want[1], got[1]) and want[2] == got[2], (n_pix, k)
         assert np.array_equal(VLMapBuilder.sample_pixels(640, 7), (lambda m: (np.random.set_state(want), np.random.shuffle(m), m[::7])[2])(np.arange(640)))
+
+
+def test_sample_pixels_is_numpys_shuffle():
+    """VLMapBuilder.sample_pixels draws shuffle_mask[::rate] through the library's host C code (int32 indices, branch-free
+    rejection): the samples and the state the global RNG is left in are exactly NumPy's, for every array-length class"""
+    from avlmaps_amd.map.vlmap_builder import VLMapBuilder
+    for n_pix, rate, k in ((1, 1, 2), (2, 1, 3), (3, 2, 3), (5, 1, 3), (8, 3, 2), (9, 2, 2), (1000, 7, 3), (4096, 5, 2), (4097, 100, 2), (70000, 100, 2)):
+        np.random.seed(7)
+        np.random.rand(3)
+        want = []
+        for _ in range(k):
+            m = np.arange(n_pix)
+            np.random.shuffle(m)
+            want.append(m[::rate].astype(np.int32))
+        ws = np.random.get_state()
+        np.random.seed(7)
+        np.random.rand(3)
+        got = [VLMapBuilder.sample_pixels(n_pix, rate) for _ in range(k)]
+        gs = np.random.get_state()
+        assert all(np.array_equal(a, b) and b.dtype == np.int32 for a, b in zip(want, got)), (n_pix, rate)
+        assert np.array_equal(ws[1], gs[1]) and ws[2] == gs[2], (n_pix, rate)
+    assert 0.0 <= np.random.rand() < 1.0                                            # the global RNG still works afterwards
