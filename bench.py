@@ -570,7 +570,8 @@ def run_pipeline_probe(torch, frames=300):
             res[f"{sampling}_pixel_sampling"] = dict(frames_per_s=frames / dt, ms_per_frame=1e3 * dt / frames,
                                                      voxels=int(len(b.last_map["grid_pos"])), checkpoints=len(b._map_writer.stats))
     res["what"] = (f"VLMapBuilder.create_mobile_base_map over {frames} in-memory 720x1080 frames, free feature extractor, checkpoints every "
-                   "100 frames, one process; reference sampling = np.random.shuffle(arange(H*W)) per frame on the global RNG (serial)")
+                   "100 frames, one process; reference sampling = the permutation np.random.shuffle(arange(H*W)) draws per frame from the global RNG "
+                   "(serial; computed by the library's host C code, NumPy's samples and RNG state)")
     return res
 
 
