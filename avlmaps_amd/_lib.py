@@ -48,6 +48,8 @@ _SIGS = {
     "avl_event_sync": (C.c_int, [_vp]),
     "avl_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "avl_sim_prepare_map": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp]),
+    "avl_sim_prepare_map24": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp, _vp]),
+    "avl_sim_scores_prepared24": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_sim_workspace_bytes_n": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_sz)]),
     "avl_sim_scores_blocks": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "avl_sim_scores_prepared": (C.c_int, [_vp, _vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

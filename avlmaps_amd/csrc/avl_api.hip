@@ -96,7 +96,7 @@ using namespace avl;
 extern "C" {
 
 const char* avl_last_error(void) { return g_err; }
-int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc, avl_get_device, avl_mt19937_skip_shuffles / _shuffle_sample
+int avl_version(void) { return 202; }   // 0.2.0: avl_sim_prepare_map gained the row-scale output (ABI change); 0.2.1: deferred fuse / flush; 0.2.2: avl_gather_rows, avl_host_alloc, avl_get_device, avl_mt19937_skip_shuffles / _shuffle_sample, avl_sim_prepare_map24 / avl_sim_scores_prepared24
 
 int avl_device_count(int* h_count) {
     AVL_REQUIRE(h_count, "avl_device_count: null output");

@@ -394,6 +394,54 @@ __global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict_
     }
 }
 
+// Compact prepared form (P24 kernels): row r of the output holds, per 32 columns, fp16 hi[32] (64 B, round to nearest) and then the
+// fp8 e4m3 images of the residuals x - hi (32 B); every row is first scaled by the power of two that brings its largest |element|
+// into [2^14, 2^15) -- the residuals of the elements that matter (down to 2^-10 of the row's maximum) then sit in e4m3's normal
+// range -- and 2^-s goes to row_scale[row].  Rows with a non-finite element get row_scale = NaN like sim_prepare_map_kernel.
+// hi carries 11 significant bits, the residual 4 more: an element is within 2^-16 of its value, a 512-column score within ~1e-5
+// (sigma), 3e-5 at the tail of 1e8 scores -- inside the 1e-4 contract, against 1.5e-6 for the 32-bit forms.
+__global__ __launch_bounds__(256) void sim_prepare_map24_kernel(const float* __restrict__ feat, int64_t N, int D, int64_t ld,
+                                                                unsigned char* __restrict__ out, float* __restrict__ row_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int g8 = D >> 3;   // groups of 8 columns per row
+    for (int64_t row = wave0; row < N; row += nwaves) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(feat + row * ld);
+        unsigned mb = 0;
+        for (int g = lane; g < 2 * g8; g += 64) {
+            const f32x4 v = p[g];
+            mb = max(max(mb, __float_as_uint(v.x) & 0x7fffffffu), __float_as_uint(v.y) & 0x7fffffffu);
+            mb = max(max(mb, __float_as_uint(v.z) & 0x7fffffffu), __float_as_uint(v.w) & 0x7fffffffu);
+        }
+        for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, off, 64));
+        int sh = 0;
+        if (mb != 0 && mb < 0x7f800000u) sh = max(-100, min(100, 14 - ilogbf(__uint_as_float(mb))));
+        const float scale = ldexpf(1.f, sh);
+        if (lane == 0) row_scale[row] = mb >= 0x7f800000u ? __uint_as_float(0x7fc00000u) : ldexpf(1.f, -sh);
+        unsigned char* orow = out + row * ((int64_t)D * 3);
+        for (int g = lane; g < g8; g += 64) {           // 8 columns: 16 B of hi and 8 B of lo inside the 96-byte block of 32 columns
+            const f32x4 v0 = p[2 * g], v1 = p[2 * g + 1];
+            const float x[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
+            half8 hi;
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hi[e] = (_Float16)x[e];
+                r[e] = x[e] - (float)hi[e];
+            }
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[4], r[5], w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[6], r[7], w1, true);
+            unsigned char* blk = orow + (g >> 2) * 96;
+            *reinterpret_cast<half8*>(blk + (g & 3) * 16) = hi;
+            *reinterpret_cast<int2*>(blk + 64 + (g & 3) * 8) = int2{w0, w1};
+        }
+    }
+}
+
 // Recompute the rows the range guard flagged (one bit per row, one word per 32 rows) in float32 on the vector ALU, wave per
 // row: every score, and the row argmax with np.argmax semantics (first NaN wins, else first maximum).  Flagged rows are rare
 // on in-range maps (none at all on LSeg-scale rows), so this is a ~3 us scan of N/32 words; on a map full of tiny rows it is
@@ -460,7 +508,10 @@ __global__ __launch_bounds__(256) void sim_gather_queries_kernel(const float* __
 // FQ (needs nkc == 1 and D <= 512): the workgroup builds its LDS query image itself from the raw float32 query rows -- the
 // same arithmetic as sim_prep_queries_kernel, so the scores are bit-identical -- instead of copying a prepared image: no
 // prep launch and no workspace, which is ~8 us per query on maps of a few hundred thousand voxels.
-template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false>
+// P24 (with PRE): the map is the COMPACT prepared form of sim_prepare_map24_kernel -- per 32 columns 64 B of fp16 hi[32] followed by
+// 32 B of fp8 (e4m3) residuals lo[32], 3 bytes per element instead of 4: a quarter less HBM traffic per pass, the residuals are
+// widened to fp16 in registers (v_cvt_scalef32_pk_f16_fp8) and the three MFMAs stay fp16.
+template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false, bool P24 = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, const float* __restrict__ q_raw, int64_t ldq, int Qtot, int KC, int nkc, int q_base,
@@ -579,6 +630,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         const int64_t row = !active ? N : (tail ? tail_row0 + (tu0 + wave) * 32 + j : (it * G + blockIdx.x) * kTileRows + wave * 32 + j);
         const int64_t rowc = row < N ? row : N - 1;
         const float* rp = feat + rowc * ld + 32 * kg;
+        const char* rp24 = reinterpret_cast<const char*>(feat) + rowc * ((int64_t)D * 3) + 96 * kg;   // P24: 96 B per 32 columns
 
         // NA independent accumulator sets per query tile (hi*hi | cross terms) so that back-to-back MFMAs never wait on
         // each other's result: a dependent 32x32x16 MFMA cannot issue until its predecessor retires
@@ -600,18 +652,35 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             const int klen = min(KC, D - kc * KC);
             const int nsteps = klen >> 6;
             const float* p = rp + kc * KC;
+            const char* p24 = rp24 + (int64_t)kc * KC * 3;
 
             f32x4 buf0[8], buf1[8];
             auto load = [&](f32x4(&b)[8], int s) {
-                const f32x4* g = reinterpret_cast<const f32x4*>(p + 64 * s);
+                if constexpr (P24) {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(p24 + 192 * s);   // hi[32] (4 x 16 B) | lo[32] (2 x 16 B)
 #pragma unroll
-                for (int t = 0; t < 8; ++t) b[t] = g[t];
+                    for (int t = 0; t < 6; ++t) b[t] = g[t];
+                } else {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(p + 64 * s);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) b[t] = g[t];
+                }
             };
             auto compute = [&](const f32x4(&b)[8], int s) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     half8 bh, bl;
-                    if constexpr (PRE) {
+                    if constexpr (P24) {
+                        bh = __builtin_bit_cast(half8, b[m]);
+                        using i32x4 = __attribute__((ext_vector_type(4))) int;
+                        const i32x4 lw = __builtin_bit_cast(i32x4, b[4 + (m >> 1)]);
+                        const int w0 = lw[(m & 1) * 2], w1 = lw[(m & 1) * 2 + 1];
+                        const half2 l0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false);
+                        const half2 l1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true);
+                        const half2 l2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false);
+                        const half2 l3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true);
+                        bl = half8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
+                    } else if constexpr (PRE) {
                         bh = __builtin_bit_cast(half8, b[2 * m]);
                         bl = __builtin_bit_cast(half8, b[2 * m + 1]);
                     } else {
@@ -1372,6 +1441,13 @@ static const void* pick_stream_kernel(int QT, bool tile_block) {
 
 static bool split_plan_is_fused(const SplitPlan& p, int D) { return !p.stream && p.nkc == 1 && D <= 512; }
 
+template <int QT>
+static const void* pick_split24_kernel(bool s8, bool fq) {   // compact prepared map (P24): dense calls only
+    if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, true, true, false, true>)
+                      : reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, true, true, false, true>);
+    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, true, false, false, true>);
+}
+
 template <int QT, bool PRE, bool QM>
 static const void* pick_split_kernel(bool s8, bool fq) {
     if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, PRE, true, QM>)
@@ -1399,7 +1475,7 @@ static int run_fixup(const float* d_feat, int64_t N, int D, int64_t ld, const fl
 template <bool PRE>
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Qg, int64_t ldq, int Qs,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, const float* d_row_scale,
-                     uint32_t* d_flags, const int32_t* d_qmap, bool first_launch, hipStream_t st) {
+                     uint32_t* d_flags, const int32_t* d_qmap, bool first_launch, hipStream_t st, bool p24 = false) {
     float* inv_scale = reinterpret_cast<float*>(d_ws);
     _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
     const bool fq = split_plan_is_fused(p, D);   // resident image built inside the kernel: no prep launch, no workspace
@@ -1431,7 +1507,8 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
         const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
-        const void* kern = d_qmap ? (c.QT == 3 ? pick_split_kernel<3, PRE, true>(s8, fq)
+        const void* kern = p24    ? (c.QT == 3 ? pick_split24_kernel<3>(s8, fq) : (c.QT == 2 ? pick_split24_kernel<2>(s8, fq) : pick_split24_kernel<1>(s8, fq)))
+                           : d_qmap ? (c.QT == 3 ? pick_split_kernel<3, PRE, true>(s8, fq)
                                                : (c.QT == 2 ? pick_split_kernel<2, PRE, true>(s8, fq) : pick_split_kernel<1, PRE, true>(s8, fq)))
                                   : (c.QT == 3 ? pick_split_kernel<3, PRE, false>(s8, fq)
                                                : (c.QT == 2 ? pick_split_kernel<2, PRE, false>(s8, fq) : pick_split_kernel<1, PRE, false>(s8, fq)));
@@ -1539,7 +1616,14 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
                            const int32_t* h_col_end = nullptr) {
     AVL_REQUIRE(N >= 0 && D > 0 && Q > 0, "avl_sim_scores: bad shape N=%lld D=%d Q=%d", (long long)N, D, Q);
     AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
-    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED, "avl_sim_scores: bad precision %d", precision);
+    AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED24, "avl_sim_scores: bad precision %d", precision);
+    const bool p24 = precision == AVL_SIM_PREPARED24;
+    if (p24) {   // compact prepared map: 3 bytes per element, dense rows, resident-query kernel only
+        AVL_REQUIRE(D % 64 == 0 && ld_feat == D && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0,
+                    "avl_sim_scores_prepared24: needs D %% 64 == 0 and dense 16-byte aligned rows (D=%d)", D);
+        precision = AVL_SIM_PREPARED;
+        h_col_begin = h_col_end = nullptr;
+    }
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat && d_queries, "avl_sim_scores: null input");
     hipStream_t st = as_stream(stream);
@@ -1547,7 +1631,7 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
     SplitPlan p;
     const bool aligned = (ld_feat % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0) &&
                          (!d_scores || (reinterpret_cast<uintptr_t>(d_scores) & 15) == 0);
-    const bool can_split = make_split_plan(D, Q, p, precision != AVL_SIM_EXACT) && aligned;
+    const bool can_split = make_split_plan(D, Q, p, precision != AVL_SIM_EXACT && !p24) && aligned;
     bool use_split, use_f32_mfma = false;
     if (precision == AVL_SIM_EXACT_VALU) use_split = false;
     else if (precision == AVL_SIM_EXACT) {
@@ -1618,7 +1702,7 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
             rc = run_mfma_f32(d_feat, N, D, ld_feat, d_queries, Q, ld_q, d_scores, amax, best, p, ws, st);
         } else if (!blocks) {
             rc = prepared ? run_split<true>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, Q, d_scores, amax, best, p, ws, d_row_scale, nullptr,
-                                            nullptr, true, st)
+                                            nullptr, true, st, p24)
                           : run_split<false>(d_feat, N, D, ld_feat, d_queries, Q, ld_q, Q, d_scores, amax, best, p, ws, nullptr, flags,
                                              nullptr, true, st);
         } else {
@@ -1676,6 +1760,30 @@ int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scale, int64
                             void* d_workspace, size_t workspace_bytes, void* stream) {
     return sim_scores_impl(d_feat, d_row_scale, N, D, ld_feat, d_queries, Q, ld_q, d_scores, d_argmax, d_best, AVL_SIM_PREPARED,
                            d_workspace, workspace_bytes, stream);
+}
+
+int avl_sim_scores_prepared24(const void* d_map24, const float* d_row_scale, int64_t N, int D, const float* d_queries, int Q,
+                              int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best, void* d_workspace,
+                              size_t workspace_bytes, void* stream) {
+    AVL_REQUIRE(d_row_scale, "avl_sim_scores_prepared24: the compact form always has row scales");
+    return sim_scores_impl(reinterpret_cast<const float*>(d_map24), d_row_scale, N, D, D, d_queries, Q, ld_q, d_scores, d_argmax, d_best,
+                           AVL_SIM_PREPARED24, d_workspace, workspace_bytes, stream);
+}
+
+int avl_sim_prepare_map24(const float* d_feat, int64_t N, int D, int64_t ld_feat, void* d_map24, float* d_row_scale, void* stream) {
+    AVL_REQUIRE(N >= 0 && D > 0 && ld_feat >= D, "avl_sim_prepare_map24: bad shape");
+    AVL_REQUIRE(D % 64 == 0 && ld_feat % 4 == 0 && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d_map24) & 15) == 0,
+                "avl_sim_prepare_map24: needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D, (long long)ld_feat);
+    if (N == 0) return AVL_OK;
+    AVL_REQUIRE(d_feat && d_map24 && d_row_scale, "avl_sim_prepare_map24: null pointer");
+    int64_t blocks = (N + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(sim_prepare_map24_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), d_feat, N, D, ld_feat,
+                       reinterpret_cast<unsigned char*>(d_map24), d_row_scale);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
 }
 
 int avl_sim_prepare_map(float* d_feat, int64_t N, int D, int64_t ld_feat, float* d_row_scale, void* stream) {

@@ -250,6 +250,29 @@ def run_index(args, torch, dist, lib, rank, ws):
         ms_prep = sustained_ms(lib, step_prepared, launches=100, warm=60)
         same = float((am2 == am).double().mean())
         del prep, rscale
+        # variant: the COMPACT resident copy (opt-in, VLMap.compact_map): 3 bytes per element, fp16 hi + fp8 residual
+        compact = None
+        if D % 64 == 0 and D <= 512:              # the compact form runs on the resident-query kernel: one pass up to 78 queries at D <= 512
+            m24 = torch.empty((N, 3 * D), dtype=torch.uint8, device="cuda")
+            rs24 = torch.empty((N,), dtype=torch.float32, device="cuda")
+            _lib.check(lib.avl_sim_prepare_map24(feat.data_ptr(), N, D, D, m24.data_ptr(), rs24.data_ptr(), None), "avl_sim_prepare_map24")
+            sc24 = torch.empty((8192, Q), dtype=torch.float32, device="cuda")
+
+            def step_compact():
+                _lib.check(lib.avl_sim_scores_prepared24(m24.data_ptr(), rs24.data_ptr(), N, D, q.data_ptr(), Q, D, None, am2.data_ptr(),
+                                                         None, wsbuf.data_ptr(), wsb.value, None), "avl_sim_scores_prepared24")
+            for _ in range(3):
+                step_compact()
+            ms24 = sustained_ms(lib, step_compact, launches=100, warm=60)
+            same24 = float((am2 == am).double().mean())
+            _lib.check(lib.avl_sim_scores_prepared24(m24.data_ptr(), rs24.data_ptr(), 8192, D, q.data_ptr(), Q, D, sc24.data_ptr(), None,
+                                                     None, wsbuf.data_ptr(), wsb.value, None), "avl_sim_scores_prepared24")
+            err24 = float((sc24.double() - feat[:8192].double() @ q.double().T).abs().max())
+            bytes24 = N * D * 3 + N * 4 + Q * D * 4 + N * 4
+            compact = dict(ms=ms24, similarities_per_s=N * Q / (ms24 * 1e-3), bytes_per_pass=bytes24, gbs=bytes24 / (ms24 * 1e-3) / 1e9,
+                           argmax_agreement_with_primary=same24, max_abs_err_vs_fp64_first_8192_rows=err24, tolerance=1e-4,
+                           what="opt-in resident copy: fp16 hi + fp8 (e4m3) residual per element, per-row power-of-two scale")
+            del m24, rs24, sc24
         # parity spot check against float64 on the device (north_star tolerance 1e-4)
         g = torch.Generator(device="cuda").manual_seed(7)
         idx = torch.randint(0, N, (8192,), device="cuda", generator=g)
@@ -262,6 +285,8 @@ def run_index(args, torch, dist, lib, rank, ws):
             scores_mat_variant=dict(ms=ms_sc, similarities_per_s=N * Q / (ms_sc * 1e-3),
                                     gbs=(alg_bytes + N * Q * 4) / (ms_sc * 1e-3) / 1e9),
             parity_sample=dict(rows=8192, max_abs_err_vs_fp64=err, argmax_agreement=am_ok, tolerance=1e-4))
+        if compact is not None:
+            out["extra"]["compact_prepared_map_variant"] = compact
         # a map of the size real scenes produce (a few hundred thousand voxels), "64 categories + other" as the reference's
         # init_categories scores them (65 columns), and the two-column query of index_map(with_init_cat=False)
         try:

@@ -108,7 +108,8 @@ enum {
                               fp16 pair would lose bits or saturate -- or non-finite is recomputed in float32 by a
                               follow-up kernel (np.argmax semantics for NaN rows), so every row is float32-class.       */
     AVL_SIM_EXACT_VALU = 3,/* force the vector-ALU float32 kernel                                                        */
-    AVL_SIM_PREPARED = 4   /* d_feat was converted by avl_sim_prepare_map: SPLIT_F16 without the on-the-fly split        */
+    AVL_SIM_PREPARED = 4,  /* d_feat was converted by avl_sim_prepare_map: SPLIT_F16 without the on-the-fly split        */
+    AVL_SIM_PREPARED24 = 5 /* internal to avl_sim_scores_prepared24 (compact 3-byte form of avl_sim_prepare_map24)      */
 };
 
 /* One-off, IN-PLACE conversion of a device-resident float32 map (N, D; D % 64 == 0, 16-byte aligned rows) into the split
@@ -159,6 +160,20 @@ AVL_API int avl_sim_scores_blocks(const float* d_feat, const float* d_row_scale,
 AVL_API int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,
                                     const float* d_queries, int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax,
                                     float* d_best, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* COMPACT resident copy of a map that is indexed many times (opt-in; VLMap.compact_map): 3 bytes per element instead of 4 --
+ * per 32 columns fp16 hi[32] then fp8 (e4m3) residuals lo[32], every row scaled by a power of two (d_row_scale out, N floats).
+ * d_map24: N * D * 3 bytes, out of place (the float32 map is left alone).  A query pass then reads a quarter less HBM; the
+ * residuals are widened to fp16 in registers and the arithmetic is the same three fp16 MFMAs.  Accuracy: 15 significant bits per
+ * element instead of 22: scores within ~1.2e-5 of float64 on LSeg-scale rows (measured, tests/test_sim_gpu.py) -- inside the
+ * 1e-4 contract of the path, ~10x the error of the 4-byte forms, hence not the default.  D % 64 == 0; dense calls only, and always
+ * on the resident-query kernel: it pays for D <= 512 and up to ~78 queries per pass (0.69 -> 0.58 ms at 2 M x 512 x 64); wider maps
+ * or larger query sets are faster in the 4-byte forms (streamed / column-block kernels). */
+AVL_API int avl_sim_prepare_map24(const float* d_feat, int64_t N, int D, int64_t ld_feat, void* d_map24, float* d_row_scale,
+                                  void* stream);
+AVL_API int avl_sim_scores_prepared24(const void* d_map24, const float* d_row_scale, int64_t N, int D, const float* d_queries,
+                                      int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax, float* d_best,
+                                      void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Host-buffer convenience wrapper (synchronous): copies in, runs, copies out. */
 AVL_API int avl_sim_scores_host(const float* h_feat, int64_t N, int D, const float* h_queries, int Q,

@@ -184,6 +184,37 @@ def test_vlmap_index_and_avlmap_index_object(golden):
             fn("x")
 
 
+def test_vlmap_with_the_compact_resident_copy(golden):
+    """VLMap.compact_map = True: the resident copy is the 3-byte form; index_map / init_categories / index_object give the masks of
+    the 4-byte copy wherever the reference's own top-2 gap exceeds 1e-4, scores within the 1e-4 contract of the reference (g3)"""
+    from avlmaps_amd.map import AVLMap
+    from avlmaps_amd.ops import PreparedMap
+    g3, g4 = golden("g3_similarity.npz"), golden("g4_heatmap.npz")
+    cfg = Cfg(map_config=Cfg(map_type="vlmap", grid_size=1000, cell_size=0.05,
+                             pose_info=Cfg(pose_type="mobile_base", camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1],
+                                           base_forward_axis=[0, 0, -1], base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0])),
+              params=Cfg(cs=0.05))
+    n = len(g4["grid_pos"])
+    feat = g3["feat"][:n] if len(g3["feat"]) >= n else np.resize(g3["feat"], (n, 512))
+    res = {}
+    for compact in (False, True):
+        av = AVLMap(cfg)
+        vm = av.vlmap
+        vm.compact_map = compact
+        vm.grid_feat, vm.grid_pos, vm.clip_model, vm.clip_feat_dim = feat, g4["grid_pos"], FakeClip(512), 512
+        mask = vm.index_map("sofa", with_init_cat=False)
+        assert isinstance(vm._dev_feat, PreparedMap) and vm._dev_feat.compact == compact
+        sm = vm.init_categories(["chair", "table", "sofa", "other"])
+        heat = av.index_object("sofa", decay_rate=0.01)
+        res[compact] = (mask, sm, heat)
+    (m0, s0, h0), (m1, s1, h1) = res[False], res[True]
+    assert np.abs(s1 - s0).max() < 1e-4                                    # measured ~1e-5
+    gap = np.sort(s0, axis=1)
+    clear = gap[:, -1] - gap[:, -2] > 2e-4
+    assert np.array_equal(np.argmax(s1, 1)[clear], np.argmax(s0, 1)[clear]) and np.mean(m0 == m1) > 0.999
+    assert h1.shape == h0.shape and np.mean(h0 == h1) > 0.99
+
+
 def test_dynamic_obstacles_map_matches_numpy_restatement(golden):
     """index_utils.py:138-184 on the GPU vs a NumPy evaluation of the same definition"""
     from avlmaps_amd.utils.clip_utils import landmark_text_feats

@@ -429,3 +429,42 @@ def test_column_windows_with_ties_zero_queries_and_bad_rows(ops, windows, counts
         assert np.array_equal(am[ok], np.argmax(sc[ok], axis=1)) and np.array_equal(best[ok], sc[ok, am[ok]]), name
         assert np.array_equal(am_only, am), name
         assert am[7] == Q - 1 and np.isnan(sc[17]).all() and am[17] == 0, name       # np.argmax of an all-NaN row is 0
+
+
+@pytest.mark.parametrize("N,D,Q", [(3000, 512, 64), (2500, 512, 65), (1000, 512, 1), (1500, 64, 9), (1200, 1024, 40), (900, 512, 170),
+                                   (700, 1536, 33)])
+def test_compact_prepared_map(ops, N, D, Q):
+    """prepare_map(compact=True): 3 bytes per element (fp16 hi + fp8 residual, per-row power-of-two scale).  Scores stay inside
+    the 1e-4 contract of the path (measured ~1e-5 on LSeg-scale rows: 15 significant bits per element instead of 22), argmax /
+    best are consistent with the scores, rows of any magnitude rank like float64, NaN rows are NaN everywhere"""
+    from avlmaps_amd.device import DeviceArray
+    rng = np.random.default_rng(N + D + Q)
+    f = rng.standard_normal((N, D)).astype(np.float32)
+    f *= (14.2857 * (0.05 + 0.95 * rng.random((N, 1)))) / np.linalg.norm(f, axis=1, keepdims=True)
+    f[3] *= 1e-9                                             # a voxel seen once from far away
+    f[4] *= 1e6
+    f[5] = 0
+    f[6, 7] = np.nan
+    t = rng.standard_normal((Q, 63, D)) * 0.7 + rng.standard_normal((Q, 1, D))
+    t /= np.linalg.norm(t, axis=2, keepdims=True)
+    q = t.mean(axis=1).astype(np.float32)
+    want = f.astype(np.float64) @ q.astype(np.float64).T
+    pm = ops.prepare_map(DeviceArray.from_numpy(f), compact=True)
+    assert pm.compact and pm.feat.shape == (N, 3 * D)
+    sc, am, best = ops.sim_scores(pm, q, want_best=True)
+    sc, am, best = sc.numpy(), am.numpy(), best.numpy()
+    ok = np.ones(N, bool)
+    ok[6] = False
+    norms = np.linalg.norm(f[ok].astype(np.float64), axis=1, keepdims=True)
+    err = np.abs(sc[ok] - want[ok]) / np.maximum(1.0, norms / 14.2857)                   # the huge row: relative to its own size
+    assert err.max() < 1e-4, err.max()
+    assert np.abs(sc[3] - want[3]).max() < 1e-5 * np.linalg.norm(f[3].astype(np.float64))   # the tiny row keeps its relative accuracy
+    assert np.array_equal(am[ok], np.argmax(sc[ok], axis=1)) and np.array_equal(best[ok], sc[ok, am[ok]])
+    assert np.isnan(sc[6]).all() and am[6] == 0 and np.all(sc[5] == 0)
+    top2 = np.sort(want[ok], axis=1)[:, -2:] if Q > 1 else None
+    if top2 is not None:
+        clear = (top2[:, 1] - top2[:, 0]) > 2e-4 * np.maximum(1.0, np.abs(top2[:, 1]))
+        assert np.array_equal(am[ok][clear], np.argmax(want[ok], axis=1)[clear])
+    # argmax-only call (what VLMap.index_map uses) gives the same indices
+    _, am2, _ = ops.sim_scores(pm, q, want_scores=False)
+    assert np.array_equal(am2.numpy(), am)
