@@ -42,7 +42,7 @@ def sim_case(i):
         q[Q - 1] = q[0]                                              # exact tie: lowest index must win
     want = f.astype(np.float64) @ q.astype(np.float64).T
     tol = 2e-5 * max(1.0, float(np.abs(want).max()))
-    mode = str(rng.choice(["raw", "prepared", "prepared_unscaled", "exact"] if D % 64 == 0 else ["raw", "exact"]))
+    mode = str(rng.choice(["raw", "prepared", "prepared_unscaled", "exact", "compact"] if D % 64 == 0 else ["raw", "exact"]))
     src = f
     kw = {}
     if mode == "prepared":
@@ -51,10 +51,16 @@ def sim_case(i):
         if float(np.abs(f).max()) > 6e4:
             return
         src = ops.prepare_map(DeviceArray.from_numpy(f), scaled=False)
+    elif mode == "compact":                                          # 3-byte resident copy: the 1e-4 contract, relative to the row's size
+        src = ops.prepare_map(DeviceArray.from_numpy(f), compact=True)
+        tol = 1e-4 * max(1.0, float(np.linalg.norm(f, axis=1).max()) * float(np.linalg.norm(q, axis=1).max()) / 14.2857)
+        windows = None
     elif mode == "exact":
         kw["precision"] = "exact"
-    if windows is None:
+    if windows is None and mode != "compact":
         kw["col_support"] = None
+    if mode == "compact":
+        kw = {}
     sc, am, best = ops.sim_scores(src, q, want_best=True, **kw)
     sc, am, best = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (sc, am, best))
     cfg = dict(kind="sim", i=i, N=N, D=D, Q=Q, mode=mode, windows=windows)
