@@ -394,12 +394,12 @@ __global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict_
     }
 }
 
-// Compact prepared form (P24 kernels): row r of the output holds, per 32 columns, fp16 hi[32] (64 B, round to nearest) and then the
-// fp8 e4m3 images of the residuals x - hi (32 B); every row is first scaled by the power of two that brings its largest |element|
-// into [2^14, 2^15) -- the residuals of the elements that matter (down to 2^-10 of the row's maximum) then sit in e4m3's normal
-// range -- and 2^-s goes to row_scale[row].  Rows with a non-finite element get row_scale = NaN like sim_prepare_map_kernel.
-// hi carries 11 significant bits, the residual 4 more: an element is within 2^-16 of its value, a 512-column score within ~1e-5
-// (sigma), 3e-5 at the tail of 1e8 scores -- inside the 1e-4 contract, against 1.5e-6 for the 32-bit forms.
+// Compact prepared form (P24 kernels): row r of the output holds, per 32 columns, fp16 hi[32] (64 B, round to nearest) and then one
+// byte per element with the residual x - hi in units of ulp(hi) / 256 (u = k + 128, k in [-128, 127]; 32 B); every row is first
+// scaled by the power of two that brings its largest |element| into [2^14, 2^15) and 2^-s goes to row_scale[row].  The residual's
+// exponent is implied by hi, so all 8 bits are significand: an element is within 2^-19 of its value (hi's 11 bits + 8), against
+// 2^-22 for the 4-byte forms; elements below 2^-11 of the row's maximum (E < 4) keep hi only.  Rows with a non-finite element
+// get row_scale = NaN like sim_prepare_map_kernel.
 __global__ __launch_bounds__(256) void sim_prepare_map24_kernel(const float* __restrict__ feat, int64_t N, int D, int64_t ld,
                                                                 unsigned char* __restrict__ out, float* __restrict__ row_scale) {
     const int lane = threadIdx.x & 63;
@@ -424,17 +424,18 @@ __global__ __launch_bounds__(256) void sim_prepare_map24_kernel(const float* __r
             const f32x4 v0 = p[2 * g], v1 = p[2 * g + 1];
             const float x[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
             half8 hi;
-            float r[8];
+            unsigned u[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                hi[e] = (_Float16)x[e];
-                r[e] = x[e] - (float)hi[e];
+                const _Float16 h = (_Float16)x[e];      // (a scalar: bit-casting a vector ELEMENT is what this compiler folds to element 0)
+                hi[e] = h;
+                const int eb = (__builtin_bit_cast(unsigned short, h) >> 10) & 31;          // biased exponent of hi
+                int k = 0;
+                if (eb > 18 && eb < 31) k = (int)rintf((x[e] - (float)h) * ldexpf(1.f, 33 - eb));       // units of 2^(E - 18), E = eb - 15
+                u[e] = (unsigned)(max(-128, min(127, k)) + 128);
             }
-            int w0 = 0, w1 = 0;
-            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[0], r[1], w0, false);
-            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(r[2], r[3], w0, true);
-            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[4], r[5], w1, false);
-            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(r[6], r[7], w1, true);
+            const int w0 = (int)(u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24));
+            const int w1 = (int)(u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24));
             unsigned char* blk = orow + (g >> 2) * 96;
             *reinterpret_cast<half8*>(blk + (g & 3) * 16) = hi;
             *reinterpret_cast<int2*>(blk + 64 + (g & 3) * 8) = int2{w0, w1};
@@ -508,9 +509,23 @@ __global__ __launch_bounds__(256) void sim_gather_queries_kernel(const float* __
 // FQ (needs nkc == 1 and D <= 512): the workgroup builds its LDS query image itself from the raw float32 query rows -- the
 // same arithmetic as sim_prep_queries_kernel, so the scores are bit-identical -- instead of copying a prepared image: no
 // prep launch and no workspace, which is ~8 us per query on maps of a few hundred thousand voxels.
+// Residuals of the compact prepared form: byte u of word w encodes k = u - 128 units of ulp(hi) / 256 = 2^(E - 18), E = exponent of
+// the hi value it belongs to.  Two of them -> packed fp16: v_perm_b32 builds the fp16 bit patterns 0x6400 | u = 1024 + u, a packed add
+// of -1152 gives k exactly, and the packed fp16 2^(E - 18) comes from hi's own exponent field (saturating subtract: 0 below
+// E = 4, where the residual is dropped).  Five vector-ALU instructions per two elements.
+template <int PAIR>
+__device__ __forceinline__ half2 residual_pair(unsigned w, unsigned hi2) {
+    using ushort2v = __attribute__((ext_vector_type(2))) unsigned short;
+    const unsigned pat = __builtin_amdgcn_perm(0x64646464u, w, PAIR == 0 ? 0x04010400u : 0x04030402u);
+    const half2 k = __builtin_bit_cast(half2, pat) + half2{(_Float16)-1152.0f, (_Float16)-1152.0f};
+    const ushort2v e = __builtin_bit_cast(ushort2v, hi2 & 0x7C007C00u);
+    const ushort2v sc = __builtin_elementwise_sub_sat(e, ushort2v{0x4800, 0x4800});
+    return k * __builtin_bit_cast(half2, sc);
+}
+
 // P24 (with PRE): the map is the COMPACT prepared form of sim_prepare_map24_kernel -- per 32 columns 64 B of fp16 hi[32] followed by
-// 32 B of fp8 (e4m3) residuals lo[32], 3 bytes per element instead of 4: a quarter less HBM traffic per pass, the residuals are
-// widened to fp16 in registers (v_cvt_scalef32_pk_f16_fp8) and the three MFMAs stay fp16.
+// 32 B of int8 residuals in units of ulp(hi) / 256, 3 bytes per element instead of 4: a quarter less HBM traffic per pass, the
+// residuals are rebuilt as fp16 in registers (residual_pair) and the three MFMAs stay fp16.
 template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false, bool P24 = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
@@ -672,13 +687,14 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                     half8 bh, bl;
                     if constexpr (P24) {
                         bh = __builtin_bit_cast(half8, b[m]);
-                        using i32x4 = __attribute__((ext_vector_type(4))) int;
-                        const i32x4 lw = __builtin_bit_cast(i32x4, b[4 + (m >> 1)]);
-                        const int w0 = lw[(m & 1) * 2], w1 = lw[(m & 1) * 2 + 1];
-                        const half2 l0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, false);
-                        const half2 l1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w0, 1.0f, true);
-                        const half2 l2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, false);
-                        const half2 l3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w1, 1.0f, true);
+                        // (bit-casting ONE element of a float ext_vector to int folded every element to element 0 in this compiler;
+                        // cast the whole vector first)
+                        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+                        const u32x4 hw = __builtin_bit_cast(u32x4, b[m]);                 // the 8 hi values, two per word
+                        const u32x4 lw = __builtin_bit_cast(u32x4, b[4 + (m >> 1)]);
+                        const unsigned w0 = lw[(m & 1) * 2], w1 = lw[(m & 1) * 2 + 1];    // their 8 residual bytes
+                        const half2 l0 = residual_pair<0>(w0, hw[0]), l1 = residual_pair<1>(w0, hw[1]);
+                        const half2 l2 = residual_pair<0>(w1, hw[2]), l3 = residual_pair<1>(w1, hw[3]);
                         bl = half8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
                     } else if constexpr (PRE) {
                         bh = __builtin_bit_cast(half8, b[2 * m]);

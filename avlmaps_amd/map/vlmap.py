@@ -41,10 +41,11 @@ class VLMap(Map):
         self.prefetch_device = True       # load_map starts the one-off upload + conversion of grid_feat (1.1 s at 2 M voxels: 4 GB over
                                           # PCIe from pageable memory) on a host thread, so that it overlaps with whatever the
                                           # caller does next (upstream: loading CLIP, seconds) instead of sitting in the first query
-        self.compact_map = False          # True: the resident copy is the 3-byte form (fp16 hi + fp8 residual, ops.prepare_map(compact=True)):
-                                          # a query pass reads a quarter less HBM (0.69 -> 0.58 ms at 2 M voxels x 64 queries) and the
-                                          # copy is a quarter smaller, for ~1e-5 instead of ~1.5e-6 of score error (the path's contract is
-                                          # 1e-4); off by default because the 4-byte form is float32-class
+        self.compact_map = True           # the resident copy is the 3-byte form for D <= 512 (ops.prepare_map(compact=True): fp16 hi + one
+                                          # byte of residual in units of ulp(hi)/256, per-row scale): a query pass reads a quarter less
+                                          # HBM (0.70 -> 0.61 ms at 2 M voxels x 64 queries), the copy is a quarter smaller, and the
+                                          # scores stay float32-class (max error 2.3e-6 against 1.4e-6 for the 4-byte form; the path's
+                                          # contract is 1e-4).  False: the 4-byte split-fp16 form
         self.shard_index_rows = True      # with torch.distributed initialised (one process per GPU) every rank keeps and scores
                                           # only its block of voxel rows; the per-voxel results are all-gathered (parallel.gather_rows)
 

@@ -117,7 +117,7 @@ def _sim_workspace(lib, N, D, Q, stream):
 class PreparedMap:
     """a device-resident map converted in place by avl_sim_prepare_map: `feat` (N, D) now holds fp16 hi | lo groups,
     `row_scale` (N,) float32 the per-row 2^-s (None: prepared without scaling).  Pass it to sim_scores as `feat`.
-    compact=True: `feat` is the separate (N, 3 D) uint8 buffer of avl_sim_prepare_map24 (fp16 hi + fp8 residual)."""
+    compact=True: `feat` is the separate (N, 3 D) uint8 buffer of avl_sim_prepare_map24 (fp16 hi + one residual byte per element)."""
     __slots__ = ("feat", "row_scale", "shape", "compact")
 
     def __init__(self, feat, row_scale, shape, compact=False):
@@ -167,8 +167,9 @@ def prepare_map(feat_dev, scaled=True, stream=None, compact=False):
     PreparedMap for sim_scores.  scaled=True (default): every row gets its own power-of-two scale, so rows of any magnitude
     -- e.g. voxels observed once from far away, feat * exp(-r^2/1.2) -- score with float32-class accuracy.  scaled=False:
     scores bit-identical to the on-the-fly split of the raw map.  feat_dev: DeviceArray or torch CUDA tensor (N, D), D % 64 == 0.
-    compact=True: out of place into the 3-byte form (avl_sim_prepare_map24: fp16 hi + fp8 residual, always row-scaled): a
-    quarter less HBM traffic per query pass for ~1.2e-5 instead of ~1.5e-6 of score error (the contract is 1e-4; pays for D <= 512); the float32
+    compact=True: out of place into the 3-byte form (avl_sim_prepare_map24: fp16 hi + the residual in units of ulp(hi)/256, always
+    row-scaled): a quarter less HBM traffic per query pass, max score error 2.3e-6 instead of 1.4e-6 (float32-class; pays for
+    D <= 512); the float32
     map is left untouched and can be freed by the caller."""
     lib = _lib.load()
     if isinstance(feat_dev, np.ndarray):

@@ -250,7 +250,7 @@ def run_index(args, torch, dist, lib, rank, ws):
         ms_prep = sustained_ms(lib, step_prepared, launches=100, warm=60)
         same = float((am2 == am).double().mean())
         del prep, rscale
-        # variant: the COMPACT resident copy (opt-in, VLMap.compact_map): 3 bytes per element, fp16 hi + fp8 residual
+        # variant: the COMPACT resident copy (VLMap's default for D <= 512): 3 bytes per element, fp16 hi + one residual byte
         compact = None
         if D % 64 == 0 and D <= 512:              # the compact form runs on the resident-query kernel: one pass up to 78 queries at D <= 512
             m24 = torch.empty((N, 3 * D), dtype=torch.uint8, device="cuda")
@@ -271,7 +271,7 @@ def run_index(args, torch, dist, lib, rank, ws):
             bytes24 = N * D * 3 + N * 4 + Q * D * 4 + N * 4
             compact = dict(ms=ms24, similarities_per_s=N * Q / (ms24 * 1e-3), bytes_per_pass=bytes24, gbs=bytes24 / (ms24 * 1e-3) / 1e9,
                            argmax_agreement_with_primary=same24, max_abs_err_vs_fp64_first_8192_rows=err24, tolerance=1e-4,
-                           what="opt-in resident copy: fp16 hi + fp8 (e4m3) residual per element, per-row power-of-two scale")
+                           what="VLMap's resident copy for D <= 512: fp16 hi + residual byte in units of ulp(hi)/256 per element, per-row power-of-two scale")
             del m24, rs24, sc24
         # parity spot check against float64 on the device (north_star tolerance 1e-4)
         g = torch.Generator(device="cuda").manual_seed(7)

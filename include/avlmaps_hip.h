@@ -161,14 +161,16 @@ AVL_API int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scal
                                     const float* d_queries, int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax,
                                     float* d_best, void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* COMPACT resident copy of a map that is indexed many times (opt-in; VLMap.compact_map): 3 bytes per element instead of 4 --
- * per 32 columns fp16 hi[32] then fp8 (e4m3) residuals lo[32], every row scaled by a power of two (d_row_scale out, N floats).
+/* COMPACT resident copy of a map that is indexed many times (VLMap.compact_map, its default for D <= 512): 3 bytes per element
+ * instead of 4 -- per 32 columns fp16 hi[32] (round to nearest) then one byte per element holding the residual x - hi in units of
+ * ulp(hi) / 256, every row scaled by a power of two (d_row_scale out, N floats).
  * d_map24: N * D * 3 bytes, out of place (the float32 map is left alone).  A query pass then reads a quarter less HBM; the
- * residuals are widened to fp16 in registers and the arithmetic is the same three fp16 MFMAs.  Accuracy: 15 significant bits per
- * element instead of 22: scores within ~1.2e-5 of float64 on LSeg-scale rows (measured, tests/test_sim_gpu.py) -- inside the
- * 1e-4 contract of the path, ~10x the error of the 4-byte forms, hence not the default.  D % 64 == 0; dense calls only, and always
- * on the resident-query kernel: it pays for D <= 512 and up to ~78 queries per pass (0.69 -> 0.58 ms at 2 M x 512 x 64); wider maps
- * or larger query sets are faster in the 4-byte forms (streamed / column-block kernels). */
+ * residuals are rebuilt as fp16 in registers (five vector-ALU instructions per two elements) and the arithmetic is the same three
+ * fp16 MFMAs.  Accuracy: 19 significant bits per element (hi's 11 + 8: the residual's exponent is implied by hi) instead of 22 --
+ * max |score - float64| 2.3e-6 on LSeg-scale rows against 1.4e-6 for the 4-byte forms (tests/test_sim_gpu.py): still float32-class.
+ * Elements below 2^-11 of their row's maximum keep hi only.  D % 64 == 0; dense calls only, and always on the resident-query
+ * kernel: it pays for D <= 512 and up to ~78 queries per pass (0.70 -> 0.61 ms at 2 M x 512 x 64); wider maps or larger query sets
+ * are faster in the 4-byte forms (streamed / column-block kernels). */
 AVL_API int avl_sim_prepare_map24(const float* d_feat, int64_t N, int D, int64_t ld_feat, void* d_map24, float* d_row_scale,
                                   void* stream);
 AVL_API int avl_sim_scores_prepared24(const void* d_map24, const float* d_row_scale, int64_t N, int D, const float* d_queries,
