@@ -269,18 +269,26 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
                                                float* __restrict__ scores, int32_t* __restrict__ argmax,
                                                float* __restrict__ best, int64_t row, int64_t N, int kg, int first_chunk,
                                                float rscale = 1.f, uint32_t* __restrict__ flags = nullptr, float rmax = 1.f,
-                                               const int32_t* __restrict__ qmap = nullptr) {
-    // qmap (column-block launches, avl_sim_scores_blocks): this launch's query rows are a gathered subset of the caller's;
-    // qmap[local row] = the caller's query index, ascending, so "first maximum" inside the launch is unchanged and only the
-    // published index / score column and the tie-break against earlier launches use the caller's numbering
+                                               const int32_t* qml = nullptr) {
+    // qml (column-block launches, avl_sim_scores_blocks): this launch's query rows are a gathered subset of the caller's;
+    // qml[row of this chunk] = the caller's query index, ascending, so "first maximum" inside the launch is unchanged and only
+    // the published index / score column and the tie-break against earlier launches use the caller's numbering.  The table
+    // lives in LDS (filled at kernel start): a global-memory table made the compiler hoist its loads above the accumulator
+    // reads and spill (17-37 VGPRs in the QM variants of round 2)
     const int qend = q_base + rows;  // first query index NOT in this chunk
+    // validity of this lane's 16 * QT columns as comparisons of compile-time constants against ONE per-lane value, opaque to the
+    // optimiser: as loop invariants of the tile loop the 16 * QT masks and column indices were hoisted out of it, which cost the
+    // kernels ~100 SGPRs (spilled to VGPR lanes) and up to 5 spilled VGPRs
+    int lim = rows - 4 * kg;         // local rows 8 g + e + 32 t (+ 4 kg) < rows
+    asm volatile("" : "+v"(lim));
     float bv = -INFINITY;
-    int bi = INT_MAX;
+    int bl = INT_MAX;                // best local row minus 4 kg
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int ql = t * 32 + 8 * g + 4 * kg;
+            const int c0 = t * 32 + 8 * g;          // compile-time
+            const int ql = c0 + 4 * kg;
             const int qg = q_base + ql;
             const f32x4 is4 = *reinterpret_cast<const f32x4*>(isc + ql);
             f32x4 v;
@@ -295,29 +303,31 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
             v.w = r.w * is4.w * rscale;
             if (scores && row < N) {
                 float* sp = scores + row * (int64_t)Q + qg;
-                if (qmap) {
+                if (qml) {
                     float* sr = scores + row * (int64_t)Q;
-                    if (qg + 0 < qend) sr[qmap[qg + 0]] = v.x;
-                    if (qg + 1 < qend) sr[qmap[qg + 1]] = v.y;
-                    if (qg + 2 < qend) sr[qmap[qg + 2]] = v.z;
-                    if (qg + 3 < qend) sr[qmap[qg + 3]] = v.w;
-                } else if (qg + 3 < qend && (Q & 3) == 0) {
+                    const int4 qm4 = *reinterpret_cast<const int4*>(qml + ql);
+                    if (c0 + 0 < lim) sr[qm4.x] = v.x;
+                    if (c0 + 1 < lim) sr[qm4.y] = v.y;
+                    if (c0 + 2 < lim) sr[qm4.z] = v.z;
+                    if (c0 + 3 < lim) sr[qm4.w] = v.w;
+                } else if (c0 + 3 < lim && (Q & 3) == 0) {
                     *reinterpret_cast<f32x4*>(sp) = v;
                 } else {
-                    if (qg + 0 < qend) sp[0] = v.x;
-                    if (qg + 1 < qend) sp[1] = v.y;
-                    if (qg + 2 < qend) sp[2] = v.z;
-                    if (qg + 3 < qend) sp[3] = v.w;
+                    if (c0 + 0 < lim) sp[0] = v.x;
+                    if (c0 + 1 < lim) sp[1] = v.y;
+                    if (c0 + 2 < lim) sp[2] = v.z;
+                    if (c0 + 3 < lim) sp[3] = v.w;
                 }
             }
-            if (qg + 0 < qend && v.x > bv) { bv = v.x; bi = qg + 0; }
-            if (qg + 1 < qend && v.y > bv) { bv = v.y; bi = qg + 1; }
-            if (qg + 2 < qend && v.z > bv) { bv = v.z; bi = qg + 2; }
-            if (qg + 3 < qend && v.w > bv) { bv = v.w; bi = qg + 3; }
+            if (c0 + 0 < lim && v.x > bv) { bv = v.x; bl = c0 + 0; }
+            if (c0 + 1 < lim && v.y > bv) { bv = v.y; bl = c0 + 1; }
+            if (c0 + 2 < lim && v.z > bv) { bv = v.z; bl = c0 + 2; }
+            if (c0 + 3 < lim && v.w > bv) { bv = v.w; bl = c0 + 3; }
         }
     }
+    int bi = bl == INT_MAX ? INT_MAX : q_base + 4 * kg + bl;
     if (argmax || best || flags) {
-        if (qmap && bi != INT_MAX) bi = qmap[bi];
+        if (qml && bi != INT_MAX) bi = qml[bi - q_base];
         const float ov = __shfl_xor(bv, 32, 64);
         const int oi = __shfl_xor(bi, 32, 64);
         if (ov > bv || (ov == bv && oi < bi)) {
@@ -337,7 +347,7 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
             }
         }
         if ((argmax || best) && kg == 0 && row < N) {
-            if (bi == INT_MAX) bi = qmap ? qmap[q_base] : q_base;
+            if (bi == INT_MAX) bi = qml ? qml[0] : q_base;
             if (!first_chunk) {  // an equal score keeps the lower query index (np.argmax: first maximum)
                 const float pv = best[row];
                 const int pi = argmax ? argmax[row] : -1;
@@ -544,6 +554,10 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const int zrow = (FQ && rows < 32 * QT) ? 1 : 0;
     const int img_b = (rows + zrow) * row_b;     // bytes of the hi (or lo) image resident in LDS
     float* isc = reinterpret_cast<float*>(smem + 2 * img_b);  // per-query 2^-S of this chunk
+    int32_t* qml = reinterpret_cast<int32_t*>(isc + QT * 32);  // QM: the caller's query index of every row of this chunk
+    if constexpr (QM) {
+        if (threadIdx.x < QT * 32) qml[threadIdx.x] = threadIdx.x < rows ? qmap[q_base + threadIdx.x] : INT_MAX;
+    }
     if constexpr (!FQ) {
         if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
     } else {
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         }
         // QM (column-block launches) is a template parameter so that the dense kernels keep their register budget
         split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax,
-                               QM ? qmap : nullptr);
+                               QM ? qml : nullptr);
     }
 }
 
@@ -801,6 +815,10 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     const int buf_b = (rows + zrow) * row_b;              // one LDS buffer = the chunk's rows, a linear copy of the image
     float* isc = reinterpret_cast<float*>(smem + 2 * buf_b);
     if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    int32_t* qml = reinterpret_cast<int32_t*>(isc + QT * 32);   // QM: the caller's query index of every row of this chunk
+    if constexpr (QM) {
+        if (threadIdx.x < QT * 32) qml[threadIdx.x] = threadIdx.x < rows ? qmap[q_base + threadIdx.x] : INT_MAX;
+    }
     const int units = (rows * row_b) >> 4;
     if (zrow)
         for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
@@ -895,6 +913,21 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
                         split8(b[2 * m], b[2 * m + 1], bh, bl);
                     }
                     const int off = (s * 64 + 8 * m) * 2;
+                    if constexpr (QT == 4) {
+                        // four tiles: the hi fragments serve both of their products before the lo fragments are fetched, so only
+                        // four operand fragments are live at a time (the term-major order below spilled 5 VGPRs here)
+                        half8 af[QT];
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) af[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bh, acc[t][0], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bl, acc[t][0], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) af[t] = *reinterpret_cast<const half8*>(ab + a_off[t] + off + lo_b);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bh, acc[t][0], 0, 0, 0);
+                    } else {
                     half8 ah[QT], al[QT];
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
@@ -907,6 +940,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
                     for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][0], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][0], 0, 0, 0);
+                    }
                 }
 #ifndef AVL_ABL_NOSTAGE
                 stage_store(cur ^ 1, i0, i1);
@@ -925,7 +959,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
             if (row_scale) rscale = row_scale[row < N ? row : N - 1];
         }
         split_epilogue<QT, 1>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax,
-                              QM ? qmap : nullptr);
+                              QM ? qml : nullptr);
     }
 }
 
@@ -971,6 +1005,10 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
     const int buf_b = (rows + zrow) * row_b;              // one LDS buffer = the chunk's rows, a linear copy of the image
     float* isc = reinterpret_cast<float*>(smem + 2 * buf_b);
     if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    int32_t* qml = reinterpret_cast<int32_t*>(isc + QT * 32);   // QM: the caller's query index of every row of this chunk
+    if constexpr (QM) {
+        if (threadIdx.x < QT * 32) qml[threadIdx.x] = threadIdx.x < rows ? qmap[q_base + threadIdx.x] : INT_MAX;
+    }
     const int units = (rows * row_b) >> 4;
     if (zrow)
         for (int i = threadIdx.x; i < row_b / 4; i += NT) {
@@ -1135,7 +1173,7 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
                     if (row_scale) rscale = row_scale[row < N ? row : N - 1];
                 }
                 split_epilogue<QT, 1>(acc[b], isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale,
-                                      PRE ? nullptr : flags, rmax[b], QM ? qmap : nullptr);
+                                      PRE ? nullptr : flags, rmax[b], QM ? qml : nullptr);
             }
         }
         tile0 = tile0_next;
@@ -1331,8 +1369,9 @@ struct SplitPlan {
     SplitChunk chunks[64];
     size_t hdr_bytes, ws_bytes;
     size_t lds_bytes(const SplitChunk& c) const {
-        if (stream) return (size_t)2 * (c.rows + 1) * (2 * KC + kRowPadHalves) * 2 + (size_t)c.QT * 32 * sizeof(float);
-        return (size_t)4 * (c.rows + 1) * (KC + kRowPadHalves) + (size_t)c.QT * 32 * sizeof(float);   // + the zero row
+        // + the per-query 2^-S table and the query-index table of column-block launches (4 B per row each)
+        if (stream) return (size_t)2 * (c.rows + 1) * (2 * KC + kRowPadHalves) * 2 + (size_t)c.QT * 32 * 2 * sizeof(float);
+        return (size_t)4 * (c.rows + 1) * (KC + kRowPadHalves) + (size_t)c.QT * 32 * 2 * sizeof(float);   // + the zero row
     }
 };
 
@@ -1341,7 +1380,7 @@ constexpr size_t kLdsBudget = 163840 - 512;  // 160 KiB per workgroup minus slac
 static bool stream_fits(int rows, int KS) {
     const size_t buf = (size_t)rows * (2 * KS + kRowPadHalves) * 2;   // one chunk: rows x (hi | lo | pad)
     const size_t zero_row = (size_t)(2 * KS + kRowPadHalves) * 2;     // + one all-zero row per buffer
-    return 2 * (buf + zero_row) + 128 * sizeof(float) <= kLdsBudget && buf <= (size_t)kStreamFill * kSplitThreads * 16;
+    return 2 * (buf + zero_row) + 256 * sizeof(float) <= kLdsBudget && buf <= (size_t)kStreamFill * kSplitThreads * 16;
 }
 
 static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true) {
@@ -1352,7 +1391,7 @@ static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true
     // rows that fit next to a <=512-wide K chunk: up to 3 MFMA tiles (96 rows) in one pass, e.g. the reference's
     // "64 categories + other" (Q = 65) runs as ONE pass with 65 resident rows instead of 64 + 1
     const int kc0 = D < 512 ? D : 512;
-    int r3 = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)(kc0 + kRowPadHalves))) - 1;   // one row is the zero row
+    int r3 = (int)((kLdsBudget - 192 * sizeof(float)) / (4 * (size_t)(kc0 + kRowPadHalves))) - 1;   // one row is the zero row
     if (r3 > 96) r3 = 96;
     // fewest passes over the feature map, balanced: npass = ceil(Q / r3) chunks of ceil(Q / npass) rows
     const int npass = (Q + r3 - 1) / r3;
@@ -1365,7 +1404,7 @@ static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true
         p.chunks[p.nchunks++] = SplitChunk{base, take, (take + 31) / 32};
         if (take > p.max_rows) p.max_rows = take;
     }
-    int kcmax = (int)((kLdsBudget - 96 * sizeof(float)) / (4 * (size_t)(p.max_rows + 1))) - kRowPadHalves;
+    int kcmax = (int)((kLdsBudget - 192 * sizeof(float)) / (4 * (size_t)(p.max_rows + 1))) - kRowPadHalves;
     kcmax = (kcmax / 64) * 64;
     if (kcmax < 64) return false;
     p.nkc = (D + kcmax - 1) / kcmax;
