@@ -264,22 +264,23 @@ __device__ __forceinline__ void guard_max8(float& m, const f32x4 v0, const f32x4
 // epilogue shared by the split-fp16 kernels: this lane holds voxel `row`, queries q_base + t*32 + 8g + 4kg + e (g<4, e<4) in
 // acc[t][a][4g+e]; the NA partial accumulators are summed, scaled back by the per-query 2^-S, optionally stored, and reduced
 // to the row's first maximum (one cross-half shuffle); later query chunks chain through `best`
-template <int QT, int NA>
+// XR: the chunk's last 1..4 query rows (local rows 32 QT ..) were contracted by v_mfma_f32_4x4x4_16b_f16 instead of a mostly
+// padded 32-row tile: xacc[r] = this lane's HALF (its 32 of the step's 64 columns) of voxel `row` . extra query r
+template <int QT, int NA, bool XR = false>
 __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], const float* isc, int q_base, int rows, int Q,
                                                float* __restrict__ scores, int32_t* __restrict__ argmax,
                                                float* __restrict__ best, int64_t row, int64_t N, int kg, int first_chunk,
                                                float rscale = 1.f, uint32_t* __restrict__ flags = nullptr, float rmax = 1.f,
-                                               const int32_t* qml = nullptr) {
+                                               const int32_t* qml = nullptr, f32x4 xacc = f32x4{0.f, 0.f, 0.f, 0.f}) {
     // qml (column-block launches, avl_sim_scores_blocks): this launch's query rows are a gathered subset of the caller's;
     // qml[row of this chunk] = the caller's query index, ascending, so "first maximum" inside the launch is unchanged and only
     // the published index / score column and the tie-break against earlier launches use the caller's numbering.  The table
     // lives in LDS (filled at kernel start): a global-memory table made the compiler hoist its loads above the accumulator
     // reads and spill (17-37 VGPRs in the QM variants of round 2)
-    const int qend = q_base + rows;  // first query index NOT in this chunk
     // validity of this lane's 16 * QT columns as comparisons of compile-time constants against ONE per-lane value, opaque to the
     // optimiser: as loop invariants of the tile loop the 16 * QT masks and column indices were hoisted out of it, which cost the
     // kernels ~100 SGPRs (spilled to VGPR lanes) and up to 5 spilled VGPRs
-    int lim = rows - 4 * kg;         // local rows 8 g + e + 32 t (+ 4 kg) < rows
+    int lim = (XR ? 32 * QT : rows) - 4 * kg;         // local rows 8 g + e + 32 t (+ 4 kg) < rows (XR: the tiles are full)
     asm volatile("" : "+v"(lim));
     float bv = -INFINITY;
     int bl = INT_MAX;                // best local row minus 4 kg
@@ -326,6 +327,18 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
         }
     }
     int bi = bl == INT_MAX ? INT_MAX : q_base + 4 * kg + bl;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (XR) {
+        const f32x4 xis = *reinterpret_cast<const f32x4*>(isc + 32 * QT);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[r] = (xacc[r] + __shfl_xor(xacc[r], 32, 64)) * xis[r] * rscale;   // both halves now hold the sum
+        if (scores && row < N && kg == 0) {
+            float* sr = scores + row * (int64_t)Q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (32 * QT + r < rows) sr[qml ? qml[32 * QT + r] : q_base + 32 * QT + r] = xv[r];
+        }
+    }
     if (argmax || best || flags) {
         if (qml && bi != INT_MAX) bi = qml[bi - q_base];
         const float ov = __shfl_xor(bv, 32, 64);
@@ -333,6 +346,14 @@ __device__ __forceinline__ void split_epilogue(const f32x16 (&acc)[QT][NA], cons
         if (ov > bv || (ov == bv && oi < bi)) {
             bv = ov;
             bi = oi;
+        }
+        if constexpr (XR) {   // the extra rows come last in the chunk: a strictly greater score only
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (32 * QT + r < rows && xv[r] > bv) {
+                    bv = xv[r];
+                    bi = qml ? qml[32 * QT + r] : q_base + 32 * QT + r;
+                }
         }
         if (flags) {
             // one word per 32-row unit: bit j = row j of the unit must be recomputed in float32 (largest |element| outside
@@ -533,10 +554,40 @@ __device__ __forceinline__ half2 residual_pair(unsigned w, unsigned hi2) {
     return k * __builtin_bit_cast(half2, sc);
 }
 
+// B operands (voxel side) of the m-th 8-column group of a 64-column step from the registers one lane loaded for it:
+// raw float32 (guard + on-the-fly split), prepared hi[8] | lo[8], or the compact form (hi[32] | residual bytes[32] per 96 B)
+template <bool PRE, bool P24>
+__device__ __forceinline__ void map_operands(const f32x4 (&b)[8], int m, half8& bh, half8& bl, float& rmax) {
+    if constexpr (P24) {
+        bh = __builtin_bit_cast(half8, b[m]);
+        // (bit-casting ONE element of a float ext_vector to int folded every element to element 0 in this compiler;
+        // cast the whole vector first)
+        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+        const u32x4 hw = __builtin_bit_cast(u32x4, b[m]);                 // the 8 hi values, two per word
+        const u32x4 lw = __builtin_bit_cast(u32x4, b[4 + (m >> 1)]);
+        const unsigned w0 = lw[(m & 1) * 2], w1 = lw[(m & 1) * 2 + 1];    // their 8 residual bytes
+        const half2 l0 = residual_pair<0>(w0, hw[0]), l1 = residual_pair<1>(w0, hw[1]);
+        const half2 l2 = residual_pair<0>(w1, hw[2]), l3 = residual_pair<1>(w1, hw[3]);
+        bl = half8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
+    } else if constexpr (PRE) {
+        bh = __builtin_bit_cast(half8, b[2 * m]);
+        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
+    } else {
+#ifndef AVL_ABL_NOGUARD
+        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
+#endif
+        split8(b[2 * m], b[2 * m + 1], bh, bl);
+    }
+}
+
 // P24 (with PRE): the map is the COMPACT prepared form of sim_prepare_map24_kernel -- per 32 columns 64 B of fp16 hi[32] followed by
 // 32 B of int8 residuals in units of ulp(hi) / 256, 3 bytes per element instead of 4: a quarter less HBM traffic per pass, the
 // residuals are rebuilt as fp16 in registers (residual_pair) and the three MFMAs stay fp16.
-template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false, bool P24 = false>
+// XR (with FQ): rows = 32 QT + 1..4 -- the last 1..4 query rows ("64 categories + other", clip_utils.py:213-215: 65 columns) are
+// contracted by v_mfma_f32_4x4x4_16b_f16 (16 blocks of 4 voxel-halves x the same 4 query rows: D[lane][r] = sum_k A[4 (lane / 4)
+// + r][k] * B[lane][k], tools/probe_mfma4.hip) instead of a third 32-row tile with one live row: 1/16 of its multiply-adds in
+// half of its issue cycles -- at the power cap that is time (Q = 65: see DESIGN.md)
+template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false, bool P24 = false, bool XR = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, const float* __restrict__ q_raw, int64_t ldq, int Qtot, int KC, int nkc, int q_base,
@@ -551,17 +602,19 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
     // FQ: a partial last MFMA tile gets one extra all-zero row that its padding lanes read -- multiplying zeros toggles far
     // fewer matrix-core bits than re-reading a valid row, and at the power cap that is time (Q = 65: see DESIGN.md)
-    const int zrow = (FQ && rows < 32 * QT) ? 1 : 0;
+    static_assert(!XR || FQ, "the extra-row path builds its query image in the kernel");
+    constexpr int TQ = (QT + (XR ? 1 : 0)) * 32;   // rows of the per-query tables
+    const int zrow = (FQ && rows < (XR ? 32 * QT + 4 : 32 * QT)) ? 1 : 0;
     const int img_b = (rows + zrow) * row_b;     // bytes of the hi (or lo) image resident in LDS
     float* isc = reinterpret_cast<float*>(smem + 2 * img_b);  // per-query 2^-S of this chunk
-    int32_t* qml = reinterpret_cast<int32_t*>(isc + QT * 32);  // QM: the caller's query index of every row of this chunk
+    int32_t* qml = reinterpret_cast<int32_t*>(isc + TQ);  // QM: the caller's query index of every row of this chunk
     if constexpr (QM) {
-        if (threadIdx.x < QT * 32) qml[threadIdx.x] = threadIdx.x < rows ? qmap[q_base + threadIdx.x] : INT_MAX;
+        if (threadIdx.x < TQ) qml[threadIdx.x] = threadIdx.x < rows ? qmap[q_base + threadIdx.x] : INT_MAX;
     }
     if constexpr (!FQ) {
-        if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+        if (threadIdx.x < TQ) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
     } else {
-        if (threadIdx.x >= rows && threadIdx.x < QT * 32) isc[threadIdx.x] = 0.f;
+        if (threadIdx.x >= rows && threadIdx.x < TQ) isc[threadIdx.x] = 0.f;
         // wave w converts query rows w, w+8, ...: the loads of four rows are issued together (lane owns k = lane + 64 t),
         // then row max -> power-of-two scale -> fp16 hi/lo straight into the LDS image, all from registers
         constexpr int RB = 4, NW = kSplitThreads / 64;
@@ -637,6 +690,9 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const char* a_base[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) a_base[t] = smem + min(t * 32 + j, rows - 1 + zrow) * row_b + kg * 64;
+    // XR: lane (block lane / 4, i = lane % 4) supplies extra query row i (the zero row beyond the last one) as the A operand
+    const char* xa_base = smem + min(32 * QT + (lane & 3), rows - 1 + zrow) * row_b + kg * 64;
+    (void)xa_base;
 
     // work split: full rounds of interleaved 256-row tiles (all workgroups sweep one compact window of the map: measured
     // 1.2 % faster at 2 M voxels than one contiguous range per workgroup), then ONE tail round in which what is left
@@ -659,7 +715,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         const int64_t row = !active ? N : (tail ? tail_row0 + (tu0 + wave) * 32 + j : (it * G + blockIdx.x) * kTileRows + wave * 32 + j);
         const int64_t rowc = row < N ? row : N - 1;
         const float* rp = feat + rowc * ld + 32 * kg;
-        const char* rp24 = reinterpret_cast<const char*>(feat) + rowc * ((int64_t)D * 3) + 96 * kg;   // P24: 96 B per 32 columns
+        const char* rp24 = reinterpret_cast<const char*>(feat) + rowc * (ld * 3) + 96 * kg;   // P24: 96 B per 32 columns, ld = columns of a full row
 
         // NA independent accumulator sets per query tile (hi*hi | cross terms) so that back-to-back MFMAs never wait on
         // each other's result: a dependent 32x32x16 MFMA cannot issue until its predecessor retires
@@ -671,6 +727,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[t][a][e] = 0.f;
         float rmax = 0.f;   // !PRE: largest |element| this lane has loaded of its row (range guard)
+        f32x4 xacc0 = {0.f, 0.f, 0.f, 0.f}, xacc1 = {0.f, 0.f, 0.f, 0.f};   // XR: two chains so that back-to-back 4x4x4 MFMAs alternate
 
         for (int kc = 0; kc < nkc; ++kc) {
             if (nkc > 1) {
@@ -699,26 +756,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     half8 bh, bl;
-                    if constexpr (P24) {
-                        bh = __builtin_bit_cast(half8, b[m]);
-                        // (bit-casting ONE element of a float ext_vector to int folded every element to element 0 in this compiler;
-                        // cast the whole vector first)
-                        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-                        const u32x4 hw = __builtin_bit_cast(u32x4, b[m]);                 // the 8 hi values, two per word
-                        const u32x4 lw = __builtin_bit_cast(u32x4, b[4 + (m >> 1)]);
-                        const unsigned w0 = lw[(m & 1) * 2], w1 = lw[(m & 1) * 2 + 1];    // their 8 residual bytes
-                        const half2 l0 = residual_pair<0>(w0, hw[0]), l1 = residual_pair<1>(w0, hw[1]);
-                        const half2 l2 = residual_pair<0>(w1, hw[2]), l3 = residual_pair<1>(w1, hw[3]);
-                        bl = half8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
-                    } else if constexpr (PRE) {
-                        bh = __builtin_bit_cast(half8, b[2 * m]);
-                        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
-                    } else {
-#ifndef AVL_ABL_NOGUARD
-                        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
-#endif
-                        split8(b[2 * m], b[2 * m + 1], bh, bl);
-                    }
+                    map_operands<PRE, P24>(b, m, bh, bl, rmax);
                     const int off = (s * 64 + 8 * m) * 2;
                     half8 ah[QT], al[QT];
 #pragma unroll
@@ -743,6 +781,21 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 #pragma unroll
                     for (int t = 0; t < QT; ++t) acc[t][X2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][X2], 0, 0, 0);
 #endif
+                    if constexpr (XR) {
+                        using half4 = __attribute__((ext_vector_type(4))) _Float16;
+                        const half8 xh = *reinterpret_cast<const half8*>(xa_base + off);
+                        const half8 xl = *reinterpret_cast<const half8*>(xa_base + off + img_b);
+                        const half4 xh0 = __builtin_shufflevector(xh, xh, 0, 1, 2, 3), xh1 = __builtin_shufflevector(xh, xh, 4, 5, 6, 7);
+                        const half4 xl0 = __builtin_shufflevector(xl, xl, 0, 1, 2, 3), xl1 = __builtin_shufflevector(xl, xl, 4, 5, 6, 7);
+                        const half4 bh0 = __builtin_shufflevector(bh, bh, 0, 1, 2, 3), bh1 = __builtin_shufflevector(bh, bh, 4, 5, 6, 7);
+                        const half4 bl0 = __builtin_shufflevector(bl, bl, 0, 1, 2, 3), bl1 = __builtin_shufflevector(bl, bl, 4, 5, 6, 7);
+                        xacc0 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh0, bh0, xacc0, 0, 0, 0);
+                        xacc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh1, bh1, xacc1, 0, 0, 0);
+                        xacc0 = __builtin_amdgcn_mfma_f32_4x4x4f16(xl0, bh0, xacc0, 0, 0, 0);
+                        xacc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(xl1, bh1, xacc1, 0, 0, 0);
+                        xacc0 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh0, bl0, xacc0, 0, 0, 0);
+                        xacc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(xh1, bl1, xacc1, 0, 0, 0);
+                    }
                 }
             };
             if constexpr (NSTEPS > 0) {
@@ -777,8 +830,8 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             if (row_scale) rscale = row_scale[rowc];
         }
         // QM (column-block launches) is a template parameter so that the dense kernels keep their register budget
-        split_epilogue<QT, NA>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax,
-                               QM ? qml : nullptr);
+        split_epilogue<QT, NA, XR>(acc, isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags, rmax,
+                                   QM ? qml : nullptr, xacc0 + xacc1);
     }
 }
 
@@ -796,7 +849,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kStreamFill = 9;   // 16-byte staging registers per thread: one LDS buffer <= 9 * 512 * 16 B = 72 KB
 
-template <int QT, int SPC, bool PRE, bool QM = false>
+template <int QT, int SPC, bool PRE, bool QM = false, bool P24 = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
@@ -847,15 +900,18 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     };
 
     const int64_t ntiles = (N + kTileRows - 1) / kTileRows;
+    // byte geometry of a lane's walk: float32 / prepared rows are 4 B per column and a lane owns 128 B of every 64-column step;
+    // the compact form (P24) is 3 B per column, 96 B per lane and step (hi[32] | residual bytes[32])
+    constexpr int kElB = P24 ? 3 : 4, kLaneB = P24 ? 96 : 128, kStepB = 2 * kLaneB, kLoads = P24 ? 6 : 8;
     auto tile_ptr = [&](int64_t tile) {
         const int64_t r = tile * kTileRows + wave * 32 + j;
-        return feat + (r < N ? r : N - 1) * ld + 32 * kg;
+        return reinterpret_cast<const char*>(feat) + (r < N ? r : N - 1) * (ld * kElB) + kLaneB * kg;
     };
     f32x4 ring[2][8];
-    auto load = [&](f32x4(&b)[8], const float* src) {
+    auto load = [&](f32x4(&b)[8], const char* src) {
         const f32x4* g = reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) b[t] = g[t];
+        for (int t = 0; t < kLoads; ++t) b[t] = g[t];
     };
     load(ring[0], tile_ptr(blockIdx.x));   // first tile, step 0: in flight while chunk 0 is brought in
 #pragma unroll
@@ -872,9 +928,9 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row = tile * kTileRows + wave * 32 + j;
-        const float* rp = tile_ptr(tile);
+        const char* rp = tile_ptr(tile);
         const bool has_next = tile + gridDim.x < ntiles;
-        const float* p_next = has_next ? tile_ptr(tile + gridDim.x) : rp;
+        const char* p_next = has_next ? tile_ptr(tile + gridDim.x) : rp;
 
         f32x16 acc[QT][1];
 #pragma unroll
@@ -892,7 +948,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #ifndef AVL_ABL_NOSTAGE
                 stage_load(cn, i0, i1);               // issued ahead of this step's voxel prefetch (older in vmcnt order)
 #endif
-                const float* nxt = rp + 64 * (c * SPC + s + 1);
+                const char* nxt = rp + kStepB * (c * SPC + s + 1);
                 if (s + 1 < SPC) {
                     load(ring[(s + 1) & 1], nxt);
                 } else if (c + 1 < nch) {
@@ -905,13 +961,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     half8 bh, bl;
-                    if constexpr (PRE) {
-                        bh = __builtin_bit_cast(half8, b[2 * m]);
-                        bl = __builtin_bit_cast(half8, b[2 * m + 1]);
-                    } else {
-                        guard_max8(rmax, b[2 * m], b[2 * m + 1]);
-                        split8(b[2 * m], b[2 * m + 1], bh, bl);
-                    }
+                    map_operands<PRE, P24>(b, m, bh, bl, rmax);
                     const int off = (s * 64 + 8 * m) * 2;
                     if constexpr (QT == 4) {
                         // four tiles: the hi fragments serve both of their products before the lo fragments are fetched, so only
@@ -973,9 +1023,12 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #ifndef AVL_TB2
 #define AVL_TB2 2
 #endif
-template <int QT>
+#ifndef AVL_TB2_P24
+#define AVL_TB2_P24 3
+#endif
+template <int QT, bool P24>
 struct StreamTB {
-    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? AVL_TB2 : 1);
+    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? (P24 ? AVL_TB2_P24 : AVL_TB2) : 1);
 };
 
 // (Tried and dropped, round 2: ONE pass over several column windows -- the chunk loop switching query rows / running the
@@ -985,14 +1038,14 @@ struct StreamTB {
 // (NT: threads per workgroup.  Two co-resident 256-thread workgroups per CU with 128-column chunks -- so that one computes
 // while the other sits in its barrier -- measured 7.5 % SLOWER than one 512-thread workgroup with 256-column chunks: config 5
 // 2.54 vs 2.36 ms on one box; only the 512-thread form is launched.)
-template <int QT, int SPC, bool PRE, bool QM = false, int NT = kSplitThreads>
+template <int QT, int SPC, bool PRE, bool QM = false, bool P24 = false, int NT = kSplitThreads>
 __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
     uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
     static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
-    constexpr int TB = StreamTB<QT>::value;
+    constexpr int TB = StreamTB<QT, P24>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 64 * SPC;
     constexpr int row_b = (2 * KS + kRowPadHalves) * 2;   // bytes per query row of one chunk: hi[KS] | lo[KS] | pad
@@ -1053,15 +1106,16 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
             cnt = it == R ? (int)(rb - ra) : 0;
         }
     };
+    constexpr int kElB = P24 ? 3 : 4, kLaneB = P24 ? 96 : 128, kStepB = 2 * kLaneB, kLoads = P24 ? 6 : 8;   // see sim_stream_f16_kernel
     auto tile_ptr = [&](int64_t tile) {
         const int64_t r = tile * (NT / 64 * 32) + wave * 32 + j;
-        return feat + (r < N ? r : N - 1) * ld + 32 * kg;
+        return reinterpret_cast<const char*>(feat) + (r < N ? r : N - 1) * (ld * kElB) + kLaneB * kg;
     };
     f32x4 ring[2][8];
-    auto load = [&](f32x4(&b)[8], const float* src) {
+    auto load = [&](f32x4(&b)[8], const char* src) {
         const f32x4* g = reinterpret_cast<const f32x4*>(src);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) b[t] = g[t];
+        for (int t = 0; t < kLoads; ++t) b[t] = g[t];
     };
     int64_t tile0;
     int cnt;
@@ -1084,10 +1138,10 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
         int64_t tile0_next;
         int cnt_next;
         block_of(it + 1, tile0_next, cnt_next);
-        const float* rp[TB];
+        const char* rp[TB];
 #pragma unroll
         for (int b = 0; b < TB; ++b) rp[b] = tile_ptr(tile0 + (b < cnt ? b : 0));
-        const float* p_next = cnt_next > 0 ? tile_ptr(tile0_next) : rp[0];
+        const char* p_next = cnt_next > 0 ? tile_ptr(tile0_next) : rp[0];
 
         f32x16 acc[TB][QT][1];
         float rmax[TB];
@@ -1117,11 +1171,11 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
                         // (the address is selected, the load itself is unconditional: a load inside a branch makes the compiler's
                         // s_waitcnt bookkeeping fall back to vmcnt(0); the very last step of a workgroup re-reads its own line)
                         if (s + 1 < SPC) {
-                            load(ring[(s + 1) & 1], rp[b] + 64 * (c * SPC + s + 1));
+                            load(ring[(s + 1) & 1], rp[b] + kStepB * (c * SPC + s + 1));
                         } else {
-                            const float* nxt = p_next;
-                            if (b + 1 < TB && b + 1 < cnt) nxt = rp[b + 1 < TB ? b + 1 : b] + 64 * (c * SPC);
-                            else if (c + 1 < nch) nxt = rp[0] + 64 * ((c + 1) * SPC);
+                            const char* nxt = p_next;
+                            if (b + 1 < TB && b + 1 < cnt) nxt = rp[b + 1 < TB ? b + 1 : b] + kStepB * (c * SPC);
+                            else if (c + 1 < nch) nxt = rp[0] + kStepB * ((c + 1) * SPC);
                             load(ring[0], nxt);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -1129,13 +1183,7 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
 #pragma unroll
                         for (int m = 0; m < 4; ++m) {
                             half8 bh, bl;
-                            if constexpr (PRE) {
-                                bh = __builtin_bit_cast(half8, v[2 * m]);
-                                bl = __builtin_bit_cast(half8, v[2 * m + 1]);
-                            } else {
-                                guard_max8(rmax[b], v[2 * m], v[2 * m + 1]);
-                                split8(v[2 * m], v[2 * m + 1], bh, bl);
-                            }
+                            map_operands<PRE, P24>(v, m, bh, bl, rmax[b]);
                             const int off = (s * 64 + 8 * m) * 2;
                             half8 ah[QT], al[QT];
 #pragma unroll
@@ -1375,6 +1423,10 @@ struct SplitPlan {
     }
 };
 
+#ifndef AVL_SIM_EXTRA_ROWS
+#define AVL_SIM_EXTRA_ROWS 1
+#endif
+constexpr bool kSimExtraRows = AVL_SIM_EXTRA_ROWS != 0;
 constexpr size_t kLdsBudget = 163840 - 512;  // 160 KiB per workgroup minus slack
 
 static bool stream_fits(int rows, int KS) {
@@ -1483,24 +1535,37 @@ static int run_exact(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     return AVL_OK;
 }
 
-template <int SPC, bool PRE, bool QM>
+template <int SPC, bool PRE, bool QM, bool P24 = false>
 static const void* pick_stream_kernel(int QT, bool tile_block) {
-    if (tile_block && QT == 2) return reinterpret_cast<const void*>(sim_stream_tb_f16_kernel<2, SPC, PRE, QM>);
+    if (tile_block && QT == 2) return reinterpret_cast<const void*>(sim_stream_tb_f16_kernel<2, SPC, PRE, QM, P24>);
     switch (QT) {
-        case 1: return reinterpret_cast<const void*>(sim_stream_f16_kernel<1, SPC, PRE, QM>);
-        case 2: return reinterpret_cast<const void*>(sim_stream_f16_kernel<2, SPC, PRE, QM>);
-        case 3: return reinterpret_cast<const void*>(sim_stream_f16_kernel<3, SPC, PRE, QM>);
-        default: return reinterpret_cast<const void*>(sim_stream_f16_kernel<4, SPC, PRE, QM>);
+        case 1: return reinterpret_cast<const void*>(sim_stream_f16_kernel<1, SPC, PRE, QM, P24>);
+        case 2: return reinterpret_cast<const void*>(sim_stream_f16_kernel<2, SPC, PRE, QM, P24>);
+        case 3: return reinterpret_cast<const void*>(sim_stream_f16_kernel<3, SPC, PRE, QM, P24>);
+        default: return reinterpret_cast<const void*>(sim_stream_f16_kernel<4, SPC, PRE, QM, P24>);
     }
+}
+
+template <bool PRE, bool QM, bool P24>
+static const void* pick_stream_kernel_spc(int SPC, int QT, bool tile_block) {
+    return SPC == 4 ? pick_stream_kernel<4, PRE, QM, P24>(QT, tile_block) : pick_stream_kernel<2, PRE, QM, P24>(QT, tile_block);
 }
 
 static bool split_plan_is_fused(const SplitPlan& p, int D) { return !p.stream && p.nkc == 1 && D <= 512; }
 
+template <int QT, bool QM>
+static const void* pick_split24_kernel(bool s8, bool fq) {   // compact prepared map (P24)
+    if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, true, true, QM, true>)
+                      : reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, true, true, QM, true>);
+    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, true, false, QM, true>);
+}
+
+// extra-row variants (Q = 32 QT + 1..4 on the fused D = 512 path): raw / prepared / compact map
 template <int QT>
-static const void* pick_split24_kernel(bool s8, bool fq) {   // compact prepared map (P24): dense calls only
-    if (fq) return s8 ? reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, true, true, false, true>)
-                      : reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, true, true, false, true>);
-    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 0, true, false, false, true>);
+static const void* pick_split_xr_kernel(bool prepared, bool p24) {
+    if (p24) return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, true, true, false, true, true>);
+    if (prepared) return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, true, true, false, false, true>);
+    return reinterpret_cast<const void*>(sim_split_f16_kernel<QT, 8, false, true, false, false, true>);
 }
 
 template <int QT, bool PRE, bool QM>
@@ -1543,9 +1608,12 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     if (p.stream) {
         for (int ci = 0; ci < p.nchunks; ++ci) {
             const SplitChunk& c = p.chunks[ci];
-            const bool tb = (ld % 1024) != 0;   // tile blocking (QT = 2 only) loses on 4 KiB-multiple row strides, see the kernel
-            const void* kern = d_qmap ? (p.SPC == 4 ? pick_stream_kernel<4, PRE, true>(c.QT, tb) : pick_stream_kernel<2, PRE, true>(c.QT, tb))
-                                      : (p.SPC == 4 ? pick_stream_kernel<4, PRE, false>(c.QT, tb) : pick_stream_kernel<2, PRE, false>(c.QT, tb));
+            const bool tb = ((ld * (p24 ? 3 : 4)) % 4096) != 0;   // tile blocking (QT = 2 only) loses on 4 KiB-multiple row strides, see the kernel
+            const void* kern = nullptr;
+            if constexpr (PRE) {
+                if (p24) kern = d_qmap ? pick_stream_kernel_spc<true, true, true>(p.SPC, c.QT, tb) : pick_stream_kernel_spc<true, false, true>(p.SPC, c.QT, tb);
+            }
+            if (!kern) kern = d_qmap ? pick_stream_kernel_spc<PRE, true, false>(p.SPC, c.QT, tb) : pick_stream_kernel_spc<PRE, false, false>(p.SPC, c.QT, tb);
             const size_t lds = p.lds_bytes(c);
             int rc = ensure_dynamic_lds(kern, lds);
             if (rc != AVL_OK) return rc;
@@ -1562,7 +1630,16 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
         const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
-        const void* kern = p24    ? (c.QT == 3 ? pick_split24_kernel<3>(s8, fq) : (c.QT == 2 ? pick_split24_kernel<2>(s8, fq) : pick_split24_kernel<1>(s8, fq)))
+        // "N categories + other": 1..4 rows beyond full 32-row tiles go to the 4x4x4 MFMA path instead of a padded tile
+        const int xr = c.rows % 32;
+        // (same-box A/B at 2 M voxels: 65 rows 0.753 -> 0.726 ms raw, 0.758 -> 0.718 prepared, 0.645 -> 0.624 compact; 33 rows on a raw
+        // map are the one case that loses -- 0.689 -> 0.718 ms, the single-tile kernel with three accumulator sets and the on-the-fly
+        // split is at its register limit -- so raw maps take the path from two full tiles on)
+        const bool use_xr = kSimExtraRows && s8 && fq && !d_qmap && xr >= 1 && xr <= 4 && c.rows > 32 && c.rows / 32 <= 2 &&
+                            (PRE || c.rows / 32 == 2);
+        const void* kern = use_xr ? (c.rows / 32 == 2 ? pick_split_xr_kernel<2>(PRE, p24) : pick_split_xr_kernel<1>(PRE, p24))
+                           : (p24 && d_qmap) ? (c.QT == 3 ? pick_split24_kernel<3, true>(s8, fq) : (c.QT == 2 ? pick_split24_kernel<2, true>(s8, fq) : pick_split24_kernel<1, true>(s8, fq)))
+                           : p24  ? (c.QT == 3 ? pick_split24_kernel<3, false>(s8, fq) : (c.QT == 2 ? pick_split24_kernel<2, false>(s8, fq) : pick_split24_kernel<1, false>(s8, fq)))
                            : d_qmap ? (c.QT == 3 ? pick_split_kernel<3, PRE, true>(s8, fq)
                                                : (c.QT == 2 ? pick_split_kernel<2, PRE, true>(s8, fq) : pick_split_kernel<1, PRE, true>(s8, fq)))
                                   : (c.QT == 3 ? pick_split_kernel<3, PRE, false>(s8, fq)
@@ -1673,11 +1750,11 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
     AVL_REQUIRE(ld_feat >= D && ld_q >= D, "avl_sim_scores: row strides must be >= D");
     AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED24, "avl_sim_scores: bad precision %d", precision);
     const bool p24 = precision == AVL_SIM_PREPARED24;
-    if (p24) {   // compact prepared map: 3 bytes per element, dense rows, resident-query kernel only
+    if (p24) {   // compact prepared map: 3 bytes per element, dense rows (resident, streamed and column-block kernels)
         AVL_REQUIRE(D % 64 == 0 && ld_feat == D && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0,
                     "avl_sim_scores_prepared24: needs D %% 64 == 0 and dense 16-byte aligned rows (D=%d)", D);
+        AVL_REQUIRE(d_row_scale, "avl_sim_scores_prepared24: the compact form always has row scales");
         precision = AVL_SIM_PREPARED;
-        h_col_begin = h_col_end = nullptr;
     }
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat && d_queries, "avl_sim_scores: null input");
@@ -1686,7 +1763,7 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
     SplitPlan p;
     const bool aligned = (ld_feat % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0) &&
                          (!d_scores || (reinterpret_cast<uintptr_t>(d_scores) & 15) == 0);
-    const bool can_split = make_split_plan(D, Q, p, precision != AVL_SIM_EXACT && !p24) && aligned;
+    const bool can_split = make_split_plan(D, Q, p, precision != AVL_SIM_EXACT) && aligned;
     bool use_split, use_f32_mfma = false;
     if (precision == AVL_SIM_EXACT_VALU) use_split = false;
     else if (precision == AVL_SIM_EXACT) {
@@ -1775,9 +1852,10 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
                 const int32_t* qmap_g = qmap + row_off;
                 hipLaunchKernelGGL(sim_gather_queries_kernel, dim3((unsigned)Qg), dim3(256), 0, st, d_queries, ld_q, qmap_g, Qg, cg.col0,
                                    cg.cols, qg_g);
-                const float* feat_g = d_feat + cg.col0;
+                // the column window of every row: 4 B per column, 3 B in the compact form (96 B per 32 columns; windows are 128-aligned)
+                const float* feat_g = p24 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_feat) + (size_t)cg.col0 * 3) : d_feat + cg.col0;
                 rc = prepared ? run_split<true>(feat_g, N, cg.cols, ld_feat, qg_g, Qg, cg.cols, Q, d_scores, amax, best, gplans[g], ws,
-                                                d_row_scale, nullptr, qmap_g, g == 0, st)
+                                                d_row_scale, nullptr, qmap_g, g == 0, st, p24)
                               : run_split<false>(feat_g, N, cg.cols, ld_feat, qg_g, Qg, cg.cols, Q, d_scores, amax, best, gplans[g], ws, nullptr,
                                                  flags, qmap_g, g == 0, st);
                 row_off += (size_t)Qg;

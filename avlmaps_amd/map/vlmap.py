@@ -41,7 +41,7 @@ class VLMap(Map):
         self.prefetch_device = True       # load_map starts the one-off upload + conversion of grid_feat (1.1 s at 2 M voxels: 4 GB over
                                           # PCIe from pageable memory) on a host thread, so that it overlaps with whatever the
                                           # caller does next (upstream: loading CLIP, seconds) instead of sitting in the first query
-        self.compact_map = True           # the resident copy is the 3-byte form for D <= 512 (ops.prepare_map(compact=True): fp16 hi + one
+        self.compact_map = True           # the resident copy is the 3-byte form (ops.prepare_map(compact=True): fp16 hi + one
                                           # byte of residual in units of ulp(hi)/256, per-row scale): a query pass reads a quarter less
                                           # HBM (0.70 -> 0.61 ms at 2 M voxels x 64 queries), the copy is a quarter smaller, and the
                                           # scores stay float32-class (max error 2.3e-6 against 1.4e-6 for the 4-byte form; the path's
@@ -141,7 +141,9 @@ class VLMap(Map):
             self._dev_feat_src = self.grid_feat
             self._sim_precision = "auto"
             if dev.shape[1] % 64 == 0 and dev.shape[0] > 0:
-                if self.compact_map and dev.shape[1] <= 512:          # the compact form only pays on the resident-query kernel (D <= 512)
+                # the compact form is read by every matrix-core kernel (resident, streamed, column-block); widths the streamed
+                # kernels cannot take (D > 512 and not a multiple of 128) keep the 4-byte copy
+                if self.compact_map and (dev.shape[1] <= 512 or dev.shape[1] % 128 == 0):
                     raw = dev
                     dev = ops.prepare_map(raw, compact=True)
                     raw.free()                                        # the float32 device copy is not needed any more

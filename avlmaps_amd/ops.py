@@ -39,7 +39,8 @@ def sim_scores(feat, queries, want_scores=True, want_argmax=True, want_best=Fals
     if isinstance(feat, PreparedMap):
         prepared, feat, precision = feat, feat.feat, "prepared"
         if prepared.compact:
-            return _sim_scores_compact(lib, prepared, queries, want_scores, want_argmax, want_best, stream, out_scores, out_argmax, out_best)
+            return _sim_scores_compact(lib, prepared, queries, want_scores, want_argmax, want_best, stream, out_scores, out_argmax, out_best,
+                                       col_support)
     if stream is None and _is_torch(feat):
         from .device import torch_stream_ptr
         stream = torch_stream_ptr()           # launch on torch's current stream so torch-side ordering holds
@@ -124,8 +125,9 @@ class PreparedMap:
         self.feat, self.row_scale, self.shape, self.compact = feat, row_scale, tuple(shape), bool(compact)
 
 
-def _sim_scores_compact(lib, pm, queries, want_scores, want_argmax, want_best, stream, out_scores, out_argmax, out_best):
-    """sim_scores on a compact prepared map (avl_sim_scores_prepared24); results as DeviceArrays / torch tensors like the map"""
+def _sim_scores_compact(lib, pm, queries, want_scores, want_argmax, want_best, stream, out_scores, out_argmax, out_best, col_support="auto"):
+    """sim_scores on a compact prepared map (avl_sim_scores_prepared24, or avl_sim_scores_blocks with AVL_SIM_PREPARED24 for
+    block-structured query sets); results as DeviceArrays / torch tensors like the map"""
     torch_mode = _is_torch(pm.feat)
     if stream is None and torch_mode:
         from .device import torch_stream_ptr
@@ -158,7 +160,17 @@ def _sim_scores_compact(lib, pm, queries, want_scores, want_argmax, want_best, s
     fptr = pm.feat.data_ptr() if torch_mode else pm.feat.ptr
     rsp = pm.row_scale.data_ptr() if _is_torch(pm.row_scale) else pm.row_scale.ptr
     wsp, wsb = _sim_workspace(lib, N, D, Q, stream)
-    _lib.check(lib.avl_sim_scores_prepared24(fptr, rsp, N, D, qptr, Q, D, sp, ap, bp, wsp, wsb, stream), "avl_sim_scores_prepared24")
+    if isinstance(col_support, str):
+        col_support = query_col_support(queries) if (col_support == "auto" and isinstance(queries, np.ndarray) and D > 128) else None
+    if col_support is not None:
+        cb = np.ascontiguousarray(col_support[0], dtype=np.int32)
+        ce = np.ascontiguousarray(col_support[1], dtype=np.int32)
+        if cb.shape != (Q,) or ce.shape != (Q,):
+            raise ValueError("col_support must be two (Q,) integer arrays")
+        _lib.check(lib.avl_sim_scores_blocks(fptr, rsp, N, D, D, qptr, Q, D, cb.ctypes.data, ce.ctypes.data, sp, ap, bp, _lib.SIM_PREPARED24,
+                                             wsp, wsb, stream), "avl_sim_scores_blocks")
+    else:
+        _lib.check(lib.avl_sim_scores_prepared24(fptr, rsp, N, D, qptr, Q, D, sp, ap, bp, wsp, wsb, stream), "avl_sim_scores_prepared24")
     return sk, ak, bk
 
 

@@ -109,7 +109,8 @@ enum {
                               follow-up kernel (np.argmax semantics for NaN rows), so every row is float32-class.       */
     AVL_SIM_EXACT_VALU = 3,/* force the vector-ALU float32 kernel                                                        */
     AVL_SIM_PREPARED = 4,  /* d_feat was converted by avl_sim_prepare_map: SPLIT_F16 without the on-the-fly split        */
-    AVL_SIM_PREPARED24 = 5 /* internal to avl_sim_scores_prepared24 (compact 3-byte form of avl_sim_prepare_map24)      */
+    AVL_SIM_PREPARED24 = 5 /* d_feat is the compact 3-byte form of avl_sim_prepare_map24 (avl_sim_scores_prepared24, or
+                              avl_sim_scores_blocks with d_feat = d_map24, ld_feat = D and its d_row_scale)               */
 };
 
 /* One-off, IN-PLACE conversion of a device-resident float32 map (N, D; D % 64 == 0, 16-byte aligned rows) into the split
@@ -150,8 +151,9 @@ AVL_API int avl_sim_scores_ws(const float* d_feat, int64_t N, int D, int64_t ld_
  * the map, one launch group per window: on a fused visual | audio map (BASELINE config 5: 512 + 1024 columns, every query
  * living in one modality block) the map is still read once overall but the matrix cores do half the work.  Results equal the
  * dense call (same products; zero products dropped); argmax ties still resolve to the lowest query index.  d_row_scale: see
- * avl_sim_scores_prepared (NULL unless precision == AVL_SIM_PREPARED on a scaled map).  Falls back to the dense path when the
- * windows do not split the queries or the shape does not allow it. */
+ * avl_sim_scores_prepared (NULL unless precision == AVL_SIM_PREPARED on a scaled map, or AVL_SIM_PREPARED24: then d_feat is the
+ * compact map of avl_sim_prepare_map24 and ld_feat == D).  Falls back to the dense path when the windows do not split the
+ * queries or the shape does not allow it. */
 AVL_API int avl_sim_scores_blocks(const float* d_feat, const float* d_row_scale, int64_t N, int D, int64_t ld_feat,
                                   const float* d_queries, int Q, int64_t ld_q, const int32_t* h_col_begin,
                                   const int32_t* h_col_end, float* d_scores, int32_t* d_argmax, float* d_best, int precision,
@@ -168,9 +170,10 @@ AVL_API int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scal
  * residuals are rebuilt as fp16 in registers (five vector-ALU instructions per two elements) and the arithmetic is the same three
  * fp16 MFMAs.  Accuracy: 19 significant bits per element (hi's 11 + 8: the residual's exponent is implied by hi) instead of 22 --
  * max |score - float64| 2.3e-6 on LSeg-scale rows against 1.4e-6 for the 4-byte forms (tests/test_sim_gpu.py): still float32-class.
- * Elements below 2^-11 of their row's maximum keep hi only.  D % 64 == 0; dense calls only, and always on the resident-query
- * kernel: it pays for D <= 512 and up to ~78 queries per pass (0.70 -> 0.61 ms at 2 M x 512 x 64); wider maps or larger query sets
- * are faster in the 4-byte forms (streamed / column-block kernels). */
+ * Elements below 2^-11 of their row's maximum keep hi only.  D % 64 == 0.  Every matrix-core kernel reads this form: the
+ * resident-query kernel (D <= 512, up to ~78 queries per pass: 0.70 -> 0.61 ms at 2 M x 512 x 64), the streamed kernels (any
+ * D % 128 == 0, up to 128 queries per pass) and the column-block launches of avl_sim_scores_blocks (precision
+ * AVL_SIM_PREPARED24; BASELINE config 5's fused 1536-column map is 9.2 GB instead of 12.3 GB per pass). */
 AVL_API int avl_sim_prepare_map24(const float* d_feat, int64_t N, int D, int64_t ld_feat, void* d_map24, float* d_row_scale,
                                   void* stream);
 AVL_API int avl_sim_scores_prepared24(const void* d_map24, const float* d_row_scale, int64_t N, int D, const float* d_queries,

@@ -163,6 +163,63 @@ def test_full_size_properties(ops):
     assert (s12 - (sc[:200_000, :32] + sc[:200_000, 32:])).abs().max() < 1e-4
 
 
+def test_config5_full_size_properties(ops):
+    """BASELINE config 5 at FULL size: 2 M voxels x (512 visual | 1024 audio) columns, 128 block-structured queries, through the
+    column-block launches on the raw float32 map and on VLMap's compact resident copy.  Size-independent properties, no CPU
+    reference: argmax / best consistent with the scores of a materialised row band, checksum of checksums over that band,
+    a random row sample against float64 (north_star: 1e-4), block launches == dense pass, compact copy == raw map up to the
+    compact form's float32-class error, linearity in the queries.  (clip_utils.py:227-229 is the op.)"""
+    import torch
+    from avlmaps_amd.device import DeviceArray
+    N, D, Q = 2_000_000, 1536, 128
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    feat = torch.randn((N, D), device="cuda", generator=gen)
+    feat *= (14.2857 * (0.05 + 0.95 * torch.rand((N, 1), device="cuda", generator=gen))) / feat.norm(dim=1, keepdim=True)
+    q = torch.randn((Q, D), device="cuda", generator=gen)
+    q /= q.norm(dim=1, keepdim=True)
+    q[:64, 512:] = 0            # text queries live in the visual columns
+    q[64:, :512] = 0            # audio queries in the AudioCLIP columns
+    qh = q.cpu().numpy()
+    cb, ce = ops.query_col_support(qh)
+    assert set(zip(cb.tolist(), ce.tolist())) == {(0, 512), (512, 1536)}
+    # (a) argmax + best over the whole map, raw float32 rows, column-block launches
+    _, am, best = ops.sim_scores(feat, q, want_scores=False, want_best=True, col_support=(cb, ce))
+    # (b) the scores of a band of rows (a 1 GB scores_mat for the whole map is not the point of the test)
+    B0, B1 = 1_000_000 - 100_000, 1_000_000 + 100_000
+    band = feat[B0:B1]
+    sc, amb, bestb = ops.sim_scores(band, q, want_best=True, col_support=(cb, ce))
+    torch.cuda.synchronize()
+    assert torch.equal(amb, am[B0:B1]) and torch.equal(bestb, best[B0:B1])
+    assert torch.equal(sc.max(dim=1).values, bestb) and torch.equal(sc.gather(1, amb.long()[:, None])[:, 0], bestb)
+    # checksum of checksums over the band (float64 on the device)
+    lhs, rhs = sc.double().sum(0), band.double().sum(0) @ q.double().T
+    assert torch.allclose(lhs, rhs, rtol=0, atol=2e-2), (lhs - rhs).abs().max()
+    # (c) a random row sample of the whole map against float64: best score and argmax
+    idx = torch.cat([torch.arange(0, 512, device="cuda"), torch.arange(N - 512, N, device="cuda"),
+                     torch.randint(0, N, (4096,), device="cuda", generator=gen)])
+    ref = feat[idx].double() @ q.double().T
+    assert (best[idx].double() - ref.max(1).values).abs().max() < 1e-4
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2e-4
+    assert torch.equal(ref.argmax(1)[clear], am[idx].long()[clear])
+    # (d) the dense single pass over the band gives the same scores (the dropped products are exact zeros)
+    scd, amd, _ = ops.sim_scores(band, q, col_support=None)
+    assert (sc - scd).abs().max() < 1e-5 and (amd == amb).double().mean() > 0.999
+    # (e) linearity in the queries (text + audio query = a query living in both blocks -> dense fallback)
+    s12, _, _ = ops.sim_scores(band, q[:64] + q[64:], want_argmax=False, col_support=None)
+    assert (s12 - (sc[:, :64] + sc[:, 64:])).abs().max() < 1e-4
+    del sc, scd, s12
+    # (f) VLMap's compact resident copy (3 bytes per element) through the same column-block launches
+    pm = ops.prepare_map(feat, compact=True)
+    assert pm.compact and tuple(pm.feat.shape) == (N, 3 * D)
+    _, am24, best24 = ops.sim_scores(pm, q, want_scores=False, want_best=True, col_support=(cb, ce))
+    torch.cuda.synchronize()
+    assert (best24[idx].double() - ref.max(1).values).abs().max() < 2e-5          # float32-class: ~3e-6 measured
+    assert torch.equal(ref.argmax(1)[clear], am24[idx].long()[clear])
+    assert (am24 == am).double().mean() > 0.9995                                   # differences only at near-ties
+    assert (best24 - best).abs().max() < 2e-5
+
+
 def test_fused_multimodal_block_queries(ops):
     """BASELINE config 5 shape family: 512 visual || 1024 audio feature columns, 128 queries each non-zero in one block."""
     from oracle import avl_oracle as O
@@ -329,7 +386,7 @@ def test_column_block_launches_equal_the_dense_pass(ops, golden):
     feat, q, ref = g["d1536_q128_feat"], g["d1536_q128_mean_feats"], g["d1536_q128_scores"]
     cb, ce = ops.query_col_support(q)
     assert set(zip(cb.tolist(), ce.tolist())) == {(0, 512), (512, 1536)}          # text / audio queries interleaved (qi % 2)
-    for src in (feat, ops.prepare_map(DeviceArray.from_numpy(feat))):
+    for src in (feat, ops.prepare_map(DeviceArray.from_numpy(feat)), ops.prepare_map(DeviceArray.from_numpy(feat), compact=True)):
         sc, am, best = ops.sim_scores(src, q, want_best=True)                      # host queries: windows derived automatically
         sc, am, best = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (sc, am, best))
         assert np.abs(sc - ref).max() < 3e-5 and np.array_equal(am, np.argmax(sc, axis=1)) and np.array_equal(best, sc.max(axis=1))
@@ -420,7 +477,8 @@ def test_column_windows_with_ties_zero_queries_and_bad_rows(ops, windows, counts
     ok = np.ones(N, bool)
     ok[17] = False
     scale = np.maximum(1.0, np.abs(want[ok]).max(axis=1, keepdims=True))
-    for name, src in (("raw", f), ("prepared", ops.prepare_map(DeviceArray.from_numpy(f)))):
+    for name, src in (("raw", f), ("prepared", ops.prepare_map(DeviceArray.from_numpy(f))),
+                      ("compact", ops.prepare_map(DeviceArray.from_numpy(f), compact=True))):
         sc, am, best = ops.sim_scores(src, q, want_best=True, col_support=(cb, np.maximum(ce, 1)))
         sc, am, best = (x.numpy() if not isinstance(x, np.ndarray) else x for x in (sc, am, best))
         _, am_only, _ = ops.sim_scores(src, q, want_scores=False, col_support=(cb, np.maximum(ce, 1)))

@@ -28,11 +28,34 @@ def child(shape, mode):
     wsb = C.c_size_t()
     lib.avl_sim_workspace_bytes_n(N, D, Q, C.byref(wsb))
     ws = torch.empty((max(wsb.value, 64),), dtype=torch.uint8, device="cuda")
-    if mode == "prepared":
+    from avlmaps_amd.ops import query_col_support
+    cb, ce = query_col_support(q.cpu().numpy())
+    blocks = D > 512 and mode.endswith("blocks")          # "rawblocks" / "preparedblocks" / "compactblocks": column-block launches
+    base = mode.replace("blocks", "") or "raw"
+    if base == "prepared":
         rs = torch.empty((N,), dtype=torch.float32, device="cuda")
         _lib.check(lib.avl_sim_prepare_map(feat.data_ptr(), N, D, D, rs.data_ptr(), None))
-        fn = lambda: _lib.check(lib.avl_sim_scores_prepared(feat.data_ptr(), rs.data_ptr(), N, D, D, q.data_ptr(), Q, D, None, am.data_ptr(),
-                                                            None, ws.data_ptr(), wsb.value, None))
+        if blocks:
+            fn = lambda: _lib.check(lib.avl_sim_scores_blocks(feat.data_ptr(), rs.data_ptr(), N, D, D, q.data_ptr(), Q, D, cb.ctypes.data, ce.ctypes.data,
+                                                              None, am.data_ptr(), None, _lib.SIM_PREPARED, ws.data_ptr(), wsb.value, None))
+        else:
+            fn = lambda: _lib.check(lib.avl_sim_scores_prepared(feat.data_ptr(), rs.data_ptr(), N, D, D, q.data_ptr(), Q, D, None, am.data_ptr(),
+                                                                None, ws.data_ptr(), wsb.value, None))
+    elif base == "compact":
+        rs = torch.empty((N,), dtype=torch.float32, device="cuda")
+        m24 = torch.empty((N, 3 * D), dtype=torch.uint8, device="cuda")
+        _lib.check(lib.avl_sim_prepare_map24(feat.data_ptr(), N, D, D, m24.data_ptr(), rs.data_ptr(), None))
+        torch.cuda.synchronize()
+        del feat
+        if blocks:
+            fn = lambda: _lib.check(lib.avl_sim_scores_blocks(m24.data_ptr(), rs.data_ptr(), N, D, D, q.data_ptr(), Q, D, cb.ctypes.data, ce.ctypes.data,
+                                                              None, am.data_ptr(), None, _lib.SIM_PREPARED24, ws.data_ptr(), wsb.value, None))
+        else:
+            fn = lambda: _lib.check(lib.avl_sim_scores_prepared24(m24.data_ptr(), rs.data_ptr(), N, D, q.data_ptr(), Q, D, None, am.data_ptr(),
+                                                                  None, ws.data_ptr(), wsb.value, None))
+    elif blocks:
+        fn = lambda: _lib.check(lib.avl_sim_scores_blocks(feat.data_ptr(), None, N, D, D, q.data_ptr(), Q, D, cb.ctypes.data, ce.ctypes.data,
+                                                          None, am.data_ptr(), None, 0, ws.data_ptr(), wsb.value, None))
     else:
         fn = lambda: _lib.check(lib.avl_sim_scores_ws(feat.data_ptr(), N, D, D, q.data_ptr(), Q, D, None, am.data_ptr(), None, 0,
                                                       ws.data_ptr(), wsb.value, None))
