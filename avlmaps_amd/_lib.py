@@ -3,6 +3,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
+import threading
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
@@ -58,6 +60,7 @@ _SIGS = {
     "avl_sim_scores_ws": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, C.c_int, _vp, _sz, _vp]),
     "avl_sim_scores_host": (C.c_int, [_vp, _i64, C.c_int, _vp, C.c_int, _vp, _vp, _vp, C.c_int]),
     "avl_mask_from_argmax": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "avl_mask_bits_from_argmax": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "avl_argmax_f32": (C.c_int, [_vp, _i64, C.POINTER(_i64), C.POINTER(C.c_float), _vp]),
     "avl_topk_f32": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _vp]),
     "avl_builder_create": (C.c_int, [C.POINTER(_vp), C.c_int, _f64, C.c_int, C.c_int, _i64]),
@@ -88,11 +91,13 @@ _SIGS = {
     "avl_finalize_merged": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),
     "avl_replay_state_apply": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
+    "avl_rows_add_f64": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "avl_pool_label_2d": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "avl_rgb_topdown": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "avl_obstacle_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "avl_obstacle_scatter": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "avl_heatmap_from_mask": (C.c_int, [_vp, _vp, _i64, _f64, _f64, _vp, _vp]),
+    "avl_lseg_merge_windows": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)
@@ -126,6 +131,34 @@ def check(rc: int, what: str = ""):
     if rc != AVL_OK:
         msg = load().avl_last_error().decode(errors="replace")
         raise AvlError(f"{what or 'libavlmaps_hip'} failed (status {rc}): {msg}")
+
+
+_tls = threading.local()
+
+
+def set_device(device: int) -> None:
+    """avl_set_device for the calling thread, remembered so that helpers started from this thread (VLMap's map-upload thread) can
+    bind to the same GPU without having to start the HIP runtime just to ask"""
+    check(load().avl_set_device(int(device)), "avl_set_device")
+    _tls.device = int(device)
+
+
+def current_device(query_runtime: bool = True):
+    """the calling thread's current GPU: what set_device recorded, else torch's current device if torch has initialised the GPU,
+    else (query_runtime) what HIP reports -- which starts the runtime (~0.8 s the first time) -- else None"""
+    d = getattr(_tls, "device", None)
+    if d is not None:
+        return d
+    t = sys.modules.get("torch")
+    try:
+        if t is not None and t.cuda.is_initialized():
+            return int(t.cuda.current_device())
+    except Exception:
+        pass
+    if not query_runtime:
+        return None
+    n = C.c_int(0)
+    return n.value if load().avl_get_device(C.byref(n)) == AVL_OK else 0
 
 
 def device_count() -> int:

@@ -1406,10 +1406,6 @@ int avl_builder_scatter_merge(avl_builder* b, int64_t n, const int64_t* d_row_of
     if (rc != AVL_OK) return rc;
     AVL_REQUIRE(n == have, "avl_builder_scatter_merge: n=%lld but the map holds %lld voxels", (long long)n, (long long)have);
     AVL_REQUIRE(ld_acc >= b->D + 4, "avl_builder_scatter_merge: ld_acc must be >= D + 4");
-    if (b->key_bias != 0) {
-        set_error("avl_builder_scatter_merge: a builder seeded by avl_builder_import_map cannot take part in a multi-GPU merge");
-        return AVL_ERR_STATE;
-    }
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(d_row_of_slot && d_global_key && d_acc, "avl_builder_scatter_merge: null pointer");
     int64_t blocks = (n + 3) / 4;
@@ -1505,6 +1501,48 @@ int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_
     return rc;
 }
 
+// dst[d_rows[i] - row0, 0:cols] += src[i, 0:cols]  (float64): folds the contributions one rank received from ONE peer into its
+// block of final rows.  A peer holds a voxel at most once, so the rows of a call are distinct: plain read-modify-write, and the
+// caller's peer-by-peer order of the calls fixes the summation order (reproducible merges).  Wave per row.
+__global__ __launch_bounds__(256) void rows_add_f64_kernel(int64_t n, int cols, const int64_t* __restrict__ rows, int64_t row0, int64_t nrows,
+                                                           const double* __restrict__ src, int64_t ld_src, double* __restrict__ dst,
+                                                           int64_t ld_dst, int* __restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < n; i += nwaves) {
+        const int64_t r = rows[i] - row0;
+        if (r < 0 || r >= nrows) {
+            if (lane == 0 && err_flag) atomicOr(err_flag, 1);
+            continue;
+        }
+        const double* a = src + i * ld_src;
+        double* o = dst + r * ld_dst;
+        for (int c = lane; c < cols; c += 64) o[c] += a[c];
+    }
+}
+
+int avl_rows_add_f64(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src, int64_t ld_src,
+                     double* d_dst, int64_t ld_dst, void* stream) {
+    AVL_REQUIRE(n >= 0 && cols > 0 && nrows >= 0 && ld_src >= cols && ld_dst >= cols, "avl_rows_add_f64: bad shape");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_rows && d_src && d_dst, "avl_rows_add_f64: null pointer");
+    hipStream_t st = as_stream(stream);
+    int* flag = static_cast<int*>(avl::scratch(64));
+    if (!flag) return AVL_ERR_HIP;
+    AVL_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
+    int64_t blocks = (n + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(rows_add_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, cols, d_rows, row0, nrows, d_src, ld_src, d_dst,
+                       ld_dst, flag);
+    int h = 0;
+    AVL_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    AVL_HIP_CHECK(hipStreamSynchronize(st));
+    AVL_REQUIRE(h == 0, "avl_rows_add_f64: a row index lies outside [row0, row0 + nrows)");
+    return AVL_OK;
+}
+
 int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream) {
     AVL_REQUIRE(n >= 0, "avl_replay_state_apply: bad n");
     if (n == 0) return AVL_OK;
@@ -1518,9 +1556,16 @@ int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint
 int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, const int32_t* d_grid_pos,
                            const float* d_weight, const uint8_t* d_grid_rgb, void* stream) {
     AVL_REQUIRE(b, "avl_builder_import_map: null handle");
-    AVL_REQUIRE(n >= 0 && n <= b->capacity, "avl_builder_import_map: %lld voxels exceed the capacity %lld", (long long)n,
-                (long long)b->capacity);
+    AVL_REQUIRE(n >= 0, "avl_builder_import_map: bad n");
     hipStream_t st = as_stream(stream);
+    // a map that grew past the initial capacity (the reference doubles its arrays, _reserve_map_space vlmap_builder.py:286-311,
+    // and resumes such a map): grow like a frame launch would, if the handle is allowed to
+    if (n > b->capacity && b->max_capacity > b->capacity) {
+        const int rcg = grow_builder(b, n, st);
+        if (rcg != AVL_OK) return rcg;
+    }
+    AVL_REQUIRE(n <= b->capacity, "avl_builder_import_map: %lld voxels exceed the capacity %lld (avl_builder_set_max_capacity lets it grow)",
+                (long long)n, (long long)b->capacity);
     int64_t have = 0;
     int rc = avl_builder_num_voxels(b, &have, stream);
     if (rc != AVL_OK) return rc;
@@ -1528,7 +1573,10 @@ int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, 
         set_error("avl_builder_import_map: the map already holds %lld voxels (import into an empty builder)", (long long)have);
         return AVL_ERR_STATE;
     }
-    if (n == 0) return AVL_OK;
+    if (n == 0) {
+        b->key_bias = 1ull << 62;   // continuing a map: the voxels of new frames order after every imported one (none here: the
+        return AVL_OK;              // other ranks of a resumed multi-GPU build import nothing but must use the same key space)
+    }
     AVL_REQUIRE(d_grid_feat && d_grid_pos && d_weight, "avl_builder_import_map: null input");
     int64_t blocks = (n + 3) / 4;
     const int64_t maxb = (int64_t)num_cus() * 16;

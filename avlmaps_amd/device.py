@@ -14,7 +14,7 @@ import numpy as np
 from . import _lib
 
 
-# Freed buffers are kept on a size-keyed free list (hipMalloc / hipFree cost ~100 us each and hipFree synchronises): the
+# Freed buffers are kept on a free list keyed by (device, size) (hipMalloc / hipFree cost ~100 us each and hipFree synchronises): the
 # per-frame staging buffers of the builder are then recycled instead of reallocated.  Bounded; oversize buffers go back.
 _POOL: dict = {}
 _POOL_BYTES = [0]
@@ -23,8 +23,15 @@ _POOL_MAX_ITEM = 256 << 20
 _H2D_PIECE = 64 << 20
 
 
-def _pool_alloc(nbytes: int) -> int:
-    lst = _POOL.get(nbytes)
+def _pool_device() -> int:
+    """the GPU the calling thread allocates on (HIP keeps the current device per thread): pooled pointers are only ever handed
+    back out on the device they were allocated on"""
+    n = C.c_int(0)
+    return n.value if _lib.load().avl_get_device(C.byref(n)) == _lib.AVL_OK else 0
+
+
+def _pool_alloc(nbytes: int, device: int) -> int:
+    lst = _POOL.get((device, nbytes))
     if lst:
         try:
             ptr = lst.pop()               # another thread (map upload, checkpoint writer) may have taken the last one
@@ -38,16 +45,16 @@ def _pool_alloc(nbytes: int) -> int:
     return p.value or 0
 
 
-def _pool_free(ptr: int, nbytes: int) -> None:
+def _pool_free(ptr: int, nbytes: int, device: int) -> None:
     if 0 < nbytes <= _POOL_MAX_ITEM and _POOL_BYTES[0] + nbytes <= _POOL_LIMIT:
-        _POOL.setdefault(nbytes, []).append(ptr)
+        _POOL.setdefault((device, nbytes), []).append(ptr)
         _POOL_BYTES[0] += nbytes
     else:
         _lib.load().avl_free(ptr)
 
 
 def empty_pool() -> None:
-    for nbytes, lst in list(_POOL.items()):
+    for key, lst in list(_POOL.items()):
         for p in lst:
             _lib.load().avl_free(p)
     _POOL.clear()
@@ -61,7 +68,8 @@ class DeviceArray:
         self.shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        self.ptr = _pool_alloc(max(self.nbytes, 1))
+        self.device = _pool_device()
+        self.ptr = _pool_alloc(max(self.nbytes, 1), self.device)
 
     @classmethod
     def from_numpy(cls, a, stream=None):
@@ -88,7 +96,7 @@ class DeviceArray:
 
     def free(self):
         if getattr(self, "ptr", 0):
-            _pool_free(self.ptr, max(self.nbytes, 1))
+            _pool_free(self.ptr, max(self.nbytes, 1), getattr(self, "device", 0))
             self.ptr = 0
 
     def __del__(self):

@@ -79,24 +79,20 @@ class VLMap(Map):
     def _start_device_prefetch(self) -> None:
         if not self.prefetch_device or self.grid_feat is None or len(self.grid_feat) == 0:
             return
-        import sys
         import threading
-        # the device the CALLING thread works on (HIP keeps the current device per thread).  Asking HIP itself would initialise the
-        # runtime right here (~0.8 s): torch knows it if it has initialised the GPU, otherwise nothing has selected a device yet
-        dev = 0
-        t = sys.modules.get("torch")
-        try:
-            if t is not None and t.cuda.is_initialized():
-                dev = int(t.cuda.current_device())
-        except Exception:
-            dev = 0
+        from .. import _lib
+        # the device the CALLING thread works on (HIP keeps the current device per thread): what it selected through
+        # _lib.set_device or torch; asking HIP itself would start the runtime right here (~0.8 s), so if nothing is known yet the
+        # upload goes to device 0 and _device_feat() checks at query time that the resident copy lives on the querying
+        # thread's device (re-uploading once if the caller picked another GPU in between)
+        dev = _lib.current_device(query_runtime=False)
+        dev = 0 if dev is None else dev
 
         def work():
             try:
-                from .. import _lib
-                lib = _lib.load()
+                _lib.load()
                 _lib.require_gpu()                                         # first HIP call of the process: runtime start-up
-                _lib.check(lib.avl_set_device(dev), "avl_set_device")
+                _lib.set_device(dev)
                 self._device_feat()
             except Exception:             # no GPU / no library / upload failed: the query path repeats it on the calling thread
                 pass                      # and reports the error there
@@ -132,7 +128,14 @@ class VLMap(Map):
             return self._device_feat_locked(ops, parallel, DeviceArray)
 
     def _device_feat_locked(self, ops, parallel, DeviceArray):
+        from .. import _lib
+        cur = _lib.current_device()
+        if self._dev_feat is not None and getattr(self, "_dev_feat_device", cur) != cur:
+            # the resident copy was uploaded before the caller selected this GPU (load_map's upload thread had nothing to go
+            # by): pointers of another device would fault or crawl through peer access -- upload again, here
+            self._dev_feat = None
         if self._dev_feat is None or self._dev_feat_src is not self.grid_feat:
+            self._dev_feat_device = cur
             rank, ws = parallel.rank_world()
             self._rows = (0, len(self.grid_feat))
             if ws > 1 and self.shard_index_rows:
@@ -161,6 +164,53 @@ class VLMap(Map):
             self._dev_pos_src = self.grid_pos
         return self._dev_pos
 
+    def adopt_device_shard(self, shard) -> bool:
+        """Take this rank's block of a freshly merged map (VLMapBuilder.map_shard: device tensors of
+        parallel.merge_accumulator_sharded) as the resident copy the index kernels read -- no 4 GB host round trip after a
+        multi-GPU build.  The host attributes (load_map) must describe the same map; returns False (and changes nothing) if the
+        block is not the one shard_index_rows would upload."""
+        from .. import _lib, ops, parallel
+        if shard is None or self.grid_feat is None or int(shard["M"]) != len(self.grid_feat) or not self.shard_index_rows:
+            return False
+        rank, ws = parallel.rank_world()
+        if tuple(shard["rows"]) != parallel.shard_rows(len(self.grid_feat), rank, ws):
+            return False
+        feat = shard["grid_feat"]
+        D = int(feat.shape[1])
+        with self._dev_lock:
+            self._rows = tuple(shard["rows"])
+            self._sim_precision = "auto"
+            dev = feat
+            if D % 64 == 0 and feat.shape[0] > 0:
+                if self.compact_map and (D <= 512 or D % 128 == 0):
+                    dev = ops.prepare_map(feat, compact=True)
+                else:
+                    dev = ops.prepare_map(feat.clone(), scaled=True)
+                self._sim_precision = "prepared"
+            self._dev_feat, self._dev_feat_src, self._dev_feat_device = dev, self.grid_feat, _lib.current_device()
+        return True
+
+    def _text_feats(self, names, use_multiple_templates=True, add_other=True):
+        """landmark_text_feats with a per-instance cache keyed by the strings: the CLIP text tower costs ~1.6 ms per call, twice
+        the similarity kernel, and a navigator asks for the same landmarks again and again"""
+        key = (tuple(names), bool(use_multiple_templates), bool(add_other), id(self.clip_model), int(self.clip_feat_dim))
+        cache = self.__dict__.setdefault("_text_cache", {})
+        q = cache.get(key)
+        if q is None:
+            q, _ = landmark_text_feats(self.clip_model, list(names), self.clip_feat_dim, use_multiple_templates=use_multiple_templates,
+                                       add_other=add_other)
+            if len(cache) >= 256:
+                cache.clear()
+            cache[key] = q
+        return q
+
+    def _score_device(self, q):
+        """row argmax of this rank's block as a DEVICE array (nothing crosses PCIe)"""
+        from .. import ops
+        feat = self._device_feat()
+        _, am, _ = ops.sim_scores(feat, q, want_scores=False, want_argmax=True, precision=self._sim_precision)
+        return am
+
     def _score(self, q, want_scores: bool):
         """(scores (N, Q) | None, argmax (N,)) as host arrays for ALL voxels: this rank's row block through the similarity
         kernel, the other ranks' blocks through one all_gather of results when the rows are sharded"""
@@ -178,8 +228,7 @@ class VLMap(Map):
     def init_categories(self, categories: List[str]) -> np.ndarray:
         """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
         self.categories = categories
-        q, _ = landmark_text_feats(self.clip_model, self.categories, self.clip_feat_dim, use_multiple_templates=True,
-                                   add_other=True)
+        q = self._text_feats(self.categories)
         # one launch gives scores_mat AND its row argmax (same values, first maximum wins like np.argmax), so index_map
         # does not have to rescan the (N, Q) host matrix per query as upstream does (vlmap.py:123)
         self.scores_mat, self._argmax = self._score(q, want_scores=True)
@@ -198,10 +247,15 @@ class VLMap(Map):
         if with_init_cat:
             raise Exception(
                 "Categories are not preloaded. Call init_categories(categories: List[str]) to initialize categories.")
-        # fused path: scores never leave the GPU, only the (N,) argmax comes back
-        q, _ = landmark_text_feats(self.clip_model, [language_desc], self.clip_feat_dim, use_multiple_templates=True,
-                                   add_other=True)
-        _, am = self._score(q, want_scores=False)
+        # fused path: scores and argmax never leave the GPU; the mask is compared and bit-packed there, 1 bit per voxel comes back
+        q = self._text_feats([language_desc])
+        self._device_feat()
+        if self._rows == (0, len(self.grid_feat)):
+            am = self._score_device(q)
+            if isinstance(am, np.ndarray):
+                return am == 0
+            return ops.mask_bool_from_argmax(am, 0)
+        _, am = self._score(q, want_scores=False)          # rows sharded over ranks: the argmax blocks are all-gathered
         return am == 0
 
     def customize_obstacle_map(self, potential_obstacle_names: List[str], obstacle_names: List[str], vis: bool = False):

@@ -9,8 +9,11 @@ with several ranks too: rank r first draws and discards the shuffles of the fram
 Feature extraction stays on PyTorch-ROCm: `feat_extractor(rgb_uint8_hwc) -> (Hf, Wf, D) float32 CUDA tensor`
 (channels-last, stays on the device).  A reference-style (1, D, Hf, Wf) array is accepted and transposed.
 With torch.distributed initialised (one process per GPU) frames are sharded contiguously over ranks and merged with one
-sparse RCCL reduce (avlmaps_amd.parallel.merge_accumulator); rank 0 writes the map file.  A seeded N-rank build gives the
-map of the seeded single-process build: grid_pos / occupied_ids / grid_rgb / weight bit-exact, grid_feat to float64 rounding.
+sparse, row-sharded exchange (avlmaps_amd.parallel.merge_accumulator_sharded; merge_mode = "reduce" selects the dense single
+RCCL reduce instead); every rank keeps its block of finished rows on the device (map_shard: what VLMap.shard_index_rows
+scores), rank 0 gathers the float32 rows and writes the map file -- at the end and, like upstream's loop, every save_every
+frames (per rank), so that a long multi-GPU build can be resumed.  A seeded N-rank build gives the map of the seeded
+single-process build: grid_pos / occupied_ids / grid_rgb / weight bit-exact, grid_feat to float64 rounding.
 """
 from __future__ import annotations
 
@@ -21,8 +24,8 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from .. import ops, parallel
-from ..utils.mapping_utils import (MapFileWriter, cvt_pose_vec2tf, load_3d_map, load_depth_npy, load_rgb_png, map_file_exists,
-                                   save_3d_map)
+from ..utils.mapping_utils import (MapFileWriter, cvt_pose_vec2tf, load_3d_map, load_depth_npy, load_rgb_png, map_checkpoint_complete,
+                                   map_file_exists, read_map_dataset, save_3d_map)
 from .map import cfg_get
 
 
@@ -61,6 +64,13 @@ class VLMapBuilder:
                                                    # seeded by ONE draw of the global RNG and the frame index (0.25 ms; not the
                                                    # reference's pixels, but reproducible under np.random.seed and independent
                                                    # of how the frames are sharded over ranks)
+        self.merge_mode = "sharded"                # several ranks: "sharded" = one all_to_all of every rank's OWN voxel rows to the
+                                                   # owners of their final rows, finalised where they land (bytes ~ what a rank
+                                                   # holds; the map stays row-sharded for the index kernels); "reduce" = ONE
+                                                   # sum-reduce of a dense (M, D + 4) float64 buffer to rank 0 (north_star's wording;
+                                                   # 9.3 GB per rank at 2.25 M voxels)
+        self.map_shard = None                      # after a multi-rank build: this rank's block of the merged map, device tensors
+                                                   # (parallel.merge_accumulator_sharded) -- VLMap.adopt_device_shard takes it as is
         self.shard_sampling = "replay"             # several ranks: "replay" = every rank first consumes the global NumPy RNG
                                                    # exactly as the frames before its shard would have (one discarded shuffle
                                                    # per skipped frame, ~6 ms each at 720x1080), so that a seeded N-rank run
@@ -274,6 +284,9 @@ class VLMapBuilder:
         if self.shard_sampling not in ("replay", "independent"):
             raise ValueError(f"shard_sampling must be 'replay' or 'independent', not {self.shard_sampling!r}")
         skip = lo if (ws > 1 and self.shard_sampling == "replay") else 0
+        # checkpoint rounds of a multi-rank build: as many as the longest shard has full save_every blocks (known to every rank)
+        rounds_total = ((n_frames + ws - 1) // ws) // self.save_every if (ws > 1 and self.save_every) else 0
+        rounds_done = 0
         for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip):
             if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
                 continue        # the pixel shuffle of the skipped frame was still drawn, so later frames sample as upstream
@@ -283,9 +296,11 @@ class VLMapBuilder:
                 self.clip_feat_dim = D
                 # the reference starts at gs*gs rows and doubles (_reserve_map_space, vlmap_builder.py:286-311); so does
                 # the accumulator (max_capacity: every cell of the grid)
+                if ws > 1:
+                    D = self._agree_on_width(D)     # collective; ranks without frames join it below
                 acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=self.capacity or max(gs * gs, 1 << 16), max_capacity=self.max_capacity,
                                            deferred_fuse=self.deferred_fuse and self.batch_frames <= 1)
-                mapped_iter_set = self._resume(acc, ws)
+                mapped_iter_set = self._resume(acc, ws, rank)
                 self._resumed_frames = frozenset(mapped_iter_set)
                 if self.skip_mapped_frames and frame_i in self._resumed_frames:
                     continue
@@ -307,25 +322,27 @@ class VLMapBuilder:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
                 self._checkpoint(acc, mapped_iter_set)
+            elif ws > 1 and self.save_every and (frame_i - lo) % self.save_every == self.save_every - 1 and rounds_done < rounds_total:
+                # upstream saves every 100 frames (vlmap_builder.py:181-183); with several ranks a checkpoint is a merge, i.e. a
+                # collective: every rank joins round j after its (j + 1) * save_every-th frame (or at the end of its shard)
+                self._flush(acc, pending, calib_mat, calib_inv, transforms)
+                self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=False)
+                rounds_done += 1
         if acc is None:
             if ws == 1:
                 raise RuntimeError("no frames to map")
-            # an empty shard (fewer frames than ranks would fill) still takes part in the merge collectives
-            import torch
-            import torch.distributed as dist
-            d = torch.zeros(1, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(d, op=dist.ReduceOp.MAX)
-            if int(d.item()) <= 0:
+            # an empty shard (fewer frames than ranks would fill) still takes part in the collectives
+            D = self._agree_on_width(0)
+            if D <= 0:
                 raise RuntimeError("no frames to map")
-            acc = ops.VoxelAccumulator(gs, cs, vh, int(d.item()), capacity=1 << 10, max_capacity=0)
-            if self.exact_rgb:
+            acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=1 << 10, max_capacity=0)
+            mapped_iter_set = self._resume(acc, ws, rank)
+            if not mapped_iter_set and self.exact_rgb:
                 acc.enable_replay_log(1)
-        elif ws > 1:
-            import torch
-            import torch.distributed as dist
-            d = torch.tensor([acc.D], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(d, op=dist.ReduceOp.MAX)
         self._flush(acc, pending, calib_mat, calib_inv, transforms)
+        while ws > 1 and rounds_done < rounds_total:      # a short (or empty) shard: the checkpoint rounds the others still run
+            self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=False)
+            rounds_done += 1
         self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
 
     def _flush(self, acc, pending, calib_mat, calib_inv, transforms):
@@ -349,27 +366,72 @@ class VLMapBuilder:
         return NotImplementedError
 
     # ------------------------------------------------------------------ helpers
-    def _resume(self, acc, ws):
+    @staticmethod
+    def _agree_on_width(D: int) -> int:
+        """feature width over the ranks (a rank without frames passes 0): one tiny MAX all-reduce at the first frame"""
+        import torch
+        import torch.distributed as dist
+        d = torch.tensor([int(D)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        return int(d.item())
+
+    def _resume(self, acc, ws, rank=0):
         """Continue from an existing map file.  Reference: vlmap_builder.py:212-222 (note: upstream restores
-        mapped_iter_set but never skips frames, so a resumed run re-fuses every frame; kept as is)."""
-        if ws > 1 or not map_file_exists(self.map_save_path):
+        mapped_iter_set but never skips frames, so a resumed run re-fuses every frame; kept as is unless
+        skip_mapped_frames).  Several ranks: rank 0 imports the map, the others only mark their accumulators as continuing
+        one (same first-touch key space), every rank learns mapped_iter_list; the merge then keeps the file's voxel ids.
+        A file whose last in-place checkpoint was interrupted (MapFileWriter.MARKER) keeps its rows but its frame list is
+        not trusted: every frame is fused again, as upstream does anyway."""
+        if not map_file_exists(self.map_save_path):
             return set()
-        mapped_iter_list, grid_feat, grid_pos, weight, _occ, grid_rgb = load_3d_map(self.map_save_path)[:6]
-        acc.import_map(grid_feat, grid_pos, weight, grid_rgb)
-        return set(mapped_iter_list)
+        if ws > 1 and rank != 0:
+            iters = read_map_dataset(self.map_save_path, "mapped_iter_list")
+            acc.mark_resumed()
+            mapped = set(np.asarray(iters).tolist()) if iters is not None else set()
+        else:
+            mapped_iter_list, grid_feat, grid_pos, weight, _occ, grid_rgb = load_3d_map(self.map_save_path)[:6]
+            acc.import_map(grid_feat, grid_pos, weight, grid_rgb)
+            mapped = set(mapped_iter_list)
+        if not map_checkpoint_complete(self.map_save_path):
+            print(f"[avlmaps_amd] {self.map_save_path}: the last checkpoint was interrupted; keeping its voxels, re-fusing every frame")
+            self.skip_mapped_frames = False
+        return mapped
 
     def _finish(self, acc, mapped_iter_set, rank, ws, gs, vh):
         if ws == 1:
             self._checkpoint(acc, mapped_iter_set, background=False)
             return
         import torch.distributed as dist
+        self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=True)
+        self._join_save()
+        dist.barrier()
+
+    def _checkpoint_ranks(self, acc, mapped_iter_set, rank, ws, final: bool) -> None:
+        """One merge of the ranks' accumulators (a collective) + the map file written by rank 0.  Non-destructive: frames keep
+        streaming into the same accumulators afterwards.  The file is written by a host thread (device-to-host copy included)
+        unless `final`."""
+        import torch.distributed as dist
         self.merge_timings = {}
-        fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=self.exact_rgb, timings=self.merge_timings)
+        if self.merge_mode == "reduce":
+            fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=self.exact_rgb, timings=self.merge_timings)
+            self.map_shard = None
+        elif self.merge_mode == "sharded":
+            shard = parallel.merge_accumulator_sharded(acc, exact_rgb=self.exact_rgb, timings=self.merge_timings, gather_to=0)
+            fin = shard.pop("full", None)
+            self.map_shard = shard if final else None
+        else:
+            raise ValueError(f"merge_mode must be 'sharded' or 'reduce', not {self.merge_mode!r}")
         sets = [None] * ws
         dist.all_gather_object(sets, sorted(mapped_iter_set))
-        if rank == 0:
-            self._save_3d_map({k: v.cpu().numpy() for k, v in fin.items()}, set(i for s in sets for i in s))
-        dist.barrier()
+        if rank != 0:
+            return
+        iters = set(i for s in sets for i in s)
+        if not final:
+            print(f"Temporarily saving {int(fin['grid_pos'].shape[0])} features of {len(iters)} frames ({ws} ranks)...")
+
+        def to_host():
+            return {k: v.cpu().numpy() for k, v in fin.items()}
+        self._save_3d_map(to_host, iters, background=not final)
 
     def _checkpoint(self, acc, mapped_iter_set, background: bool = True) -> None:
         """Save while frames keep coming (and the final save of a single-process run).  After the first full write only the rows
@@ -415,9 +477,11 @@ class VLMapBuilder:
         """Reference: vlmap_builder.py:313-327 -> mapping_utils.save_3d_map.  The periodic checkpoints (every
         `save_every` frames upstream rewrites the whole file) are written by a host thread while fusion continues; the
         final save, and any save that follows an unfinished one, waits."""
-        self.last_map = arrays
         self._join_save()
         iters = list(mapped_iter_set)
+        thunk = arrays if callable(arrays) else None      # multi-rank checkpoints: the device-to-host copy runs on the writer thread
+        if thunk is None:
+            self.last_map = arrays
 
         writer = getattr(self, "_map_writer", None)
         if writer is None or writer.path != Path(self.map_save_path):
@@ -425,11 +489,14 @@ class VLMapBuilder:
 
         def write():
             try:
+                a = arrays
+                if thunk is not None:
+                    a = thunk()
+                    self.last_map = a
                 if self.incremental_checkpoints:
-                    writer.save(arrays, iters, arrays.get("row_dirty"))
+                    writer.save(a, iters, a.get("row_dirty"))
                 else:
-                    save_3d_map(self.map_save_path, arrays["grid_feat"], arrays["grid_pos"], arrays["weight"], arrays["occupied_ids"],
-                                iters, arrays["grid_rgb"])
+                    save_3d_map(self.map_save_path, a["grid_feat"], a["grid_pos"], a["weight"], a["occupied_ids"], iters, a["grid_rgb"])
             except BaseException as e:
                 self._save_error = e
                 if not background:

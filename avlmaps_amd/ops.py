@@ -228,6 +228,20 @@ def mask_from_argmax(argmax, cat_id, stream=None):
     return m.numpy(stream).astype(bool) if isinstance(argmax, np.ndarray) else m
 
 
+def mask_bool_from_argmax(argmax, cat_id, stream=None) -> np.ndarray:
+    """host bool mask (N,) = (argmax == cat_id) of a DEVICE-resident argmax (DeviceArray / torch tensor): the comparison and a
+    64-to-1 bit packing run on the GPU (avl_mask_bits_from_argmax), N / 8 bytes cross PCIe instead of 4 N, np.unpackbits expands
+    them -- what VLMap.index_map returns (vlmap.py:123-124)"""
+    lib = _lib.load()
+    ap, ashape, ak = as_device(argmax, np.int32, stream)
+    N = int(ashape[0])
+    bits = DeviceArray(((N + 63) // 64,), np.uint64)
+    _lib.check(lib.avl_mask_bits_from_argmax(ap, N, int(cat_id), bits.ptr, stream), "avl_mask_bits_from_argmax")
+    packed = bits.numpy(stream)
+    bits.free()
+    return np.unpackbits(packed.view(np.uint8), count=N, bitorder="little").view(np.bool_)
+
+
 def argmax_f32(vals, stream=None):
     """(index, value) of the first maximum of a float32 vector (habitat_lang_robot.py:427-430)."""
     lib = _lib.load()
@@ -432,6 +446,12 @@ class VoxelAccumulator:
             rgb8 = np.clip(np.asarray(grid_rgb), 0, 255).astype(np.uint8) if isinstance(grid_rgb, np.ndarray) else grid_rgb
             rp, _, k4 = as_device(rgb8, np.uint8, stream)
         _lib.check(lib.avl_builder_import_map(self._h, fshape[0], fp_, pp, wp, rp, stream), "avl_builder_import_map")
+        return self
+
+    def mark_resumed(self, stream=None):
+        """this (empty) accumulator continues a map another rank imported: same first-touch key space as that rank, so that in the
+        merge the voxels of new frames order after every imported one (avl_builder_import_map with n = 0)"""
+        _lib.check(_lib.load().avl_builder_import_map(self._h, 0, None, None, None, None, stream), "avl_builder_import_map")
         return self
 
     def num_voxels(self, stream=None):

@@ -1,13 +1,23 @@
 """Category matching helper with the reference's name (avlmaps/utils/index_utils.py:8-32).
 
-Upstream asks an OpenAI model to pick the closest category; that network call is outside the hot path, so
-this mirror resolves exact / case-insensitive / substring matches locally and otherwise raises."""
+Upstream asks an OpenAI model to pick the closest category; that network call is outside the hot path.  This mirror resolves
+exact / case-insensitive / substring matches locally and hands everything else to a pluggable matcher -- the navigator's LLM
+hook goes there (set_category_matcher, or the `matcher=` argument); without one an unmatched name raises."""
 from __future__ import annotations
 
-from typing import List
+from typing import Callable, List, Optional
+
+_MATCHER: Optional[Callable[[str, List[str]], int]] = None
 
 
-def find_similar_category_id(class_name: str, classes_list: List[str]) -> int:
+def set_category_matcher(matcher: Optional[Callable[[str, List[str]], int]]) -> None:
+    """matcher(class_name, classes_list) -> index into classes_list, used when the local rules find no unique match (what
+    upstream's find_similar_category_id asks its LLM, index_utils.py:8-32).  None removes it."""
+    global _MATCHER
+    _MATCHER = matcher
+
+
+def find_similar_category_id(class_name: str, classes_list: List[str], matcher: Optional[Callable[[str, List[str]], int]] = None) -> int:
     if class_name in classes_list:
         return classes_list.index(class_name)
     low = [c.lower() for c in classes_list]
@@ -17,8 +27,14 @@ def find_similar_category_id(class_name: str, classes_list: List[str]) -> int:
     hits = [i for i, c in enumerate(low) if name in c or c in name]
     if len(hits) == 1:
         return hits[0]
-    raise KeyError(f"{class_name!r} does not match one of the initialised categories {classes_list}; "
-                   "upstream delegates this to an LLM (index_utils.py:8-32), which is out of scope here")
+    fn = matcher or _MATCHER
+    if fn is not None:
+        i = int(fn(class_name, list(classes_list)))
+        if not 0 <= i < len(classes_list):
+            raise ValueError(f"the category matcher returned {i} for {class_name!r}: not an index into {len(classes_list)} categories")
+        return i
+    raise KeyError(f"{class_name!r} does not match one of the initialised categories {classes_list}; upstream delegates this to an "
+                   "LLM (index_utils.py:8-32): plug one in with utils.index_utils.set_category_matcher")
 
 
 def get_dynamic_obstacles_map_3d(clip_model, obstacles_cropped, potential_obstacle_classes, obstacle_classes, grid_feat,

@@ -6,6 +6,8 @@ HIP builder kernels.
 """
 from __future__ import annotations
 
+import os
+
 from pathlib import Path
 from typing import List, Optional, Sequence
 
@@ -164,6 +166,8 @@ class MapFileWriter:
             ends = np.concatenate([ends[:-1][keep[1:]], ends[-1:]])
         return [(int(a), int(b)) for a, b in zip(starts, ends)]
 
+    MARKER = "checkpoint_complete"   # int32[1]: 0 while an in-place patch is under way (an extra dataset upstream's loader ignores)
+
     def __init__(self, path):
         self.path = Path(path)
         self.n_saved = None          # rows in the file, None = nothing written by this writer yet
@@ -193,13 +197,17 @@ class MapFileWriter:
             self.n_saved = n
             return
         if not incremental:
-            with h5lite.H5File(self.path, "w") as f:
+            # a full save never leaves a half-written map behind: written next to the target, then renamed over it
+            tmp = self.path.with_name(self.path.name + ".tmp")
+            with h5lite.H5File(tmp, "w") as f:
                 f.create_dataset("mapped_iter_list", data=iters, maxshape=(None,))
                 for k in self.ROW_SETS:
                     a = np.asarray(arrays[k])
                     chunks = (self.FEAT_CHUNK_ROWS,) + a.shape[1:] if k == "grid_feat" else None
                     f.create_dataset(k, data=a, maxshape=(None,) + a.shape[1:], chunks=chunks)
                 f.create_dataset("occupied_ids", data=np.asarray(arrays["occupied_ids"]))
+                f.create_dataset(self.MARKER, data=np.ones(1, np.int32))
+            os.replace(tmp, self.path)
             self.stats.append(dict(mode="full", rows_written=n, rows_total=n))
             self.n_saved = n
             self._adopt(arrays)
@@ -227,6 +235,12 @@ class MapFileWriter:
         cruns = self.row_runs(cd, full_old, n_chunks, self.MAX_RUNS)
         runs = [(a * C, min(b * C, n)) for a, b in cruns]
         with h5lite.H5File(self.path, "r+") as f:
+            # an in-place patch is not atomic: the marker is cleared (and flushed) first and set again last, so that a run resumed
+            # after a crash in between can tell that mapped_iter_list and the feature rows may not belong together
+            marked = self.MARKER in f
+            if marked:
+                f.write_rows(self.MARKER, 0, np.zeros(1, np.int32))
+                f.flush()
             for k in self.ROW_SETS:
                 f.resize(k, n)
                 if k == "grid_feat":
@@ -245,6 +259,9 @@ class MapFileWriter:
                     f.write_rows("occupied_ids", r0, self.mirror_occ[r0:r1])
             f.resize("mapped_iter_list", len(iters))
             f.write_rows("mapped_iter_list", 0, iters)
+            if marked:
+                f.flush()
+                f.write_rows(self.MARKER, 0, np.ones(1, np.int32))
         return runs
 
     def _adopt(self, arrays) -> None:
@@ -290,6 +307,31 @@ class MapFileWriter:
         out = {k: self.mirror[k][:n] for k in self.ROW_SETS}
         out["occupied_ids"] = self.mirror_occ
         return out
+
+
+def read_map_dataset(map_path, name: str):
+    """one dataset of a map file (e.g. mapped_iter_list: what the ranks of a resumed multi-GPU build need, not the 4 GB of features)"""
+    if Path(map_path).exists():
+        backend = hdf5_backend()
+        if backend == "h5py":
+            with h5py.File(map_path, "r") as f:
+                return f[name][()] if name in f else None
+        if backend == "h5lite":
+            with h5lite.H5File(map_path, "r") as f:
+                return f.read(name) if name in f else None
+        raise RuntimeError(f"{map_path} is an HDF5 map but neither h5py nor the HDF5 C library (libhdf5) is available")
+    with np.load(_npz_path(map_path)) as z:
+        return z[name] if name in z.files else None
+
+
+def map_checkpoint_complete(map_path) -> bool:
+    """False if the file's last in-place checkpoint was interrupted (MapFileWriter.MARKER == 0): its mapped_iter_list may be
+    older than its rows.  Files without the marker (upstream's, full saves of other writers) count as complete."""
+    try:
+        m = read_map_dataset(map_path, MapFileWriter.MARKER)
+    except Exception:
+        return True
+    return m is None or int(np.asarray(m).ravel()[0]) != 0
 
 
 def map_file_exists(map_path) -> bool:

@@ -186,6 +186,9 @@ AVL_API int avl_sim_scores_host(const float* h_feat, int64_t N, int D, const flo
 
 /* mask[i] = (argmax[i] == cat_id) as uint8 -- avlmaps/map/vlmap.py:124 */
 AVL_API int avl_mask_from_argmax(const int32_t* d_argmax, int64_t N, int32_t cat_id, uint8_t* d_mask, void* stream);
+/* the same mask bit-packed: d_bits (ceil(N / 64),) uint64, word w bit i = (argmax[64 w + i] == cat_id), i.e. the byte / bit order of
+ * np.unpackbits(bitorder="little"); bits beyond N are 0.  1 bit instead of 4 bytes per voxel has to reach the host. */
+AVL_API int avl_mask_bits_from_argmax(const int32_t* d_argmax, int64_t N, int32_t cat_id, uint64_t* d_bits, void* stream);
 
 /* index and value of the maximum of a float32 vector, first maximum wins -- the navigator's
  * heatmap argmax, avlmaps/robot/habitat_lang_robot.py:427-430.  Synchronous (returns host scalars). */
@@ -295,7 +298,10 @@ AVL_API int avl_points_bbox(const void* d_depth, int depth_is_u16, double depth_
 
 /* Seed an EMPTY builder from a finished map so that more frames can be fused on top (the reference's resume path,
  * vlmap_builder.py:212-222): d_grid_feat (n,D) f32, d_grid_pos (n,3) i32, d_weight (n,) f32, d_grid_rgb (n,3) u8 or NULL.
- * Voxel ids 0..n-1 are kept; new voxels are appended after them.  Synchronous. */
+ * Voxel ids 0..n-1 are kept; new voxels are appended after them.  The accumulators grow to n first when the handle may
+ * (avl_builder_set_max_capacity): a map that outgrew gs*gs voxels resumes like upstream's.  n == 0 only marks the builder as
+ * continuing a map (the other ranks of a resumed multi-GPU build: same first-touch key space as the rank that imported).
+ * Synchronous. */
 AVL_API int avl_builder_import_map(avl_builder* b, int64_t n, const float* d_grid_feat, const int32_t* d_grid_pos,
                                    const float* d_weight, const uint8_t* d_grid_rgb, void* stream);
 
@@ -377,6 +383,13 @@ AVL_API int avl_finalize_merged(int64_t n, int64_t row0, int D, int gs, int vh, 
 AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                                      void* stream);
 AVL_API int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream);
+/* Row-sharded merge (parallel.merge_accumulator_sharded; SURVEY.md 8e "reduce-scatter by voxel range"): rank r owns the final
+ * rows [row0, row0 + nrows) and receives from every peer only that peer's contributions to them -- n rows of `cols` = D + 4
+ * float64 with their final row index d_rows (n,) int64, a peer holds a voxel at most once so the indices of one call are
+ * distinct.  d_dst[d_rows[i] - row0, :cols] += d_src[i, :cols].  Calls in peer order give a reproducible sum.  Synchronous
+ * (reports an out-of-range row as AVL_ERR_INVALID). */
+AVL_API int avl_rows_add_f64(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src,
+                             int64_t ld_src, double* d_dst, int64_t ld_dst, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (3) nearest-target distance-decay heatmap
@@ -408,6 +421,19 @@ AVL_API int avl_obstacle_map(const int32_t* d_occupied_ids, int n0, int n1, int 
 AVL_API int avl_obstacle_scatter(const int32_t* d_grid_pos, const int32_t* d_class, int64_t N, const uint8_t* h_class_is_obstacle,
                                  int Q, int rmin, int cmin, int H, int W, const uint8_t* d_cropped_free, uint8_t* d_out_free,
                                  void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (6) sliding-window merge of the pixel-feature extractor's output (device-resident, channels-last)
+ *     replaces  avlmaps/utils/lseg_utils.py:61-102 (window accumulation, count normalisation, crop, and the per-frame
+ *               device-to-host copy of the (1, D, Hf, Wf) result)
+ *     d_win     (G, D, crop, crop) row-major: the model's output for the batch of G windows, float32 (is_f16 = 0) or float16
+ *     h_origin  (G, 2) host int32: (h0, w0) of every window on the padded canvas, in the reference's loop order (idh major)
+ *     d_out     (height, width, D) float32 channels-last -- the layout avl_builder_integrate_frame gathers from:
+ *               out[y, x, :] = (sum over the windows g covering (y, x), in window order, of win[g, :, y - h0, x - w0]) / count
+ *     G <= 64.  Every pixel of (height, width) must be covered by a window (AVL_ERR_INVALID otherwise).
+ * ------------------------------------------------------------------------------------------------ */
+AVL_API int avl_lseg_merge_windows(const void* d_win, int is_f16, int G, int D, int crop, const int32_t* h_origin, int height,
+                                   int width, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

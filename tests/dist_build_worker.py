@@ -6,6 +6,7 @@ shard from the golden frames and joins the merge; rank 0 writes <out>/vlmap/vlma
     python -m torch.distributed.run --nproc-per-node 2 tests/dist_build_worker.py <golden.npz> <out_dir> <n_frames> [sampling [seed]]
 """
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -34,31 +35,30 @@ def main():
     pose_path = out_dir / f"poses_rank{rank}.txt"
     np.savetxt(pose_path, g["poses"][:n_frames])
 
-    frame_of_call = []
+    loaded = []                                               # frame indices in the order the builder asked for them
 
     def extractor(rgb):
-        return g["feats"][frame_of_call[-1]][None]           # reference layout (1, D, Hf, Wf)
+        return g["feats"][loaded[-1]][None]                   # reference layout (1, D, Hf, Wf)
 
     b = VLMapBuilder(out_dir, cfg, pose_path, [None] * n_frames, [None] * n_frames, m.base2cam_tf, m.base_transform,
                      feat_extractor=extractor)
+    stop_after = int(os.environ.get("AVL_TEST_STOP_AFTER", "0"))       # simulated interruption after that many local frames
 
     def load_frame(i):
+        if stop_after and len(loaded) >= stop_after:
+            b._join_save()                                    # the checkpoint that was being written completes, then the run dies
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+            os._exit(0)
+        loaded.append(i)
         return g["rgbs"][i], g["depths"][i]
 
     b.load_frame = load_frame
     b.prefetch_frames = 0                                     # inline loading: extractor calls follow load_frame calls in order
-    orig = b._features_hwc
-
-    def feats(rgb):
-        return orig(rgb)
-    # frame index of the extractor call = order of the frames this rank streams
-    lo, hi = parallel.shard_frames(n_frames, rank, ws)
-    it = iter(range(lo, hi))
-
-    def features_hwc(rgb):
-        frame_of_call.append(next(it))
-        return feats(rgb)
-    b._features_hwc = features_hwc
+    b.merge_mode = os.environ.get("AVL_TEST_MERGE_MODE", b.merge_mode)
+    b.save_every = int(os.environ.get("AVL_TEST_SAVE_EVERY", b.save_every))
+    b.skip_mapped_frames = os.environ.get("AVL_TEST_SKIP_MAPPED", "0") == "1"
     b.capacity = 64                                           # forces the accumulators to double a few times
     if sampling == "uniform":
         b.pixel_sampling = "uniform"                          # per-frame generators: the sharding does not matter
@@ -66,8 +66,13 @@ def main():
         b.shard_sampling = sampling
     np.random.seed(seed)                                      # the state the reference run started from, on EVERY rank
     b.create_mobile_base_map()
+    tim = dict(getattr(b, "merge_timings", {}))
+    if b.map_shard is not None:
+        tim["shard_rows"] = list(b.map_shard["rows"])
+        tim["shard_feat_shape"] = list(b.map_shard["grid_feat"].shape)
+    (out_dir / f"merge_timings_rank{rank}.json").write_text(json.dumps(tim))
     if rank == 0:
-        (out_dir / "merge_timings.json").write_text(json.dumps(getattr(b, "merge_timings", {})))
+        (out_dir / "merge_timings.json").write_text(json.dumps(tim))
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()

@@ -343,9 +343,34 @@ def test_get_lseg_feat_protocol_on_the_gpu(golden):
     for name in ("pad_short", "grid_2x3", "tall"):
         crop, base = (int(x) for x in g[f"{name}_cfg"])
         ref = g[f"{name}_feat"]
-        f = get_lseg_feat(CudaFake(), g[f"{name}_img"], ["example"], None, "cuda", crop, base)
+        fake = CudaFake()
+        calls = []
+        counted = lambda x, labels: calls.append(int(x.shape[0])) or fake(x, labels)
+        counted.out_c = fake.out_c
+        f = get_lseg_feat(counted, g[f"{name}_img"], ["example"], None, "cuda", crop, base)
         assert f.is_cuda and f.is_contiguous() and tuple(f.shape) == (ref.shape[2], ref.shape[3], ref.shape[1])
+        assert len(calls) == 1 and calls[0] in (2, 6)                 # ONE model call for all windows of the frame
+        # the resize runs on the GPU here and on the CPU in the reference run (bilinear weights to the last bit of float32)
         np.testing.assert_allclose(f.cpu().numpy(), np.transpose(ref[0], (1, 2, 0)), rtol=1e-5, atol=1e-5)
+        # window by window (what upstream does) gives the same map bit for bit: the merge sums in window order
+        f1 = get_lseg_feat(fake, g[f"{name}_img"], ["example"], None, "cuda", crop, base, window_batch_size=1)
+        assert torch.equal(f, f1)
+        # reference layout on request
+        fr = get_lseg_feat(fake, g[f"{name}_img"], ["example"], None, "cuda", crop, base, channels_last=False)
+        assert tuple(fr.shape) == ref.shape and torch.equal(fr[0].permute(1, 2, 0), f)
+    # the merge kernel alone against its definition, float32 and float16 windows, a channel count that is not a multiple of 64
+    from avlmaps_amd.utils.lseg_utils import WindowPlan, merge_windows
+    plan = WindowPlan.make(72, 108, 48, 100)
+    G, D = len(plan.origins), 70
+    win = torch.randn((G, D, 48, 48), device="cuda")
+    for w in (win, win.half()):
+        acc = torch.zeros((D,) + plan.canvas, device="cuda")
+        cnt = torch.zeros((1,) + plan.canvas, device="cuda")
+        for (h0, w0), o in zip(plan.origins, w.float()):
+            acc[:, h0:h0 + 48, w0:w0 + 48] += o
+            cnt[:, h0:h0 + 48, w0:w0 + 48] += 1
+        want = (acc / cnt)[:, :plan.height, :plan.width].permute(1, 2, 0)
+        assert torch.equal(merge_windows(w, plan), want)
 
 
 def test_bench_line_contract():
@@ -381,33 +406,37 @@ def test_bench_line_contract():
         assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
 
 
-def _run_ranks(nproc, args, port, timeout=900):
+def _run_ranks(nproc, args, port, timeout=900, **env_extra):
     import os
     import subprocess
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, AVLMAPS_DIST_BACKEND="gloo")        # several ranks share this box's single GPU
+    env.update({k: str(v) for k, v in env_extra.items()})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(root / "tests" / "dist_build_worker.py")] + [str(a) for a in args]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-@pytest.mark.parametrize("nproc,n_frames,name", [(2, 6, "g2a_builder_small.npz"), (3, 4, "g2a_builder_small.npz"),
-                                                 (2, 16, "g2b_builder_growth.npz")])
-def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, nproc, n_frames, name):
-    """VLMapBuilder under N ranks (one process each, frames sharded contiguously, the device merge with ONE sum-reduce and the
-    chained colour replay) with the global NumPy RNG seeded like the reference run: the map file rank 0 writes is the
-    single-rank map -- grid_pos / occupied_ids / grid_rgb / weight bit-exact, grid_feat to float64 rounding -- and, for the
-    full sequence, the reference's own map (golden).  (3 ranks, 4 frames: the last shard is empty.)"""
+@pytest.mark.parametrize("nproc,n_frames,name,mode", [(2, 6, "g2a_builder_small.npz", "sharded"), (3, 4, "g2a_builder_small.npz", "sharded"),
+                                                      (2, 16, "g2b_builder_growth.npz", "sharded"), (3, 16, "g2b_builder_growth.npz", "sharded"),
+                                                      (2, 6, "g2a_builder_small.npz", "reduce"), (2, 16, "g2b_builder_growth.npz", "reduce")])
+def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, nproc, n_frames, name, mode):
+    """VLMapBuilder under N ranks (one process each, frames sharded contiguously; the device merge -- row-sharded all_to_all of
+    every rank's own voxel rows, or ONE dense sum-reduce -- and the chained colour replay) with the global NumPy RNG seeded like
+    the reference run: the map file rank 0 writes is the single-rank map -- grid_pos / occupied_ids / grid_rgb / weight
+    bit-exact, grid_feat to float64 rounding (identical float32 values but for the odd last bit) -- and, for the full sequence,
+    the reference's own map (golden).  (3 ranks, 4 frames: the last shard is empty.)"""
     import json
+    from avlmaps_amd import parallel
     from avlmaps_amd.utils.mapping_utils import load_3d_map
     GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
     one, many = tmp_path / "one", tmp_path / "many"
     seed = 1234 if name.startswith("g2a") else 99              # what tools/gen_golden.py seeded the reference run with
     _run_ranks(1, [GOLDEN_DIR / name, one, n_frames, "replay", seed], 29541)
-    _run_ranks(nproc, [GOLDEN_DIR / name, many, n_frames, "replay", seed], 29542)
+    _run_ranks(nproc, [GOLDEN_DIR / name, many, n_frames, "replay", seed], 29542, AVL_TEST_MERGE_MODE=mode)
     a = load_3d_map(one / "vlmap" / "vlmaps.h5df")
     b = load_3d_map(many / "vlmap" / "vlmaps.h5df")
     assert a[0] == b[0] == list(range(n_frames))
@@ -415,8 +444,23 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
         assert np.array_equal(a[i], b[i]), k
         assert a[i].dtype == b[i].dtype
     np.testing.assert_allclose(b[1], a[1], rtol=1e-6, atol=1e-7)
+    assert np.mean(a[1] == b[1]) > 0.999                       # (p + q) + r against p + (q + r) in float64, rounded to float32 once
     tim = json.loads((many / "merge_timings.json").read_text())
     assert tim["exact_rgb"] is True and tim["merged_voxels"] == len(a[2]) and tim["local_voxels"] <= tim["merged_voxels"]
+    if mode == "sharded":
+        M, D = len(a[2]), a[1].shape[1]
+        sent = rows = 0
+        for r in range(nproc):
+            t = json.loads((many / f"merge_timings_rank{r}.json").read_text())
+            assert t["mode"].startswith("row-sharded") and t["world_size"] == nproc and t["backend"] == "gloo"
+            assert tuple(t["shard_rows"]) == parallel.shard_rows(M, r, nproc) and t["shard_feat_shape"] == [t["own_rows"], D]
+            assert t["rows_sent"] <= t["local_voxels"] and t["payload_bytes_sent"] == t["rows_sent"] * ((D + 4) * 8 + 8)
+            assert t["bytes_sent_per_rank"] >= t["payload_bytes_sent"]
+            sent += t["payload_bytes_sent"]
+            rows += t["local_voxels"]
+        # the exchange moves what the ranks hold -- at most every local row once -- not ws dense copies of the map
+        assert sent <= 1.3 * rows * (D + 4) * 8
+        assert rows * (D + 4) * 8 < nproc * tim["dense_reduce_payload_bytes"]
     g = golden(name)
     if n_frames == len(g["depths"]):
         assert np.array_equal(b[2], g["grid_pos"])
@@ -428,6 +472,41 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
         _run_ranks(nproc, [GOLDEN_DIR / name, ind, n_frames, "independent", seed], 29543)
         c = load_3d_map(ind / "vlmap" / "vlmaps.h5df")
         assert not (c[2].shape == a[2].shape and np.array_equal(c[2], a[2]))
+
+
+def test_multi_rank_checkpoints_and_resume(golden, tmp_path):
+    """Several ranks, like upstream's loop (vlmap_builder.py:181-183, :212-222): every save_every local frames the ranks merge
+    and rank 0 writes the map file; a run that dies after such a checkpoint is resumed by the same number of ranks -- rank 0
+    imports the file, everybody skips the frames it lists, the merge keeps the file's voxel ids -- and ends with the map of
+    the uninterrupted build: same cells, same weights, same features (to the float32 round trip of the checkpoint)."""
+    from avlmaps_amd.utils.mapping_utils import load_3d_map, map_checkpoint_complete, read_map_dataset
+    GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+    name, n_frames, seed = "g2b_builder_growth.npz", 16, 99
+    whole, cut = tmp_path / "whole", tmp_path / "cut"
+    _run_ranks(2, [GOLDEN_DIR / name, whole, n_frames, "replay", seed], 29561, AVL_TEST_SAVE_EVERY=3)
+    a = load_3d_map(whole / "vlmap" / "vlmaps.h5df")
+    assert a[0] == list(range(n_frames)) and map_checkpoint_complete(whole / "vlmap" / "vlmaps.h5df")
+    # interrupted after 5 local frames per rank: ONE checkpoint round (after the 3rd local frame) has been written
+    _run_ranks(2, [GOLDEN_DIR / name, cut, n_frames, "replay", seed], 29562, AVL_TEST_SAVE_EVERY=3, AVL_TEST_STOP_AFTER=5)
+    part = read_map_dataset(cut / "vlmap" / "vlmaps.h5df", "mapped_iter_list").tolist()
+    assert part == [0, 1, 2, 8, 9, 10]
+    n_part = len(read_map_dataset(cut / "vlmap" / "vlmaps.h5df", "grid_pos"))
+    assert 0 < n_part < len(a[2])
+    # resumed by two ranks, skipping what the file already holds
+    _run_ranks(2, [GOLDEN_DIR / name, cut, n_frames, "replay", seed], 29563, AVL_TEST_SAVE_EVERY=3, AVL_TEST_SKIP_MAPPED=1)
+    b = load_3d_map(cut / "vlmap" / "vlmaps.h5df")
+    assert b[0] == list(range(n_frames)) and len(b[2]) == len(a[2])
+    part_pos = read_map_dataset(cut / "vlmap" / "vlmaps.h5df", "grid_pos")[:n_part]
+    cells = lambda pos: (pos[:, 0].astype(np.int64) * 100000 + pos[:, 1]) * 1000 + pos[:, 2]
+    ca, cb = cells(a[2]), cells(b[2])
+    assert np.array_equal(np.sort(ca), np.sort(cb))                       # the same voxels ...
+    ia, ib = np.argsort(ca), np.argsort(cb)
+    np.testing.assert_allclose(b[3][ib], a[3][ia], rtol=2e-6)              # ... the same weights
+    np.testing.assert_allclose(b[1][ib], a[1][ia], rtol=2e-5, atol=2e-6)   # ... the same features
+    assert np.abs(b[5][ib].astype(int) - a[5][ia].astype(int)).max() <= 3  # colour: closed form after a resume (no replay log)
+    # the checkpoint's voxels keep their ids; occupied_ids is consistent with grid_pos
+    assert np.array_equal(b[2][:n_part], part_pos)
+    assert np.array_equal(b[4][b[2][:, 0], b[2][:, 1], b[2][:, 2]], np.arange(len(b[2])))
 
 
 def test_uniform_pixel_sampling(golden, tmp_path):
@@ -497,7 +576,7 @@ def test_bench_two_ranks_share_one_gpu():
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, AVLMAPS_DIST_BACKEND="gloo")
-    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--build-frames", "12"], "voxel_query_similarities_per_sec"),
+    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--build-frames", "12", "--standin-frames", "8"], "voxel_query_similarities_per_sec"),
                           (["--workload", "build"], "map_build_frames_per_sec")):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"] + extra
@@ -513,7 +592,18 @@ def test_bench_two_ranks_share_one_gpu():
         assert ex["voxels_merged"] >= ex["voxels_local"] > 0 and ex["frames_per_gpu"] * 2 == ex["total_frames"]
         mb = ex["merge_breakdown"]
         assert mb["exact_rgb"] is True and mb["merged_voxels"] == ex["voxels_merged"]
-        assert ex["merge_finalize_seconds"] >= mb["scatter_reduce_s"] > 0
+        # the N-GPU line says what the merge moved and what carried it: per-phase seconds AND bytes, per rank
+        assert mb["mode"].startswith("row-sharded") and ex["merge_finalize_seconds"] >= mb["exchange_s"] > 0
+        assert mb["world_size"] == 2 and len(mb["per_rank"]) == 2
+        assert all(p["bytes_sent_per_rank"] >= p["payload_bytes_sent"] >= 0 and p["rows_sent"] <= p["local_voxels"] for p in mb["per_rank"])
+        assert sum(p["payload_bytes_sent"] for p in mb["per_rank"]) <= 1.3 * sum(p["local_voxels"] for p in mb["per_rank"]) * (512 + 4) * 8
+        col = d["extra"]["collectives"]
+        assert col["backend"] == "gloo" and col["world_size"] == 2 and [r["rank"] for r in col["ranks"]] == [0, 1]
+        if not metric.startswith("map_build"):
+            assert "no data-path collective" in d["config"]["parallelism"].lower()
+            sv = d["extra"]["map_build_strong_vit_standin"]
+            assert sv["feature_standin"] == "vit-l16" and "NOT LSeg" in sv["note"] and sv["total_frames"] >= 4
+            assert d["extra"]["merge_breakdown"]["bytes_sent_per_rank"] > 0
         if metric.startswith("map_build"):
             assert d["scaling"] == "strong" and abs(d["value"] - 4 / ex["seconds"]) < 1e-6 * d["value"]
 

@@ -99,24 +99,6 @@ def test_map_attribute_surface_and_obstacles():
     assert VLMapBuilder(Path("/tmp"), cfg, None, [], [], None, None).create_camera_map() is NotImplementedError
 
 
-def test_get_lseg_feat_protocol_matches_reference(golden):
-    """sliding-window evaluation of lseg_utils.py:20-119, device-resident channels-last output (CPU tensors here)"""
-    import sys
-    from pathlib import Path
-    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
-    from gen_golden import FakeLSeg
-    from avlmaps_amd.utils.lseg_utils import get_lseg_feat
-    g = golden("g5_lseg_protocol.npz")
-    for name in ("pad_short", "grid_2x3", "tall"):
-        crop, base = (int(x) for x in g[f"{name}_cfg"])
-        ref = g[f"{name}_feat"]                                   # (1, D, Hf, Wf) as the reference returns it
-        f = get_lseg_feat(FakeLSeg(), g[f"{name}_img"], ["example"], None, "cpu", crop, base)
-        assert tuple(f.shape) == (ref.shape[2], ref.shape[3], ref.shape[1]) and f.is_contiguous()
-        np.testing.assert_allclose(f.numpy(), np.transpose(ref[0], (1, 2, 0)), rtol=1e-6, atol=1e-6)
-        f2 = get_lseg_feat(FakeLSeg(), g[f"{name}_img"], ["example"], None, "cpu", crop, base, channels_last=False)
-        np.testing.assert_allclose(f2.numpy(), ref, rtol=1e-6, atol=1e-6)
-
-
 def test_map_file_is_the_reference_hdf5_layout(tmp_path):
     """save_3d_map writes a real HDF5 file with the six dataset names / dtypes / shapes of the reference writer
     (mapping_utils.py:499-505) -- through h5py, or through the HDF5 C library where h5py is missing -- and load_3d_map reads
@@ -323,3 +305,35 @@ def test_sample_pixels_is_numpys_shuffle():
         assert all(np.array_equal(a, b) and b.dtype == np.int32 for a, b in zip(want, got)), (n_pix, rate)
         assert np.array_equal(ws[1], gs[1]) and ws[2] == gs[2], (n_pix, rate)
     assert 0.0 <= np.random.rand() < 1.0                                            # the global RNG still works afterwards
+
+
+def test_lseg_window_plan_reproduces_the_reference_windows(golden):
+    """WindowPlan + window_batch (the geometry of lseg_utils.py:36-96 as one canvas and one batch of views) with the reference's
+    accumulation done in torch on the CPU: the reference run's feature maps (g5) bit for bit -- so what is left for the GPU
+    kernel is the summation itself"""
+    import sys
+    import torch
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    from gen_golden import FakeLSeg
+    from avlmaps_amd.utils.lseg_utils import WindowPlan, default_transform, window_batch
+    g = golden("g5_lseg_protocol.npz")
+    for name, n_win in (("pad_short", 2), ("grid_2x3", 6), ("tall", 6)):
+        crop, base = (int(x) for x in g[f"{name}_cfg"])
+        img = default_transform(g[f"{name}_img"]).unsqueeze(0)
+        plan = WindowPlan.make(img.shape[2], img.shape[3], crop, base)
+        assert len(plan.origins) == n_win and (plan.height, plan.width) == g[f"{name}_feat"].shape[2:]
+        batch = window_batch(img, plan, (0.5,) * 3, (0.5,) * 3)
+        assert tuple(batch.shape) == (n_win, 3, crop, crop)
+        out, _ = FakeLSeg()(batch, ["example"])
+        acc = torch.zeros((out.shape[1],) + plan.canvas)
+        cnt = torch.zeros((1,) + plan.canvas)
+        for (h0, w0), o in zip(plan.origins, out):
+            acc[:, h0:h0 + crop, w0:w0 + crop] += o
+            cnt[:, h0:h0 + crop, w0:w0 + crop] += 1
+        assert np.array_equal((acc / cnt)[:, :plan.height, :plan.width].numpy(), g[f"{name}_feat"][0])
+    # base_size <= crop_size: one window holds the resized image (upstream raises UnboundLocalError on that branch)
+    p1 = WindowPlan.make(720, 1080, 480, 400)
+    assert p1.origins == [(0, 0)] and p1.canvas == (480, 480) and (p1.height, p1.width) == (267, 400)
+    # the reference's default: 720 x 1080 -> 347 x 520, crops of 480, stride 320 -> 1 x 2 windows
+    p2 = WindowPlan.make(720, 1080, 480, 520)
+    assert (p2.height, p2.width) == (347, 520) and p2.origins == [(0, 0), (0, 320)] and p2.canvas == (480, 800)

@@ -120,6 +120,77 @@ def test_merge_world_size_2_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
+def _sharded_worker(rank, ws, port, tmpdir):
+    """row-sharded merge (merge_raw_sharded): every rank ends with ITS block of final rows, equal to the dense single-reduce
+    result; bytes sent = the rank's own rows that belong to other owners, never the whole map"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
+    parallel.init_distributed("gloo")
+    D = 12
+    rng = np.random.default_rng(7)
+    # contiguous frame shards see mostly disjoint voxels, a few shared ones; rank ws-1 may hold nothing
+    cellsets = [sorted(set(rng.integers(0, 400, 40 + 10 * k).tolist())) for k in range(ws)]
+    if ws == 3:
+        cellsets[2] = []
+    raws = [make_rank_raw(20 + k, D, cellsets[k], frame_lo=1000 * k) for k in range(ws)]
+    cells, table = expected_merge(raws)
+    dense = parallel.merge_raw(raws[rank], dst=0)
+    sh = parallel.merge_raw_sharded(raws[rank])
+    M = len(cells)
+    assert sh["M"] == M and sh["cell"].tolist() == cells and sh["rows"] == parallel.shard_rows(M, rank, ws)
+    r0, r1 = sh["rows"]
+    assert sh["acc"].shape == (r1 - r0, D + 4)
+    for i in range(r0, r1):
+        e = table[cells[i]]
+        want = e["sf"] - e["fa"] * (1.0 - e["fa"]) * e["ff"].astype(np.float64)
+        np.testing.assert_allclose(sh["acc"][i - r0, :D].numpy(), want, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(sh["acc"][i - r0, D:].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
+        assert int(sh["first_key"][i]) == e["key"]
+    # the blocks, gathered, are the dense reduce of merge_raw bit for bit when at most two ranks touch a voxel (same two addends)
+    blocks = [None] * ws
+    dist.all_gather_object(blocks, sh["acc"].numpy())
+    if rank == 0:
+        full = np.concatenate(blocks, axis=0)
+        np.testing.assert_allclose(full, dense["acc"].numpy(), rtol=1e-15, atol=1e-15)
+    # traffic: only rows owned elsewhere travel, (D + 4) * 8 B + the 8 B row index each
+    n_local = len(cellsets[rank])
+    own = sum(1 for c in cellsets[rank] if r0 <= cells.index(c) < r1)
+    assert sh["bytes_sent"] == (n_local - own) * ((D + 4) * 8 + 8)
+    total = [None] * ws
+    dist.all_gather_object(total, (sh["bytes_sent"], n_local))
+    if rank == 0:
+        assert sum(t[0] for t in total) <= 1.3 * sum(t[1] for t in total) * (D + 4) * 8     # VERDICT r2: <= 1.3 x the local rows
+    # the dense voxel-id grid comes from the plan alone
+    occ = parallel.occupied_ids_from_cells(sh["cell"], 1, 20, 20)
+    assert occ.shape == (1, 20, 20) and int((occ >= 0).sum()) == M and int(occ.view(-1)[cells[3]]) == 3
+    # gather of finished row blocks to one rank
+    shard = dict(grid_feat=sh["acc"][:, :D].float().contiguous(), grid_pos=torch.arange(r0, r1, dtype=torch.int32)[:, None].repeat(1, 3),
+                 weight=sh["acc"][:, D].float().contiguous(), grid_rgb=torch.full((r1 - r0, 3), rank, dtype=torch.uint8))
+    fullmap = parallel.gather_row_shards(shard, ws - 1, parallel._Coll(), rank, ws)
+    if rank == ws - 1:
+        assert fullmap["grid_pos"][:, 0].tolist() == list(range(M)) and fullmap["grid_feat"].shape == (M, D)
+        assert fullmap["grid_rgb"][:, 0].tolist() == [min(i // max(1, (M + ws - 1) // ws), ws - 1) for i in range(M)]
+    else:
+        assert fullmap is None
+    Path(tmpdir, f"sh{rank}").write_text("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ws", [2, 3])
+def test_row_sharded_merge_gloo(tmp_path, ws):
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(ws, port, str(tmp_path)), nprocs=ws, join=True)
+    assert all((tmp_path / f"sh{r}").exists() for r in range(ws))
+
+
+def test_row_sharded_merge_single_process():
+    raw = make_rank_raw(3, 6, [4, 2, 9, 11], 0)
+    sh = parallel.merge_raw_sharded(raw)
+    dense = parallel.merge_raw(raw)
+    assert sh["rows"] == (0, 4) and sh["bytes_sent"] == 0
+    assert torch.equal(sh["acc"], dense["acc"]) and torch.equal(sh["cell"], dense["cell"])
+
+
 def test_sharding_helpers():
     assert [parallel.shard_frames(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert [parallel.shard_frames(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
