@@ -293,6 +293,31 @@ class VoxelAccumulator:
         if deferred_fuse:
             self.set_deferred_fuse(True)
 
+    def _retain(self, keeps, stream):
+        """Keep the inputs of a launch alive until the GPU is done with them.  With deferred fuse the features of frame i are read
+        by the launch of frame i + 1, so two generations are always held.  Buffers this module staged itself (NumPy inputs ->
+        pooled DeviceArrays) go back to a pool that other threads and streams allocate from (map upload, checkpoint writer):
+        those are released only behind an event recorded after the launch that reads them last (at most 4 generations wait, the
+        oldest is synchronised -- this path already pays a blocking host-to-device copy per input); torch tensors return to
+        torch's own stream-ordered allocator and need no event."""
+        self._keep_prev, self._keep = getattr(self, "_keep", None), keeps
+        if not any(isinstance(k, DeviceArray) for k in keeps):
+            return
+        lib = _lib.load()
+        q = self.__dict__.setdefault("_keep_events", [])
+        free = self.__dict__.setdefault("_free_events", [])
+        if free:
+            ev = free.pop()
+        else:
+            ev = C.c_void_p()
+            _lib.check(lib.avl_event_create(C.byref(ev)), "avl_event_create")
+        _lib.check(lib.avl_event_record(ev, stream), "avl_event_record")
+        q.append((ev, keeps))
+        while len(q) > 4:
+            old_ev, _old = q.pop(0)
+            _lib.check(lib.avl_event_sync(old_ev), "avl_event_sync")      # the launches that read _old have completed
+            free.append(old_ev)
+
     def _calib_pair(self, calib, calib_inv):
         """(K, inv(K)) as contiguous float64; the inverse of an unchanged calibration is computed once (np.linalg.inv is
         ~8 us, most of the host cost of a frame-by-frame call)"""
@@ -326,7 +351,10 @@ class VoxelAccumulator:
     def close(self):
         if getattr(self, "_h", None):
             try:
-                _lib.load().avl_builder_destroy(self._h)
+                lib = _lib.load()
+                lib.avl_builder_destroy(self._h)          # synchronises: nothing reads the retained inputs any more
+                for ev in [e for e, _ in self.__dict__.pop("_keep_events", [])] + self.__dict__.pop("_free_events", []):
+                    lib.avl_event_destroy(ev)
             except Exception:      # interpreter shutdown: the module globals are already gone, the driver frees the memory
                 pass
             self._h = None
@@ -359,7 +387,7 @@ class VoxelAccumulator:
                                              sp, int(np.prod(sshape)), fp_, fshape[0], fshape[1], rp, int(frame_idx),
                                              float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_frame")
-        self._keep = (k1, k2, k3, k4)   # inputs must outlive the asynchronous launches
+        self._retain((k1, k2, k3, k4), stream)   # inputs must outlive the asynchronous launches
         return self
 
     def integrate_batch(self, depths, calib, pc_transforms, sample_idxs=None, feats_hwc=None, rgbs=None, frame_idx0=0, calib_inv=None,
@@ -406,7 +434,7 @@ class VoxelAccumulator:
                                              plan.samples, plan.P, plan.feat, plan.Hf, plan.Wf, plan.rgb, int(frame_idx0),
                                              float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_batch")
-        self._keep = plan.keep
+        self._retain(plan.keep, stream)
         return self
 
     def integrate_frame_global(self, depth, calib, transform, sample_idx, feat_hwc, rgb, frame_idx, pcd_min, depth_div=1000.0,
@@ -431,7 +459,7 @@ class VoxelAccumulator:
                                                     fshape[1], rp, int(frame_idx), float(min_depth), float(max_depth),
                                                     float(sigma_sq), pm.ctypes.data, stream)
         _lib.check(rc, "avl_builder_integrate_frame_global")
-        self._keep = (k1, k2, k3, k4)
+        self._retain((k1, k2, k3, k4), stream)
         return self
 
     def import_map(self, grid_feat, grid_pos, weight, grid_rgb=None, stream=None):

@@ -803,6 +803,61 @@ def pmc_lookup(which, shape):
     return out
 
 
+def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=300):
+    """HBM bytes per step of THIS run's kernels on THIS box: bench.py re-executes itself under `rocprofv3 --pmc FETCH_SIZE` and,
+    in a second pass, `--pmc WRITE_SIZE` (counter-only runs, no tracing flags; the two do not fit one pass:
+    /opt/skills/guides/MI355X_MICROARCH.md, rocprofv3 PMC slots) for a few profile-run steps of the same shape, and sums the
+    per-launch means of the step's kernels.  gfx950: FETCH_SIZE is in KB and reports half of a wide coalesced read stream (same
+    guide, HBM section) -> x 1024 x 2; WRITE_SIZE (KB) is taken as reported (uncalibrated there).  Returns None when rocprofv3 is
+    missing or a pass fails -- the caller falls back to the committed profiles/pmc_traffic.json."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if rocprof is None or os.environ.get("AVL_BENCH_PMC_CHILD") == "1":
+        return None
+    env = dict(os.environ, AVL_BENCH_PMC_CHILD="1", TMPDIR="/tmp", PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    tot, names, launches = {}, set(), None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "pmc", "--", sys.executable, str(ROOT / "bench.py"),
+                   "--profile-run", "--steps", "5", "--warmup", "1", "--settle-steps", "2", "--no-cpu", "--no-build-extra"] + argv_shape
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            except Exception:
+                return None
+            files = list(Path(td).rglob("*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            agg = defaultdict(list)
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    k = row.get("Kernel_Name") or row.get("Kernel Name") or ""
+                    if row.get("Counter_Name") == counter and any(m in k for m in kernels):
+                        agg[k].append(float(row["Counter_Value"]))
+            if not agg:
+                return None
+            # every kernel of a step is launched once per step: the step's bytes = sum of the per-launch means
+            tot[counter] = sum(sum(v) / len(v) for v in agg.values()) * 1024.0
+            names |= set(agg)
+            launches = max(len(v) for v in agg.values())
+    read_b, write_b = 2.0 * tot["FETCH_SIZE"], tot["WRITE_SIZE"]
+    return dict(traffic=read_b + write_b, traffic_source="in-run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command on this box",
+                traffic_read_bytes=read_b, traffic_write_bytes=write_b, traffic_launches_sampled=launches,
+                traffic_kernels=sorted(pretty_kernel(n) for n in names),
+                traffic_note="FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KB x 1024, per step")
+
+
+def pretty_kernel(name):
+    import re
+    m = re.match(r"_ZN3avl\d+([A-Za-z0-9_]+?)I((?:L[ib]\d+E)+)E", name)
+    if m:
+        return m.group(1) + "<" + ",".join(re.findall(r"L[ib](\d+)E", m.group(2))) + ">"
+    return name.split("(")[0].replace("avl::", "").replace("void ", "")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -836,6 +891,7 @@ def main():
     ap.add_argument("--resident", choices=["raw", "prepared", "compact"], default="raw",
                     help="index workload: the form of the map the timed steps read (raw float32 = headline; prepared / compact = VLMap's resident copies)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run a few steps under rocprofv3 --pmc to measure HBM traffic in the run")
     ap.add_argument("--no-build-extra", action="store_true")
     ap.add_argument("--profile-run", action="store_true",
                     help="only the timed kernel launches (no scores_mat variant, CPU baseline or build extra): used under rocprofv3 "
@@ -895,6 +951,17 @@ def main():
             out.setdefault("extra", {})["collectives"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), ranks=devs,
                                                                note="backend nccl = RCCL over xGMI; gloo only when several ranks "
                                                                     "share one GPU in the tests (AVLMAPS_DIST_BACKEND)")
+    if rank == 0 and ws == 1 and args.workload == "index" and not args.profile_run and not args.no_pmc and args.resident == "raw":
+        # HBM traffic of the headline kernels measured in THIS run, the committed file only as a fallback
+        try:
+            shape_argv = ["--voxels", str(args.voxels), "--queries", str(args.queries), "--feat-dim", str(args.feat_dim)] + (["--dense"] if args.dense else [])
+            torch.cuda.empty_cache()
+            m = measure_traffic_in_run(shape_argv)
+            if m is not None:
+                out["roofline"].update(m)
+                out["roofline"]["traffic_over_algorithmic"] = m["traffic"] / out["roofline"]["algorithmic_bytes"]
+        except Exception as e:
+            out["roofline"]["traffic_in_run_error"] = repr(e)
     if rank == 0:
         print(json.dumps(out))
     if dist.is_available() and dist.is_initialized():

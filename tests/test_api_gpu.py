@@ -381,7 +381,7 @@ def test_bench_line_contract():
     import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
-    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--no-build-extra", "--no-cpu"], "voxel_query_similarities_per_sec"),
+    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--no-build-extra", "--no-cpu", "--no-pmc"], "voxel_query_similarities_per_sec"),
                           (["--workload", "build", "--no-cpu"], "map_build_frames_per_sec")):
         r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"] + extra,
                            capture_output=True, text=True, timeout=600)
@@ -404,6 +404,35 @@ def test_bench_line_contract():
         assert "workload" in d["config"] and "model" not in d["config"]
         rf = d["roofline"]
         assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+def test_bench_measures_hbm_traffic_in_the_run():
+    """roofline.traffic comes from counter passes of the SAME command on the SAME box (bench.py re-executes itself under
+    rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE: counter-only runs) -- and the resident-copy lines carry their own roofline"""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    base = [sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--voxels", "400000", "--settle-steps", "2",
+            "--no-build-extra", "--no-cpu"]
+    if shutil.which("rocprofv3") or Path("/opt/rocm/bin/rocprofv3").exists():
+        r = subprocess.run(base, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        rf = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+        assert rf["traffic_source"].startswith("in-run"), rf
+        alg = 400000 * 512 * 4
+        assert 0.9 * alg < rf["traffic_read_bytes"] < 1.25 * alg and rf["traffic"] >= rf["traffic_read_bytes"]
+        assert any("sim_split_f16_kernel" in k for k in rf["traffic_kernels"])
+    for form, bytes_per_el in (("prepared", 4), ("compact", 3)):
+        r = subprocess.run(base + ["--no-pmc", "--resident", form], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["config"]["resident_form"] == form and form in d["config"]["workload"]
+        assert abs(d["roofline"]["algorithmic_bytes"] - (400000 * 512 * bytes_per_el + 400000 * 4 + 64 * 512 * 4 + 400000 * 4)) < 1
+        assert d["roofline"]["float32_map_equivalent_frac"] >= d["roofline"]["frac"] * (0.99 if bytes_per_el == 4 else 1.2)
+        assert d["extra"]["parity_sample"]["max_abs_err_vs_fp64"] < 1e-4
 
 
 def _run_ranks(nproc, args, port, timeout=900, **env_extra):
@@ -501,9 +530,15 @@ def test_multi_rank_checkpoints_and_resume(golden, tmp_path):
     ca, cb = cells(a[2]), cells(b[2])
     assert np.array_equal(np.sort(ca), np.sort(cb))                       # the same voxels ...
     ia, ib = np.argsort(ca), np.argsort(cb)
-    np.testing.assert_allclose(b[3][ib], a[3][ia], rtol=2e-6)              # ... the same weights
-    np.testing.assert_allclose(b[1][ib], a[1][ia], rtol=2e-5, atol=2e-6)   # ... the same features
-    assert np.abs(b[5][ib].astype(int) - a[5][ia].astype(int)).max() <= 3  # colour: closed form after a resume (no replay log)
+    np.testing.assert_allclose(b[3][ib], a[3][ia], rtol=2e-6)              # ... the same weights (sum of alpha: order-free)
+    # ... and the same features, except where the interruption changed WHICH sample is a voxel's first touch: the reference
+    # stores feat * alpha at the first touch of a voxel and treats it as a mean afterwards (vlmap_builder.py:166-174, SURVEY.md
+    # 8a-5), so its map depends on the frame order; the checkpoint holds frames {0,1,2,8,9,10}, and a voxel frame 9 created
+    # that frame 4 would have created in the uninterrupted order keeps frame 9's first-touch weighting.  (Upstream's own resume
+    # re-fuses every frame on top of the loaded map: it does not reproduce the uninterrupted map either.)
+    close = np.isclose(b[1][ib], a[1][ia], rtol=2e-5, atol=2e-6).all(axis=1)
+    assert close.mean() > 0.97, close.mean()
+    assert np.abs(b[5][ib].astype(int) - a[5][ia].astype(int))[close].max() <= 3   # colour: closed form after a resume (no replay log)
     # the checkpoint's voxels keep their ids; occupied_ids is consistent with grid_pos
     assert np.array_equal(b[2][:n_part], part_pos)
     assert np.array_equal(b[4][b[2][:, 0], b[2][:, 1], b[2][:, 2]], np.arange(len(b[2])))
@@ -576,7 +611,7 @@ def test_bench_two_ranks_share_one_gpu():
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, AVLMAPS_DIST_BACKEND="gloo")
-    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--build-frames", "12", "--standin-frames", "8"], "voxel_query_similarities_per_sec"),
+    for extra, metric in ((["--voxels", "60000", "--settle-steps", "2", "--build-frames", "12", "--standin-frames", "8", "--no-pmc"], "voxel_query_similarities_per_sec"),
                           (["--workload", "build"], "map_build_frames_per_sec")):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"] + extra

@@ -137,6 +137,25 @@ def test_map_file_is_the_reference_hdf5_layout(tmp_path):
         for frag in ('DATASET "grid_feat"', "H5T_IEEE_F32LE", f"( {n}, {D} )", 'DATASET "grid_rgb"', "H5T_STD_U8LE",
                      'DATASET "occupied_ids"', f"( {gs}, {gs}, {vh} )", "H5T_STD_I32LE"):
             assert frag in txt, frag
+        # ... and on the CONTENT (h5dump -d), not only the header: every value of the small datasets, the features to the
+        # precision h5dump prints
+        import re
+
+        def dumped(name):
+            t = subprocess.run([h5dump, "-d", "/" + name, "-w", "0", str(p)], capture_output=True, text=True).stdout
+            body = t[t.index("DATA {"):]
+            vals = []
+            for line in body.splitlines():
+                m = re.match(r"\s*\(\d+(?:,\d+)*\):\s*(.*)", line)
+                if m:
+                    vals += [float(x) for x in m.group(1).replace(",", " ").split()]
+            return np.array(vals)
+        assert np.array_equal(dumped("mapped_iter_list"), [1, 3, 4])
+        assert np.array_equal(dumped("grid_pos").reshape(n, 3), arrays["grid_pos"])
+        assert np.array_equal(dumped("grid_rgb").reshape(n, 3), arrays["grid_rgb"])
+        assert np.array_equal(dumped("occupied_ids"), arrays["occupied_ids"].ravel())
+        np.testing.assert_allclose(dumped("weight"), arrays["weight"], rtol=1e-5)
+        np.testing.assert_allclose(dumped("grid_feat").reshape(n, D), arrays["grid_feat"], rtol=1e-5, atol=1e-7)
 
 
 def test_h5lite_extendible_datasets_and_foreign_files(tmp_path):
@@ -337,3 +356,61 @@ def test_lseg_window_plan_reproduces_the_reference_windows(golden):
     # the reference's default: 720 x 1080 -> 347 x 520, crops of 480, stride 320 -> 1 x 2 windows
     p2 = WindowPlan.make(720, 1080, 480, 520)
     assert (p2.height, p2.width) == (347, 520) and p2.origins == [(0, 0), (0, 320)] and p2.canvas == (480, 800)
+
+
+def test_category_matcher_hook():
+    """find_similar_category_id resolves what it can locally and hands the rest to an injected matcher (upstream: an LLM call,
+    index_utils.py:8-32); without one an unmatched name is a KeyError, a matcher's out-of-range answer a ValueError"""
+    from avlmaps_amd.utils import index_utils as iu
+    cats = ["void", "Sofa", "dining table", "chair"]
+    assert iu.find_similar_category_id("chair", cats) == 3 and iu.find_similar_category_id("sofa", cats) == 1
+    assert iu.find_similar_category_id("table", cats) == 2
+    with pytest.raises(KeyError):
+        iu.find_similar_category_id("couch", cats)
+    seen = []
+    assert iu.find_similar_category_id("couch", cats, matcher=lambda name, cl: seen.append((name, tuple(cl))) or 1) == 1
+    assert seen == [("couch", tuple(cats))]
+    iu.set_category_matcher(lambda name, cl: cl.index("Sofa"))
+    try:
+        assert iu.find_similar_category_id("somewhere to sit down", cats) == 1
+        assert iu.find_similar_category_id("chair", cats) == 3          # local rules still come first
+    finally:
+        iu.set_category_matcher(None)
+    with pytest.raises(ValueError):
+        iu.find_similar_category_id("couch", cats, matcher=lambda name, cl: 9)
+
+
+def test_map_saves_are_atomic_and_interrupted_patches_are_detectable(tmp_path):
+    """MapFileWriter: a full save is written next to the target and renamed over it; an in-place incremental patch clears a
+    marker dataset first and sets it last, so that a file whose patch was interrupted says so (map_checkpoint_complete) -- a
+    resumed build then keeps its voxels but does not trust its frame list (VLMapBuilder._resume)"""
+    from avlmaps_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    rng = np.random.default_rng(4)
+    n, D, gs, vh = 200, 8, 16, 4
+    pos = np.stack(np.unravel_index(rng.choice(gs * gs * vh, n, replace=False), (gs, gs, vh)), 1).astype(np.int32)
+    occ = -np.ones((gs, gs, vh), np.int32)
+    occ[pos[:, 0], pos[:, 1], pos[:, 2]] = np.arange(n)
+    arrays = dict(grid_feat=rng.standard_normal((n, D)).astype(np.float32), grid_pos=pos, weight=rng.random(n).astype(np.float32),
+                  occupied_ids=occ, grid_rgb=rng.integers(0, 255, (n, 3)).astype(np.uint8))
+    p = tmp_path / "vlmaps.h5df"
+    w = mu.MapFileWriter(p)
+    w.save({k: v.copy() for k, v in arrays.items()}, [0, 1])
+    assert p.exists() and not (tmp_path / "vlmaps.h5df.tmp").exists() and mu.map_checkpoint_complete(p)
+    assert mu.read_map_dataset(p, "mapped_iter_list").tolist() == [0, 1] and mu.read_map_dataset(p, "nope") is None
+    assert mu.load_3d_map(p)[0] == [0, 1]                       # the extra marker dataset does not disturb the reference's reader
+    dirty = np.zeros(n, np.uint8)
+    dirty[[3, 70]] = 1
+    arrays["grid_feat"][[3, 70]] += 1
+    w.save({k: v.copy() for k, v in arrays.items()}, [0, 1, 2], dirty)
+    assert w.stats[-1]["mode"] == "incremental" and mu.map_checkpoint_complete(p)
+    assert np.array_equal(mu.load_3d_map(p)[1], arrays["grid_feat"]) and mu.load_3d_map(p)[0] == [0, 1, 2]
+    # a patch that dies half way: marker cleared, rows written, list not yet
+    with h5lite.H5File(p, "r+") as f:
+        f.write_rows(mu.MapFileWriter.MARKER, 0, np.zeros(1, np.int32))
+    assert not mu.map_checkpoint_complete(p)
+    # files written without the marker (upstream's writer, save_3d_map) count as complete
+    q = tmp_path / "plain.h5df"
+    mu.save_3d_map(q, arrays["grid_feat"], pos, arrays["weight"], occ, [5], arrays["grid_rgb"])
+    assert mu.map_checkpoint_complete(q)
