@@ -3,7 +3,7 @@
 # judged summaries to profiles/<tag>_*).   usage: tools/collect_profiles.sh <tag>
 # Kernel traces (--kernel-trace --stats) and PMC passes (--pmc only) are separate runs: never combined with tracing flags.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
@@ -26,6 +26,13 @@ pmc index_fetch FETCH_SIZE --steps 5 --warmup 2 --settle-steps 0 --profile-run
 pmc index_write WRITE_SIZE --steps 5 --warmup 2 --settle-steps 0 --profile-run
 pmc index_sq "$SQ" --steps 5 --warmup 2 --settle-steps 0 --profile-run
 python $R/tools/summarize_prof.py $O/pmc_index.json /tmp/q_index_fetch /tmp/q_index_write /tmp/q_index_sq > /dev/null
+# --- the same shape on VLMap's compact resident copy (3 B per element), and the reference's 65-column query ("64 categories + other")
+trace index_compact --profile-run --resident compact
+pmc ic_fetch FETCH_SIZE --steps 5 --warmup 2 --settle-steps 0 --profile-run --resident compact
+pmc ic_write WRITE_SIZE --steps 5 --warmup 2 --settle-steps 0 --profile-run --resident compact
+pmc ic_sq "$SQ" --steps 5 --warmup 2 --settle-steps 0 --profile-run --resident compact
+python $R/tools/summarize_prof.py $O/pmc_index_compact.json /tmp/q_ic_fetch /tmp/q_ic_write /tmp/q_ic_sq > /dev/null
+trace index_q65 --profile-run --queries 65
 # --- config 5: 2M x 1536, 128 block-structured queries (column-block launches) and the dense single pass
 C5="--feat-dim 1536 --queries 128"
 trace config5 $C5 --steps 100 --profile-run
@@ -34,6 +41,11 @@ pmc c5_fetch FETCH_SIZE $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run
 pmc c5_write WRITE_SIZE $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run
 pmc c5_sq "$SQ" $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run
 python $R/tools/summarize_prof.py $O/pmc_config5.json /tmp/q_c5_fetch /tmp/q_c5_write /tmp/q_c5_sq > /dev/null
+trace config5_compact $C5 --steps 100 --profile-run --resident compact
+pmc c5c_fetch FETCH_SIZE $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run --resident compact
+pmc c5c_write WRITE_SIZE $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run --resident compact
+pmc c5c_sq "$SQ" $C5 --steps 5 --warmup 2 --settle-steps 0 --profile-run --resident compact
+python $R/tools/summarize_prof.py $O/pmc_config5_compact.json /tmp/q_c5c_fetch /tmp/q_c5c_write /tmp/q_c5c_sq > /dev/null
 # --- build: per-frame launches and 16 frames per launch, 10k frames, finalize inside the timed region
 trace build --workload build --steps 10000 --warmup 20 --no-cpu
 trace build_b16 --workload build --steps 10000 --warmup 20 --no-cpu --build-batch 16
@@ -48,7 +60,10 @@ python $R/tools/summarize_prof.py $O/pmc_build_b16.json /tmp/q_build16_fetch /tm
 cd $R
 # --- plain runs (no profiler): the lines the judge reads
 (timeout 900 python bench.py) > $O/bench_default.log 2>&1
-(timeout 600 python bench.py $C5 --steps 200) > $O/config5_line.log 2>&1
+(timeout 600 python bench.py $C5 --steps 200 --no-pmc) > $O/config5_line.log 2>&1
+(timeout 600 python bench.py $C5 --steps 200 --resident compact --no-pmc) > $O/config5_compact_line.log 2>&1
+(timeout 600 python bench.py --resident compact --no-build-extra) > $O/index_compact_line.log 2>&1
+(timeout 600 python bench.py --queries 65 --no-build-extra --no-pmc) > $O/index_q65_line.log 2>&1
 (timeout 600 python bench.py --workload build --steps 10000) > $O/build_10k.log 2>&1
 (timeout 600 python bench.py --workload build --steps 5000) > $O/build_config3.log 2>&1
 (timeout 600 python bench.py --workload build --steps 10000 --deferred-fuse --no-cpu) > $O/build_10k_deferred.log 2>&1
