@@ -143,10 +143,15 @@ constexpr int kRowPadHalves = 8;  // +16 B per query row: consecutive rows shift
 // 8 waves per workgroup, one workgroup per CU (LDS-bound).  Measured alternatives on the config-2 shape: 12 or 16 waves
 // (0.81 / 1.37 ms vs 0.75 ms) and no register prefetch (1.10 ms) are slower.
 constexpr int kSplitThreads = 512;
-#ifndef AVL_RING
-#define AVL_RING 2
+// register buffers of the unrolled k loop (resident kernel): the loads of the next ring - 1 steps are in flight while a step is
+// computed.  Same-box A/B at 2 M x 512 x 64 (profiles/r03_ab_ring_depth.txt): raw float32 map 0.7100 (2) / 0.7053 (3) / 0.878 ms
+// (4: spills); prepared 0.7006 / 0.7221 / 0.7187; compact 0.6083 / 0.6121 / 0.6108 -- so the raw kernel takes 3 since the epilogue
+// rewrite of round 3 freed the registers (251 VGPRs), the others and the extra-row variant (spills at 3) stay at 2.
+#ifdef AVL_RING
+template <bool PRE, bool XR> struct RingDepth { static constexpr int value = AVL_RING; };
+#else
+template <bool PRE, bool XR> struct RingDepth { static constexpr int value = (!PRE && !XR) ? 3 : 2; };
 #endif
-constexpr int kRing = AVL_RING;   // register buffers of the unrolled k loop (resident kernel)
 constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup iteration
 
 // One workgroup per (padded) query row: row max -> power-of-two scale 2^S with max|q|*2^S in [512, 1024)
@@ -800,8 +805,8 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             };
             if constexpr (NSTEPS > 0) {
                 // compile-time trip count, ring of kRing register buffers: the loads of the next kRing - 1 steps are in flight
-                // while step s is computed, all waits are counted vmcnt.  Rings of 2 and 3 measure the same (0.717 / 0.718 ms,
-                // DESIGN.md); 2 leaves the 32 VGPRs the range guard and the epilogue need without spilling.
+                // while step s is computed, all waits are counted vmcnt (depth per variant: RingDepth)
+                constexpr int kRing = RingDepth<PRE, XR>::value;
                 f32x4 ring[kRing][8];
 #pragma unroll
                 for (int r = 0; r + 1 < kRing; ++r)

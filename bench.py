@@ -278,7 +278,7 @@ def run_index(args, torch, dist, lib, rank, ws):
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                            kernel_ms=ev_ms, algorithmic_bytes=alg_bytes,
-                           **(pmc_lookup("index", dict(N=N, D=D, Q=Q)) if resident == "raw" else dict(traffic=None, traffic_source=None)))
+                           **pmc_lookup("index", dict(N=N, D=D, Q=Q, resident=resident)))
     if resident != "raw":
         # the same pass priced on the float32 map's bytes, for comparison with the headline (the work it replaces)
         out["roofline"]["float32_map_equivalent_frac"] = (N * D * 4 + Q * D * 4 + N * 4) / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -656,6 +656,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         del fin
         torch.cuda.empty_cache()
         single_gpu_merge = {}
+        merge_ranks(parallel, acc, mode, exact_rgb)            # untimed: torch's sort kernels, RCCL's communicator (forced collectives)
+        torch.cuda.empty_cache()
         merge_ranks(parallel, acc, mode, exact_rgb, timings=single_gpu_merge)
         t_fin = time.perf_counter()
         acc.finalize(as_torch=True)
@@ -835,7 +837,7 @@ def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=300):
             for f in files:
                 for row in csv.DictReader(open(f)):
                     k = row.get("Kernel_Name") or row.get("Kernel Name") or ""
-                    if row.get("Counter_Name") == counter and any(m in k for m in kernels):
+                    if row.get("Counter_Name") == counter and any(m in k for m in kernels) and "prepare_map" not in k:
                         agg[k].append(float(row["Counter_Value"]))
             if not agg:
                 return None
@@ -951,10 +953,11 @@ def main():
             out.setdefault("extra", {})["collectives"] = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), ranks=devs,
                                                                note="backend nccl = RCCL over xGMI; gloo only when several ranks "
                                                                     "share one GPU in the tests (AVLMAPS_DIST_BACKEND)")
-    if rank == 0 and ws == 1 and args.workload == "index" and not args.profile_run and not args.no_pmc and args.resident == "raw":
+    if rank == 0 and ws == 1 and args.workload == "index" and not args.profile_run and not args.no_pmc:
         # HBM traffic of the headline kernels measured in THIS run, the committed file only as a fallback
         try:
-            shape_argv = ["--voxels", str(args.voxels), "--queries", str(args.queries), "--feat-dim", str(args.feat_dim)] + (["--dense"] if args.dense else [])
+            shape_argv = ["--voxels", str(args.voxels), "--queries", str(args.queries), "--feat-dim", str(args.feat_dim), "--resident", args.resident]
+            shape_argv += ["--dense"] if args.dense else []
             torch.cuda.empty_cache()
             m = measure_traffic_in_run(shape_argv)
             if m is not None:

@@ -55,7 +55,7 @@ def per_step(d, match, counter, how="mean"):
     """sum over the kernels of one step (each is launched once per step) of a counter's per-launch mean"""
     tot, names = 0.0, []
     for k, v in d.items():
-        if any(m in k for m in match) and counter in v:
+        if any(m in k for m in match) and "prepare_map" not in k and counter in v:      # the one-off conversion is not part of a step
             tot += v[counter][how]
             names.append(pretty(k))
     return tot, names
@@ -74,7 +74,10 @@ def busy(d, match):
 # (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) -> doubled.  WRITE_SIZE is uncalibrated (atomics inflate it).
 entries = []
 SIM = ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel", "sim_fixup_rows_kernel", "sim_gather_queries_kernel", "sim_prep_queries_kernel")
-for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64), "index_bench"), ("pmc_config5", dict(N=2000000, D=1536, Q=128), "config5_bench")):
+for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64, resident="raw"), "index_bench"),
+                          ("pmc_config5", dict(N=2000000, D=1536, Q=128, resident="raw"), "config5_bench"),
+                          ("pmc_index_compact", dict(N=2000000, D=512, Q=64, resident="compact"), "index_compact_bench"),
+                          ("pmc_config5_compact", dict(N=2000000, D=1536, Q=128, resident="compact"), "config5_compact_bench")):
     if stem not in pmc:
         continue
     f, names = per_step(pmc[stem], SIM, "FETCH_SIZE")
