@@ -1779,7 +1779,6 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat && d_queries, "avl_sim_scores: null input");
     hipStream_t st = as_stream(stream);
-
     SplitPlan p;
     const bool aligned = (ld_feat % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_feat) & 15) == 0) &&
                          (!d_scores || (reinterpret_cast<uintptr_t>(d_scores) & 15) == 0);
