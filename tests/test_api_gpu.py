@@ -373,6 +373,62 @@ def test_get_lseg_feat_protocol_on_the_gpu(golden):
         assert torch.equal(merge_windows(w, plan), want)
 
 
+def test_lseg_adapter_with_a_stub_upstream_model(tmp_path, monkeypatch):
+    """lseg_adapter.load_upstream_lseg end to end against a stand-in for the upstream package: same import path, constructor
+    call and checkpoint format as vlmap_builder.py:226-264 (LSegEncNet("", arch_option=0, block_depth=0, activation="lrelu",
+    crop_size=480), state_dict keys prefixed "net."), a forward that is batch-general like lseg_net.py:287-337.  The real
+    weights are not on this machine; what runs here is everything around them: checkpoint loading, the window batch, ONE model
+    call per frame, the device merge, channels-last output on the GPU."""
+    import sys
+    import types
+    import torch
+    calls = []
+
+    class LSegEncNet(torch.nn.Module):
+        out_c = 24
+
+        def __init__(self, labels, arch_option=0, block_depth=0, activation="lrelu", crop_size=480):
+            super().__init__()
+            assert labels == "" and crop_size == 480 and activation == "lrelu"
+            self.conv = torch.nn.Conv2d(3, self.out_c, 3, padding=1)
+
+        def forward(self, x, labelset):
+            calls.append(tuple(x.shape))
+            f = self.conv(x)
+            f = 14.2857 * f / f.norm(dim=1, keepdim=True)
+            return f.half().float(), f[:, :1]
+
+    pkg = types.ModuleType("avlmaps")
+    pkg.__file__ = str(tmp_path / "avlmaps" / "__init__.py")
+    pkg.__path__ = [str(tmp_path / "avlmaps")]
+    mods = {"avlmaps": pkg}
+    for name in ("avlmaps.lseg", "avlmaps.lseg.modules", "avlmaps.lseg.modules.models", "avlmaps.lseg.modules.models.lseg_net"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        mods[name] = m
+    mods["avlmaps.lseg.modules.models.lseg_net"].LSegEncNet = LSegEncNet
+    for k, v in mods.items():
+        monkeypatch.setitem(sys.modules, k, v)
+    torch.manual_seed(0)
+    ref_model = LSegEncNet("")
+    ckpt = tmp_path / "avlmaps" / "lseg" / "checkpoints" / "demo_e200.ckpt"
+    ckpt.parent.mkdir(parents=True)
+    torch.save({"state_dict": {"net." + k: v for k, v in ref_model.state_dict().items()}}, ckpt)
+    from avlmaps_amd.lseg_adapter import load_upstream_lseg
+    extract = load_upstream_lseg()                                 # default path: <avlmaps>/lseg/checkpoints/demo_e200.ckpt
+    rgb = np.random.default_rng(0).integers(0, 256, (72, 108, 3), dtype=np.uint8)
+    f = extract(rgb)
+    assert f.is_cuda and f.dtype == torch.float32 and f.is_contiguous() and tuple(f.shape) == (347, 520, 24)
+    assert calls == [(2, 3, 480, 480)]                            # both windows of the frame in ONE call
+    assert torch.allclose(f.norm(dim=2), torch.full((347, 520), 14.2857, device="cuda"), atol=0.05)
+    # the builder takes it as is
+    from avlmaps_amd import ops
+    acc = ops.VoxelAccumulator(200, 0.05, 30, 24, capacity=4096)
+    depth = np.full((72, 108), 2.0, np.float32)
+    acc.integrate_frame(depth, np.array([54, 0, 54, 0, 54, 36, 0, 0, 1.0]), np.eye(4), np.arange(0, 72 * 108, 7, dtype=np.int32), f, rgb, frame_idx=0)
+    assert acc.num_voxels() > 0
+
+
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the fields the driver reads (metric/value/unit/n_gpus/steps/warmup/ms_per_step/
     higher_is_better/scaling/vs_baseline/dtype/data/config) plus the roofline object; small shapes, a few steps"""
