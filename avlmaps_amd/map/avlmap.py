@@ -33,9 +33,8 @@ class AVLMap:
             return get_heatmap_from_mask_3d(self.vlmap.grid_pos, mask, cell_size=cs, decay_rate=decay_rate)
         # query -> argmax -> mask -> heat without leaving the GPU: only the (N,) float32 heat comes back
         from .. import ops
-        from ..utils.clip_utils import landmark_text_feats
         vm = self.vlmap
-        q, _ = landmark_text_feats(vm.clip_model, [object_name], vm.clip_feat_dim, use_multiple_templates=True, add_other=True)
+        q = vm._text_feats([object_name])            # cached per string: the text tower costs more than the kernels below
         feat = vm._device_feat()
         if vm._rows != (0, len(vm.grid_feat)):          # voxel rows sharded over ranks: gather the argmax, heat on the full map
             mask = vm._score(q, want_scores=False)[1] == 0

@@ -140,8 +140,30 @@ def index_map_api_probe(feat_h, D, reps=30):
         vm.index_map(f"chair number {i}", with_init_cat=False)
         fresh.append(time.perf_counter() - t0)
     assert m.dtype == np.bool_ and m.shape == (len(feat_h),) and np.array_equal(m, m0)
-    return dict(voxels=len(feat_h), first_call_s=first, cached_query_ms=float(np.median(cached)) * 1e3, new_query_ms=float(np.median(fresh)) * 1e3,
-                mask_true=int(m.sum()), what="VLMap.index_map(name, with_init_cat=False): (N,) bool on the host; text tower = hash stand-in")
+    out = dict(voxels=len(feat_h), first_call_s=first, cached_query_ms=float(np.median(cached)) * 1e3, new_query_ms=float(np.median(fresh)) * 1e3,
+               mask_true=int(m.sum()), what="VLMap.index_map(name, with_init_cat=False): (N,) bool on the host; text tower = hash stand-in")
+    # AVLMap.index_object (avlmap.py:67-76): query -> argmax -> mask -> nearest-target decay heat, (N,) float32 back on the host
+    try:
+        from avlmaps_amd.map.avlmap import AVLMap
+        N = len(feat_h)
+        rng = np.random.default_rng(3)
+        side = int(round((N / 0.07) ** (1 / 3))) + 1
+        lin = rng.choice(side ** 3, size=N, replace=False)
+        am = AVLMap(Cfg(map_config=cfg, params=Cfg(cs=0.05, gs=1000)))
+        am.vlmap = vm
+        vm.grid_pos = np.stack([lin // (side * side), (lin // side) % side, lin % side], 1).astype(np.int32)
+        for _ in range(3):
+            am.index_object("sofa", decay_rate=0.01)
+        ts = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            heat = am.index_object("sofa", decay_rate=0.01)
+            ts.append(time.perf_counter() - t0)
+        out["index_object_cached_query_ms"] = float(np.median(ts)) * 1e3
+        assert heat.shape == (N,) and heat.dtype == np.float32 and float(heat.max()) == 1.0
+    except Exception as e:
+        out["index_object_error"] = repr(e)
+    return out
 
 
 def cpu_index_baseline(feat_h, q_h, repeats=3):
