@@ -73,6 +73,12 @@ class VLMap(Map):
         (self.mapped_iter_list, self.grid_feat, self.grid_pos, self.weight, self.occupied_ids,
          self.grid_rgb) = load_3d_map(self.map_save_path)[:6]
         self._dev_feat = None
+        # straight after a multi-GPU build in this process the merged map already lies row-sharded in the ranks' HBM
+        # (VLMapBuilder.map_shard): take this rank's block as the resident copy instead of uploading it again from the file
+        shard = getattr(getattr(self, "map_builder", None), "map_shard", None)
+        if shard is not None and self.adopt_device_shard(shard):
+            self.map_builder.map_shard = None            # the compact copy replaces the float32 block
+            return True
         self._start_device_prefetch()
         return True
 
@@ -217,7 +223,8 @@ class VLMap(Map):
         from .. import ops, parallel
         feat = self._device_feat()
         sc, am, _ = ops.sim_scores(feat, q, want_scores=want_scores, want_argmax=True, precision=self._sim_precision)
-        to_np = lambda x: None if x is None else (x if isinstance(x, np.ndarray) else x.numpy())
+        from ..utils.clip_utils import _to_numpy
+        to_np = lambda x: None if x is None else _to_numpy(x)        # DeviceArray or (adopted shard) torch tensor
         sc, am = to_np(sc), to_np(am)
         n = len(self.grid_feat)
         if self._rows != (0, n):

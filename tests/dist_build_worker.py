@@ -66,6 +66,27 @@ def main():
         b.shard_sampling = sampling
     np.random.seed(seed)                                      # the state the reference run started from, on EVERY rank
     b.create_mobile_base_map()
+    if os.environ.get("AVL_TEST_ADOPT") == "1":
+        # straight from the build to the index: every rank adopts its block of the merged map (no upload), the sharded VLMap
+        # answers like a single process that loaded the file
+        from avlmaps_amd.map.vlmap import VLMap
+        import avlmaps_amd.map.vlmap as vlmap_mod
+        D = int(b.clip_feat_dim)
+        qrng = np.random.default_rng(5)
+        table = {"sofa": qrng.standard_normal((2, D)).astype(np.float32)}
+        vlmap_mod.landmark_text_feats = lambda m, names, d, use_multiple_templates=False, add_other=True: (table[names[0]], list(names))
+        vm = VLMap(cfg)
+        vm.map_builder = b
+        shard_rows = tuple(b.map_shard["rows"]) if b.map_shard is not None else None
+        uploads = []
+        vm._start_device_prefetch = lambda: uploads.append(1)
+        assert vm.load_map(out_dir)
+        vm.clip_model, vm.clip_feat_dim = None, D
+        adopted = bool(ws > 1 and not uploads and vm._dev_feat is not None and vm._rows == shard_rows)
+        mask = vm.index_map("sofa", with_init_cat=False)
+        if rank == 0:
+            want = np.argmax(vm.grid_feat.astype(np.float64) @ table["sofa"].astype(np.float64).T, axis=1) == 0
+            np.savez(out_dir / "adopt.npz", mask=mask, want=want, adopted=np.array(adopted), rows=np.array(vm._rows))
     tim = dict(getattr(b, "merge_timings", {}))
     if b.map_shard is not None:
         tim["shard_rows"] = list(b.map_shard["rows"])

@@ -606,6 +606,18 @@ def test_multi_rank_checkpoints_and_resume(golden, tmp_path):
     assert np.array_equal(b[4][b[2][:, 0], b[2][:, 1], b[2][:, 2]], np.arange(len(b[2])))
 
 
+def test_sharded_build_feeds_the_sharded_index_without_an_upload(golden, tmp_path):
+    """after a 2-rank build every rank's block of the merged map is already in its HBM (VLMapBuilder.map_shard): VLMap.load_map
+    in the same process adopts it as the resident copy (no second upload) and index_map returns what float64 NumPy returns on
+    the file's features"""
+    GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+    out = tmp_path / "adopt"
+    _run_ranks(2, [GOLDEN_DIR / "g2b_builder_growth.npz", out, 16, "replay", 99], 29571, AVL_TEST_ADOPT=1)
+    z = np.load(out / "adopt.npz")
+    assert bool(z["adopted"]) and z["rows"][0] == 0 and 0 < z["rows"][1] < len(z["mask"])
+    assert z["mask"].dtype == np.bool_ and np.mean(z["mask"] == z["want"]) > 0.999 and z["want"].any() and (~z["want"]).any()
+
+
 def test_uniform_pixel_sampling(golden, tmp_path):
     """pixel_sampling = "uniform": ceil(H*W / rate) distinct pixels per frame from a generator seeded by one draw of the global
     RNG and the frame index -- reproducible under np.random.seed, other pixels than the reference's shuffle, and the same map
