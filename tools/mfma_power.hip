@@ -42,6 +42,23 @@ __global__ __launch_bounds__(512) void burn(const int4* __restrict__ src, int it
             asm volatile("" : "+v"(c0), "+v"(c1));
         }
         sink = c0[0] + c1[3];
+    } else if constexpr (KIND == 5 || KIND == 6 || KIND == 7) {
+        // operand-toggling dependence: A (5) / A and B (6) with the fp16 mantissas cut to 3 bits, (7) A all zero
+        int4 am = a4, bm = b4;
+        const int mask = (int)0xFF80FF80u;
+        if (KIND == 7) am = int4{0, 0, 0, 0};
+        else { am.x &= mask; am.y &= mask; am.z &= mask; am.w &= mask; }
+        if (KIND == 6) { bm.x &= mask; bm.y &= mask; bm.z &= mask; bm.w &= mask; }
+        const half8 a = __builtin_bit_cast(half8, am), b = __builtin_bit_cast(half8, bm);
+        f32x16 c0 = {}, c1 = {};
+        for (int i = 0; i < iters; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            gap<GAP>();
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+            gap<GAP>();
+            asm volatile("" : "+v"(c0), "+v"(c1));
+        }
+        sink = c0[0] + c1[3];
     } else if constexpr (KIND == 3) {
         using f32x4v = __attribute__((ext_vector_type(4))) float;
         const half8 a = __builtin_bit_cast(half8, a4), b = __builtin_bit_cast(half8, b4);
@@ -181,5 +198,8 @@ int main() {
     run<2, 0>("f16s", d_src, d_out, pf); run<2, 1>("f16s", d_src, d_out, pf);
     run<3, 0>("f16m", d_src, d_out, pf); run<3, 1>("f16m", d_src, d_out, pf); run<3, 3>("f16m", d_src, d_out, pf);
     run<4, 1>("fp8", d_src, d_out, pf); run<4, 3>("fp8", d_src, d_out, pf);
+    run<0, 3>("f16", d_src, d_out, pf);
+    run<5, 3>("f16a3", d_src, d_out, pf); run<6, 3>("f16ab3", d_src, d_out, pf); run<7, 3>("f16a0", d_src, d_out, pf);
+    run<5, 1>("f16a3", d_src, d_out, pf); run<6, 1>("f16ab3", d_src, d_out, pf); run<7, 1>("f16a0", d_src, d_out, pf);
     return 0;
 }
