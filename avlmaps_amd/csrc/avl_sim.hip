@@ -1031,9 +1031,10 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #ifndef AVL_TB2_P24
 #define AVL_TB2_P24 3
 #endif
-template <int QT, bool P24>
+// (prepared and compact maps need no split / guard registers: three tiles per chunk pass fit without a spill, 245-255 VGPRs)
+template <int QT, bool P24, bool PRE = false>
 struct StreamTB {
-    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? (P24 ? AVL_TB2_P24 : AVL_TB2) : 1);
+    static constexpr int value = QT == 1 ? 4 : (QT == 2 ? ((P24 || PRE) ? AVL_TB2_P24 : AVL_TB2) : 1);
 };
 
 // (Tried and dropped, round 2: ONE pass over several column windows -- the chunk loop switching query rows / running the
@@ -1050,7 +1051,7 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
     uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
     static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
-    constexpr int TB = StreamTB<QT, P24>::value;
+    constexpr int TB = StreamTB<QT, P24, PRE>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 64 * SPC;
     constexpr int row_b = (2 * KS + kRowPadHalves) * 2;   // bytes per query row of one chunk: hi[KS] | lo[KS] | pad

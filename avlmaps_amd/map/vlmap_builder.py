@@ -411,6 +411,18 @@ class VLMapBuilder:
         streaming into the same accumulators afterwards.  The file is written by a host thread (device-to-host copy included)
         unless `final`."""
         import torch.distributed as dist
+        if not final:
+            # a periodic checkpoint is only worth a merge if rank 0 can take it: while its writer thread is still busy with the
+            # previous one (a 2 M-voxel map is ~5 GB of file) the round is skipped by everybody -- the build is never throttled
+            # to the disk's speed, checkpoints simply come as often as the disk allows
+            import torch
+            prev = getattr(self, "_save_thread", None)
+            busy = torch.tensor([1 if (rank == 0 and prev is not None and prev.is_alive()) else 0], dtype=torch.int64,
+                                device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(busy, op=dist.ReduceOp.MAX)
+            if int(busy.item()):
+                self.checkpoints_skipped = getattr(self, "checkpoints_skipped", 0) + 1
+                return
         self.merge_timings = {}
         if self.merge_mode == "reduce":
             fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=self.exact_rgb, timings=self.merge_timings)
