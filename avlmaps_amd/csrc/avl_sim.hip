@@ -147,10 +147,12 @@ constexpr int kSplitThreads = 512;
 // computed.  Same-box A/B at 2 M x 512 x 64 (profiles/r03_ab_ring_depth.txt): raw float32 map 0.7100 (2) / 0.7053 (3) / 0.878 ms
 // (4: spills); prepared 0.7006 / 0.7221 / 0.7187; compact 0.6083 / 0.6121 / 0.6108 -- so the raw kernel takes 3 since the epilogue
 // rewrite of round 3 freed the registers (251 VGPRs), the others and the extra-row variant (spills at 3) stay at 2.
+// The column-block variant (QM: 2 KB sub-rows of a wider row) is better off at 2 as well: config 5's visual block 720 us at 2,
+// 746 us at 3 on a box whose dense kernel was 2.6 % FASTER than the first one's (profiles/r03_config5_kernel_stats.csv history).
 #ifdef AVL_RING
-template <bool PRE, bool XR> struct RingDepth { static constexpr int value = AVL_RING; };
+template <bool PRE, bool XR, bool QM> struct RingDepth { static constexpr int value = AVL_RING; };
 #else
-template <bool PRE, bool XR> struct RingDepth { static constexpr int value = (!PRE && !XR) ? 3 : 2; };
+template <bool PRE, bool XR, bool QM> struct RingDepth { static constexpr int value = (!PRE && !XR && !QM) ? 3 : 2; };
 #endif
 constexpr int kTileRows = (kSplitThreads / 64) * 32;  // voxels per workgroup iteration
 
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             if constexpr (NSTEPS > 0) {
                 // compile-time trip count, ring of kRing register buffers: the loads of the next kRing - 1 steps are in flight
                 // while step s is computed, all waits are counted vmcnt (depth per variant: RingDepth)
-                constexpr int kRing = RingDepth<PRE, XR>::value;
+                constexpr int kRing = RingDepth<PRE, XR, QM>::value;
                 f32x4 ring[kRing][8];
 #pragma unroll
                 for (int r = 0; r + 1 < kRing; ++r)
