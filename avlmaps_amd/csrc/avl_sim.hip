@@ -147,8 +147,8 @@ constexpr int kSplitThreads = 512;
 // computed.  Same-box A/B at 2 M x 512 x 64 (profiles/r03_ab_ring_depth.txt): raw float32 map 0.7100 (2) / 0.7053 (3) / 0.878 ms
 // (4: spills); prepared 0.7006 / 0.7221 / 0.7187; compact 0.6083 / 0.6121 / 0.6108 -- so the raw kernel takes 3 since the epilogue
 // rewrite of round 3 freed the registers (251 VGPRs), the others and the extra-row variant (spills at 3) stay at 2.
-// The column-block variant (QM: 2 KB sub-rows of a wider row) is better off at 2 as well: config 5's visual block 720 us at 2,
-// 746 us at 3 on a box whose dense kernel was 2.6 % FASTER than the first one's (profiles/r03_config5_kernel_stats.csv history).
+// The column-block variant (QM: 2 KB sub-rows of a wider row) is better off at 2 as well: config 5 on the raw map 2.3362 ms at 2,
+// 2.3523 ms at 3 (same box, n = 3, profiles/r03_ab_config5_ring_tb.txt).
 #ifdef AVL_RING
 template <bool PRE, bool XR, bool QM> struct RingDepth { static constexpr int value = AVL_RING; };
 #else
