@@ -827,7 +827,7 @@ def pmc_lookup(which, shape):
     return out
 
 
-def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=300):
+def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=120):
     """HBM bytes per step of THIS run's kernels on THIS box: bench.py re-executes itself under `rocprofv3 --pmc FETCH_SIZE` and,
     in a second pass, `--pmc WRITE_SIZE` (counter-only runs, no tracing flags; the two do not fit one pass:
     /opt/skills/guides/MI355X_MICROARCH.md, rocprofv3 PMC slots) for a few profile-run steps of the same shape, and sums the

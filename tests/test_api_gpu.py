@@ -606,6 +606,21 @@ def test_multi_rank_checkpoints_and_resume(golden, tmp_path):
     assert np.array_equal(b[4][b[2][:, 0], b[2][:, 1], b[2][:, 2]], np.arange(len(b[2])))
 
 
+def test_checkpoint_rounds_with_uneven_shards_do_not_change_the_map(golden, tmp_path):
+    """3 ranks, 16 frames (shards of 6, 6 and 4), a checkpoint round every 3 local frames: the short shard joins the second
+    round at the end of its frames, the merges are non-destructive -- the final map is the map of the run without periodic
+    checkpoints, array for array"""
+    from avlmaps_amd.utils.mapping_utils import load_3d_map
+    GOLDEN_DIR = Path(__file__).resolve().parent / "golden"
+    plain, ck = tmp_path / "plain", tmp_path / "ck"
+    _run_ranks(3, [GOLDEN_DIR / "g2b_builder_growth.npz", plain, 16, "replay", 99], 29581)
+    _run_ranks(3, [GOLDEN_DIR / "g2b_builder_growth.npz", ck, 16, "replay", 99], 29582, AVL_TEST_SAVE_EVERY=3)
+    a, b = load_3d_map(plain / "vlmap" / "vlmaps.h5df"), load_3d_map(ck / "vlmap" / "vlmaps.h5df")
+    assert a[0] == b[0] == list(range(16))
+    for x, y in zip(a[1:6], b[1:6]):
+        assert np.array_equal(x, y)
+
+
 def test_sharded_build_feeds_the_sharded_index_without_an_upload(golden, tmp_path):
     """after a 2-rank build every rank's block of the merged map is already in its HBM (VLMapBuilder.map_shard): VLMap.load_map
     in the same process adopts it as the resident copy (no second upload) and index_map returns what float64 NumPy returns on
