@@ -5,8 +5,9 @@
 <scene>/ holds rgb/*.png, depth/*.npy (float32 metres) and poses.txt (x y z qx qy qz qw per line), the layout of the
 reference's dataset/README.md:76-93; the map goes to <scene>/vlmap/vlmaps.h5df (a real HDF5 file: through h5py, or through
 the HDF5 C library where h5py is missing).
-Multi-GPU: launch with torchrun; frames are sharded over ranks and merged with one sparse RCCL reduce; with --seed the N-rank
-map equals the single-process map (every rank replays the RNG draws of the frames before its shard)."""
+Multi-GPU: launch with torchrun; frames are sharded over ranks and merged with one row-sharded RCCL exchange (every --save-every
+frames per rank as a checkpoint, and at the end); an interrupted run is continued with --resume; with --seed the N-rank map
+equals the single-process map (every rank replays the RNG draws of the frames before its shard)."""
 from __future__ import annotations
 
 import argparse
@@ -34,6 +35,11 @@ def main(argv=None):
     ap.add_argument("--shard-sampling", choices=["replay", "independent"], default=None,
                     help="several ranks: replay = sample the pixels of the single-process run (default); independent = do not "
                          "fast-forward the RNG past the other ranks' frames (unseeded runs)")
+    ap.add_argument("--merge-mode", choices=["sharded", "reduce"], default=None,
+                    help="several ranks: sharded = all_to_all of every rank's own voxel rows (default); reduce = one dense sum-reduce")
+    ap.add_argument("--save-every", type=int, default=None, help="checkpoint every N frames (per rank); default 100 like upstream")
+    ap.add_argument("--resume", action="store_true",
+                    help="continue from an existing vlmaps.h5df and skip the frames it lists (upstream re-fuses every frame)")
     args = ap.parse_args(argv)
 
     from avlmaps_amd import parallel
@@ -45,7 +51,8 @@ def main(argv=None):
         np.random.seed(args.seed)
     extractor = HashFeatureExtractor(args.feat_dim) if args.features == "hash" else None
     avlmap = AVLMap(cfg, data_dir=args.data_dir)
-    if args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling or args.deferred_fuse or args.pixel_sampling:
+    if (args.capacity or args.prefetch is not None or args.batch_frames or args.shard_sampling or args.deferred_fuse or args.pixel_sampling
+            or args.merge_mode or args.save_every is not None or args.resume):
         import avlmaps_amd.map.vlmap_builder as vb
         orig = vb.VLMapBuilder.__init__
 
@@ -63,6 +70,12 @@ def main(argv=None):
                 self.deferred_fuse = True
             if args.pixel_sampling:
                 self.pixel_sampling = args.pixel_sampling
+            if args.merge_mode:
+                self.merge_mode = args.merge_mode
+            if args.save_every is not None:
+                self.save_every = args.save_every
+            if args.resume:
+                self.skip_mapped_frames = True
         vb.VLMapBuilder.__init__ = patched
     t0 = time.perf_counter()
     avlmap.create_map(args.data_dir, feat_extractor=extractor)
