@@ -72,13 +72,21 @@ extern "C" int avl_lseg_merge_windows(const void* d_win, int is_f16, int G, int 
         ws.h0[g] = h_origin[2 * g];
         ws.w0[g] = h_origin[2 * g + 1];
     }
-    // every output pixel must be covered by a window (the reference asserts count_norm != 0, lseg_utils.py:97)
-    for (int yy = 0; yy < height; yy += crop > 1 ? crop - 1 : 1)
-        for (int xx = 0; xx < width; xx += crop > 1 ? crop - 1 : 1) {
+    // every output pixel must be covered by a window (the reference asserts count_norm != 0, lseg_utils.py:97).  If the union of
+    // the windows leaves a hole in [0, height) x [0, width), the hole's top-left corner lies at y in {0, h0 + crop} and x in
+    // {0, w0 + crop}: testing those candidate points is exact
+    int ys[kMaxWindows + 1], xs[kMaxWindows + 1], ny = 1, nx = 1;
+    ys[0] = xs[0] = 0;
+    for (int g = 0; g < G; ++g) {
+        if (ws.h0[g] + crop > 0 && ws.h0[g] + crop < height) ys[ny++] = ws.h0[g] + crop;
+        if (ws.w0[g] + crop > 0 && ws.w0[g] + crop < width) xs[nx++] = ws.w0[g] + crop;
+    }
+    for (int a = 0; a < ny; ++a)
+        for (int b = 0; b < nx; ++b) {
             bool covered = false;
             for (int g = 0; g < G && !covered; ++g)
-                covered = yy >= ws.h0[g] && yy < ws.h0[g] + crop && xx >= ws.w0[g] && xx < ws.w0[g] + crop;
-            AVL_REQUIRE(covered, "avl_lseg_merge_windows: pixel (%d, %d) is covered by no window", yy, xx);
+                covered = ys[a] >= ws.h0[g] && ys[a] < ws.h0[g] + crop && xs[b] >= ws.w0[g] && xs[b] < ws.w0[g] + crop;
+            AVL_REQUIRE(covered, "avl_lseg_merge_windows: pixel (%d, %d) is covered by no window", ys[a], xs[b]);
         }
     const dim3 grid((unsigned)((width + 63) / 64), (unsigned)height, (unsigned)((D + 63) / 64));
     if (is_f16)

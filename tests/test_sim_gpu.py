@@ -526,3 +526,43 @@ def test_compact_prepared_map(ops, N, D, Q):
     # argmax-only call (what VLMap.index_map uses) gives the same indices
     _, am2, _ = ops.sim_scores(pm, q, want_scores=False)
     assert np.array_equal(am2.numpy(), am)
+
+
+def test_packed_mask_rows_add_and_window_merge_edge_cases(ops):
+    """the small round-3 entry points through the C ABI: avl_mask_bits_from_argmax (lengths around the 64-voxel word, NumPy's
+    little-endian bit order), avl_rows_add_f64 (empty call, out-of-range row -> AVL_ERR_INVALID, peer-ordered sums),
+    avl_lseg_merge_windows (a pixel no window covers is an error, as the reference's count_norm assertion lseg_utils.py:97)"""
+    import ctypes as C
+    import torch
+    from avlmaps_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(8)
+    for N in (1, 63, 64, 65, 1000, 4096 + 17):
+        am = rng.integers(0, 3, N).astype(np.int32)
+        assert np.array_equal(ops.mask_bool_from_argmax(torch.from_numpy(am).cuda(), 1), am == 1)
+    assert lib.avl_mask_bits_from_argmax(None, 0, 0, None, None) == 0
+    # rows add
+    dst = torch.zeros((5, 6), dtype=torch.float64, device="cuda")
+    src = torch.arange(18, dtype=torch.float64, device="cuda").reshape(3, 6)
+    rows = torch.tensor([12, 10, 14], dtype=torch.int64, device="cuda")
+    assert lib.avl_rows_add_f64(0, 6, None, 10, 5, None, 6, None, 6, None) == 0
+    for _ in range(2):
+        _lib.check(lib.avl_rows_add_f64(3, 6, rows.data_ptr(), 10, 5, src.data_ptr(), 6, dst.data_ptr(), 6, None))
+    want = torch.zeros_like(dst)
+    want[[2, 0, 4]] = 2 * src
+    assert torch.equal(dst, want)
+    bad = torch.tensor([9], dtype=torch.int64, device="cuda")
+    assert lib.avl_rows_add_f64(1, 6, bad.data_ptr(), 10, 5, src.data_ptr(), 6, dst.data_ptr(), 6, None) != 0
+    assert b"outside" in lib.avl_last_error()
+    # window merge: coverage is checked on the host before anything is launched
+    win = torch.ones((2, 4, 8, 8), device="cuda")
+    out = torch.empty((8, 20, 4), device="cuda")
+    origin = np.array([[0, 0], [0, 12]], np.int32)               # columns 8..11 are covered by no window
+    assert lib.avl_lseg_merge_windows(win.data_ptr(), 0, 2, 4, 8, origin.ctypes.data, 8, 20, out.data_ptr(), None) != 0
+    assert b"covered by no window" in lib.avl_last_error()
+    origin = np.array([[0, 0], [0, 6], [0, 12]], np.int32)
+    win = torch.arange(3, device="cuda", dtype=torch.float32).view(3, 1, 1, 1).expand(3, 4, 8, 8).contiguous()
+    _lib.check(lib.avl_lseg_merge_windows(win.data_ptr(), 0, 3, 4, 8, origin.ctypes.data, 8, 20, out.data_ptr(), None))
+    cols = out[0, :, 0].cpu().numpy()
+    assert np.array_equal(cols[:6], np.zeros(6)) and np.array_equal(cols[6:8], [0.5, 0.5]) and np.array_equal(cols[8:12], np.ones(4))
+    assert np.array_equal(cols[12:14], [1.5, 1.5]) and np.array_equal(cols[14:], 2 * np.ones(6))
