@@ -868,7 +868,33 @@ def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=120):
             names |= set(agg)
             launches = max(len(v) for v in agg.values())
     read_b, write_b = 2.0 * tot["FETCH_SIZE"], tot["WRITE_SIZE"]
-    return dict(traffic=read_b + write_b, traffic_source="in-run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command on this box",
+    # third pass: how busy the matrix pipe is (SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs against GRBM_GUI_ACTIVE, which
+    # counts per XCD: x 1024 / 8), for the step's dominant kernel; optional -- a failure leaves the committed figure in place
+    busy = None
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [rocprof, "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", td, "-o", "pmc", "--",
+                   sys.executable, str(ROOT / "bench.py"), "--profile-run", "--steps", "5", "--warmup", "1", "--settle-steps", "2", "--no-cpu",
+                   "--no-build-extra"] + argv_shape
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd="/tmp")
+            agg = defaultdict(lambda: defaultdict(list))
+            for f in Path(td).rglob("*counter_collection.csv"):
+                for row in csv.DictReader(open(f)):
+                    k = row.get("Kernel_Name") or row.get("Kernel Name") or ""
+                    if ("sim_split" in k or "sim_stream" in k) and "prepare_map" not in k:
+                        agg[k][row.get("Counter_Name")].append(float(row["Counter_Value"]))
+            if r.returncode == 0 and agg:
+                busy = {}
+                for k, c in agg.items():
+                    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+                        b = (sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])) / (
+                            1024.0 * (sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])) / 8.0)
+                        busy[pretty_kernel(k)] = b
+                busy = (list(busy.values())[0] if len(busy) == 1 else busy) or None
+    except Exception:
+        busy = None
+    extra_busy = dict(mfma_busy_frac=busy, mfma_busy_source="in-run: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE") if busy else {}
+    return dict(**extra_busy, traffic=read_b + write_b, traffic_source="in-run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of this command on this box",
                 traffic_read_bytes=read_b, traffic_write_bytes=write_b, traffic_launches_sampled=launches,
                 traffic_kernels=sorted(pretty_kernel(n) for n in names),
                 traffic_note="FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE KB x 1024, per step")
