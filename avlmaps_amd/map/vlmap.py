@@ -232,6 +232,19 @@ class VLMap(Map):
             sc = parallel.gather_rows(sc, n) if sc is not None else None
         return sc, am
 
+    def index_queries(self, queries, want_scores: bool = False):
+        """Row argmax (N,) int32 -- and, on request, scores (N, Q) float32 -- of the map against an explicit query matrix (Q, D):
+        the entry for query sets that do not come from the CLIP text tower.  On a fused visual | audio map (BASELINE config 5:
+        D = 512 + 1024, every query non-zero in one modality block) the non-zero column window of every query is detected and
+        each group of queries is scored against its own columns of the compact resident copy (ops.sim_scores ->
+        avl_sim_scores_blocks); same semantics as scores = grid_feat @ queries.T; np.argmax(scores, axis=1)
+        (clip_utils.py:227-229, vlmap.py:123)."""
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or self.grid_feat is None or q.shape[1] != self.grid_feat.shape[1]:
+            raise ValueError(f"queries must be (Q, {None if self.grid_feat is None else self.grid_feat.shape[1]}), got {q.shape}")
+        sc, am = self._score(q, want_scores=want_scores)
+        return (am, sc) if want_scores else am
+
     def init_categories(self, categories: List[str]) -> np.ndarray:
         """scores_mat (N, Q) float32 cached on the instance.  Reference: vlmap.py:92-102."""
         self.categories = categories

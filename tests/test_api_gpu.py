@@ -373,6 +373,38 @@ def test_get_lseg_feat_protocol_on_the_gpu(golden):
         assert torch.equal(merge_windows(w, plan), want)
 
 
+def test_vlmap_indexes_a_fused_visual_audio_map_with_block_queries():
+    """BASELINE config 5 through the product: a VLMap whose grid_feat is 512 visual | 1024 audio columns keeps the compact
+    resident copy (3 bytes per element) and scores text / audio queries against their own column blocks
+    (VLMap.index_queries); results = NumPy's grid_feat @ q.T and its argmax (clip_utils.py:227-229, vlmap.py:123)"""
+    from test_host_mirror import Cfg
+    from avlmaps_amd.map.vlmap import VLMap
+    rng = np.random.default_rng(12)
+    N, D, Q = 5000, 1536, 128
+    feat = rng.standard_normal((N, D)).astype(np.float32)
+    feat *= (14.2857 * (0.05 + 0.95 * rng.random((N, 1)))) / np.linalg.norm(feat, axis=1, keepdims=True)
+    q = rng.standard_normal((Q, D)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0::2, 512:] = 0                      # text queries (interleaved with the audio ones)
+    q[1::2, :512] = 0
+    cfg = Cfg(map_type="vlmap", grid_size=1000, cell_size=0.05,
+              pose_info=Cfg(camera_height=1.5, base2cam_rot=[1, 0, 0, 0, -1, 0, 0, 0, -1], base_forward_axis=[0, 0, -1],
+                            base_left_axis=[-1, 0, 0], base_up_axis=[0, 1, 0]))
+    vm = VLMap(cfg)
+    vm.grid_feat = feat
+    am, sc = vm.index_queries(q, want_scores=True)
+    assert vm._dev_feat.compact and tuple(vm._dev_feat.feat.shape) == (N, 3 * D)
+    want = feat.astype(np.float64) @ q.astype(np.float64).T
+    assert sc.shape == (N, Q) and np.abs(sc - want).max() < 2e-5
+    assert np.array_equal(am, np.argmax(sc, axis=1))
+    top2 = np.sort(want, axis=1)[:, -2:]
+    clear = top2[:, 1] - top2[:, 0] > 1e-4
+    assert np.array_equal(am[clear], np.argmax(want, axis=1)[clear]) and clear.mean() > 0.9
+    assert np.array_equal(vm.index_queries(q), am)
+    with pytest.raises(ValueError):
+        vm.index_queries(q[:, :512])
+
+
 def test_lseg_adapter_with_a_stub_upstream_model(tmp_path, monkeypatch):
     """lseg_adapter.load_upstream_lseg end to end against a stand-in for the upstream package: same import path, constructor
     call and checkpoint format as vlmap_builder.py:226-264 (LSegEncNet("", arch_option=0, block_depth=0, activation="lrelu",
