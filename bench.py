@@ -842,6 +842,8 @@ def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=120):
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
     if rocprof is None or os.environ.get("AVL_BENCH_PMC_CHILD") == "1":
         return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ):
+        return None            # this process is itself being profiled: no nested counter passes
     env = dict(os.environ, AVL_BENCH_PMC_CHILD="1", TMPDIR="/tmp", PYTHONPATH=str(ROOT) + os.pathsep + os.environ.get("PYTHONPATH", ""))
     tot, names, launches = {}, set(), None
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
