@@ -678,9 +678,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         del fin
         torch.cuda.empty_cache()
         single_gpu_merge = {}
-        merge_ranks(parallel, acc, mode, exact_rgb)            # untimed: torch's sort kernels, RCCL's communicator (forced collectives)
-        torch.cuda.empty_cache()
-        merge_ranks(parallel, acc, mode, exact_rgb, timings=single_gpu_merge)
+        merge_ranks(parallel, acc, mode, exact_rgb)            # untimed: torch's sort kernels, RCCL's communicator (forced collectives),
+        merge_ranks(parallel, acc, mode, exact_rgb, timings=single_gpu_merge)      # and the allocator's first multi-GB blocks
         t_fin = time.perf_counter()
         acc.finalize(as_torch=True)
         torch.cuda.synchronize()
