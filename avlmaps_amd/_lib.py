@@ -48,6 +48,7 @@ _SIGS = {
     "avl_event_destroy": (C.c_int, [_vp]),
     "avl_event_record": (C.c_int, [_vp, _vp]),
     "avl_event_sync": (C.c_int, [_vp]),
+    "avl_stream_wait_event": (C.c_int, [_vp, _vp]),
     "avl_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "avl_sim_prepare_map": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp]),
     "avl_sim_prepare_map24": (C.c_int, [_vp, _i64, C.c_int, _i64, _vp, _vp, _vp]),
@@ -92,6 +93,9 @@ _SIGS = {
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),
     "avl_replay_state_apply": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_rows_add_f64": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "avl_builder_export_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
+    "avl_builder_export_rows_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "avl_finalize_side": (C.c_int, [_i64, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_pool_label_2d": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "avl_rgb_topdown": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "avl_obstacle_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
@@ -144,11 +148,15 @@ def set_device(device: int) -> None:
 
 
 def current_device(query_runtime: bool = True):
-    """the calling thread's current GPU: what set_device recorded, else torch's current device if torch has initialised the GPU,
-    else (query_runtime) what HIP reports -- which starts the runtime (~0.8 s the first time) -- else None"""
-    d = getattr(_tls, "device", None)
-    if d is not None:
-        return d
+    """the calling thread's current GPU.  Once this thread has called set_device the HIP runtime is running, so HIP itself is asked
+    (a torch.cuda.set_device or hipSetDevice made elsewhere in between is then seen: the remembered value alone went stale, ADVICE
+    r3); before that: torch's current device if torch has initialised the GPU, else (query_runtime) what HIP reports -- which
+    starts the runtime (~0.8 s the first time) -- else None"""
+    if getattr(_tls, "device", None) is not None:
+        n = C.c_int(0)
+        if load().avl_get_device(C.byref(n)) == AVL_OK:
+            _tls.device = n.value
+        return _tls.device
     t = sys.modules.get("torch")
     try:
         if t is not None and t.cuda.is_initialized():

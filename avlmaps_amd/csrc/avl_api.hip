@@ -419,6 +419,12 @@ int avl_event_sync(void* event) {
     return AVL_OK;
 }
 
+int avl_stream_wait_event(void* stream, void* event) {
+    AVL_REQUIRE(event, "avl_stream_wait_event: null event");
+    AVL_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return AVL_OK;
+}
+
 int avl_event_elapsed_ms(void* start, void* stop, float* h_ms) {
     AVL_REQUIRE(h_ms, "avl_event_elapsed_ms: null output");
     AVL_HIP_CHECK(hipEventElapsedTime(h_ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));

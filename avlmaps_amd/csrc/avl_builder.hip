@@ -648,6 +648,77 @@ __global__ __launch_bounds__(256) void scatter_merge_kernel(int64_t n, int D, co
     }
 }
 
+// Row-sharded merge with the mixed payload (avlmaps_amd/parallel.py, round 4).  A voxel that only ONE rank ever touched needs no
+// float64 exchange: its finished float32 feature row (sum - a1 (1 - a1) f1) / sum alpha is computed where the accumulators live --
+// the same float64 expression finalize_kernel evaluates, so the row is bit-identical to the single-process map -- and travels as
+// 4 B per element.  Only voxels that several ranks touched ship float64 partial sums (own != 0: this rank holds the global first
+// touch and folds the reference's first-touch term in).  Wave per listed slot; output row i belongs to slot slots[i].
+__global__ __launch_bounds__(256) void export_rows_f32_kernel(int64_t k, int D, const int32_t* __restrict__ slots,
+                                                              const double* __restrict__ sum_feat, const double* __restrict__ sum_w4,
+                                                              const float* __restrict__ first_feat, const double* __restrict__ first_alpha,
+                                                              float* __restrict__ out, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < k; i += nwaves) {
+        const int64_t sl = slots[i];
+        const double w = sum_w4[sl * 4];
+        const double a1 = first_alpha[sl];
+        const double corr = a1 * (1.0 - a1);
+        const double* s = sum_feat + sl * D;
+        const float* f1 = first_feat + sl * D;
+        float* o = out + i * ld;
+        for (int c = lane; c < D; c += 64) o[c] = (float)((s[c] - corr * (double)f1[c]) / w);
+    }
+}
+
+__global__ __launch_bounds__(256) void export_rows_f64_kernel(int64_t k, int D, const int32_t* __restrict__ slots,
+                                                              const uint8_t* __restrict__ own, const double* __restrict__ sum_feat,
+                                                              const float* __restrict__ first_feat, const double* __restrict__ first_alpha,
+                                                              double* __restrict__ out, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < k; i += nwaves) {
+        const int64_t sl = slots[i];
+        const double a1 = first_alpha[sl];
+        const double corr = a1 * (1.0 - a1);
+        const double* s = sum_feat + sl * D;
+        const float* f1 = first_feat + sl * D;
+        double* o = out + i * ld;
+        if (own[i] && corr != 0.0) {
+            for (int c = lane; c < D; c += 64) o[c] = s[c] - corr * (double)f1[c];
+        } else {
+            for (int c = lane; c < D; c += 64) o[c] = s[c];
+        }
+    }
+}
+
+// grid_pos / weight / grid_rgb / occupied_ids of n merged rows from their cells and [sum alpha, sum alpha rgb] quadruples alone
+// (the feature rows of the mixed payload are finished elsewhere); same arithmetic as finalize_kernel's lane-0 part
+__global__ __launch_bounds__(256) void finalize_side_kernel(int64_t n, int gs, int vh, int64_t row0, const int32_t* __restrict__ cell,
+                                                            const double* __restrict__ w4, int32_t* __restrict__ grid_pos,
+                                                            float* __restrict__ weight, uint8_t* __restrict__ grid_rgb,
+                                                            int32_t* __restrict__ occupied) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t cl = cell[r];
+        const double w = w4[r * 4];
+        if (grid_pos) {
+            grid_pos[r * 3 + 0] = cl / (gs * vh);
+            grid_pos[r * 3 + 1] = (cl / vh) % gs;
+            grid_pos[r * 3 + 2] = cl % vh;
+        }
+        if (weight) weight[r] = (float)w;
+        if (occupied) occupied[cl] = (int32_t)(row0 + r);
+        if (grid_rgb)
+            for (int k = 0; k < 3; ++k) {
+                double m = w4[r * 4 + 1 + k] / w;
+                m = fmin(fmax(m, 0.0), 255.0);
+                grid_rgb[r * 3 + k] = (uint8_t)m;
+            }
+    }
+}
+
 // first / one-past-last position of every slot's run in the slot-sorted log
 __global__ void log_segments_kernel(const uint32_t* __restrict__ sorted_slot, long long L, long long nslots,
                                     long long* __restrict__ seg_start, long long* __restrict__ seg_end) {
@@ -728,8 +799,9 @@ __global__ __launch_bounds__(256) void replay_chain_kernel(int64_t n, unsigned l
                                                            const long long* __restrict__ seg_end, ReplayLog log,
                                                            ReplayState* __restrict__ state) {
     for (int64_t sl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; sl < n; sl += (int64_t)gridDim.x * blockDim.x) {
-        if (seg_start[sl] >= seg_end[sl]) continue;
-        ReplayState& st = state[row_of_slot[sl]];
+        const int64_t si = row_of_slot[sl];
+        if (si < 0 || seg_start[sl] >= seg_end[sl]) continue;          // negative index: slot not part of this call
+        ReplayState& st = state[si];
         double w = st.w, c[3] = {(double)st.c[0], (double)st.c[1], (double)st.c[2]};
         bool started = st.started != 0;
         for (long long i = seg_start[sl]; i < seg_end[sl]; ++i) {
@@ -834,6 +906,7 @@ __global__ __launch_bounds__(256) void bbox_kernel(FrameParams fp, const float* 
 
 using namespace avl;
 
+struct LogSegments;
 struct avl_builder {
     int n0, gs, vh, D;   // grid n0 x gs x vh (n0 == gs for the square mobile-base map)
     double cs;
@@ -868,6 +941,11 @@ struct avl_builder {
     int table_cap = 0;
     int64_t vox_bound = 0;       // host-side upper bound on the voxel counter (every fused sample may create one voxel)
     int64_t max_capacity = 0;    // 0: the capacity is fixed; else the accumulators double up to this many voxels
+    // the slot-sorted replay log of the last avl_builder_replay_chain call: the round-4 merge calls it twice per merge (voxels that
+    // depend on no other rank, then the ones whose predecessor's state had to arrive first) and sorts the log once
+    LogSegments* ls_cache = nullptr;
+    long long ls_log_used = -1;
+    int64_t ls_n = -1;
 };
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
@@ -1029,6 +1107,15 @@ struct LogSegments {
     }
 };
 
+static void drop_log_segments(avl_builder* b, hipStream_t st) {
+    if (!b->ls_cache) return;
+    b->ls_cache->release(st);
+    delete b->ls_cache;
+    b->ls_cache = nullptr;
+    b->ls_log_used = -1;
+    b->ls_n = -1;
+}
+
 // K3 over one launch's records (CH = 256-float register chunks of a feature row)
 static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, const BatchEntry* batch, int P_frame, const Recs& recs,
                        int32_t* head, const float* d_feat, hipStream_t st) {
@@ -1087,11 +1174,13 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     b->key_bias = 0;
     b->log_used = 0;
     b->vox_bound = 0;
+    drop_log_segments(b, st);
     return AVL_OK;
 }
 
 int avl_builder_destroy(avl_builder* b) {
     if (!b) return AVL_OK;
+    drop_log_segments(b, nullptr);
     (void)hipFree(b->cell_slot); (void)hipFree(b->slot_cell); (void)hipFree(b->slot_key); (void)hipFree(b->sum_feat);
     (void)hipFree(b->sum_w4); (void)hipFree(b->first_feat); (void)hipFree(b->first_alpha); (void)hipFree(b->head);
     (void)hipFree(b->head_alt);
@@ -1266,6 +1355,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     fp.capacity = b->capacity;
     const unsigned long long frame_key = b->key_bias | ((unsigned long long)frame_idx << 32);
 
+    if (b->ls_cache) drop_log_segments(b, st);   // the sorted log of the last merge is stale from here on
     if (b->log.slot && b->log_used + P > b->log_cap) {
         set_error("replay log full (%lld samples): enable it with a larger max_samples", b->log_cap);
         return AVL_ERR_CAPACITY;
@@ -1418,6 +1508,51 @@ int avl_builder_scatter_merge(avl_builder* b, int64_t n, const int64_t* d_row_of
     return AVL_OK;
 }
 
+static int check_slot_list(avl_builder* b, int64_t k, const void* slots, const void* out, int64_t ld, const char* who, void* stream) {
+    AVL_REQUIRE(b, "%s: null handle", who);
+    AVL_REQUIRE(k >= 0 && ld >= b->D, "%s: bad shape", who);
+    int64_t have = 0;
+    int rc = avl_builder_num_voxels(b, &have, stream);
+    if (rc != AVL_OK) return rc;
+    AVL_REQUIRE(k <= have, "%s: %lld slots listed but the map holds %lld voxels", who, (long long)k, (long long)have);
+    AVL_REQUIRE(k == 0 || (slots && out), "%s: null pointer", who);
+    return AVL_OK;
+}
+
+int avl_builder_export_rows_f32(avl_builder* b, int64_t k, const int32_t* d_slots, float* d_out, int64_t ld, void* stream) {
+    int rc = check_slot_list(b, k, d_slots, d_out, ld, "avl_builder_export_rows_f32", stream);
+    if (rc != AVL_OK || k == 0) return rc;
+    const int64_t blocks = std::min<int64_t>((k + 3) / 4, (int64_t)num_cus() * 16);
+    hipLaunchKernelGGL(export_rows_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), k, b->D, d_slots, b->sum_feat,
+                       b->sum_w4, b->first_feat, b->first_alpha, d_out, ld);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_builder_export_rows_f64(avl_builder* b, int64_t k, const int32_t* d_slots, const uint8_t* d_own, double* d_out, int64_t ld,
+                                void* stream) {
+    int rc = check_slot_list(b, k, d_slots, d_out, ld, "avl_builder_export_rows_f64", stream);
+    if (rc != AVL_OK || k == 0) return rc;
+    AVL_REQUIRE(d_own, "avl_builder_export_rows_f64: null ownership flags");
+    const int64_t blocks = std::min<int64_t>((k + 3) / 4, (int64_t)num_cus() * 16);
+    hipLaunchKernelGGL(export_rows_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), k, b->D, d_slots, d_own, b->sum_feat,
+                       b->first_feat, b->first_alpha, d_out, ld);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_finalize_side(int64_t n, int64_t row0, int gs, int vh, const int32_t* d_cell, const double* d_w4, int32_t* d_grid_pos,
+                      float* d_weight, uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream) {
+    AVL_REQUIRE(n >= 0 && row0 >= 0 && gs > 0 && vh > 0, "avl_finalize_side: bad shape");
+    AVL_REQUIRE(row0 + n < (1ll << 31), "avl_finalize_side: voxel ids must fit int32");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_cell && d_w4, "avl_finalize_side: null input");
+    hipLaunchKernelGGL(finalize_side_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, as_stream(stream), n, gs,
+                       vh, row0, d_cell, d_w4, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids);
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
 int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
                          uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream) {
     return avl_builder_finalize_ex(b, n, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, nullptr, 0, stream);
@@ -1489,15 +1624,22 @@ int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_
     }
     if (n == 0 || b->log_used == 0) return AVL_OK;
     AVL_REQUIRE(d_row_of_slot && d_state, "avl_builder_replay_chain: null pointer");
-    LogSegments ls;
-    rc = ls.build(b, n, st);
-    if (rc == AVL_OK) {
-        hipLaunchKernelGGL(replay_chain_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
-                           (unsigned long long)grow_key, d_row_of_slot, ls.order, ls.seg_start, ls.seg_end, b->log,
-                           reinterpret_cast<ReplayState*>(d_state));
-        if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
+    if (!b->ls_cache || b->ls_log_used != b->log_used || b->ls_n != n) {
+        drop_log_segments(b, st);
+        b->ls_cache = new LogSegments();
+        rc = b->ls_cache->build(b, n, st);
+        if (rc != AVL_OK) {
+            drop_log_segments(b, st);
+            return rc;
+        }
+        b->ls_log_used = b->log_used;
+        b->ls_n = n;
     }
-    ls.release(st);
+    const LogSegments& ls = *b->ls_cache;
+    hipLaunchKernelGGL(replay_chain_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
+                       (unsigned long long)grow_key, d_row_of_slot, ls.order, ls.seg_start, ls.seg_end, b->log,
+                       reinterpret_cast<ReplayState*>(d_state));
+    if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
     return rc;
 }
 

@@ -783,10 +783,12 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                     // term-major, tile-minor issue order: consecutive MFMAs target different accumulators
 #pragma unroll
                     for (int t = 0; t < QT; ++t) acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][0], 0, 0, 0);
+#ifndef AVL_ABL_HIONLY   // ablation for the argmax-only question: what ONE product per pair would cost
 #pragma unroll
                     for (int t = 0; t < QT; ++t) acc[t][X1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][X1], 0, 0, 0);
 #pragma unroll
                     for (int t = 0; t < QT; ++t) acc[t][X2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][X2], 0, 0, 0);
+#endif
 #endif
                     if constexpr (XR) {
                         using half4 = __attribute__((ext_vector_type(4))) _Float16;

@@ -278,14 +278,26 @@ class VLMapBuilder:
         lo, hi = parallel.shard_frames(n_frames, rank, ws)
 
         vh = int(camera_height / cs)                 # vlmap_builder.py:201
-        acc = None
-        mapped_iter_set = set()
-        pending = []
         if self.shard_sampling not in ("replay", "independent"):
             raise ValueError(f"shard_sampling must be 'replay' or 'independent', not {self.shard_sampling!r}")
         skip = lo if (ws > 1 and self.shard_sampling == "replay") else 0
         # checkpoint rounds of a multi-rank build: as many as the longest shard has full save_every blocks (known to every rank)
         rounds_total = ((n_frames + ws - 1) // ws) // self.save_every if (ws > 1 and self.save_every) else 0
+        try:
+            self._build_loop(lo, hi, depth_sample_rate, skip, rank, ws, gs, cs, vh, calib_mat, calib_inv, transforms, rounds_total)
+        except _RanksAborted:
+            raise
+        except BaseException as e:
+            # several ranks: the others are (or will be) waiting in the next checkpoint / merge collective -- tell them, so that
+            # every rank fails now instead of hanging until the RCCL timeout
+            if ws > 1:
+                self._announce_failure(rank, e)
+            raise
+
+    def _build_loop(self, lo, hi, depth_sample_rate, skip, rank, ws, gs, cs, vh, calib_mat, calib_inv, transforms, rounds_total):
+        acc = None
+        mapped_iter_set = set()
+        pending = []
         rounds_done = 0
         for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip):
             if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
@@ -368,12 +380,16 @@ class VLMapBuilder:
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _agree_on_width(D: int) -> int:
-        """feature width over the ranks (a rank without frames passes 0): one tiny MAX all-reduce at the first frame"""
+        """feature width over the ranks (a rank without frames passes 0): one tiny MAX all-reduce at the first frame -- of the same
+        [value, failure flag] shape as the status all-reduce of the checkpoint rounds, so that a rank that failed before its first
+        frame (_announce_failure) is understood here too"""
         import torch
         import torch.distributed as dist
-        d = torch.tensor([int(D)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        d = torch.tensor([int(D), 0], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(d, op=dist.ReduceOp.MAX)
-        return int(d.item())
+        if int(d[1].item()):
+            raise _RanksAborted("multi-rank build aborted: another rank reported a failure (see its traceback)")
+        return int(d[0].item())
 
     def _resume(self, acc, ws, rank=0):
         """Continue from an existing map file.  Reference: vlmap_builder.py:212-222 (note: upstream restores
@@ -382,20 +398,53 @@ class VLMapBuilder:
         one (same first-touch key space), every rank learns mapped_iter_list; the merge then keeps the file's voxel ids.
         A file whose last in-place checkpoint was interrupted (MapFileWriter.MARKER) keeps its rows but its frame list is
         not trusted: every frame is fused again, as upstream does anyway."""
-        if not map_file_exists(self.map_save_path):
-            return set()
-        if ws > 1 and rank != 0:
-            iters = read_map_dataset(self.map_save_path, "mapped_iter_list")
-            acc.mark_resumed()
-            mapped = set(np.asarray(iters).tolist()) if iters is not None else set()
+        if ws > 1:
+            # rank 0's view of the file decides for everybody (a node-local disk may show the file to some ranks only: a rank that
+            # neither imports the map nor marks its accumulator as continuing one would hand out first-touch keys that sort BEFORE
+            # the imported voxels and the file's voxel ids would be lost; ADVICE r3)
+            import torch.distributed as dist
+            info = [None]
+            if rank == 0:
+                exists = bool(map_file_exists(self.map_save_path))
+                iters = read_map_dataset(self.map_save_path, "mapped_iter_list") if exists else None
+                info = [(exists, [] if iters is None else np.asarray(iters).tolist(),
+                         bool(map_checkpoint_complete(self.map_save_path)) if exists else True)]
+            dist.broadcast_object_list(info, src=0)
+            exists, iters, complete = info[0]
+            if not exists:
+                return set()
+            if rank == 0:
+                print(f"[avlmaps_amd] {self.map_save_path} exists: continuing that map ({len(iters)} frames fused so far) on {ws} ranks, "
+                      "like upstream's single-process builder does (vlmap_builder.py:212-222); delete the file to start over, set "
+                      "skip_mapped_frames to skip the frames it lists", flush=True)
+                _, grid_feat, grid_pos, weight, _occ, grid_rgb = load_3d_map(self.map_save_path)[:6]
+                acc.import_map(grid_feat, grid_pos, weight, grid_rgb)
+            else:
+                acc.mark_resumed()
+            mapped = set(iters)
         else:
+            if not map_file_exists(self.map_save_path):
+                return set()
             mapped_iter_list, grid_feat, grid_pos, weight, _occ, grid_rgb = load_3d_map(self.map_save_path)[:6]
             acc.import_map(grid_feat, grid_pos, weight, grid_rgb)
             mapped = set(mapped_iter_list)
-        if not map_checkpoint_complete(self.map_save_path):
+            complete = map_checkpoint_complete(self.map_save_path)
+        if not complete:
             print(f"[avlmaps_amd] {self.map_save_path}: the last checkpoint was interrupted; keeping its voxels, re-fusing every frame")
             self.skip_mapped_frames = False
         return mapped
+
+    def _announce_failure(self, rank, exc) -> None:
+        """a rank that failed locally joins the collective the others will reach next -- the status all-reduce that opens every
+        checkpoint round -- with its error flag set; they raise _RanksAborted there"""
+        try:
+            import torch
+            import torch.distributed as dist
+            print(f"[avlmaps_amd] rank {rank}: {type(exc).__name__}: {exc} -- telling the other ranks", flush=True)
+            flags = torch.tensor([0, 1], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        except BaseException:      # the process group itself is gone: nothing more to do
+            pass
 
     def _finish(self, acc, mapped_iter_set, rank, ws, gs, vh):
         if ws == 1:
@@ -410,19 +459,24 @@ class VLMapBuilder:
         """One merge of the ranks' accumulators (a collective) + the map file written by rank 0.  Non-destructive: frames keep
         streaming into the same accumulators afterwards.  The file is written by a host thread (device-to-host copy included)
         unless `final`."""
+        import torch
         import torch.distributed as dist
-        if not final:
-            # a periodic checkpoint is only worth a merge if rank 0 can take it: while its writer thread is still busy with the
-            # previous one (a 2 M-voxel map is ~5 GB of file) the round is skipped by everybody -- the build is never throttled
-            # to the disk's speed, checkpoints simply come as often as the disk allows
-            import torch
-            prev = getattr(self, "_save_thread", None)
-            busy = torch.tensor([1 if (rank == 0 and prev is not None and prev.is_alive()) else 0], dtype=torch.int64,
-                                device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(busy, op=dist.ReduceOp.MAX)
-            if int(busy.item()):
-                self.checkpoints_skipped = getattr(self, "checkpoints_skipped", 0) + 1
-                return
+        # ONE tiny MAX all-reduce opens every round: [rank 0's writer still busy, some rank failed].  A periodic checkpoint is
+        # only worth a merge if rank 0 can take it: while its writer thread is still busy with the previous one (a 2 M-voxel map
+        # is ~5 GB of file) the round is skipped by everybody -- the build is never throttled to the disk's speed.  A failure
+        # anywhere (a frame that could not be read, the writer thread's exception on rank 0) makes EVERY rank raise here.
+        prev = getattr(self, "_save_thread", None)
+        err = 1 if (rank == 0 and getattr(self, "_save_error", None) is not None and (prev is None or not prev.is_alive())) else 0
+        flags = torch.tensor([1 if (not final and rank == 0 and prev is not None and prev.is_alive()) else 0, err], dtype=torch.int64,
+                             device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        if int(flags[1].item()):
+            if err:
+                self._join_save()                         # raises the writer thread's exception on rank 0
+            raise _RanksAborted("multi-rank build aborted: another rank reported a failure (see its traceback)")
+        if int(flags[0].item()):
+            self.checkpoints_skipped = getattr(self, "checkpoints_skipped", 0) + 1
+            return
         self.merge_timings = {}
         if self.merge_mode == "reduce":
             fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=self.exact_rgb, timings=self.merge_timings)
@@ -520,6 +574,10 @@ class VLMapBuilder:
             self._save_thread.start()
         else:
             write()
+
+
+class _RanksAborted(RuntimeError):
+    """raised on every rank of a multi-rank build when one of them reported a failure"""
 
 
 def _dist_rank_ws():

@@ -80,61 +80,159 @@ def _dist_on(group=None) -> bool:
     return dist.get_world_size(group) > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1"
 
 
+class _SharedGpuLock:
+    """Rehearsals that put several ranks on ONE GPU (AVLMAPS_SHARED_GPU_LOCK=<file>): a rank holds this cross-process lock
+    whenever it computes inside a merge and drops it while it sits in a collective, so the ranks take turns on the device.
+
+    Why: torch's large sorts / scans / selects are rocPRIM kernels whose workgroups spin on each other's look-back flags.  Eight
+    processes launching them on one GPU at the same moment fill the CUs with spinning workgroups of different processes while
+    the workgroups they wait for are not resident; progress then comes only from the scheduler's time slices -- 4 to 160 s
+    inside a single torch.argsort of 1.25 M elements, on every rank at once (profiles/r04_shared_gpu_stall.txt), against
+    < 1 ms alone.  One process per GPU -- the real launch -- cannot see this.  With the lock a rank's compute time is also what
+    it would be on a GPU of its own; the time spent waiting for the lock is reported separately (shared_gpu_wait_s)."""
+    _inst = None
+
+    def __init__(self):
+        self.path = os.environ.get("AVLMAPS_SHARED_GPU_LOCK")
+        self.fd, self.held, self.wait_s = None, False, 0.0
+        if self.path:
+            self.fd = os.open(self.path, os.O_CREAT | os.O_RDWR, 0o666)
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def acquire(self):
+        if self.fd is None or self.held:
+            return
+        import fcntl
+        import time
+        t0 = time.perf_counter()
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        self.wait_s += time.perf_counter() - t0
+        self.held = True
+
+    def release(self, device_sync=True):
+        if self.fd is None or not self.held:
+            return
+        import fcntl
+        if device_sync:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.synchronize()
+            except Exception:
+                pass
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        self.held = False
+
+
 class _Coll:
     """the handful of collectives the merge uses; with the gloo backend (tests: several ranks on one GPU, or CPU tensors)
-    device tensors are staged through the host, with nccl (= RCCL) they go as they are"""
+    device tensors are staged through the host, with nccl (= RCCL) they go as they are.  Every call is bracketed by device
+    synchronisations and adds its wall time to `comm_s` and its payload to `bytes_out`: merge_breakdown separates the time a
+    rank spends INSIDE collectives (transfer + waiting for the peers) from its own compute."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.ws, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.stage = dist.get_backend(group) == "gloo"
+        self.comm_s, self.bytes_out, self.calls = 0.0, 0, 0
+        self.gpu_lock = _SharedGpuLock.get()
+        self._relock = False
 
     def _h(self, t):
         return t.cpu() if (self.stage and t.is_cuda) else t
 
+    def _tic(self, t):
+        import time
+        if t.is_cuda:
+            import torch
+            torch.cuda.synchronize()
+        self._relock = self.gpu_lock.held
+        self.gpu_lock.release(device_sync=False)          # a rank waiting for its peers does not keep the shared GPU
+        return time.perf_counter()
+
+    def _toc(self, t, t0, nbytes):
+        import time
+        if t.is_cuda:
+            import torch
+            torch.cuda.synchronize()
+        self.comm_s += time.perf_counter() - t0
+        self.bytes_out += int(nbytes)
+        self.calls += 1
+        if self._relock:
+            self.gpu_lock.acquire()
+
     def all_gather(self, t):
+        t0 = self._tic(t)
         h = self._h(t)
         out = [h.new_empty(h.shape) for _ in range(self.ws)]
         self.dist.all_gather(out, h, group=self.group)
-        return [o.to(t.device) for o in out]
+        res = [o.to(t.device) for o in out]
+        del out, h                              # host staging (gloo rehearsals) is released inside the timed bracket
+        self._toc(t, t0, t.numel() * t.element_size() * (self.ws - 1))
+        return res
 
     def all_reduce(self, t, op):
+        t0 = self._tic(t)
         h = self._h(t)
         self.dist.all_reduce(h, op=op, group=self.group)
         if h is not t:
             t.copy_(h)
+        del h
+        self._toc(t, t0, t.numel() * t.element_size())
         return t
 
     def reduce(self, t, dst, op):
+        t0 = self._tic(t)
         h = self._h(t)
         self.dist.reduce(h, dst=dst, op=op, group=self.group)
         if h is not t and self.rank == dst:
             t.copy_(h)
+        del h
+        self._toc(t, t0, 0 if self.rank == dst else t.numel() * t.element_size())
         return t
 
     def broadcast(self, t, src):
+        t0 = self._tic(t)
         h = self._h(t)
         self.dist.broadcast(h, src=src, group=self.group)
         if h is not t:
             t.copy_(h)
+        del h
+        self._toc(t, t0, t.numel() * t.element_size() if self.rank == src else 0)
         return t
 
     def all_to_all(self, inp, in_splits, out_splits):
         """all_to_all_single along dim 0 with split sizes (rows); returns the received tensor (sum(out_splits), ...)"""
+        t0 = self._tic(inp)
         h = self._h(inp).contiguous()
         out = h.new_empty((int(sum(out_splits)),) + tuple(h.shape[1:]))
         self.dist.all_to_all_single(out, h, [int(x) for x in out_splits], [int(x) for x in in_splits], group=self.group)
-        return out.to(inp.device)
+        res = out.to(inp.device)
+        del out, h                              # gloo rehearsals: GBs of pageable staging are unmapped here, not on the rank's compute clock
+        row_b = inp.element_size() * (int(inp.numel() // inp.shape[0]) if inp.shape[0] else 0)
+        self._toc(inp, t0, row_b * sum(int(c) for r, c in enumerate(in_splits) if r != self.rank))
+        return res
 
     def send(self, t, dst):
-        self.dist.send(self._h(t).contiguous(), dst=dst, group=self.group)
+        t0 = self._tic(t)
+        h = self._h(t).contiguous()
+        self.dist.send(h, dst=dst, group=self.group)
+        del h
+        self._toc(t, t0, t.numel() * t.element_size())
 
     def recv(self, t, src):
+        t0 = self._tic(t)
         h = self._h(t)
         self.dist.recv(h, src=src, group=self.group)
         if h is not t:
             t.copy_(h)
+        self._toc(t, t0, 0)
         return t
 
 
@@ -235,8 +333,8 @@ class ShardExchange:
         self.send_counts, self.recv_counts = self.send_counts.cpu().tolist(), self.recv_counts.cpu().tolist()
 
 
-def merge_raw_sharded(raw: Dict[str, "torch.Tensor"], group=None):
-    """Row-sharded merge of per-rank raw accumulators given as torch tensors (the arithmetic of merge_accumulator_sharded on
+def _merge_raw_sharded_general(raw: Dict[str, "torch.Tensor"], group=None):
+    """(general plan: every rank sorts all M voxels) Row-sharded merge of per-rank raw accumulators given as torch tensors (the arithmetic of merge_accumulator_sharded on
     exported tensors: CPU + gloo in the tests, the cross-check of the device path on the GPU).  Returns on EVERY rank
     dict(M, rows=(r0, r1), cell (M,) int32, first_key (M,) int64, acc (r1 - r0, D + 4) float64 = this rank's block of final
     rows with the first-touch term folded in, bytes_sent)."""
@@ -273,8 +371,10 @@ def occupied_ids_from_cells(cell, n0: int, gs: int, vh: int):
     return occ.view(n0, gs, vh)
 
 
-def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: Optional[dict] = None, gather_to: Optional[int] = None):
-    """The product path of the multi-GPU build, row-sharded: merge the ranks' VoxelAccumulators with ONE sparse exchange and
+def _merge_accumulator_sharded_general(acc, group=None, exact_rgb: bool = True, timings: Optional[dict] = None, gather_to: Optional[int] = None):
+    """(general plan, round 3: every rank sorts all M voxels and the colour replay is a dense chain over all ranks -- kept as the
+    fall-back for first-touch keys that are not rank-monotone and as the A/B baseline, AVLMAPS_MERGE_PLAN=general)
+    The product path of the multi-GPU build, row-sharded: merge the ranks' VoxelAccumulators with ONE sparse exchange and
     finalise every rank's block of final rows where it lives.
 
     Everything per-voxel runs in the HIP library on the builder's own device arrays (avl_builder_scatter_merge into the send
@@ -386,7 +486,7 @@ def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: 
     if timings is not None:
         sent_rows = sum(c for r, c in enumerate(ex.send_counts) if r != plan.rank)
         plan_bytes = (4 * n + 8 * M + 8 * plan.ws) if plan.coll is not None else 0
-        timings.update(mode="row-sharded all_to_all", plan_s=t1 - t0, scatter_s=t2 - t1, exchange_s=t3 - t2, accumulate_s=t4 - t3,
+        timings.update(mode="row-sharded all_to_all", plan="general (every rank sorts all M voxels; dense replay chain)", plan_s=t1 - t0, scatter_s=t2 - t1, exchange_s=t3 - t2, accumulate_s=t4 - t3,
                        replay_chain_s=t5 - t4, finalize_s=t6 - t5, gather_s=t7 - t6, merged_voxels=M, local_voxels=n, own_rows=n_own,
                        rows_sent=sent_rows, payload_bytes_sent=sent_rows * (W * 8 + 8), plan_bytes_sent=plan_bytes,
                        chain_bytes_sent=chain_bytes, gather_bytes_sent=gather_bytes,
@@ -396,11 +496,599 @@ def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: 
     return out
 
 
-def gather_row_shards(shard: dict, dst: int, coll, rank: int, ws: int):
+# --------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the DIRECTORY plan.  Nothing a rank computes or holds is O(M): its critical path shrinks with the rank count.
+# --------------------------------------------------------------------------------------------------------------------------------
+U64_ALL_ONES = (1 << 64) - 1
+
+
+def _dir_owner(cell64, ws: int):
+    """directory rank of a linear cell: a multiplicative hash, so a map that occupies one corner of the grid still spreads evenly"""
+    return (((cell64 * 2654435761) & 0xFFFFFFFF) >> 12) % ws
+
+
+class _Trace:
+    """AVLMAPS_MERGE_TRACE=1: wall time of every step of the merge on every rank (device synchronised at each mark), to stderr"""
+
+    def __init__(self, what, dev):
+        import time
+        self.on = os.environ.get("AVLMAPS_MERGE_TRACE") == "1"
+        self.cuda = getattr(dev, "type", str(dev)) == "cuda"
+        self.what, self.t, self.marks, self.t_abs = what, time.perf_counter(), [], time.time()
+
+    def __call__(self, label):
+        if not self.on:
+            return
+        import time
+        if self.cuda:
+            import torch
+            torch.cuda.synchronize()
+        t = time.perf_counter()
+        self.marks.append(f"{label} {1e3 * (t - self.t):.1f}")
+        self.t = t
+
+    def done(self, rank):
+        if self.on:
+            import sys
+            print(f"[merge trace] rank {rank} {self.what} @{self.t_abs % 1000:.2f}s: " + " | ".join(self.marks) + " (ms)", file=sys.stderr, flush=True)
+
+
+class ShardPlan:
+    """What a rank knows after plan_merge_directory -- about its OWN voxels only:
+        row_of_slot (n,) int64  final row (= the reference's voxel id) of every local voxel
+        is_new      (n,) bool   this rank holds the voxel's global first touch (no lower rank has the cell)
+        prev / next (n,) int64  the neighbouring contributors of the voxel in rank order, -1 if none: the colour replay of a
+                                voxel runs prev -> this rank -> next; a voxel with prev == next == -1 belongs to this rank alone
+        M, bases, counts        merged voxel count, and per rank the first row / the number of its new voxels
+        grow_key                first-touch key of row `grow_row` (plan_merge_directory(grow_row=...)), all ones if M is smaller
+        aux_all                 (ws, k) the `aux` integers of every rank (rides on the plan's first all_gather)
+        monotone                False: the first-touch keys are not ordered by rank (frames were not sharded contiguously);
+                                only aux_all is valid and the caller falls back to the general plan (plan_merge)"""
+    __slots__ = ("M", "n", "row_of_slot", "is_new", "prev", "next", "bases", "counts", "grow_key", "aux_all", "monotone", "rank", "ws",
+                 "coll", "dir_entries")
+
+
+def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=None, grow_row: Optional[int] = None, aux=(),
+                         local: bool = False) -> ShardPlan:
+    """The merge plan without any O(M) step on any rank (plan_merge sorts / uniques ALL M voxels on EVERY rank).
+
+    Contiguous frame shards make the first-touch keys rank-monotone (every key of rank r < every key of rank r + 1; checked, with
+    a fall-back), so the reference's voxel-id order is: the voxels first touched by rank 0 in key order, then those first touched
+    by rank 1, ...  A rank therefore only has to learn which of ITS voxels a lower rank already holds:
+      1. every rank sends its cell list to DIRECTORY ranks (hash of the cell; one all_to_all, 4 B / voxel); a directory rank
+         sorts what it received (~ M / ws entries) by (cell, source rank) and answers every entry with the neighbouring
+         contributors (prev, next) of that cell (second all_to_all, 4 B / voxel);
+      2. a rank sorts its NEW voxels (prev == -1) by key; one tiny all_gather of the counts gives every rank its row base;
+      3. the final rows of shared voxels reach their other contributors through the directory (two all_to_alls over the shared
+         voxels only).
+    Collective over the group; plain local arithmetic without torch.distributed."""
+    import torch
+    i64 = torch.int64
+    dev = cell.device
+    n = int(cell.shape[0])
+    key = first_key.to(i64)
+    coll = _Coll(group) if (_dist_on(group) and not local) else None      # local: this process alone (warm_up_merge)
+    ws, rank = (coll.ws, coll.rank) if coll is not None else (1, 0)
+
+    def a2a(t, ins, outs):
+        return coll.all_to_all(t, ins, outs) if coll is not None else t
+
+    def gather(t):
+        return coll.all_gather(t) if coll is not None else [t]
+
+    plan = ShardPlan()
+    plan.rank, plan.ws, plan.coll, plan.n = rank, ws, coll, n
+    tr = _Trace('plan', dev)
+    cell64 = cell.to(i64)
+    tr('to i64')
+    dest = _dir_owner(cell64, ws)
+    tr('hash')
+    ordd = torch.argsort(dest, stable=True)                       # local slots grouped by directory rank
+    tr('argsort')
+    dest_o = dest[ordd]
+    sc = torch.bincount(dest, minlength=ws)[:ws]
+    tr('bincount')
+    kmin = key.min().reshape(1) if n else torch.full((1,), I64_MAX, dtype=i64, device=dev)
+    kmax = key.max().reshape(1) if n else torch.full((1,), -1, dtype=i64, device=dev)
+    tr('minmax')
+    head = torch.cat([sc, torch.tensor([n], dtype=i64, device=dev), kmin, kmax, torch.tensor([int(a) for a in aux], dtype=i64, device=dev)])
+    tr('hash+sort+head')
+    allh = torch.stack(gather(head)).cpu()
+    tr('gather head')
+    plan.aux_all = allh[:, ws + 3:].numpy()
+    last = -1
+    plan.monotone = True
+    for r in range(ws):
+        if int(allh[r, ws]) > 0:
+            if int(allh[r, ws + 1]) <= last:
+                plan.monotone = False
+            last = int(allh[r, ws + 2])
+    if not plan.monotone:
+        return plan
+    sc_l = allh[rank, :ws].tolist()
+    rc_l = allh[:, rank].tolist()
+    # 1. directory: (cell, source rank) order -> neighbouring contributors of every entry
+    recv = a2a(cell[ordd].contiguous(), sc_l, rc_l)
+    R = int(recv.shape[0])
+    plan.dir_entries = R
+    tr('a2a cells')
+    src = torch.repeat_interleave(torch.arange(ws, dtype=i64, device=dev), torch.tensor(rc_l, dtype=i64, device=dev))
+    perm = torch.argsort(recv, stable=True)                      # arrival order is by source rank: stable = (cell, rank) order
+    cs, ss = recv[perm], src[perm]
+    first = torch.ones(R, dtype=torch.bool, device=dev)
+    lastm = torch.ones(R, dtype=torch.bool, device=dev)
+    if R > 1:
+        first[1:] = cs[1:] != cs[:-1]
+        lastm[:-1] = first[1:]
+    neg = torch.full((R,), -1, dtype=i64, device=dev)
+    prev_r = torch.empty(R, dtype=i64, device=dev)
+    next_r = torch.empty(R, dtype=i64, device=dev)
+    prev_r[perm] = torch.where(first, neg, torch.roll(ss, 1))
+    next_r[perm] = torch.where(lastm, neg, torch.roll(ss, -1))
+    tr('directory sort')
+    back = a2a(((prev_r + 1) | ((next_r + 1) << 16)).to(torch.int32), rc_l, sc_l).to(i64)
+    tr('a2a reply')
+    prev = torch.empty(n, dtype=i64, device=dev)
+    nxt = torch.empty(n, dtype=i64, device=dev)
+    prev[ordd] = (back & 0xFFFF) - 1
+    nxt[ordd] = (back >> 16) - 1
+    # 2. new voxels in key order; row bases
+    is_new = prev < 0
+    idx_new = torch.nonzero(is_new).reshape(-1)
+    idx_new = idx_new[torch.argsort(key[idx_new])]
+    c = int(idx_new.shape[0])
+    # the counts of the two directory round trips below ride on the same tiny all_gather
+    m3 = (is_new & (nxt >= 0))[ordd]                             # my new voxels that others share, in sending order
+    m4 = (~is_new)[ordd]                                         # my voxels whose row somebody else assigns
+    m3r = (prev_r < 0) & (next_r >= 0)
+    m4r = prev_r >= 0
+    cnt = torch.cat([torch.tensor([c], dtype=i64, device=dev), torch.bincount(dest_o[m3], minlength=ws)[:ws],
+                     torch.bincount(src[m3r], minlength=ws)[:ws], torch.bincount(src[m4r], minlength=ws)[:ws],
+                     torch.bincount(dest_o[m4], minlength=ws)[:ws]])
+    tr('new voxels + counts')
+    allc = torch.stack(gather(cnt)).cpu()
+    tr('gather counts')
+    counts = allc[:, 0].tolist()
+    bases = [0] * ws
+    for r in range(1, ws):
+        bases[r] = bases[r - 1] + counts[r - 1]
+    plan.M, plan.bases, plan.counts = int(sum(counts)), bases, counts
+    s3, r3, s4, r4 = (allc[rank, 1 + k * ws:1 + (k + 1) * ws].tolist() for k in range(4))
+    row = torch.full((n,), -1, dtype=i64, device=dev)
+    row[idx_new] = bases[rank] + torch.arange(c, dtype=i64, device=dev)
+    # 3. rows of shared voxels: first contributor -> directory -> the other contributors
+    recv3 = a2a(row[ordd][m3].contiguous(), s3, r3)
+    tr('a2a first rows')
+    rowfirst_r = torch.full((R,), -1, dtype=i64, device=dev)
+    rowfirst_r[m3r] = recv3                                      # both sides keep the order of the first all_to_all
+    seg = torch.cumsum(first.to(i64), 0) - 1
+    row_s = rowfirst_r[perm][first][seg] if R else rowfirst_r
+    row_r = torch.empty(R, dtype=i64, device=dev)
+    row_r[perm] = row_s
+    tr('propagate')
+    recv4 = a2a(row_r[m4r].contiguous(), s4, r4)
+    row[ordd[m4]] = recv4
+    tr('a2a other rows')
+    plan.row_of_slot, plan.is_new, plan.prev, plan.next = row, is_new, prev, nxt
+    # the key after which the reference's arrays have their post-growth dtypes (vlmap_builder.py:286-311)
+    plan.grow_key = U64_ALL_ONES
+    if grow_row is not None and plan.M > grow_row >= 0:
+        holder = max(r for r in range(ws) if bases[r] <= grow_row)
+        val = torch.zeros(1, dtype=i64, device=dev)
+        if rank == holder:
+            val[0] = key[idx_new[grow_row - bases[rank]]]
+        if coll is not None:
+            coll.broadcast(val, holder)
+        plan.grow_key = int(val.item()) & U64_ALL_ONES
+    tr('grow key')
+    tr.done(rank)
+    return plan
+
+
+def warm_up_merge(n: int = 1 << 20, device="cuda") -> None:
+    """Run the tensor plumbing of a merge once, locally, at a realistic size.  torch loads the code objects of its sort / unique /
+    scan kernels lazily, per process and per size class (a 30 k-voxel warm-up merge takes other sort kernels than a 1 M-voxel
+    merge): ~1 s in a single process, and tens of seconds when 8 processes on one box load them at the same moment (seen in the
+    8-ranks-on-one-GPU rehearsal, profiles/r04_build_8ranks_one_gpu.json: 27-52 s inside the first large torch.argsort on every
+    rank).  A benchmark calls this in its warm-up; a production build simply pays it in its first checkpoint merge."""
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cell = torch.randperm(max(int(n), 2) * 4, generator=g)[:n].to(torch.int32).to(device)
+    key = torch.randperm(max(int(n), 2), generator=g).to(device)
+    plan = plan_merge_directory(cell, key, grow_row=n // 2, local=True)
+    ex = MixedExchange.__new__(MixedExchange)
+    rows = plan.row_of_slot
+    order = torch.argsort(rows)
+    torch.bincount(torch.clamp(rows[order] // max(1, n // 8), max=7), minlength=8)
+    u, inv = torch.unique(rows % max(1, n // 3), return_inverse=True)
+    buf = torch.zeros((u.shape[0], 4), dtype=torch.float64, device=device)
+    buf.index_add_(0, inv, torch.ones((n, 4), dtype=torch.float64, device=device))
+    out = torch.zeros((n, 8), dtype=torch.float32, device=device)
+    out.index_copy_(0, order, torch.ones((n, 8), dtype=torch.float32, device=device))
+    st = torch.zeros((n, 3), dtype=torch.int64, device=device)
+    st[rows[rows % 2 == 0]] = 1
+    torch.where((plan.next < 0)[:, None], st, torch.zeros_like(st))
+    idx = torch.nonzero(plan.prev == -1).reshape(-1)
+    idx[torch.argsort(cell[idx])]
+    del ex
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+
+
+def chain_replay(plan: ShardPlan, cell: "torch.Tensor", replay_fn, tr=None) -> "torch.Tensor":
+    """The sequential weight / colour replay across ranks, restricted to what has to be sequential.
+
+    replay_fn(state (n, 3) int64, sel (n,) bool) continues the 24-byte state of the selected local voxels with this rank's
+    sample log (avl_builder_replay_chain).  Voxels no lower rank holds (prev == -1: almost all of them) are replayed at once on
+    every rank in parallel; a voxel shared with lower ranks waits for its predecessor's state, which arrives point-to-point
+    from rank `prev` (lists in cell order on both sides, so no indices travel) -- the round-3 chain moved a dense 24 B x M
+    state through every rank in turn.  Returns the local states; they are FINAL where plan.next == -1."""
+    import torch
+    i64 = torch.int64
+    n, ws, rank, coll = plan.n, plan.ws, plan.rank, plan.coll
+    dev = cell.device
+    state = torch.zeros((n, 3), dtype=i64, device=dev)
+    tr = tr or (lambda label: None)
+    sel_a = plan.prev < 0
+    if n:
+        replay_fn(state, sel_a)
+    tr('phase A (no lower rank)')
+    if coll is None or ws == 1:
+        return state
+    both = torch.stack([torch.bincount(plan.prev[plan.prev >= 0], minlength=ws)[:ws], torch.bincount(plan.next[plan.next >= 0], minlength=ws)[:ws]]).cpu()
+    n_prev, n_next = both[0].tolist(), both[1].tolist()
+
+    def slots_of(which, r):
+        idx = torch.nonzero(which == r).reshape(-1)
+        return idx[torch.argsort(cell[idx])]
+    for p in range(rank):
+        if n_prev[p]:
+            idx = slots_of(plan.prev, p)
+            buf = torch.empty((n_prev[p], 3), dtype=i64, device=dev)
+            coll.recv(buf, p)
+            state[idx] = buf
+    tr('recv from prev ranks')
+    if sum(n_prev):
+        replay_fn(state, ~sel_a)
+    tr('phase B (continued)')
+    for q in range(rank + 1, ws):
+        if n_next[q]:
+            coll.send(state[slots_of(plan.next, q)].contiguous(), q)
+    tr('send to next ranks')
+    return state
+
+
+class MixedExchange:
+    """Row-sharded exchange with the mixed payload.  Final rows are dealt out in contiguous blocks shard_rows(M, r, ws); a rank's
+    voxels, sorted by final row, are grouped by destination.  Three lists travel (all_to_all_single with split sizes each):
+        side    every local voxel: [row | cell << 32, sum_w4 (4 x f64), replay state (3 x i64)] = 64 B
+        done    voxels of this rank ALONE (prev == next == -1): the finished float32 feature row, D x 4 B
+        part    voxels shared between ranks: float64 partial sums of the features, D x 8 B"""
+    __slots__ = ("order", "rows_sorted", "single_sorted", "send_all", "recv_all", "send_done", "recv_done", "send_part", "recv_part",
+                 "r0", "r1", "per")
+
+    def __init__(self, plan: ShardPlan):
+        import torch
+        i64 = torch.int64
+        rows = plan.row_of_slot
+        ws, M = plan.ws, plan.M
+        self.per = max(1, (M + ws - 1) // ws)
+        self.r0, self.r1 = shard_rows(M, plan.rank, ws)
+        self.order = torch.argsort(rows)
+        self.rows_sorted = rows[self.order].contiguous()
+        single = (plan.prev < 0) & (plan.next < 0)
+        self.single_sorted = single[self.order]
+        dest = torch.clamp(self.rows_sorted // self.per, max=ws - 1)
+        cnt = torch.stack([torch.bincount(dest, minlength=ws)[:ws], torch.bincount(dest[self.single_sorted], minlength=ws)[:ws],
+                           torch.bincount(dest[~self.single_sorted], minlength=ws)[:ws]]).to(i64)
+        if plan.coll is not None:
+            allc = torch.stack(plan.coll.all_gather(cnt)).cpu()                         # (ws, 3, ws): [sender, list, receiver]
+            recv = allc[:, :, plan.rank]
+        else:
+            recv = cnt.cpu().t()
+        cnt = cnt.cpu()
+        self.send_all, self.send_done, self.send_part = (cnt[k].tolist() for k in range(3))
+        self.recv_all, self.recv_done, self.recv_part = (recv[:, k].tolist() for k in range(3))
+
+
+def _fold_mixed(plan, ex, D, side, done, part, rows_add):
+    """owner side of the mixed exchange, shared by the device path and its torch twin: returns (own_cell, w4 (n_own, 4) f64,
+    state (n_own, 3) i64, done_rows, done_feat, part_rows (k,), part_acc (k, D) f64) -- rows relative to this rank's block"""
+    import torch
+    i64 = torch.int64
+    dev = side.device
+    n_own = ex.r1 - ex.r0
+    word = side[:, 0]
+    rows = (word & 0xFFFFFFFF) - ex.r0
+    own_cell = torch.zeros(n_own, dtype=torch.int32, device=dev)
+    own_cell[rows] = ((word >> 32) & 0x7FFFFFFF).to(torch.int32)
+    w4 = torch.zeros((max(n_own, 1), 4), dtype=torch.float64, device=dev)
+    o = 0
+    for c in ex.recv_all:                           # peer by peer, in rank order: a reproducible float64 sum
+        if c:
+            rows_add(rows[o:o + c], side[o:o + c, 1:5].view(torch.float64), w4)
+        o += c
+    st = side[:, 5:8]
+    fin = (st[:, 2] >> 32) != 0                     # `started` of the 24-byte state: only a voxel's LAST contributor sends it
+    state = torch.zeros((max(n_own, 1), 3), dtype=i64, device=dev)
+    state[rows[fin]] = st[fin]
+    # rows of the two feature lists: the side list of a peer is in final-row order, and so are its done / part sublists
+    single_flag = (word >> 63) != 0                 # bit 63 of the word: the voxel travelled as a finished row
+    done_rows, part_rows_all = rows[single_flag], rows[~single_flag]
+    part_rows, inv = (torch.unique(part_rows_all, return_inverse=True) if part_rows_all.numel() else
+                      (part_rows_all, part_rows_all))
+    acc = torch.zeros((max(int(part_rows.shape[0]), 1), D), dtype=torch.float64, device=dev)
+    o = 0
+    for c in ex.recv_part:
+        if c:
+            rows_add(inv[o:o + c], part[o:o + c], acc)
+        o += c
+    return own_cell, w4, state, done_rows, done, part_rows, acc
+
+
+def merge_raw_sharded(raw: Dict[str, "torch.Tensor"], group=None, replay_fn=None, gs2: Optional[int] = None):
+    """Row-sharded merge of per-rank raw accumulators given as torch tensors: the arithmetic and the choreography of
+    merge_accumulator_sharded on exported tensors (CPU + gloo in the tests, the cross-check of the device path on the GPU).
+    Returns on EVERY rank dict(M, rows=(r0, r1), cell (n_own,) int32 and first_key (n_own,) int64 of this rank's block of final
+    rows, grid_feat (n_own, D) float32, w4 (n_own, 4) float64 = summed [alpha, alpha rgb], part_rows (k,) = the block's rows that
+    several ranks touched with part_acc (k, D) float64 their summed features (first-touch term folded in), bytes_sent,
+    payload_bytes_fp64_form, plan="directory" | "general"; with replay_fn also state (n_own, 3) int64, the final replay states)."""
+    import torch
+    i64 = torch.int64
+    cell, key = raw["cell"], raw["first_key"].to(i64)
+    dev = cell.device
+    D = raw["sum_feat"].shape[1]
+    plan = plan_merge_directory(cell, key, group, grow_row=None if gs2 is None else gs2 - 1)
+    if not plan.monotone or os.environ.get("AVLMAPS_MERGE_PLAN") == "general":
+        out = _merge_raw_sharded_general(raw, group)
+        r0, r1 = out["rows"]
+        ar = torch.arange(r1 - r0, device=dev)
+        out.update(cell=out["cell"][r0:r1], first_key=out["first_key"][r0:r1], plan="general", w4=out["acc"][:, D:], part_rows=ar,
+                   part_acc=out["acc"][:, :D], grid_feat=(out["acc"][:, :D] / out["acc"][:, D:D + 1]).float())
+        return out
+    ex = MixedExchange(plan)
+    n = plan.n
+    a1 = raw["first_alpha"]
+    corr = torch.where(plan.is_new, a1 * (1.0 - a1), torch.zeros_like(a1))
+    contrib = raw["sum_feat"] - corr[:, None] * raw["first_feat"].double()
+    o = ex.order
+    single = ex.single_sorted
+    done = (contrib[o][single] / raw["sum_w4"][o][single][:, :1]).float().contiguous()
+    part = contrib[o][~single].contiguous()
+    state = torch.zeros((n, 3), dtype=i64, device=dev)
+    if replay_fn is not None:
+        state = chain_replay(plan, cell, replay_fn)
+        state = torch.where((plan.next < 0)[:, None], state, torch.zeros_like(state))
+    side = torch.empty((n, 8), dtype=i64, device=dev)
+    side[:, 0] = ex.rows_sorted | (cell[o].to(i64) << 32) | (single.to(i64) << 63)
+    side[:, 1:5] = raw["sum_w4"][o].contiguous().view(i64)
+    side[:, 5:8] = state[o]
+    keys_o = torch.where(plan.is_new, key, torch.full_like(key, I64_MAX))[o].contiguous()
+    if plan.coll is not None:
+        side = plan.coll.all_to_all(side, ex.send_all, ex.recv_all)
+        done = plan.coll.all_to_all(done, ex.send_done, ex.recv_done)
+        part = plan.coll.all_to_all(part, ex.send_part, ex.recv_part)
+        keys_o = plan.coll.all_to_all(keys_o, ex.send_all, ex.recv_all)
+
+    def rows_add(rows, src, dst):
+        dst.index_add_(0, rows, src)
+    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    n_own = ex.r1 - ex.r0
+    grid_feat = torch.zeros((n_own, D), dtype=torch.float32, device=dev)
+    grid_feat[done_rows] = done_feat
+    if part_rows.numel():
+        grid_feat[part_rows] = (part_acc / w4[part_rows, :1]).float()
+    own_key = torch.full((max(n_own, 1),), I64_MAX, dtype=i64, device=dev)
+    own_key.scatter_reduce_(0, (side[:, 0] & 0xFFFFFFFF) - ex.r0, keys_o, reduce="amin")
+    sent_all = sum(c for r, c in enumerate(ex.send_all) if r != plan.rank)
+    sent_done = sum(c for r, c in enumerate(ex.send_done) if r != plan.rank)
+    sent_part = sum(c for r, c in enumerate(ex.send_part) if r != plan.rank)
+    out = dict(M=plan.M, rows=(ex.r0, ex.r1), cell=own_cell, first_key=own_key[:n_own], grid_feat=grid_feat, w4=w4[:n_own],
+               part_rows=part_rows, part_acc=part_acc[:int(part_rows.shape[0])], plan="directory",
+               bytes_sent=sent_all * 64 + sent_done * D * 4 + sent_part * D * 8, payload_bytes_fp64_form=sent_all * ((D + 4) * 8 + 8),
+               grow_key=plan.grow_key)
+    if replay_fn is not None:
+        out["state"] = own_state[:n_own]
+    return out
+
+
+def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: Optional[dict] = None, gather_to: Optional[int] = None,
+                              status: int = 0):
+    """The product path of the multi-GPU build, row-sharded (round 4: directory plan + mixed payload + point-to-point replay).
+
+    Merges the ranks' VoxelAccumulators with ONE sparse exchange and finalises every rank's block of final rows where it lives.
+    Nothing a rank computes is O(M): the plan (plan_merge_directory) touches its own voxels and ~M / ws directory entries; a voxel
+    that only this rank touched (the bulk: contiguous frame shards see mostly disjoint space) is FINISHED here in float64 and
+    ships as a float32 row (avl_builder_export_rows_f32: bit-identical to the single-process map), only voxels several ranks
+    touched ship float64 partial sums (avl_builder_export_rows_f64 -> avl_rows_add_f64 in rank order at the owner); the exact
+    sequential weight / colour replay runs in parallel for every voxel no lower rank holds and point-to-point, rank prev -> next,
+    for the shared ones (chain_replay).  torch.distributed carries the collectives (backend nccl == RCCL over xGMI).
+
+    Returns on every rank a dict of DEVICE tensors
+        M, rows=(r0, r1), grid_feat (r1-r0, D) f32, grid_pos (r1-r0, 3) i32, weight (r1-r0,) f32, grid_rgb (r1-r0, 3) u8, cell (r1-r0,)
+    = this rank's block of the merged map in the reference's voxel-id order (the block VLMap.shard_index_rows scores).
+    gather_to = r: rank r also gets "full": the whole map (grid_feat, grid_pos, weight, grid_rgb, occupied_ids) as device tensors,
+    e.g. to write the file.  exact_rgb needs the replay log on every rank.  status != 0 on ANY rank makes every rank raise
+    (a rank that failed locally still joins this collective, so that nobody waits for it until the RCCL timeout)."""
+    import torch
+    torch.cuda.synchronize()
+    glock = _SharedGpuLock.get()
+    glock.acquire()                             # (a no-op unless several ranks share one GPU in a rehearsal)
+    try:
+        return _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_to, status, glock)
+    finally:
+        glock.release()
+
+
+def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_to, status, glock):
+    import time
+    import torch
+    from . import _lib
+    from .device import torch_stream_ptr
+    lib = _lib.load()
+    st = torch_stream_ptr()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    i64 = torch.int64
+    t0 = time.perf_counter()
+    lw0 = glock.wait_s
+    tr = _Trace('merge', dev)
+    n = acc.num_voxels(st) if not status else 0
+    tr('num_voxels')
+    cell = torch.empty((n,), dtype=torch.int32, device=dev)
+    key = torch.empty((n,), dtype=i64, device=dev)
+    w4_loc = torch.empty((max(n, 1), 4), dtype=torch.float64, device=dev)
+    if n:
+        _lib.check(lib.avl_builder_export_raw(acc._h, n, cell.data_ptr(), key.data_ptr(), None, w4_loc.data_ptr(), None, None, st),
+                   "avl_builder_export_raw")
+    have_log = 1 if (exact_rgb and acc.has_replay_log()) else 0
+    tr('export cell/key/w4')
+    plan = plan_merge_directory(cell, key, group, grow_row=acc.n_rows * acc.gs - 1, aux=(have_log, int(status)))
+    tr('plan')
+    bad = [r for r in range(plan.ws) if int(plan.aux_all[r, 1]) != 0]
+    if bad:
+        raise RuntimeError(f"multi-rank merge aborted: rank(s) {bad} reported a failure (status {[int(plan.aux_all[r, 1]) for r in bad]})")
+    if not plan.monotone or os.environ.get("AVLMAPS_MERGE_PLAN") == "general":
+        out = _merge_accumulator_sharded_general(acc, group, exact_rgb, timings, gather_to)
+        r0, r1 = out["rows"]
+        out["cell"] = out["cell"][r0:r1]
+        return out
+    have_log = int(plan.aux_all[:, 0].min())
+    coll = plan.coll
+    D, M = acc.D, plan.M
+    ex = MixedExchange(plan)
+    tr('exchange bookkeeping')
+    tr.done(plan.rank)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    c1 = coll.comm_s if coll is not None else 0.0
+    lw1 = glock.wait_s
+    # ---- local rows -> the three send lists (final-row order = destination order)
+    o32 = ex.order.to(torch.int32)
+    single = ex.single_sorted
+    slots_done = o32[single].contiguous()
+    slots_part = o32[~single].contiguous()
+    n_done, n_part = int(slots_done.shape[0]), int(slots_part.shape[0])
+    done = torch.empty((max(n_done, 1), D), dtype=torch.float32, device=dev)
+    part = torch.empty((max(n_part, 1), D), dtype=torch.float64, device=dev)
+    _lib.check(lib.avl_builder_export_rows_f32(acc._h, n_done, slots_done.data_ptr(), done.data_ptr(), D, st), "avl_builder_export_rows_f32")
+    own_part = plan.is_new[ex.order][~single].to(torch.uint8).contiguous()
+    _lib.check(lib.avl_builder_export_rows_f64(acc._h, n_part, slots_part.data_ptr(), own_part.data_ptr(), part.data_ptr(), D, st),
+               "avl_builder_export_rows_f64")
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    c2 = coll.comm_s if coll is not None else 0.0
+    lw2 = glock.wait_s
+    # ---- exact sequential weight / colour: parallel where it can be, point-to-point where it has to be sequential
+    state = torch.zeros((n, 3), dtype=i64, device=dev)
+    chain_bytes0 = coll.bytes_out if coll is not None else 0
+    if have_log:
+        ar = torch.arange(n, dtype=i64, device=dev)
+        minus = torch.full((n,), -1, dtype=i64, device=dev)
+
+        def replay_fn(stt, sel):
+            idx = torch.where(sel, ar, minus).contiguous()
+            _lib.check(lib.avl_builder_replay_chain(acc._h, n, idx.data_ptr(), plan.grow_key, stt.data_ptr(), st), "avl_builder_replay_chain")
+        state = chain_replay(plan, cell, replay_fn, tr2 := _Trace('replay', dev))
+        state = torch.where((plan.next < 0)[:, None], state, torch.zeros_like(state))
+        tr2('final mask')
+        tr2.done(plan.rank)
+    chain_bytes = (coll.bytes_out - chain_bytes0) if coll is not None else 0
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    c3 = coll.comm_s if coll is not None else 0.0
+    lw3 = glock.wait_s
+    side = torch.empty((n, 8), dtype=i64, device=dev)
+    side[:, 0] = ex.rows_sorted | (cell[ex.order].to(i64) << 32) | (single.to(i64) << 63)
+    side[:, 1:5] = w4_loc[:n][ex.order].view(i64)
+    side[:, 5:8] = state[ex.order]
+    if coll is not None:
+        side = coll.all_to_all(side, ex.send_all, ex.recv_all)
+        done = coll.all_to_all(done[:n_done], ex.send_done, ex.recv_done)
+        part = coll.all_to_all(part[:n_part], ex.send_part, ex.recv_part)
+    else:
+        done, part = done[:n_done], part[:n_part]
+    torch.cuda.synchronize()
+    t4 = time.perf_counter()
+    c4 = coll.comm_s if coll is not None else 0.0
+    lw4 = glock.wait_s
+    # ---- owner side: fold what arrived into this rank's block of final rows
+    n_own = ex.r1 - ex.r0
+
+    def rows_add(rows, src, dst):
+        src = src.contiguous()
+        rows = rows.contiguous()
+        _lib.check(lib.avl_rows_add_f64(int(rows.shape[0]), int(src.shape[1]), rows.data_ptr(), 0, int(dst.shape[0]), src.data_ptr(),
+                                        int(src.shape[1]), dst.data_ptr(), int(dst.shape[1]), st), "avl_rows_add_f64")
+    tr3 = _Trace('fold', dev)
+    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    tr3('fold lists')
+    out = dict(M=M, rows=(ex.r0, ex.r1), cell=own_cell,
+               grid_feat=torch.empty((n_own, D), dtype=torch.float32, device=dev),
+               grid_pos=torch.empty((n_own, 3), dtype=torch.int32, device=dev),
+               weight=torch.empty((n_own,), dtype=torch.float32, device=dev),
+               grid_rgb=torch.empty((n_own, 3), dtype=torch.uint8, device=dev))
+    tr3('alloc out')
+    if n_own:
+        out["grid_feat"].index_copy_(0, done_rows, done_feat)
+        tr3('copy done rows')
+        if part_rows.numel():
+            out["grid_feat"].index_copy_(0, part_rows, (part_acc / w4[part_rows, :1]).float())
+        tr3('divide shared rows')
+        _lib.check(lib.avl_finalize_side(n_own, ex.r0, acc.gs, acc.vh, own_cell.data_ptr(), w4.data_ptr(), out["grid_pos"].data_ptr(),
+                                         out["weight"].data_ptr(), out["grid_rgb"].data_ptr(), None, st), "avl_finalize_side")
+        if have_log:
+            _lib.check(lib.avl_replay_state_apply(n_own, own_state.data_ptr(), out["weight"].data_ptr(), out["grid_rgb"].data_ptr(), st),
+                       "avl_replay_state_apply")
+    tr3('side + state apply')
+    tr3.done(plan.rank)
+    del side, done, part, part_acc
+    torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    c5 = coll.comm_s if coll is not None else 0.0
+    lw5 = glock.wait_s
+    gather_bytes = 0
+    if gather_to is not None:
+        full = gather_row_shards(out, gather_to, coll, plan.rank, plan.ws, names=("grid_feat", "grid_pos", "weight", "grid_rgb", "cell"))
+        if plan.rank != gather_to:
+            gather_bytes = n_own * (D * 4 + 12 + 4 + 3 + 4)
+        if full is not None:
+            full["occupied_ids"] = occupied_ids_from_cells(full.pop("cell"), acc.n_rows, acc.gs, acc.vh)
+            out["full"] = full
+    torch.cuda.synchronize()
+    t6 = time.perf_counter()
+    c6 = coll.comm_s if coll is not None else 0.0
+    lw6 = glock.wait_s
+    if timings is not None:
+        W = D + 4
+        sent_all = sum(c for r, c in enumerate(ex.send_all) if r != plan.rank)
+        sent_done = sum(c for r, c in enumerate(ex.send_done) if r != plan.rank)
+        sent_part = sum(c for r, c in enumerate(ex.send_part) if r != plan.rank)
+        payload = sent_all * 64 + sent_done * D * 4 + sent_part * D * 8
+        plan_bytes = (n * 8 + (plan.dir_entries or 0) * 4 + 16 * plan.ws * plan.ws) if coll is not None else 0
+        comm = dict(plan=c1, export=c2 - c1, replay_chain=c3 - c2, exchange=c4 - c3, fold_finalize=c5 - c4, gather=c6 - c5)
+        lockw = dict(plan=lw1 - lw0, export=lw2 - lw1, replay_chain=lw3 - lw2, exchange=lw4 - lw3, fold_finalize=lw5 - lw4, gather=lw6 - lw5)
+        wall = dict(plan=t1 - t0, export=t2 - t1, replay_chain=t3 - t2, exchange=t4 - t3, fold_finalize=t5 - t4, gather=t6 - t5)
+        wall = {k: wall[k] - lockw[k] for k in wall}          # rehearsals on one GPU: waiting for the shared device is not merge time
+        timings.update(mode="row-sharded all_to_all", plan="directory (nothing O(M) per rank; mixed float32 / float64 payload; point-to-point replay)",
+                       plan_s=wall["plan"], scatter_s=wall["export"], replay_chain_s=wall["replay_chain"], exchange_s=wall["exchange"],
+                       accumulate_s=wall["fold_finalize"], finalize_s=0.0, gather_s=wall["gather"], wall_s=wall, in_collectives_s=comm, shared_gpu_wait_s=sum(lockw.values()),
+                       compute_s={k: wall[k] - comm[k] for k in wall},
+                       compute_total_s=sum(wall[k] - comm[k] for k in wall if k != "gather"),
+                       in_collectives_total_s=sum(comm[k] for k in comm if k != "gather"),
+                       merged_voxels=M, local_voxels=n, own_rows=n_own, new_voxels=int(plan.counts[plan.rank]), single_rank_voxels=n_done,
+                       shared_voxels_local=n_part, shared_rows_owned=int(part_rows.numel()), directory_entries=int(plan.dir_entries or 0),
+                       rows_sent=sent_all, payload_bytes_sent=payload, payload_bytes_fp64_form=sent_all * (W * 8 + 8),
+                       plan_bytes_sent=plan_bytes, chain_bytes_sent=chain_bytes, gather_bytes_sent=gather_bytes,
+                       bytes_sent_per_rank=payload + plan_bytes + chain_bytes + gather_bytes,
+                       local_row_bytes=n * W * 8, dense_reduce_payload_bytes=M * W * 8, exact_rgb=bool(have_log), collectives=(coll.calls if coll else 0),
+                       world_size=plan.ws, backend=(coll.dist.get_backend(coll.group) if coll is not None else "none"))
+    return out
+
+
+def gather_row_shards(shard: dict, dst: int, coll, rank: int, ws: int, names=("grid_feat", "grid_pos", "weight", "grid_rgb")):
     """the ranks' blocks of finished rows (grid_feat / grid_pos / weight / grid_rgb device tensors, rank order = row order) ->
     the whole arrays on rank `dst`; None elsewhere.  One all_to_all_single per array in which only `dst` receives."""
     import torch
-    names = ("grid_feat", "grid_pos", "weight", "grid_rgb")
     if coll is None:
         return {k: shard[k] for k in names}
     n_own = int(shard["grid_feat"].shape[0])

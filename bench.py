@@ -525,12 +525,47 @@ def make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed):
     return depths, rgbs, feats
 
 
-def trajectory(n):
+def _json_default(o):
+    """0-d tensors / NumPy scalars that slipped into a record"""
+    if hasattr(o, "item"):
+        return o.item()
+    if hasattr(o, "tolist"):
+        return o.tolist()
+    return str(o)
+
+
+def trajectory(n, kind="loop", radius=8.0):
+    """synthetic base poses (x y z qx qy qz qw, dataset/README.md:93).  "loop": a 3 m circle walked every 1 571 frames while the
+    camera turns once per 524 frames -- a 10 k-frame sequence revisits the same room six times, so EVERY contiguous frame shard
+    sees nearly the whole map (the merge's worst case: almost every voxel is shared by all ranks).  "spiral": exploration -- a
+    square spiral outwards from the start, rings 4 m apart, inside the +-25 m the 1000 x 0.05 m grid spans, camera along the
+    direction of travel with a slow sweep: contiguous frame shards map mostly disjoint space and share their ring borders
+    (radius 8 m: a 10 k-frame sequence maps about as many voxels as the loop, ~2.3 M; 18 m: ~12 M)."""
     from scipy.spatial.transform import Rotation as R
     i = np.arange(n)
-    yaw = 0.012 * i
+    if kind == "loop":
+        yaw = 0.012 * i
+        p = np.stack([3.0 * np.sin(0.004 * i), np.zeros(n), -3.0 * (1 - np.cos(0.004 * i))], 1)
+    elif kind == "spiral":
+        pts, d, seg, pos = [np.zeros(2)], 0, 4.0, np.zeros(2)
+        dirs = np.array([[1.0, 0.0], [0.0, -1.0], [-1.0, 0.0], [0.0, 1.0]])
+        while np.abs(pos).max() < radius:
+            for _ in range(2):
+                pos = pos + dirs[d % 4] * seg
+                pts.append(pos.copy())
+                d += 1
+            seg += 4.0
+        pts = np.array(pts)
+        cum = np.concatenate([[0.0], np.cumsum(np.linalg.norm(np.diff(pts, axis=0), axis=1))])
+        s = np.linspace(0.0, cum[-1], n)
+        xz = np.stack([np.interp(s, cum, pts[:, 0]), np.interp(s, cum, pts[:, 1])], 1)
+        k = np.clip(np.searchsorted(cum, s, side="right") - 1, 0, len(pts) - 2)
+        head = np.arctan2(-(pts[k + 1, 0] - pts[k, 0]), -(pts[k + 1, 1] - pts[k, 1]))      # camera looks along -z of the base frame
+        yaw = np.unwrap(head) + 0.6 * np.sin(0.01 * i)
+        p = np.stack([xz[:, 0], np.zeros(n), xz[:, 1]], 1)
+    else:
+        raise ValueError(kind)
     q = R.from_euler("y", yaw).as_quat()
-    p = np.stack([3.0 * np.sin(0.004 * i), np.zeros(n), -3.0 * (1 - np.cos(0.004 * i))], 1)
     return np.concatenate([p, q], 1)
 
 
@@ -586,7 +621,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     nbuf = 4
     depths, rgbs, feats = make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=99 + rank)
     lo, hi = parallel.shard_frames(total_frames, rank, ws)
-    Ts = pc_transforms(trajectory(total_frames))
+    Ts = pc_transforms(trajectory(total_frames, getattr(args, "trajectory", "loop"), getattr(args, "spiral_radius", 8.0)))
     calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
     rs = np.random.RandomState(5 + rank)
     samples = []
@@ -633,6 +668,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     # the warm-up covers the tail of the path too: the first merge of a process pays for torch's sort / unique kernels, RCCL's
     # lazily created point-to-point communicators and the allocator's first large blocks (tens to hundreds of ms, once)
     mode = getattr(args, "merge_mode", "sharded")
+    if ws > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1":
+        parallel.warm_up_merge(1 << 20)                                  # torch's large-size sort / unique code objects (lazy, per process)
     if ws > 1:
         merge_ranks(parallel, acc, mode, exact_rgb)                      # every rank, also one without warm-up frames
     elif warmup:
@@ -668,8 +705,10 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     if ws > 1 and tim:
         # per-rank merge traffic next to the times (rank 0's own breakdown stays at the top level)
         per_rank = [None] * ws
-        dist.all_gather_object(per_rank, {k: tim.get(k) for k in ("bytes_sent_per_rank", "payload_bytes_sent", "rows_sent", "local_voxels",
-                                                                     "own_rows", "exchange_s", "scatter_reduce_s")})
+        dist.all_gather_object(per_rank, {k: tim.get(k) for k in ("bytes_sent_per_rank", "payload_bytes_sent", "payload_bytes_fp64_form", "rows_sent",
+                                                                     "local_voxels", "own_rows", "single_rank_voxels", "shared_voxels_local",
+                                                                     "directory_entries", "compute_total_s", "in_collectives_total_s", "compute_s",
+                                                                     "in_collectives_s", "wall_s", "shared_gpu_wait_s", "exchange_s", "scatter_reduce_s")})
         tim["per_rank"] = per_rank
     single_gpu_merge = None
     if ws == 1:
@@ -693,7 +732,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, deferred_fuse=bool(deferred) and BATCH == 1,
                frames_per_s=total_frames / dt,
                seconds=dt, fuse_seconds_max_rank=fuse_s, merge_finalize_seconds=dt - fuse_s, exact_rgb_replay=bool(exact_rgb),
-               feature_standin=feature_standin,
+               feature_standin=feature_standin, trajectory=getattr(args, "trajectory", "loop"),
                merge_mode=mode,
                timed_region=("fuse shard + merge (row-sharded all_to_all of the ranks' own voxel rows, chained replay) + finalize of every "
                              "rank's block of rows; " if mode != "reduce" else
@@ -923,6 +962,10 @@ def main():
                          "create 2.1 M voxels)")
     ap.add_argument("--build-frames", type=int, default=10_000,
                     help="index workload: total frames of the map-creation strong-scaling extra (north_star: a 10k-frame sequence)")
+    ap.add_argument("--trajectory", choices=["loop", "spiral"], default="loop",
+                    help="build workload: 'loop' = the same room revisited six times per 10 k frames (every frame shard sees nearly the "
+                         "whole map); 'spiral' = exploration, contiguous frame shards map mostly disjoint space")
+    ap.add_argument("--spiral-radius", type=float, default=8.0, help="extent of the spiral trajectory in metres (rings 4 m apart)")
     ap.add_argument("--feature-standin", choices=["vit-l16"], default=None,
                     help="build workload: run a random-weight ViT-L/16-shaped encoder (2 crops, bf16) before every frame as a "
                          "stand-in for LSeg's per-frame cost (no weights exist here; it is NOT LSeg)")
@@ -1015,7 +1058,7 @@ def main():
         except Exception as e:
             out["roofline"]["traffic_in_run_error"] = repr(e)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out, default=_json_default))
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

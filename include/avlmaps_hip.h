@@ -89,6 +89,10 @@ AVL_API int avl_event_create(void** h_event_out);
 AVL_API int avl_event_destroy(void* event);
 AVL_API int avl_event_record(void* event, void* stream);
 AVL_API int avl_event_sync(void* event);
+/* work submitted to `stream` after this call waits (on the device, the host does not block) until `event` has completed: the
+ * hand-over between the copy stream of the builder's pinned frame staging (avlmaps_amd/device.py FrameStager: depth / rgb / sample
+ * list of frame i + k cross PCIe while frame i is fused) and the stream the frame kernels run on */
+AVL_API int avl_stream_wait_event(void* stream, void* event);
 AVL_API int avl_event_elapsed_ms(void* start, void* stop, float* h_ms);
 
 /* ------------------------------------------------------------------------------------------------
@@ -377,12 +381,26 @@ AVL_API int avl_finalize_merged(int64_t n, int64_t row0, int D, int gs, int vh, 
                                 int32_t* d_occupied_ids, void* stream);
 /* Exact sequential weight / grid_rgb across ranks (needs the replay log): the per-voxel state {float64 weight, float32 rgb[3],
  * uint32 started} = 24 bytes, d_state (M, 24 B) zero-initialised on the first rank, is continued with this rank's log for its
- * own voxels (row d_row_of_slot[s]) and handed to the next rank, in rank order (contiguous frame shards).  grow_key = first-touch
+ * own voxels (row d_row_of_slot[s]; a NEGATIVE index leaves slot s out of this call: the round-4 merge replays the voxels that do not
+ * depend on another rank first and the others once their predecessor's state has arrived) and handed to the next rank, in rank
+ * order (contiguous frame shards).  grow_key = first-touch
  * key of the voxel with global id gs*gs - 1 (after it the reference's arrays have been re-allocated with other dtypes,
  * vlmap_builder.py:286-311), or ~0 if the map is smaller.  avl_replay_state_apply writes weight / grid_rgb from the final state. */
 AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                                      void* stream);
 AVL_API int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream);
+/* Mixed payload of the row-sharded merge (round 4).  A voxel only ONE rank touched is finished where its accumulators live:
+ * d_out[i, :D] = (float)((sum_feat[s] - a1 (1 - a1) first_feat[s]) / sum alpha), s = d_slots[i] -- the float64 expression of the
+ * single-process finalisation (vlmap_builder.py:166-178 closed form), so the row is bit-identical to the single-process map and
+ * travels as 4 B per element.  Voxels several ranks touched ship float64 partial sums: d_out[i, :D] = sum_feat[s] - d_own[i] *
+ * a1 (1 - a1) first_feat[s] (d_own[i] != 0: this rank holds the voxel's global first touch).  d_slots (k,) int32 distinct slots. */
+AVL_API int avl_builder_export_rows_f32(avl_builder* b, int64_t k, const int32_t* d_slots, float* d_out, int64_t ld, void* stream);
+AVL_API int avl_builder_export_rows_f64(avl_builder* b, int64_t k, const int32_t* d_slots, const uint8_t* d_own, double* d_out,
+                                        int64_t ld, void* stream);
+/* grid_pos / weight / grid_rgb / occupied_ids of n merged rows from their linear cells and their [sum alpha, sum alpha * (r, g, b)]
+ * float64 quadruples d_w4 (n, 4) alone (avl_finalize_merged without the feature part); output row r is voxel id row0 + r. */
+AVL_API int avl_finalize_side(int64_t n, int64_t row0, int gs, int vh, const int32_t* d_cell, const double* d_w4, int32_t* d_grid_pos,
+                              float* d_weight, uint8_t* d_grid_rgb, int32_t* d_occupied_ids, void* stream);
 /* Row-sharded merge (parallel.merge_accumulator_sharded; SURVEY.md 8e "reduce-scatter by voxel range"): rank r owns the final
  * rows [row0, row0 + nrows) and receives from every peer only that peer's contributions to them -- n rows of `cols` = D + 4
  * float64 with their final row index d_rows (n,) int64, a peer holds a voxel at most once so the indices of one call are

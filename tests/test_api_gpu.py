@@ -542,6 +542,7 @@ def _run_ranks(nproc, args, port, timeout=900, **env_extra):
 
 @pytest.mark.parametrize("nproc,n_frames,name,mode", [(2, 6, "g2a_builder_small.npz", "sharded"), (3, 4, "g2a_builder_small.npz", "sharded"),
                                                       (2, 16, "g2b_builder_growth.npz", "sharded"), (3, 16, "g2b_builder_growth.npz", "sharded"),
+                                                      (8, 16, "g2b_builder_growth.npz", "sharded"),
                                                       (2, 6, "g2a_builder_small.npz", "reduce"), (2, 16, "g2b_builder_growth.npz", "reduce")])
 def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, nproc, n_frames, name, mode):
     """VLMapBuilder under N ranks (one process each, frames sharded contiguously; the device merge -- row-sharded all_to_all of
@@ -574,8 +575,13 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
             t = json.loads((many / f"merge_timings_rank{r}.json").read_text())
             assert t["mode"].startswith("row-sharded") and t["world_size"] == nproc and t["backend"] == "gloo"
             assert tuple(t["shard_rows"]) == parallel.shard_rows(M, r, nproc) and t["shard_feat_shape"] == [t["own_rows"], D]
-            assert t["rows_sent"] <= t["local_voxels"] and t["payload_bytes_sent"] == t["rows_sent"] * ((D + 4) * 8 + 8)
+            assert t["plan"].startswith("directory")             # contiguous frame shards: nothing O(M) on any rank
+            assert t["rows_sent"] <= t["local_voxels"] and t["payload_bytes_fp64_form"] == t["rows_sent"] * ((D + 4) * 8 + 8)
+            # mixed payload: 64 B of side record per row + a float32 row (voxels of this rank alone) or a float64 row (shared)
+            assert t["rows_sent"] * (64 + D * 4) <= t["payload_bytes_sent"] <= t["rows_sent"] * (64 + D * 8)
+            assert t["single_rank_voxels"] + t["shared_voxels_local"] == t["local_voxels"]
             assert t["bytes_sent_per_rank"] >= t["payload_bytes_sent"]
+            assert abs(t["compute_total_s"] + t["in_collectives_total_s"] - sum(v for k, v in t["wall_s"].items() if k != "gather")) < 1e-6
             sent += t["payload_bytes_sent"]
             rows += t["local_voxels"]
         # the exchange moves what the ranks hold -- at most every local row once -- not ws dense copies of the map

@@ -120,51 +120,93 @@ def test_merge_world_size_2_gloo(tmp_path):
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 
-def _sharded_worker(rank, ws, port, tmpdir):
+def _fake_replay(rank, cell):
+    """stand-in for avl_builder_replay_chain on CPU tensors: an order-dependent update of the 24-byte state of the selected voxels"""
+    def fn(state, sel):
+        c = cell.to(torch.int64)
+        state[sel, 0] = state[sel, 0] * 31 + (rank + 1) * 1000 + c[sel]
+        state[sel, 1] = state[sel, 1] + 1
+        state[sel, 2] = 1 << 32                    # `started`
+    return fn
+
+
+def _sharded_worker(rank, ws, port, tmpdir, monotone=True):
     """row-sharded merge (merge_raw_sharded): every rank ends with ITS block of final rows, equal to the dense single-reduce
-    result; bytes sent = the rank's own rows that belong to other owners, never the whole map"""
+    result; the plan is the directory plan (nothing O(M) per rank), voxels of one rank alone travel as finished float32 rows,
+    shared voxels as float64 partial sums, and the order-dependent replay state reaches the owner through the contributors in
+    rank order"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank))
     parallel.init_distributed("gloo")
     D = 12
     rng = np.random.default_rng(7)
-    # contiguous frame shards see mostly disjoint voxels, a few shared ones; rank ws-1 may hold nothing
-    cellsets = [sorted(set(rng.integers(0, 400, 40 + 10 * k).tolist())) for k in range(ws)]
-    if ws == 3:
+    # contiguous frame shards see mostly disjoint voxels, a few shared ones (some by three and more ranks); one rank may hold nothing
+    cellsets = [sorted(set(rng.integers(0, 400, 40 + 10 * (k % 3)).tolist())) for k in range(ws)]
+    if ws >= 3:
         cellsets[2] = []
-    raws = [make_rank_raw(20 + k, D, cellsets[k], frame_lo=1000 * k) for k in range(ws)]
+    lo = [1000 * k for k in range(ws)]
+    if not monotone:
+        lo[0], lo[1] = lo[1], lo[0]                # frames NOT sharded contiguously: the general plan must take over
+    raws = [make_rank_raw(20 + k, D, cellsets[k], frame_lo=lo[k]) for k in range(ws)]
     cells, table = expected_merge(raws)
     dense = parallel.merge_raw(raws[rank], dst=0)
-    sh = parallel.merge_raw_sharded(raws[rank])
+    mycell = raws[rank]["cell"]
+    sh = parallel.merge_raw_sharded(raws[rank], replay_fn=_fake_replay(rank, mycell) if monotone else None, gs2=7)
     M = len(cells)
-    assert sh["M"] == M and sh["cell"].tolist() == cells and sh["rows"] == parallel.shard_rows(M, rank, ws)
+    assert sh["plan"] == ("directory" if monotone else "general")
+    assert sh["M"] == M and sh["rows"] == parallel.shard_rows(M, rank, ws)
     r0, r1 = sh["rows"]
-    assert sh["acc"].shape == (r1 - r0, D + 4)
+    assert sh["cell"].tolist() == cells[r0:r1] and sh["grid_feat"].shape == (r1 - r0, D)
+    holders = {c: [k for k in range(ws) if c in cellsets[k]] for c in cells}
+    part = {int(r): i for i, r in enumerate(sh["part_rows"].tolist())}
     for i in range(r0, r1):
         e = table[cells[i]]
         want = e["sf"] - e["fa"] * (1.0 - e["fa"]) * e["ff"].astype(np.float64)
-        np.testing.assert_allclose(sh["acc"][i - r0, :D].numpy(), want, rtol=1e-13, atol=1e-13)
-        np.testing.assert_allclose(sh["acc"][i - r0, D:].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
-        assert int(sh["first_key"][i]) == e["key"]
-    # the blocks, gathered, are the dense reduce of merge_raw bit for bit when at most two ranks touch a voxel (same two addends)
+        np.testing.assert_allclose(sh["w4"][i - r0].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
+        assert int(sh["first_key"][i - r0]) == e["key"]
+        if monotone and len(holders[cells[i]]) == 1:
+            # a voxel of ONE rank: finished where it was accumulated, in float64, rounded once -- the single-process value
+            assert (i - r0) not in part
+            assert np.array_equal(sh["grid_feat"][i - r0].numpy(), (want / e["w4"][0]).astype(np.float32))
+        else:
+            np.testing.assert_allclose(sh["part_acc"][part[i - r0]].numpy(), want, rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(sh["grid_feat"][i - r0].numpy(), (want / e["w4"][0]).astype(np.float32), rtol=2e-7)
+    # the blocks, gathered, are the dense reduce of merge_raw
     blocks = [None] * ws
-    dist.all_gather_object(blocks, sh["acc"].numpy())
+    dist.all_gather_object(blocks, (sh["grid_feat"].numpy(), sh["w4"].numpy()))
     if rank == 0:
-        full = np.concatenate(blocks, axis=0)
-        np.testing.assert_allclose(full, dense["acc"].numpy(), rtol=1e-15, atol=1e-15)
-    # traffic: only rows owned elsewhere travel, (D + 4) * 8 B + the 8 B row index each
-    n_local = len(cellsets[rank])
-    own = sum(1 for c in cellsets[rank] if r0 <= cells.index(c) < r1)
-    assert sh["bytes_sent"] == (n_local - own) * ((D + 4) * 8 + 8)
-    total = [None] * ws
-    dist.all_gather_object(total, (sh["bytes_sent"], n_local))
-    if rank == 0:
-        assert sum(t[0] for t in total) <= 1.3 * sum(t[1] for t in total) * (D + 4) * 8     # VERDICT r2: <= 1.3 x the local rows
-    # the dense voxel-id grid comes from the plan alone
-    occ = parallel.occupied_ids_from_cells(sh["cell"], 1, 20, 20)
+        gf = np.concatenate([b[0] for b in blocks], axis=0)
+        w4 = np.concatenate([b[1] for b in blocks], axis=0)
+        dacc = dense["acc"].numpy()
+        np.testing.assert_allclose(w4, dacc[:, D:], rtol=1e-15, atol=1e-15)
+        np.testing.assert_allclose(gf, (dacc[:, :D] / dacc[:, D:D + 1]).astype(np.float32), rtol=2e-7, atol=0)
+    # the key after which the reference's arrays change dtype (vlmap_builder.py:286-311): first-touch key of voxel id gs2 - 1
+    if monotone:
+        assert sh["grow_key"] == (table[cells[6]]["key"] if M >= 7 else (1 << 64) - 1)
+        # replay state: continued by every contributor of a voxel in rank order, delivered to the row's owner
+        for i in range(r0, r1):
+            c, s0 = cells[i], 0
+            for k in holders[c]:
+                s0 = s0 * 31 + (k + 1) * 1000 + c
+            assert sh["state"][i - r0].tolist() == [s0, len(holders[c]), 1 << 32], (i, holders[c])
+        # traffic: 64 B of side record per row that leaves, + 4 B x D (single-rank voxels) or 8 B x D (shared) -- about half of
+        # the all-float64 form
+        n_local = len(cellsets[rank])
+        away = [c for c in cellsets[rank] if not (r0 <= cells.index(c) < r1)]
+        single = sum(1 for c in away if len(holders[c]) == 1)
+        assert sh["bytes_sent"] == len(away) * 64 + single * D * 4 + (len(away) - single) * D * 8
+        assert sh["payload_bytes_fp64_form"] == len(away) * ((D + 4) * 8 + 8)
+        total = [None] * ws
+        dist.all_gather_object(total, (sh["bytes_sent"], n_local))
+        if rank == 0:
+            assert sum(t[0] for t in total) <= 1.3 * sum(t[1] for t in total) * (D + 4) * 8     # VERDICT r2: <= 1.3 x the local rows
+    # the dense voxel-id grid from the gathered cell blocks
+    allcells = [None] * ws
+    dist.all_gather_object(allcells, sh["cell"].tolist())
+    occ = parallel.occupied_ids_from_cells(torch.tensor(sum(allcells, []), dtype=torch.int32), 1, 20, 20)
     assert occ.shape == (1, 20, 20) and int((occ >= 0).sum()) == M and int(occ.view(-1)[cells[3]]) == 3
     # gather of finished row blocks to one rank
-    shard = dict(grid_feat=sh["acc"][:, :D].float().contiguous(), grid_pos=torch.arange(r0, r1, dtype=torch.int32)[:, None].repeat(1, 3),
-                 weight=sh["acc"][:, D].float().contiguous(), grid_rgb=torch.full((r1 - r0, 3), rank, dtype=torch.uint8))
+    shard = dict(grid_feat=sh["grid_feat"], grid_pos=torch.arange(r0, r1, dtype=torch.int32)[:, None].repeat(1, 3),
+                 weight=sh["w4"][:, 0].float().contiguous(), grid_rgb=torch.full((r1 - r0, 3), rank, dtype=torch.uint8))
     fullmap = parallel.gather_row_shards(shard, ws - 1, parallel._Coll(), rank, ws)
     if rank == ws - 1:
         assert fullmap["grid_pos"][:, 0].tolist() == list(range(M)) and fullmap["grid_feat"].shape == (M, D)
@@ -176,19 +218,28 @@ def _sharded_worker(rank, ws, port, tmpdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ws", [2, 3])
+@pytest.mark.parametrize("ws", [2, 3, 8])
 def test_row_sharded_merge_gloo(tmp_path, ws):
     port = _free_port()
     mp.spawn(_sharded_worker, args=(ws, port, str(tmp_path)), nprocs=ws, join=True)
     assert all((tmp_path / f"sh{r}").exists() for r in range(ws))
 
 
+def test_row_sharded_merge_falls_back_when_keys_are_not_rank_monotone(tmp_path):
+    """frames not sharded contiguously: the directory plan's shortcut (voxel-id order = rank order, then key order) does not
+    hold, every rank sees that from the plan's first all_gather and the general plan (sort of all M keys) takes over"""
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(3, port, str(tmp_path), False), nprocs=3, join=True)
+    assert all((tmp_path / f"sh{r}").exists() for r in range(3))
+
+
 def test_row_sharded_merge_single_process():
     raw = make_rank_raw(3, 6, [4, 2, 9, 11], 0)
     sh = parallel.merge_raw_sharded(raw)
     dense = parallel.merge_raw(raw)
-    assert sh["rows"] == (0, 4) and sh["bytes_sent"] == 0
-    assert torch.equal(sh["acc"], dense["acc"]) and torch.equal(sh["cell"], dense["cell"])
+    assert sh["rows"] == (0, 4) and sh["bytes_sent"] == 0 and sh["plan"] == "directory" and sh["part_rows"].numel() == 0
+    assert torch.equal(sh["w4"], dense["acc"][:, 4 + 2:]) and torch.equal(sh["cell"], dense["cell"])
+    assert torch.equal(sh["grid_feat"], (dense["acc"][:, :6] / dense["acc"][:, 6:7]).float())
 
 
 def test_sharding_helpers():
