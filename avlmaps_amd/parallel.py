@@ -914,10 +914,19 @@ def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: 
     torch.cuda.synchronize()
     glock = _SharedGpuLock.get()
     glock.acquire()                             # (a no-op unless several ranks share one GPU in a rehearsal)
+    prof = None
+    if timings is not None and os.environ.get("AVLMAPS_MERGE_PROFILE") == str(rank_world(group)[0]):
+        from torch.profiler import ProfilerActivity, profile      # developer aid: where a rank's host + device time goes
+        prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
+        prof.__enter__()
     try:
         return _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_to, status, glock)
     finally:
         glock.release()
+        if prof is not None:
+            import sys
+            prof.__exit__(None, None, None)
+            print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40), file=sys.stderr, flush=True)
 
 
 def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_to, status, glock):
