@@ -52,6 +52,13 @@ class VLMapBuilder:
                                                    # extractor must hand out a NEW feature tensor per frame (LSeg on PyTorch
                                                    # does; one that refills a single buffer would be read one frame late)
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
+        self.stage_frames = True                   # with prefetch_frames > 0: depth / rgb / sample lists travel through page-locked
+                                                   # buffers on a copy stream (device.FrameStager) instead of three pageable,
+                                                   # synchronous copies per frame on the fusing thread
+        self.skip_busy_checkpoints = True          # a periodic checkpoint that comes due while the previous one is still being
+                                                   # written is skipped (the next one carries its rows): the build is never
+                                                   # throttled to the disk's speed; the final save always happens.  False = every
+                                                   # save_every frames like upstream, waiting for the writer if need be
         self.skip_mapped_frames = False            # True: a resumed run skips the frames listed in the map file's
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
         self.incremental_checkpoints = True        # periodic saves write only the rows that changed + the new rows
@@ -109,7 +116,9 @@ class VLMapBuilder:
             if lib is not None:
                 key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
                 pos = C.c_int(int(st[2]))
-                scratch = np.empty(n_pix, np.int32)
+                scratch = _SCRATCH.__dict__.get("buf")          # per thread: a fresh 3 MB array per frame is 0.2 ms of page faults
+                if scratch is None or scratch.shape[0] < n_pix:
+                    scratch = _SCRATCH.buf = np.empty(n_pix, np.int32)
                 out = np.empty((n_pix + depth_sample_rate - 1) // depth_sample_rate, np.int32)
                 _lib.check(lib.avl_mt19937_shuffle_sample(key.ctypes.data, C.byref(pos), int(n_pix), int(depth_sample_rate),
                                                           scratch.ctypes.data, out.ctypes.data), "avl_mt19937_shuffle_sample")
@@ -162,13 +171,19 @@ class VLMapBuilder:
         depth = load_depth_npy(self.depth_paths[frame_i])
         return rgb, depth
 
-    def _frame_stream(self, lo: int, hi: int, depth_sample_rate: int, skip_shuffles: int = 0):
-        """(frame_i, rgb, depth, samples) in frame order; before the first frame is sampled the RNG is advanced past
-        `skip_shuffles` frames (skip_pixel_shuffles).  With prefetch_frames > 0 the PNG / npy decoding of the next
-        frames runs on host threads and ONE sampler thread draws the pixel shuffles, strictly in frame order, so the
-        global NumPy RNG is consumed exactly as in the reference loop (vlmap_builder.py:275-277) - provided nothing else
-        draws from np.random while the map is being built (upstream's loop does not).  Pillow, np.load and
-        np.random.shuffle release the GIL, so all of this overlaps with the GPU work of the current frame."""
+    def _frame_stream(self, lo: int, hi: int, depth_sample_rate: int, skip_shuffles: int = 0, stage: bool = False):
+        """(frame_i, rgb, depth, samples, staged) in frame order; before the first frame is sampled the RNG is advanced past
+        `skip_shuffles` frames (skip_pixel_shuffles).  With prefetch_frames > 0 three kinds of host threads keep the fusing
+        thread fed (a frame was 22 us of kernels inside 1.5-3 ms of host work on one thread):
+          * a pool decodes the PNG / npy files of the next frames;
+          * ONE sampler thread draws the pixel lists strictly in frame order, so the global NumPy RNG is consumed exactly as
+            in the reference loop (vlmap_builder.py:275-277) - provided nothing else draws from np.random while the map is
+            being built (upstream's loop does not).  It does nothing else: the reference's shuffle is the one inherently serial
+            stage (2 ms per 720x1080 frame), everything around it overlaps with it;
+          * (stage=True) ONE stager thread copies depth / rgb / samples into page-locked slots and starts their asynchronous
+            transfer on a copy stream (device.FrameStager); `staged` then carries device views + the event the fusing stream
+            waits for.  staged is None otherwise (the arrays are copied synchronously by the fusing thread, as before).
+        Pillow, np.load, the shuffle (host C) and large NumPy copies release the GIL."""
         n = int(self.prefetch_frames or 0)
         if self.pixel_sampling not in ("reference", "uniform"):
             raise ValueError(f"pixel_sampling must be 'reference' or 'uniform', not {self.pixel_sampling!r}")
@@ -181,19 +196,29 @@ class VLMapBuilder:
                 if i == lo and skip_shuffles:
                     self._announce_skip(skip_shuffles, depth.shape[0] * depth.shape[1])
                     self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
-                yield i, rgb, depth, self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate)
+                yield i, rgb, depth, self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate), None
             return
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor
-        out = queue.Queue(maxsize=n)
+        import time
+        st_ = self.pipeline_stats = dict(sampler_busy_s=0.0, stager_busy_s=0.0, fuse_thread_wait_s=0.0, frames=0)
+        sampled = queue.Queue(maxsize=n)                  # sampler -> stager (or straight to the consumer)
+        out = queue.Queue(maxsize=n) if stage else sampled
         stop = threading.Event()
+        stager = None
+        if stage:
+            from .. import _lib
+            from ..device import FrameStager
+            dev = _lib.current_device()
+            # slots: frames queued for the consumer + the one being staged + the one being fused + a batch held back for one launch
+            stager = self._stager = FrameStager(n + max(1, int(self.batch_frames or 1)) + 3, device=dev)
 
-        def put(item) -> bool:
+        def put(q, item) -> bool:
             """blocking put that gives up once the consumer has gone (never blocks forever on a full queue)"""
             while not stop.is_set():
                 try:
-                    out.put(item, timeout=0.1)
+                    q.put(item, timeout=0.1)
                     return True
                 except queue.Full:
                     continue
@@ -211,26 +236,57 @@ class VLMapBuilder:
                     if i == lo and skip_shuffles:
                         self._announce_skip(skip_shuffles, depth.shape[0] * depth.shape[1])
                         self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
-                    if not put((i, rgb, depth, self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate))):
+                    t_ = time.perf_counter()
+                    smp = self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate)
+                    st_["sampler_busy_s"] += time.perf_counter() - t_
+                    if not put(sampled, (i, rgb, depth, smp, None)):
                         return
-                put(None)
+                put(sampled, None)
             except BaseException as e:     # surfaced on the consuming thread
-                put(e)
+                put(sampled, e)
+
+        def stage_frames():
+            try:
+                from .. import _lib
+                _lib.set_device(dev)       # HIP keeps the current device per thread
+                while not stop.is_set():
+                    try:
+                        item = sampled.get(timeout=0.1)
+                    except queue.Empty:
+                        continue
+                    if item is None or isinstance(item, BaseException):
+                        put(out, item)
+                        return
+                    i, rgb, depth, samples, _ = item
+                    t_ = time.perf_counter()
+                    sf = stager.stage(depth, rgb, samples)
+                    st_["stager_busy_s"] += time.perf_counter() - t_
+                    if not put(out, (i, rgb, depth, samples, sf)):
+                        return
+            except BaseException as e:
+                put(out, e)
 
         with ThreadPoolExecutor(max_workers=min(n, 8), thread_name_prefix="avl-frame") as ex:
-            th = threading.Thread(target=sampler, args=(ex,), name="avl-sampler", daemon=True)
-            th.start()
+            threads = [threading.Thread(target=sampler, args=(ex,), name="avl-sampler", daemon=True)]
+            if stage:
+                threads.append(threading.Thread(target=stage_frames, name="avl-stager", daemon=True))
+            for th in threads:
+                th.start()
             try:
                 while True:
+                    t_ = time.perf_counter()
                     item = out.get()
+                    st_["fuse_thread_wait_s"] += time.perf_counter() - t_
                     if item is None:
                         break
                     if isinstance(item, BaseException):
                         raise item
+                    st_["frames"] += 1
                     yield item
             finally:
                 stop.set()
-                th.join()
+                for th in threads:
+                    th.join()
 
     def _init_lseg(self):
         """Reference: vlmap_builder.py:226-264 builds LSegEncNet from demo_e200.ckpt.  The model is not part of this
@@ -299,7 +355,13 @@ class VLMapBuilder:
         mapped_iter_set = set()
         pending = []
         rounds_done = 0
-        for frame_i, rgb, depth, samples in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip):
+        import time
+        stage = bool(self.stage_frames and (self.prefetch_frames or 0) > 0)
+        self._stager = None
+        self.pipeline_stats = {}
+        self.build_times = dict(checkpoints_on_fusing_thread_s=0.0, checkpoints=0)
+        t_loop = time.perf_counter()
+        for frame_i, rgb, depth, samples, staged in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip, stage=stage):
             if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
                 continue        # the pixel shuffle of the skipped frame was still drawn, so later frames sample as upstream
             feat = self._features_hwc(rgb)
@@ -321,19 +383,30 @@ class VLMapBuilder:
                     # ranks: the replay state is chained through the ranks in frame order, parallel.merge_accumulator)
                     npix = depth.shape[0] * depth.shape[1]
                     acc.enable_replay_log((hi - lo) * ((npix + depth_sample_rate - 1) // depth_sample_rate))
+            if staged is not None:
+                # the frame's arrays are already on their way to the device (page-locked slot, copy stream): the fusing stream
+                # waits for them on the device, the host does not
+                self._stager.acquire(staged)
+                depth, samples, rgb = staged.depth, staged.samples, staged.rgb
             if self.batch_frames > 1:
-                pending.append((frame_i, depth, samples, feat, rgb))
+                pending.append((frame_i, depth, samples, feat, rgb, staged))
                 if len(pending) >= self.batch_frames:
                     self._flush(acc, pending, calib_mat, calib_inv, transforms)
             else:
                 acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
                                     calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,
                                     sigma_sq=self.sigma_sq)
+                if staged is not None:
+                    self._stager.release(staged)          # depth / rgb / samples are read by this launch only (features: deferred)
             mapped_iter_set.add(frame_i)
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
-                print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
+                t_ck = time.perf_counter()
+                if not (self.skip_busy_checkpoints and getattr(self, "_save_thread", None) is not None and self._save_thread.is_alive()):
+                    print(f"Temporarily saving {acc.num_voxels()} features at iter {frame_i}...")
                 self._checkpoint(acc, mapped_iter_set)
+                self.build_times["checkpoints_on_fusing_thread_s"] += time.perf_counter() - t_ck
+                self.build_times["checkpoints"] += 1
             elif ws > 1 and self.save_every and (frame_i - lo) % self.save_every == self.save_every - 1 and rounds_done < rounds_total:
                 # upstream saves every 100 frames (vlmap_builder.py:181-183); with several ranks a checkpoint is a merge, i.e. a
                 # collective: every rank joins round j after its (j + 1) * save_every-th frame (or at the end of its shard)
@@ -352,10 +425,18 @@ class VLMapBuilder:
             if not mapped_iter_set and self.exact_rgb:
                 acc.enable_replay_log(1)
         self._flush(acc, pending, calib_mat, calib_inv, transforms)
+        if self._stager is not None:
+            self._stager.close()                       # waits for the launches that still read its slots
+            self._stager = None
         while ws > 1 and rounds_done < rounds_total:      # a short (or empty) shard: the checkpoint rounds the others still run
             self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=False)
             rounds_done += 1
+        acc.flush()
+        acc.num_voxels()                                  # (synchronises: the frame loop's device work ends here)
+        t_fin = time.perf_counter()
+        self.build_times.update(frame_loop_s=t_fin - t_loop, checkpoints_skipped=getattr(self, "checkpoints_skipped", 0), **self.pipeline_stats)
         self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
+        self.build_times["final_save_s"] = time.perf_counter() - t_fin
 
     def _flush(self, acc, pending, calib_mat, calib_inv, transforms):
         """fuse the buffered frames (consecutive indices, equal shapes) with one launch pair"""
@@ -368,9 +449,12 @@ class VLMapBuilder:
                                 [p[3] for p in pending], [p[4] for p in pending], frame_idx0=i0, calib_inv=calib_inv,
                                 min_depth=self.min_depth, max_depth=self.max_depth, sigma_sq=self.sigma_sq)
         else:
-            for fi, depth, samples, feat, rgb in pending:
+            for fi, depth, samples, feat, rgb, _st in pending:
                 acc.integrate_frame(depth, calib_mat, transforms[fi], samples, feat, rgb, frame_idx=fi, calib_inv=calib_inv,
                                     min_depth=self.min_depth, max_depth=self.max_depth, sigma_sq=self.sigma_sq)
+        for p in pending:
+            if p[5] is not None:
+                self._stager.release(p[5])
         pending.clear()
 
     def create_camera_map(self):
@@ -505,6 +589,10 @@ class VLMapBuilder:
         host mirror of the map and the file): at 2 M voxels a full copy costs 0.3-0.5 s on this thread, as much as the feature
         extractor needs for the 100 frames between two checkpoints."""
         from ..utils import h5lite
+        prev = getattr(self, "_save_thread", None)
+        if background and self.skip_busy_checkpoints and prev is not None and prev.is_alive():
+            self.checkpoints_skipped = getattr(self, "checkpoints_skipped", 0) + 1
+            return
         self._join_save()
         writer = getattr(self, "_map_writer", None)
         lean_ok = (self.incremental_checkpoints and h5lite.available() and writer is not None and writer.n_saved is not None
@@ -574,6 +662,11 @@ class VLMapBuilder:
             self._save_thread.start()
         else:
             write()
+
+
+import threading as _threading
+
+_SCRATCH = _threading.local()
 
 
 class _RanksAborted(RuntimeError):

@@ -315,7 +315,9 @@ class VoxelAccumulator:
         q.append((ev, keeps))
         while len(q) > 4:
             old_ev, _old = q.pop(0)
-            _lib.check(lib.avl_event_sync(old_ev), "avl_event_sync")      # the launches that read _old have completed
+            # the launches that read _old must have completed: its own launch -- or, with deferred fuse, the NEXT one, which
+            # fuses that frame's features (an event later in the stream covers the earlier one)
+            _lib.check(lib.avl_event_sync(q[0][0] if getattr(self, "_deferred", False) else old_ev), "avl_event_sync")
             free.append(old_ev)
 
     def _calib_pair(self, calib, calib_inv):
@@ -332,6 +334,7 @@ class VoxelAccumulator:
 
     def set_deferred_fuse(self, on, stream=None):
         _lib.check(_lib.load().avl_builder_set_deferred_fuse(self._h, int(bool(on)), stream), "avl_builder_set_deferred_fuse")
+        self._deferred = bool(on)
         return self
 
     def flush(self, stream=None):

@@ -78,6 +78,9 @@ def merge_windows(outputs, plan: WindowPlan):
     from .. import _lib
     from ..device import torch_stream_ptr
     G, D = int(outputs.shape[0]), int(outputs.shape[1])
+    if G > 64:
+        raise ValueError(f"{G} sliding windows per frame: avl_lseg_merge_windows takes at most 64 (a 480-pixel window grid over an image "
+                         "whose long side is resized to 520 has 1-2); use a larger crop_size")
     if outputs.dtype not in (torch.float32, torch.float16):
         outputs = outputs.float()
     outputs = outputs.contiguous()
@@ -92,13 +95,15 @@ def get_lseg_feat(model, image: np.ndarray, labels, transform, device, crop_size
                   norm_mean=(0.5, 0.5, 0.5), norm_std=(0.5, 0.5, 0.5), vis=False, channels_last=True, window_batch_size=None):
     """image (H, W, 3) uint8 -> pixel embeddings on `device`: (Hf, Wf, D) float32 if channels_last (default), else the
     reference layout (1, D, Hf, Wf).  Reference: lseg_utils.py:20-119 (the logits / visualisation branch is not part of the
-    map-building path).  window_batch_size: windows per model call (default: all windows of the frame in one call)."""
+    map-building path).  window_batch_size: windows per model call; default: all windows of the frame in one call up to 8 (the
+    reference's shapes have 1-2 windows; activation memory grows with the batch, so larger grids go in chunks of 8 -- the merge
+    arithmetic is the same bits either way, the model's own kernels may round a batched call differently from single calls)."""
     import torch
     img = (transform or default_transform)(image).unsqueeze(0).to(device)
     plan = WindowPlan.make(int(img.shape[2]), int(img.shape[3]), int(crop_size), int(base_size))
     with torch.no_grad():
         batch = window_batch(img, plan, norm_mean, norm_std)
-        step = int(window_batch_size or batch.shape[0])
+        step = int(window_batch_size or min(int(batch.shape[0]), 8))
         outs = [model(batch[i:i + step], labels)[0] for i in range(0, batch.shape[0], step)]
         outputs = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         feat = merge_windows(outputs, plan)

@@ -789,8 +789,15 @@ def run_pipeline_probe(torch, frames=300):
             with contextlib.redirect_stdout(io.StringIO()):          # "Temporarily saving ..." lines of the checkpoints
                 b.create_mobile_base_map()
             dt = time.perf_counter() - t0
+            bt = dict(b.build_times)
             res[f"{sampling}_pixel_sampling"] = dict(frames_per_s=frames / dt, ms_per_frame=1e3 * dt / frames,
-                                                     voxels=int(len(b.last_map["grid_pos"])), checkpoints=len(b._map_writer.stats))
+                                                     voxels=int(len(b.last_map["grid_pos"])), checkpoints=len(b._map_writer.stats),
+                                                     # the frame loop alone (decode queue, sampling, pinned staging, kernels, the periodic
+                                                     # checkpoints' share of the fusing thread) and the final save of the whole map
+                                                     frame_loop_frames_per_s=frames / bt["frame_loop_s"], final_save_s=bt["final_save_s"],
+                                                     checkpoints_skipped_writer_busy=bt.get("checkpoints_skipped", 0),
+                                                     host_threads={k: bt.get(k) for k in ("sampler_busy_s", "stager_busy_s", "fuse_thread_wait_s",
+                                                                                          "checkpoints_on_fusing_thread_s")})
     res["what"] = (f"VLMapBuilder.create_mobile_base_map over {frames} in-memory 720x1080 frames, free feature extractor, checkpoints every "
                    "100 frames, one process; reference sampling = the permutation np.random.shuffle(arange(H*W)) draws per frame from the global RNG "
                    "(serial; computed by the library's host C code, NumPy's samples and RNG state)")

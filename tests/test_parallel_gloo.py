@@ -292,8 +292,8 @@ def test_frame_stream_skips_and_never_hangs_on_a_full_queue(tmp_path):
         np.random.seed(5)
         got = list(b._frame_stream(4, 8, rate, skip_shuffles=4))
         assert [g[0] for g in got] == [4, 5, 6, 7]
-        for i, _, depth, s in got:
-            assert depth[0, 0] == i and np.array_equal(s, whole[i])
+        for i, _, depth, s, staged in got:
+            assert depth[0, 0] == i and np.array_equal(s, whole[i]) and staged is None
     b.prefetch_frames = 1
     before = threading.active_count()
     gen = b._frame_stream(0, n, rate)

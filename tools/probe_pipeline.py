@@ -54,6 +54,9 @@ for sampling, deferred, save_every in CASES:
         nv = len(b.last_map["grid_pos"])
         print(f"pixel_sampling={sampling:9s} deferred_fuse={deferred!s:5s} save_every={save_every:3d}: {n / dt:7.1f} frames/s ({1e3 * dt / n:.2f} ms/frame), {nv} voxels, "
               f"{len(b._map_writer.stats)} saves", flush=True)
+        bt = b.build_times
+        print("   frame loop %.1f frames/s; final save %.3f s; %s" % (n / bt["frame_loop_s"], bt["final_save_s"],
+              {k: round(v, 3) if isinstance(v, float) else v for k, v in bt.items() if k not in ("frame_loop_s", "final_save_s")}), flush=True)
         if save_every and sampling == "uniform" and deferred:
             for st in b._map_writer.stats:
                 print("   save:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}, flush=True)
