@@ -41,7 +41,11 @@ def _stale(out: Path, deps) -> bool:
     return any(Path(d).stat().st_mtime > t for d in deps)
 
 
+LAST_BUILD = dict(compiled=[], reused=[], linked=False)      # what the last build() call actually did (checked by the driver's log)
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
+    force = force or os.environ.get("AVLMAPS_FORCE_BUILD") == "1"
     hipcc = _hipcc()
     LIBDIR.mkdir(exist_ok=True)
     objdir = PKG / "build"
@@ -67,8 +71,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
+    LAST_BUILD.update(compiled=[j[0] for j in jobs], reused=[s for s in srcs if s not in {j[0] for j in jobs}], linked=False)
     objs = [objdir / (Path(s).stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, objs):
+        LAST_BUILD["linked"] = True
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", str(LIB), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

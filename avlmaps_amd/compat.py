@@ -13,6 +13,10 @@ so `from avlmaps.utils.clip_utils import get_lseg_score` in avlmaps/map/vlmap.py
   avlmaps.utils.visualize_utils.pool_3d_label_to_2d      (visualize_utils.py:77-83)
   avlmaps.map.vlmap_builder.VLMapBuilder.create_mobile_base_map (vlmap_builder.py:54-185) -> builder kernels
   avlmaps.map.map.Map.generate_obstacle_map / generate_rgb_topdown_map (map.py:79-95, :106-113) -> top-down scatter kernels
+  avlmaps.robot.habitat_lang_robot.HabitatLanguageRobot.get_vl_distribution_map_3d (habitat_lang_robot.py:242-265) -> heat kernels
+      (only if that module is already imported -- it needs habitat_sim -- and only for a robot whose map holds grid_pos: the
+      navigator's own decay loop never calls get_heatmap_from_mask_3d; upstream it indexes a Python list -- global_pc comes
+      from grid_id2base_pos_3d_batch, mapping_utils.py:369-376 -- so the adapter is for the day that is fixed)
 
 The upstream objects keep their classes, attributes and files (vlmaps.h5df): VLMap / AVLMap / the Habitat navigator run
 unchanged on top.  CLIP text encoding and LSeg stay the upstream PyTorch models.
@@ -71,6 +75,27 @@ def _map_adapters():
     return dict(generate_obstacle_map=generate_obstacle_map, generate_rgb_topdown_map=generate_rgb_topdown_map)
 
 
+def _navigator_adapter(module):
+    def get_vl_distribution_map_3d(self, name: str, decay_rate: float = 0.1):
+        """avlmaps.robot.habitat_lang_robot.HabitatLanguageRobot.get_vl_distribution_map_3d on the heat kernels: per voxel
+        clip(1 - (distance to the nearest voxel of category `name` in CELLS) * decay_rate, 0, 1), 1 on the category's own voxels
+        (upstream divides metre distances of global_pc = grid_pos * cs by cs: distances in cells, habitat_lang_robot.py:252-256)"""
+        import numpy as np
+        from . import ops
+        predict = np.argmax(self.map.scores_mat, axis=1)
+        i = module.find_similar_category_id(name, self.map.categories)
+        sim = predict == i
+        heat = ops.heatmap_from_mask(np.ascontiguousarray(self.map.grid_pos, dtype=np.int32), sim, 1.0, decay_rate).astype(np.float32)
+        cfg = getattr(self, "config", None)
+        try:
+            if cfg is not None and cfg["nav"]["vis"]:
+                self._vis_dist_map_3d(heat[:, None], name=name)
+        except (KeyError, TypeError):
+            pass
+        return heat
+    return get_vl_distribution_map_3d
+
+
 def install(upstream: str = "avlmaps") -> Dict[str, int]:
     """Patch the upstream package (must be importable).  Returns {patched name: number of references re-pointed}."""
     if upstream in _INSTALLED:
@@ -121,6 +146,13 @@ def install(upstream: str = "avlmaps") -> Dict[str, int]:
                 counts[f"map.map.Map.{name}"] = 1
     except Exception:
         pass
+    nav = sys.modules.get(f"{upstream}.robot.habitat_lang_robot")       # never imported from here: it pulls in habitat_sim
+    cls = getattr(nav, "HabitatLanguageRobot", None) if nav is not None else None
+    if cls is not None and "get_vl_distribution_map_3d" in cls.__dict__ and hasattr(nav, "find_similar_category_id"):
+        old = cls.__dict__["get_vl_distribution_map_3d"]
+        setattr(cls, "get_vl_distribution_map_3d", _navigator_adapter(nav))
+        log.append((cls, "get_vl_distribution_map_3d", old))
+        counts["robot.habitat_lang_robot.HabitatLanguageRobot.get_vl_distribution_map_3d"] = 1
     _INSTALLED[upstream] = log
     return counts
 

@@ -1257,3 +1257,36 @@ def global_top1(best_val: "torch.Tensor", best_row: "torch.Tensor", row_offset: 
     vmax = V.max(dim=0).values
     cand = torch.where(V == vmax[None, :], I, torch.full_like(I, I64_MAX))
     return vmax, cand.min(dim=0).values
+
+
+def global_topk(vals: "torch.Tensor", rows: "torch.Tensor", row_offset: int, k: int, group=None):
+    """Per-query k best voxels over row shards ("allgather of k * Q candidates"): vals / rows (Q, k_local) = this
+    rank's candidates per query (k_local <= k; e.g. ops.topk_f32 per query column), local row indices; returns (values (Q, k),
+    global rows (Q, k)) ordered like np.argsort(-v, kind="stable") over the whole map: descending value, ties by ascending global
+    row (ranks hold ascending row blocks), NaN last.  Missing candidates (fewer than k voxels) are (-inf, -1).  The exchange is
+    k * Q (value, row) pairs per rank -- never features."""
+    import torch
+    vals = vals.to(torch.float64) if vals.dtype == torch.float64 else vals.float()
+    Q, kl = int(vals.shape[0]), int(vals.shape[1])
+    g_rows = rows.to(torch.int64) + int(row_offset)
+    pad = max(0, int(k) - kl)
+    if pad:
+        vals = torch.cat([vals, torch.full((Q, pad), float("-inf"), dtype=vals.dtype, device=vals.device)], dim=1)
+        g_rows = torch.cat([g_rows, torch.full((Q, pad), -1, dtype=torch.int64, device=vals.device)], dim=1)
+    vals, g_rows = vals[:, :k].contiguous(), g_rows[:, :k].contiguous()
+    if _dist_on(group):
+        coll = _Coll(group)
+        vals = torch.cat(coll.all_gather(vals), dim=1)                      # (Q, ws * k)
+        g_rows = torch.cat(coll.all_gather(g_rows), dim=1)
+    # order: value descending with NaN last, then global row ascending; padding (-inf, -1) sorts behind every real candidate
+    key_v = torch.where(torch.isnan(vals), torch.full_like(vals, float("-inf")), vals)
+    is_pad = g_rows < 0
+    big = torch.iinfo(torch.int64).max
+    r_key = torch.where(is_pad, torch.full_like(g_rows, big), g_rows)
+    nan_last = torch.isnan(vals) | is_pad
+    # lexicographic sort by (nan_last asc, value desc, row asc): three stable sorts, least significant key first
+    order = torch.argsort(r_key, dim=1, stable=True)
+    order = order.gather(1, torch.argsort(key_v.gather(1, order), dim=1, descending=True, stable=True))
+    order = order.gather(1, torch.argsort(nan_last.gather(1, order).to(torch.int8), dim=1, stable=True))
+    order = order[:, :k]
+    return vals.gather(1, order), g_rows.gather(1, order)

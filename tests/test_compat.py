@@ -30,8 +30,17 @@ def _fake_upstream(tmp_path, name):
     (root / "map" / "vlmap.py").write_text(f"from {name}.utils.clip_utils import get_lseg_score\n"
                                            f"from {name}.utils.index_utils import get_dynamic_obstacles_map_3d\n")
     (root / "map" / "avlmap.py").write_text(f"from {name}.utils.visualize_utils import get_heatmap_from_mask_3d\n")
+    (root / "robot").mkdir(exist_ok=True)
+    (root / "robot" / "__init__.py").write_text("")
+    (root / "robot" / "habitat_lang_robot.py").write_text(textwrap.dedent("""
+        def find_similar_category_id(name, categories):
+            return categories.index(name)
+        class HabitatLanguageRobot:
+            def get_vl_distribution_map_3d(self, name, decay_rate=0.1):
+                return 'upstream-decay-loop'
+    """))
     sys.path.insert(0, str(tmp_path))
-    for m in ("map.vlmap", "map.avlmap", "map.vlmap_builder"):
+    for m in ("map.vlmap", "map.avlmap", "map.vlmap_builder", "robot.habitat_lang_robot"):
         importlib.import_module(f"{name}.{m}")
 
 
@@ -55,7 +64,12 @@ def test_install_repoints_every_reference_and_uninstall_restores(tmp_path):
         assert vu.pool_3d_label_to_2d is visualize_utils.pool_3d_label_to_2d
         assert vb.VLMapBuilder.create_mobile_base_map.__doc__.startswith("avlmaps.map.vlmap_builder.VLMapBuilder.create_mobile_base_map")
         assert counts["utils.clip_utils.get_lseg_score"] == 2 and compat.install(name) == {}
+        # the navigator's inline decay loop (habitat_lang_robot.py:242-265) is re-pointed when its module is loaded
+        rb = sys.modules[f"{name}.robot.habitat_lang_robot"]
+        assert counts["robot.habitat_lang_robot.HabitatLanguageRobot.get_vl_distribution_map_3d"] == 1
+        assert "heat kernels" in rb.HabitatLanguageRobot.get_vl_distribution_map_3d.__doc__
         compat.uninstall(name)
+        assert rb.HabitatLanguageRobot().get_vl_distribution_map_3d("x") == "upstream-decay-loop"
         assert cu.get_lseg_score() == "upstream-score" and vl.get_lseg_score() == "upstream-score"
         assert iu.get_lseg_score() == "upstream-score-dup" and av.get_heatmap_from_mask_3d() == "upstream-heat"
         assert vb.VLMapBuilder().create_mobile_base_map() == "upstream-build"

@@ -156,6 +156,26 @@ def test_map_file_is_the_reference_hdf5_layout(tmp_path):
         assert np.array_equal(dumped("occupied_ids"), arrays["occupied_ids"].ravel())
         np.testing.assert_allclose(dumped("weight"), arrays["weight"], rtol=1e-5)
         np.testing.assert_allclose(dumped("grid_feat").reshape(n, D), arrays["grid_feat"], rtol=1e-5, atol=1e-7)
+    # the navigator reads the file with h5py (mapping_utils.py:508-541): the first box that has it proves the interop for real --
+    # also for a file written through the HDF5 C library (h5lite), which is what this image's builder produces
+    try:
+        import h5py
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(p, "r") as f:
+            assert sorted(f.keys()) == sorted(mu.MAP_DATASETS + ("init_height_id",))
+            assert f["mapped_iter_list"][:].tolist() == [1, 3, 4] and int(f["init_height_id"][()]) == 7
+            for k in ("grid_feat", "grid_pos", "weight", "occupied_ids", "grid_rgb"):
+                assert np.array_equal(f[k][:], arrays[k]) and f[k].dtype == arrays[k].dtype, k
+        if h5lite.available():
+            p2 = tmp_path / "via_h5lite.h5df"
+            with h5lite.H5File(p2, "w") as g:
+                for k, v in arrays.items():
+                    g.create_dataset(k, v)
+            with h5py.File(p2, "r") as f:
+                for k, v in arrays.items():
+                    assert np.array_equal(f[k][:], v), k
 
 
 def test_h5lite_extendible_datasets_and_foreign_files(tmp_path):

@@ -109,6 +109,19 @@ def _worker(rank, ws, port, tmpdir):
     rows = torch.tensor([[3, 1, 2], [0, 4, 9]])[rank]
     v, i = parallel.global_top1(vals, rows, row_offset=100 * rank)
     assert v.tolist() == [4.0, 5.0, 2.0] and i.tolist() == [100, 1, 2]
+    # row-sharded per-query top-k: k * Q candidates per rank; order = np.argsort(-v, kind="stable") of the whole map
+    whole = np.array([[0.5, 3.0, 3.0, np.nan, 1.0, 3.0, -1.0, 2.0], [1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0]], np.float32)     # (Q, N)
+    lo, hi = parallel.shard_rows(8, rank, ws)
+    loc = torch.from_numpy(whole[:, lo:hi])
+    lv, li = [], []
+    for qrow in loc:                                # local top-3 per query, stable, NaN last (what ops.topk_f32 returns)
+        o = np.argsort(-np.where(np.isnan(qrow.numpy()), -np.inf, qrow.numpy()), kind="stable")[:3]
+        lv.append(qrow[o])
+        li.append(torch.from_numpy(o))
+    gv, gi = parallel.global_topk(torch.stack(lv), torch.stack(li), lo, 3)
+    want = [np.argsort(-np.where(np.isnan(w), -np.inf, w), kind="stable")[:3] for w in whole]
+    assert gi.tolist() == [w.tolist() for w in want], gi
+    assert gv[0].tolist() == [3.0, 3.0, 3.0] and gv[1].tolist() == [1.0, 1.0, 1.0]
     Path(tmpdir, f"ok{rank}").write_text("ok")
     dist.barrier()
     dist.destroy_process_group()
