@@ -93,6 +93,7 @@ _SIGS = {
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),
     "avl_replay_state_apply": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_rows_add_f64": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "avl_rows_add_f64_async": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "avl_builder_export_rows_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "avl_builder_export_rows_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "avl_finalize_side": (C.c_int, [_i64, _i64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

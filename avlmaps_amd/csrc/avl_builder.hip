@@ -1192,9 +1192,27 @@ int avl_builder_destroy(avl_builder* b) {
     return AVL_OK;
 }
 
+// The finalisation / replay / merge paths take their temporaries from the device's default stream-ordered pool (hipMallocAsync).
+// HIP's default release threshold is 0: every synchronisation hands the pool's memory back to the driver and the next call maps
+// it again -- tens of ms per GB, which showed as 30-60 ms of "allocation" inside a 30 ms merge (profiles/r04_build_8ranks_*).
+// Keep what the pool has grown to (bounded by what one finalisation needs); once per device and process.
+static void keep_mempool_once() {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || done_for == dev) return;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    done_for = dev;
+}
+
 int avl_builder_create_grid(avl_builder** h_out, int n0, int gs, int vh, double cs, int D, int64_t capacity) {
     AVL_REQUIRE(h_out, "avl_builder_create: null output");
     *h_out = nullptr;
+    keep_mempool_once();
     AVL_REQUIRE(n0 > 0 && gs > 0 && vh > 0 && D > 0 && cs > 0 && capacity > 0, "avl_builder_create: bad parameters");
     const double ncell_d = (double)n0 * gs * vh;
     AVL_REQUIRE(ncell_d < 2.0e9, "avl_builder_create: gs*gs*vh = %.0f cells exceeds the int32 cell index", ncell_d);
@@ -1682,6 +1700,20 @@ int avl_rows_add_f64(int64_t n, int cols, const int64_t* d_rows, int64_t row0, i
     AVL_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     AVL_REQUIRE(h == 0, "avl_rows_add_f64: a row index lies outside [row0, row0 + nrows)");
+    return AVL_OK;
+}
+
+int avl_rows_add_f64_async(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src, int64_t ld_src,
+                           double* d_dst, int64_t ld_dst, int32_t* d_err_flag, void* stream) {
+    AVL_REQUIRE(n >= 0 && cols > 0 && nrows >= 0 && ld_src >= cols && ld_dst >= cols, "avl_rows_add_f64_async: bad shape");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_rows && d_src && d_dst && d_err_flag, "avl_rows_add_f64_async: null pointer");
+    int64_t blocks = (n + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(rows_add_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n, cols, d_rows, row0, nrows, d_src, ld_src,
+                       d_dst, ld_dst, reinterpret_cast<int*>(d_err_flag));
+    AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
 

@@ -152,26 +152,40 @@ class _Coll:
         if t.is_cuda:
             import torch
             torch.cuda.synchronize()
-        self._relock = self.gpu_lock.held
-        self.gpu_lock.release(device_sync=False)          # a rank waiting for its peers does not keep the shared GPU
+        self._lw_tic = self.gpu_lock.wait_s
         return time.perf_counter()
+
+    def _net(self):
+        """context of the pure network part of a collective: a rank waiting for its peers does not keep the shared GPU of a
+        one-GPU rehearsal (_SharedGpuLock); the device staging copies around it (gloo only) stay inside the lock, so that no rank
+        ever computes while another one's copies are on the device"""
+        coll = self
+
+        class _N:
+            def __enter__(self_n):
+                coll._relock = coll.gpu_lock.held
+                coll.gpu_lock.release(device_sync=True)
+
+            def __exit__(self_n, *a):
+                if coll._relock:
+                    coll.gpu_lock.acquire()
+        return _N()
 
     def _toc(self, t, t0, nbytes):
         import time
         if t.is_cuda:
             import torch
             torch.cuda.synchronize()
-        self.comm_s += time.perf_counter() - t0
+        self.comm_s += time.perf_counter() - t0 - (self.gpu_lock.wait_s - self._lw_tic)     # (waiting for the shared GPU is booked separately)
         self.bytes_out += int(nbytes)
         self.calls += 1
-        if self._relock:
-            self.gpu_lock.acquire()
 
     def all_gather(self, t):
         t0 = self._tic(t)
         h = self._h(t)
         out = [h.new_empty(h.shape) for _ in range(self.ws)]
-        self.dist.all_gather(out, h, group=self.group)
+        with self._net():
+            self.dist.all_gather(out, h, group=self.group)
         res = [o.to(t.device) for o in out]
         del out, h                              # host staging (gloo rehearsals) is released inside the timed bracket
         self._toc(t, t0, t.numel() * t.element_size() * (self.ws - 1))
@@ -180,7 +194,8 @@ class _Coll:
     def all_reduce(self, t, op):
         t0 = self._tic(t)
         h = self._h(t)
-        self.dist.all_reduce(h, op=op, group=self.group)
+        with self._net():
+            self.dist.all_reduce(h, op=op, group=self.group)
         if h is not t:
             t.copy_(h)
         del h
@@ -190,7 +205,8 @@ class _Coll:
     def reduce(self, t, dst, op):
         t0 = self._tic(t)
         h = self._h(t)
-        self.dist.reduce(h, dst=dst, op=op, group=self.group)
+        with self._net():
+            self.dist.reduce(h, dst=dst, op=op, group=self.group)
         if h is not t and self.rank == dst:
             t.copy_(h)
         del h
@@ -200,7 +216,8 @@ class _Coll:
     def broadcast(self, t, src):
         t0 = self._tic(t)
         h = self._h(t)
-        self.dist.broadcast(h, src=src, group=self.group)
+        with self._net():
+            self.dist.broadcast(h, src=src, group=self.group)
         if h is not t:
             t.copy_(h)
         del h
@@ -212,7 +229,8 @@ class _Coll:
         t0 = self._tic(inp)
         h = self._h(inp).contiguous()
         out = h.new_empty((int(sum(out_splits)),) + tuple(h.shape[1:]))
-        self.dist.all_to_all_single(out, h, [int(x) for x in out_splits], [int(x) for x in in_splits], group=self.group)
+        with self._net():
+            self.dist.all_to_all_single(out, h, [int(x) for x in out_splits], [int(x) for x in in_splits], group=self.group)
         res = out.to(inp.device)
         del out, h                              # gloo rehearsals: GBs of pageable staging are unmapped here, not on the rank's compute clock
         row_b = inp.element_size() * (int(inp.numel() // inp.shape[0]) if inp.shape[0] else 0)
@@ -222,14 +240,16 @@ class _Coll:
     def send(self, t, dst):
         t0 = self._tic(t)
         h = self._h(t).contiguous()
-        self.dist.send(h, dst=dst, group=self.group)
+        with self._net():
+            self.dist.send(h, dst=dst, group=self.group)
         del h
         self._toc(t, t0, t.numel() * t.element_size())
 
     def recv(self, t, src):
         t0 = self._tic(t)
         h = self._h(t)
-        self.dist.recv(h, src=src, group=self.group)
+        with self._net():
+            self.dist.recv(h, src=src, group=self.group)
         if h is not t:
             t.copy_(h)
         self._toc(t, t0, 0)
@@ -508,13 +528,19 @@ def _dir_owner(cell64, ws: int):
 
 
 class _Trace:
-    """AVLMAPS_MERGE_TRACE=1: wall time of every step of the merge on every rank (device synchronised at each mark), to stderr"""
+    """AVLMAPS_MERGE_TRACE=1: wall time of every step of the merge on every rank (device synchronised at each mark), to stderr;
+    with `coll` also the step's own time = wall minus what it spent inside collectives and waiting for a shared GPU"""
 
-    def __init__(self, what, dev):
+    def __init__(self, what, dev, coll=None):
         import time
         self.on = os.environ.get("AVLMAPS_MERGE_TRACE") == "1"
         self.cuda = getattr(dev, "type", str(dev)) == "cuda"
+        self.coll = coll
         self.what, self.t, self.marks, self.t_abs = what, time.perf_counter(), [], time.time()
+        self.busy = self._busy()
+
+    def _busy(self):
+        return (self.coll.comm_s + self.coll.gpu_lock.wait_s) if self.coll is not None else 0.0
 
     def __call__(self, label):
         if not self.on:
@@ -523,9 +549,10 @@ class _Trace:
         if self.cuda:
             import torch
             torch.cuda.synchronize()
-        t = time.perf_counter()
-        self.marks.append(f"{label} {1e3 * (t - self.t):.1f}")
-        self.t = t
+        t, b = time.perf_counter(), self._busy()
+        own = f" (own {1e3 * ((t - self.t) - (b - self.busy)):.1f})" if self.coll is not None else ""
+        self.marks.append(f"{label} {1e3 * (t - self.t):.1f}{own}")
+        self.t, self.busy = t, b
 
     def done(self, rank):
         if self.on:
@@ -685,7 +712,7 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     return plan
 
 
-def warm_up_merge(n: int = 1 << 20, device="cuda") -> None:
+def warm_up_merge(n: int = 1 << 20, device="cuda", D: int = 0, n_exchange: Optional[int] = None) -> None:
     """Run the tensor plumbing of a merge once, locally, at a realistic size.  torch loads the code objects of its sort / unique /
     scan kernels lazily, per process and per size class (a 30 k-voxel warm-up merge takes other sort kernels than a 1 M-voxel
     merge): ~1 s in a single process, and tens of seconds when 8 processes on one box load them at the same moment (seen in the
@@ -710,6 +737,11 @@ def warm_up_merge(n: int = 1 << 20, device="cuda") -> None:
     torch.where((plan.next < 0)[:, None], st, torch.zeros_like(st))
     idx = torch.nonzero(plan.prev == -1).reshape(-1)
     idx[torch.argsort(cell[idx])]
+    for m in (3, 40):                       # chain_replay's grouping: composite int64 keys over a subset of the slots
+        sub = torch.nonzero(rows % m == 0).reshape(-1)
+        sub = sub[torch.argsort(((rows[sub] % 7) << 32) | cell[sub].to(torch.int64))]
+        torch.bincount(rows[sub] % 7, minlength=8)
+        st[sub] = st[sub.flip(0)].contiguous()
     del ex
     if str(device).startswith("cuda"):
         torch.cuda.synchronize()
@@ -735,25 +767,36 @@ def chain_replay(plan: ShardPlan, cell: "torch.Tensor", replay_fn, tr=None) -> "
     tr('phase A (no lower rank)')
     if coll is None or ws == 1:
         return state
-    both = torch.stack([torch.bincount(plan.prev[plan.prev >= 0], minlength=ws)[:ws], torch.bincount(plan.next[plan.next >= 0], minlength=ws)[:ws]]).cpu()
+    # ONE sort per direction groups the shared voxels by neighbour rank, in cell order inside a group (the same order on both
+    # sides of a hop, so no indices travel); the per-rank lists are slices
+    def grouped(which):
+        idx = torch.nonzero(which >= 0).reshape(-1)
+        idx = idx[torch.argsort((which[idx] << 32) | cell[idx].to(i64))]
+        return idx, torch.bincount(which[idx], minlength=ws)[:ws]
+    idx_p, cnt_p = grouped(plan.prev)
+    idx_n, cnt_n = grouped(plan.next)
+    both = torch.stack([cnt_p, cnt_n]).cpu()
+    tr('group by neighbour')
     n_prev, n_next = both[0].tolist(), both[1].tolist()
-
-    def slots_of(which, r):
-        idx = torch.nonzero(which == r).reshape(-1)
-        return idx[torch.argsort(cell[idx])]
-    for p in range(rank):
-        if n_prev[p]:
-            idx = slots_of(plan.prev, p)
-            buf = torch.empty((n_prev[p], 3), dtype=i64, device=dev)
-            coll.recv(buf, p)
-            state[idx] = buf
+    if sum(n_prev):
+        buf = torch.empty((int(idx_p.shape[0]), 3), dtype=i64, device=dev)
+        o = 0
+        for p in range(rank):
+            if n_prev[p]:
+                coll.recv(buf[o:o + n_prev[p]], p)
+                o += n_prev[p]
+        state[idx_p] = buf
     tr('recv from prev ranks')
     if sum(n_prev):
         replay_fn(state, ~sel_a)
     tr('phase B (continued)')
-    for q in range(rank + 1, ws):
-        if n_next[q]:
-            coll.send(state[slots_of(plan.next, q)].contiguous(), q)
+    if sum(n_next):
+        out = state[idx_n].contiguous()
+        o = 0
+        for q in range(rank + 1, ws):
+            if n_next[q]:
+                coll.send(out[o:o + n_next[q]], q)
+                o += n_next[q]
     tr('send to next ranks')
     return state
 
@@ -938,6 +981,17 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
     st = torch_stream_ptr()
     dev = torch.device("cuda", torch.cuda.current_device())
     i64 = torch.int64
+    null_launch_us = None
+    if os.environ.get("AVLMAPS_MERGE_TRACE") == "1":
+        # what ONE tiny kernel launch costs in this set-up (a dedicated GPU: 4-6 us; eight processes taking turns on one GPU:
+        # 30-40 us -- the merge's tensor plumbing is a few hundred such launches, so this factor scales its compute time)
+        z = torch.zeros(8, device=dev)
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        for _ in range(64):
+            z.add_(1.0)
+        torch.cuda.synchronize()
+        null_launch_us = (time.perf_counter() - tq) / 64 * 1e6
     t0 = time.perf_counter()
     lw0 = glock.wait_s
     tr = _Trace('merge', dev)
@@ -997,7 +1051,7 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
         def replay_fn(stt, sel):
             idx = torch.where(sel, ar, minus).contiguous()
             _lib.check(lib.avl_builder_replay_chain(acc._h, n, idx.data_ptr(), plan.grow_key, stt.data_ptr(), st), "avl_builder_replay_chain")
-        state = chain_replay(plan, cell, replay_fn, tr2 := _Trace('replay', dev))
+        state = chain_replay(plan, cell, replay_fn, tr2 := _Trace('replay', dev, coll))
         state = torch.where((plan.next < 0)[:, None], state, torch.zeros_like(state))
         tr2('final mask')
         tr2.done(plan.rank)
@@ -1023,13 +1077,17 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
     # ---- owner side: fold what arrived into this rank's block of final rows
     n_own = ex.r1 - ex.r0
 
+    err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
     def rows_add(rows, src, dst):
         src = src.contiguous()
         rows = rows.contiguous()
-        _lib.check(lib.avl_rows_add_f64(int(rows.shape[0]), int(src.shape[1]), rows.data_ptr(), 0, int(dst.shape[0]), src.data_ptr(),
-                                        int(src.shape[1]), dst.data_ptr(), int(dst.shape[1]), st), "avl_rows_add_f64")
+        _lib.check(lib.avl_rows_add_f64_async(int(rows.shape[0]), int(src.shape[1]), rows.data_ptr(), 0, int(dst.shape[0]), src.data_ptr(),
+                                              int(src.shape[1]), dst.data_ptr(), int(dst.shape[1]), err_flag.data_ptr(), st), "avl_rows_add_f64_async")
     tr3 = _Trace('fold', dev)
     own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    if int(err_flag.item()):
+        raise RuntimeError("multi-rank merge: a received row index lies outside this rank's block of final rows")
     tr3('fold lists')
     out = dict(M=M, rows=(ex.r0, ex.r1), cell=own_cell,
                grid_feat=torch.empty((n_own, D), dtype=torch.float32, device=dev),
@@ -1080,7 +1138,7 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
         wall = {k: wall[k] - lockw[k] for k in wall}          # rehearsals on one GPU: waiting for the shared device is not merge time
         timings.update(mode="row-sharded all_to_all", plan="directory (nothing O(M) per rank; mixed float32 / float64 payload; point-to-point replay)",
                        plan_s=wall["plan"], scatter_s=wall["export"], replay_chain_s=wall["replay_chain"], exchange_s=wall["exchange"],
-                       accumulate_s=wall["fold_finalize"], finalize_s=0.0, gather_s=wall["gather"], wall_s=wall, in_collectives_s=comm, shared_gpu_wait_s=sum(lockw.values()),
+                       accumulate_s=wall["fold_finalize"], finalize_s=0.0, gather_s=wall["gather"], null_launch_us=null_launch_us, wall_s=wall, in_collectives_s=comm, shared_gpu_wait_s=sum(lockw.values()),
                        compute_s={k: wall[k] - comm[k] for k in wall},
                        compute_total_s=sum(wall[k] - comm[k] for k in wall if k != "gather"),
                        in_collectives_total_s=sum(comm[k] for k in comm if k != "gather"),

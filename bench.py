@@ -679,7 +679,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     # lazily created point-to-point communicators and the allocator's first large blocks (tens to hundreds of ms, once)
     mode = getattr(args, "merge_mode", "sharded")
     if ws > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1":
-        parallel.warm_up_merge(1 << 20)                                  # torch's large-size sort / unique code objects (lazy, per process)
+        # torch's large-size sort / unique code objects (lazy, per process) and the allocator's first exchange-sized blocks
+        parallel.warm_up_merge(1 << 20, D=D, n_exchange=cap)
     if ws > 1:
         merge_ranks(parallel, acc, mode, exact_rgb)                      # every rank, also one without warm-up frames
     elif warmup:
@@ -718,7 +719,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         dist.all_gather_object(per_rank, {k: tim.get(k) for k in ("bytes_sent_per_rank", "payload_bytes_sent", "payload_bytes_fp64_form", "rows_sent",
                                                                      "local_voxels", "own_rows", "single_rank_voxels", "shared_voxels_local",
                                                                      "directory_entries", "compute_total_s", "in_collectives_total_s", "compute_s",
-                                                                     "in_collectives_s", "wall_s", "shared_gpu_wait_s", "exchange_s", "scatter_reduce_s")})
+                                                                     "in_collectives_s", "wall_s", "shared_gpu_wait_s", "null_launch_us", "exchange_s", "scatter_reduce_s")})
         tim["per_rank"] = per_rank
     single_gpu_merge = None
     if ws == 1 and not solo:          # (solo: rank 0 of an N-rank run measuring the single-GPU reference while the others wait)

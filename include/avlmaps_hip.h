@@ -408,6 +408,10 @@ AVL_API int avl_finalize_side(int64_t n, int64_t row0, int gs, int vh, const int
  * (reports an out-of-range row as AVL_ERR_INVALID). */
 AVL_API int avl_rows_add_f64(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src,
                              int64_t ld_src, double* d_dst, int64_t ld_dst, void* stream);
+/* The same fold without the host round trip: an out-of-range row index sets *d_err_flag (device int32, zeroed by the caller) to 1
+ * and is skipped; the caller reads the flag once after the last peer (the round-4 merge folds up to ws lists per exchange). */
+AVL_API int avl_rows_add_f64_async(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src,
+                                   int64_t ld_src, double* d_dst, int64_t ld_dst, int32_t* d_err_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (3) nearest-target distance-decay heatmap

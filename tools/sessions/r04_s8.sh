@@ -6,8 +6,7 @@ run() { # name nproc extra...
   timeout 600 env "$@" python -m torch.distributed.run --nnodes=1 --nproc-per-node $np --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus $np --workload build --steps 10000 --warmup 8 --no-cpu $EXTRA > gpurun_out/s8/$name.json 2> gpurun_out/s8/$name.err
   echo "rc=$?"
   grep "merge trace" gpurun_out/s8/$name.err | grep "rank 3 " | tail -4
-  python -c "
-import json;d=json.loads([l for l in open('gpurun_out/s8/$name.json') if l.startswith('{')][-1]);mb=d['extra']['merge_breakdown'];print('$name', d['extra']['seconds'], d['extra']['voxels_merged'], mb['wall_s'], mb['compute_s'], mb['shared_gpu_wait_s'], [round(r['compute_total_s']*1e3,1) for r in mb['per_rank']], [r['local_voxels'] for r in mb['per_rank']])"
+  python tools/summarize_merge.py gpurun_out/s8/$name.json
 }
 EXTRA="" run r8_loop 8 A=1
 EXTRA="--trajectory spiral" run r8_spiral 8 A=1

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""one line per bench.py --workload build record: merge phases (rank 0) and every rank's compute / local voxels"""
+import json
+import sys
+
+for path in sys.argv[1:]:
+    d = json.loads([l for l in open(path) if l.startswith("{")][-1])
+    e = d["extra"] if "voxels_merged" in d.get("extra", {}) else d["extra"]["map_build_strong"]
+    mb = e["merge_breakdown"]
+    r = lambda x: round(x * 1e3, 2)
+    print(path, f"frames/s {e['frames_per_s']:.0f}  total {e['seconds']:.3f} s  fuse {e['fuse_seconds_max_rank']:.3f} s  M {e['voxels_merged']}")
+    print("   rank0 wall ms   ", {k: r(v) for k, v in mb["wall_s"].items()})
+    print("   rank0 compute ms", {k: r(v) for k, v in mb["compute_s"].items()}, "wait for shared GPU s", round(mb.get("shared_gpu_wait_s") or 0, 3))
+    print("   per rank: compute ms", [r(p["compute_total_s"]) for p in mb["per_rank"]], "local voxels", [p["local_voxels"] for p in mb["per_rank"]],
+          "single-rank voxels", [p.get("single_rank_voxels") for p in mb["per_rank"]], "null launch us", [round(p.get("null_launch_us") or 0, 1) for p in mb["per_rank"]])
+    print("   payload MB sent", [round(p["payload_bytes_sent"] / 1e6) for p in mb["per_rank"]], "fp64 form", [round((p.get("payload_bytes_fp64_form") or 0) / 1e6) for p in mb["per_rank"]])
