@@ -47,10 +47,15 @@ class VLMapBuilder:
         self.sigma_sq = 0.6                        # vlmap_builder.py:157
         self.exact_rgb = True                      # replay weight / grid_rgb sequentially at finalisation
         self.batch_frames = 1                      # >1: fuse that many frames per launch pair (same map, fewer launches)
-        self.deferred_fuse = False                 # frame-by-frame runs: ONE launch per frame (the feature fusion of frame i
-                                                   # runs inside the launch of frame i + 1; same map).  Opt-in: the
-                                                   # extractor must hand out a NEW feature tensor per frame (LSeg on PyTorch
-                                                   # does; one that refills a single buffer would be read one frame late)
+        self.deferred_fuse = "auto"                # frame-by-frame runs: ONE launch per frame (the feature fusion of frame i runs
+                                                   # inside the launch of frame i + 1: 22 -> 13 us per frame, the same map bit for
+                                                   # bit).  The features of a frame are then read one call late, so the extractor
+                                                   # must hand out a NEW tensor per frame.  "auto" (default) finds out: the first
+                                                   # frames are fused at once while the builder holds on to each frame's feature
+                                                   # tensor; an extractor that still returns the same storage refills one buffer
+                                                   # -> stays frame-at-once; one that returns fresh storage (any torch model
+                                                   # does: the caching allocator cannot reuse memory that is still referenced) ->
+                                                   # deferral is switched on from the third frame.  True / False force it.
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
         self.stage_frames = True                   # with prefetch_frames > 0: depth / rgb / sample lists travel through page-locked
                                                    # buffers on a copy stream (device.FrameStager) instead of three pageable,
@@ -355,6 +360,8 @@ class VLMapBuilder:
         mapped_iter_set = set()
         pending = []
         rounds_done = 0
+        probation = None
+        self.deferred_fuse_active = self.deferred_fuse is True and self.batch_frames <= 1
         import time
         stage = bool(self.stage_frames and (self.prefetch_frames or 0) > 0)
         self._stager = None
@@ -373,7 +380,8 @@ class VLMapBuilder:
                 if ws > 1:
                     D = self._agree_on_width(D)     # collective; ranks without frames join it below
                 acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=self.capacity or max(gs * gs, 1 << 16), max_capacity=self.max_capacity,
-                                           deferred_fuse=self.deferred_fuse and self.batch_frames <= 1)
+                                           deferred_fuse=self.deferred_fuse is True and self.batch_frames <= 1)
+                probation = [] if (self.deferred_fuse == "auto" and self.batch_frames <= 1) else None
                 mapped_iter_set = self._resume(acc, ws, rank)
                 self._resumed_frames = frozenset(mapped_iter_set)
                 if self.skip_mapped_frames and frame_i in self._resumed_frames:
@@ -398,6 +406,16 @@ class VLMapBuilder:
                                     sigma_sq=self.sigma_sq)
                 if staged is not None:
                     self._stager.release(staged)          # depth / rgb / samples are read by this launch only (features: deferred)
+                if probation is not None:
+                    # deferred fuse on probation: does the extractor hand out fresh storage while the previous tensor is alive?
+                    probation.append(feat)
+                    if len(probation) == 2:
+                        ptrs = [f.data_ptr() if hasattr(f, "data_ptr") else id(f) for f in probation]
+                        fresh = not hasattr(feat, "data_ptr") or ptrs[0] != ptrs[1]     # NumPy features are staged by us: always fresh
+                        if fresh:
+                            acc.set_deferred_fuse(True)
+                        self.deferred_fuse_active = bool(fresh)
+                        probation = None
             mapped_iter_set.add(frame_i)
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)

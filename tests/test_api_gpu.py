@@ -31,6 +31,13 @@ class MemoryBuilder:
             if feats_as == "torch_hwc":
                 import torch
                 return torch.from_numpy(np.ascontiguousarray(np.transpose(f[0], (1, 2, 0)))).cuda()
+            if feats_as == "torch_refill":               # an extractor that REFILLS one output buffer: deferred fuse would read it late
+                import torch
+                t = torch.from_numpy(np.ascontiguousarray(np.transpose(f[0], (1, 2, 0))))
+                if "buf" not in counter:
+                    counter["buf"] = torch.empty(t.shape, dtype=t.dtype, device="cuda")
+                counter["buf"].copy_(t)
+                return counter["buf"]
             return f
 
         b = VLMapBuilder(tmp_path, cfg, pose_path, [None] * nfr, [None] * nfr, m.base2cam_tf, m.base_transform,
@@ -41,16 +48,23 @@ class MemoryBuilder:
 
 
 @pytest.mark.parametrize("feats_as,batch", [("numpy_chw", 1), ("torch_hwc", 1), ("torch_hwc", 4), ("numpy_chw", 2),
-                                            ("torch_hwc", "deferred"), ("numpy_chw", "deferred")])
+                                            ("torch_hwc", "deferred"), ("numpy_chw", "deferred"), ("torch_refill", 1), ("torch_hwc", "off")])
 def test_vlmapbuilder_reproduces_reference_map(golden, tmp_path, feats_as, batch):
     from avlmaps_amd.utils.mapping_utils import load_3d_map
     g = golden("g2a_builder_small.npz")
     b = MemoryBuilder.make(g, tmp_path, feats_as)
     if batch == "deferred":                  # one launch per frame; checkpoints (save_every) flush the pending fusion
         b.deferred_fuse, b.save_every, batch = True, 3, 1
+    elif batch == "off":
+        b.deferred_fuse, batch = False, 1
+    auto = b.deferred_fuse == "auto"
     b.batch_frames = batch
     np.random.seed(1234)                     # same global-RNG state the reference run had
     b.create_mobile_base_map()
+    if auto and batch == 1:
+        # deferred fuse is the default now, decided on probation: an extractor that hands out fresh storage per frame (any torch
+        # model; NumPy features are staged by the builder) gets one launch per frame, one that refills a single buffer does not
+        assert b.deferred_fuse_active == (feats_as != "torch_refill")
     it, gf, gp, w, occ, rgb = load_3d_map(tmp_path / "vlmap" / "vlmaps.h5df")
     assert it == list(range(len(g["depths"])))
     assert np.array_equal(gp, g["grid_pos"]) and gp.dtype == np.int32

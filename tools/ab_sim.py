@@ -78,7 +78,10 @@ def main():
             for mode in a.modes.split(","):
                 for v in a.variants:
                     env = dict(os.environ)
-                    if v != "stock":
+                    if v.startswith("env:"):              # the stock library with an environment switch, e.g. env:AVL_SIM_PAIR=1
+                        k, _, val = v[4:].partition("=")
+                        env[k] = val or "1"
+                    elif v != "stock":
                         env["AVLMAPS_HIP_LIB"] = str(ROOT / "variants" / f"libavlmaps_hip_{v}.so")
                     r = subprocess.run([sys.executable, __file__, "--child", shape, mode], env=env, capture_output=True, text=True, timeout=600)
                     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
