@@ -25,7 +25,7 @@ bench-config5: build
 golden:
 	$(PY) tools/gen_golden.py --all
 
-TAG ?= r02
+TAG ?= r04
 profiles:
 	bash tools/collect_profiles.sh $(TAG) && $(PY) tools/publish_profiles.py $(TAG)
 

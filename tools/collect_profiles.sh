@@ -3,7 +3,7 @@
 # judged summaries to profiles/<tag>_*).   usage: tools/collect_profiles.sh <tag>
 # Kernel traces (--kernel-trace --stats) and PMC passes (--pmc only) are separate runs: never combined with tracing flags.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
@@ -71,5 +71,18 @@ cd $R
 (timeout 600 python bench.py --workload build --steps 40000 --build-batch 16 --no-cpu) > $O/build_40k_b16.log 2>&1
 AVLMAPS_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 timeout 600 python bench.py --workload build --steps 10000 --build-batch 16 --no-cpu > $O/build_rccl_1rank.log 2>&1
 AVLMAPS_DIST_BACKEND=nccl timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --workload build --steps 2000 --no-cpu > $O/rccl_two_ranks_one_gpu.log 2>&1
+# --- round 4: eight ranks on this ONE GPU (gloo; a cross-process lock serialises the ranks' compute, see parallel._SharedGpuLock): the merge's
+#     choreography and per-rank compute, on the loop (every shard sees the whole map) and on exploration trajectories
+for cfg in "loop:" "spiral:--trajectory spiral" "spiral6:--trajectory spiral --spiral-radius 6"; do
+  name=${cfg%%:*}; extra=${cfg#*:}
+  (timeout 600 python bench.py --workload build --steps 10000 --no-cpu $extra) > $O/build_10k_${name}_1rank.log 2>&1
+  AVLMAPS_DIST_BACKEND=gloo AVLMAPS_MERGE_TRACE=1 AVLMAPS_SHARED_GPU_LOCK=/tmp/avl_gpu.lock timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+    --master-addr 127.0.0.1 --master-port 29713 bench.py --gpus 8 --workload build --steps 10000 --warmup 8 --no-cpu $extra > $O/build_8ranks_one_gpu_${name}.log 2> $O/build_8ranks_one_gpu_${name}.err
+  grep "merge trace" $O/build_8ranks_one_gpu_${name}.err > $O/build_8ranks_one_gpu_${name}_trace.txt
+  python tools/summarize_merge.py $O/build_8ranks_one_gpu_${name}.log > $O/build_8ranks_one_gpu_${name}_summary.txt 2>&1
+done
+AVLMAPS_DIST_BACKEND=gloo AVLMAPS_SHARED_GPU_LOCK=/tmp/avl_gpu.lock timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 \
+  --master-port 29714 bench.py --gpus 2 --no-pmc --no-cpu > $O/index_2ranks_one_gpu.log 2> $O/index_2ranks_one_gpu.err
+timeout 600 python tools/probe_pipeline.py 2000 2>&1 | grep -v "Temporarily\|amdgpu.ids" > $O/pipeline_probe.txt
 timeout 300 python tools/power_probe.py 3 2>&1 | grep -v '^/sys/class/drm\|amdgpu.ids' > $O/power_probe.txt
 ls -la $O

@@ -10,7 +10,7 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = ROOT / "gpurun_out" / f"prof_{tag}", ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 ours = lambda name: "avl" in name or "rocclr" in name or "rocprim" in name or "ccl" in name.lower()
@@ -28,6 +28,8 @@ for f in sorted(src.glob("pmc_*.json")):
     pmc[f.stem] = d
 if (src / "power_probe.txt").exists():
     shutil.copy(src / "power_probe.txt", dst / f"{tag}_power_probe.txt")
+for f in sorted(src.glob("build_8ranks_one_gpu_*_summary.txt")) + sorted(src.glob("build_8ranks_one_gpu_*_trace.txt")) + sorted(src.glob("pipeline_probe.txt")):
+    shutil.copy(f, dst / f"{tag}_{f.name}")
 lines = {}
 for f in sorted(src.glob("*.log")):
     if f.name.startswith("pmc_"):
