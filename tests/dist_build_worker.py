@@ -44,7 +44,11 @@ def main():
                      feat_extractor=extractor)
     stop_after = int(os.environ.get("AVL_TEST_STOP_AFTER", "0"))       # simulated interruption after that many local frames
 
+    fail_rank = int(os.environ.get("AVL_TEST_FAIL_RANK", "-1"))             # that rank cannot read its second frame
+
     def load_frame(i):
+        if rank == fail_rank and len(loaded) >= 1:
+            raise OSError(f"frame {i}: disk gone (simulated on rank {rank})")
         if stop_after and len(loaded) >= stop_after:
             b._join_save()                                    # the checkpoint that was being written completes, then the run dies
             import torch.distributed as dist

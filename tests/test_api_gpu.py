@@ -615,6 +615,25 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
         assert not (c[2].shape == a[2].shape and np.array_equal(c[2], a[2]))
 
 
+def test_a_failing_rank_takes_the_others_down_instead_of_hanging_them(tmp_path):
+    """a rank that fails in its frame loop (here: rank 1 cannot read its second frame) joins the status collective the
+    others reach next with its failure flag set; every rank raises promptly -- nobody sits in a merge collective until the timeout"""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, AVLMAPS_DIST_BACKEND="gloo", AVL_TEST_FAIL_RANK="1", AVL_TEST_SAVE_EVERY="3")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", str(root / "tests" / "dist_build_worker.py"), str(root / "tests" / "golden" / "g2b_builder_growth.npz"),
+           str(tmp_path / "out"), "16", "replay", "99"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "disk gone (simulated on rank 1)" in r.stderr                       # the rank that failed says why ...
+    assert "another rank reported a failure" in r.stderr                       # ... and rank 0 stops because of it, not by a timeout
+
+
 def test_multi_rank_checkpoints_and_resume(golden, tmp_path):
     """Several ranks, like upstream's loop (vlmap_builder.py:181-183, :212-222): every save_every local frames the ranks merge
     and rank 0 writes the map file; a run that dies after such a checkpoint is resumed by the same number of ranks -- rank 0

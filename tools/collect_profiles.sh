@@ -73,7 +73,7 @@ AVLMAPS_FORCE_COLLECTIVES=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0
 AVLMAPS_DIST_BACKEND=nccl timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --workload build --steps 2000 --no-cpu > $O/rccl_two_ranks_one_gpu.log 2>&1
 # --- round 4: eight ranks on this ONE GPU (gloo; a cross-process lock serialises the ranks' compute, see parallel._SharedGpuLock): the merge's
 #     choreography and per-rank compute, on the loop (every shard sees the whole map) and on exploration trajectories
-for cfg in "loop:" "spiral:--trajectory spiral" "spiral6:--trajectory spiral --spiral-radius 6"; do
+for cfg in "loop:" "spiral:--trajectory spiral" "spiral4:--trajectory spiral --spiral-radius 4"; do
   name=${cfg%%:*}; extra=${cfg#*:}
   (timeout 600 python bench.py --workload build --steps 10000 --no-cpu $extra) > $O/build_10k_${name}_1rank.log 2>&1
   AVLMAPS_DIST_BACKEND=gloo AVLMAPS_MERGE_TRACE=1 AVLMAPS_SHARED_GPU_LOCK=/tmp/avl_gpu.lock timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
