@@ -1,0 +1,149 @@
+"""GPU checks of the round-4 C-ABI entry points behind the multi-GPU merge and the pinned frame staging, each against NumPy on
+the accumulators the library itself exports (avl_builder_export_raw)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from avlmaps_amd import _lib, ops
+    from avlmaps_amd.device import DeviceArray
+    lib = _lib.load()
+    _lib.require_gpu()
+    return _lib, lib, ops, DeviceArray
+
+
+def small_build(ops, golden, D=None):
+    from oracle import avl_oracle as O                      # (the checker's pose chain, as in tests/test_builder_gpu.py)
+    from test_builder_gpu import run_gpu_builder
+    g = golden("g2a_builder_small.npz")
+    Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    acc = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"], g["rgbs"],
+                          g["feats"], g["samples"], capacity=4000, replay=True)
+    return g, acc
+
+
+def test_export_rows_match_the_single_process_finalisation(env, golden):
+    """avl_builder_export_rows_f32 = the finished float32 row of a voxel one rank touched alone: bit for bit what finalize() emits
+    for that voxel; avl_builder_export_rows_f64 = sum_feat minus the first-touch term where the caller owns it"""
+    _lib, lib, ops, DeviceArray = env
+    g, acc = small_build(ops, golden)
+    n, D = acc.num_voxels(), acc.D
+    raw = acc.export_raw()
+    fin = acc.finalize()
+    order = np.argsort(raw["first_key"].astype(np.uint64), kind="stable")         # finalize emits voxels in first-touch-key order
+    rng = np.random.default_rng(0)
+    slots = rng.permutation(n)[: max(1, n // 2)].astype(np.int32)
+    d_slots = DeviceArray.from_numpy(slots)
+    out32 = DeviceArray((len(slots), D + 8), np.float32)                           # a padded row stride
+    _lib.check(lib.avl_builder_export_rows_f32(acc._h, len(slots), d_slots.ptr, out32.ptr, D + 8, None), "export_rows_f32")
+    rows32 = out32.numpy()[:, :D]
+    row_of_slot = np.empty(n, np.int64)
+    row_of_slot[order] = np.arange(n)
+    assert np.array_equal(rows32, fin["grid_feat"][row_of_slot[slots]])           # bit-identical to the single-process map
+    a1 = raw["first_alpha"][slots]
+    want32 = ((raw["sum_feat"][slots] - (a1 * (1 - a1))[:, None] * raw["first_feat"][slots].astype(np.float64)) / raw["sum_w4"][slots, :1])
+    assert np.array_equal(rows32, want32.astype(np.float32))
+    own = (rng.random(len(slots)) < 0.5).astype(np.uint8)
+    out64 = DeviceArray((len(slots), D), np.float64)
+    _lib.check(lib.avl_builder_export_rows_f64(acc._h, len(slots), d_slots.ptr, DeviceArray.from_numpy(own).ptr, out64.ptr, D, None), "export_rows_f64")
+    want64 = raw["sum_feat"][slots] - (own * a1 * (1 - a1))[:, None] * raw["first_feat"][slots].astype(np.float64)
+    assert np.array_equal(out64.numpy(), want64)
+    # argument checks: more slots than voxels, a row stride below D
+    assert lib.avl_builder_export_rows_f32(acc._h, n + 1, d_slots.ptr, out32.ptr, D + 8, None) != 0
+    assert lib.avl_builder_export_rows_f32(acc._h, 1, d_slots.ptr, out32.ptr, D - 1, None) != 0
+    acc.close()
+
+
+def test_finalize_side_is_the_side_part_of_finalize_merged(env, golden):
+    """avl_finalize_side (grid_pos / weight / grid_rgb / occupied_ids from cells + [sum alpha, sum alpha rgb]) against
+    avl_finalize_merged on the same rows"""
+    _lib, lib, ops, DeviceArray = env
+    g, acc = small_build(ops, golden)
+    n, D = acc.num_voxels(), acc.D
+    raw = acc.export_raw()
+    gs, vh = acc.gs, acc.vh
+    accbuf = np.concatenate([raw["sum_feat"], raw["sum_w4"]], axis=1)
+    d_cell, d_acc = DeviceArray.from_numpy(raw["cell"]), DeviceArray.from_numpy(accbuf)
+    ref = {k: DeviceArray(s, t) for k, s, t in (("pos", (n, 3), np.int32), ("w", (n,), np.float32), ("rgb", (n, 3), np.uint8), ("occ", (gs, gs, vh), np.int32))}
+    got = {k: DeviceArray(v.shape, v.dtype) for k, v in ref.items()}
+    for d in (ref["occ"], got["occ"]):
+        _lib.check(lib.avl_memset(d.ptr, 0xFF, d.nbytes, None))
+    feat = DeviceArray((n, D), np.float32)
+    _lib.check(lib.avl_finalize_merged(n, 5, D, gs, vh, d_cell.ptr, d_acc.ptr, D + 4, feat.ptr, ref["pos"].ptr, ref["w"].ptr, ref["rgb"].ptr, ref["occ"].ptr, None))
+    d_w4 = DeviceArray.from_numpy(np.ascontiguousarray(raw["sum_w4"]))
+    _lib.check(lib.avl_finalize_side(n, 5, gs, vh, d_cell.ptr, d_w4.ptr, got["pos"].ptr, got["w"].ptr, got["rgb"].ptr, got["occ"].ptr, None), "finalize_side")
+    for k in ref:
+        assert np.array_equal(ref[k].numpy(), got[k].numpy()), k
+    assert lib.avl_finalize_side(n, (1 << 31) - 2, gs, vh, d_cell.ptr, d_w4.ptr, None, None, None, None, None) != 0        # ids beyond int32
+    acc.close()
+
+
+def test_replay_chain_in_two_calls_equals_one(env, golden):
+    """avl_builder_replay_chain with a negative index per skipped slot: replaying an arbitrary half of the voxels first and the rest
+    in a second call (the round-4 merge: voxels without a predecessor, then the ones whose state arrived) is the single call"""
+    _lib, lib, ops, DeviceArray = env
+    g, acc = small_build(ops, golden)
+    n = acc.num_voxels()
+    ar = np.arange(n, dtype=np.int64)
+    one = DeviceArray((n, 3), np.int64).zero_()
+    _lib.check(lib.avl_builder_replay_chain(acc._h, n, DeviceArray.from_numpy(ar).ptr, C.c_uint64((1 << 64) - 1), one.ptr, None), "replay_chain")
+    sel = np.random.default_rng(1).random(n) < 0.5
+    two = DeviceArray((n, 3), np.int64).zero_()
+    for mask in (sel, ~sel):
+        idx = np.where(mask, ar, -1)
+        _lib.check(lib.avl_builder_replay_chain(acc._h, n, DeviceArray.from_numpy(idx).ptr, C.c_uint64((1 << 64) - 1), two.ptr, None), "replay_chain")
+    assert np.array_equal(one.numpy(), two.numpy())
+    # ... and the final states are the weights / colours of the exact single-process finalisation
+    fin = acc.finalize()
+    order = np.argsort(acc.export_raw()["first_key"].astype(np.uint64), kind="stable")
+    w = DeviceArray((n,), np.float32).zero_()
+    rgb = DeviceArray((n, 3), np.uint8).zero_()
+    st = DeviceArray.from_numpy(np.ascontiguousarray(one.numpy()[order]))
+    _lib.check(lib.avl_replay_state_apply(n, st.ptr, w.ptr, rgb.ptr, None))
+    assert np.array_equal(w.numpy(), fin["weight"]) and np.array_equal(rgb.numpy(), fin["grid_rgb"])
+    acc.close()
+
+
+def test_rows_add_async_flags_an_out_of_range_row(env):
+    _lib, lib, ops, DeviceArray = env
+    rng = np.random.default_rng(2)
+    src = rng.standard_normal((6, 5))
+    dst0 = rng.standard_normal((4, 7))
+    rows = np.array([3, 0, 2, 9, 1, -1], np.int64)                                # 9 and -1 lie outside the 4-row block
+    d_dst, flag = DeviceArray.from_numpy(dst0.copy()), DeviceArray((1,), np.int32).zero_()
+    _lib.check(lib.avl_rows_add_f64_async(6, 5, DeviceArray.from_numpy(rows).ptr, 0, 4, DeviceArray.from_numpy(src).ptr, 5, d_dst.ptr, 7, flag.ptr, None),
+               "rows_add_async")
+    want = dst0.copy()
+    for i, r in enumerate(rows):
+        if 0 <= r < 4:
+            want[r, :5] += src[i]
+    assert np.array_equal(d_dst.numpy(), want) and int(flag.numpy()[0]) == 1
+
+
+def test_frame_stager_hands_over_exact_copies_and_follows_shape_changes(env):
+    """device.FrameStager: what the fusing stream reads after avl_stream_wait_event is the frame that was staged, slot reuse waits
+    for the release event, a change of the frame shape re-sizes the ring"""
+    _lib, lib, ops, DeviceArray = env
+    from avlmaps_amd.device import FrameStager
+    st = FrameStager(3)
+    rng = np.random.default_rng(3)
+    try:
+        for k, (H, W, P) in enumerate([(12, 16, 40), (12, 16, 33), (12, 16, 40), (12, 16, 7), (12, 16, 40), (20, 8, 50), (20, 8, 50)]):
+            depth = rng.random((H, W)).astype(np.float32)
+            rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+            samples = rng.integers(0, H * W, P).astype(np.int32)
+            sf = st.stage(depth, rgb, samples)
+            st.acquire(sf)                                            # the (null) stream waits for the copies on the device
+            back = [np.empty(v.shape, v.dtype) for v in (sf.depth, sf.rgb, sf.samples)]
+            for b, v in zip(back, (sf.depth, sf.rgb, sf.samples)):
+                _lib.check(lib.avl_memcpy_d2h(b.ctypes.data, v.ptr, v.nbytes, None))
+            st.release(sf)
+            assert np.array_equal(back[0], depth) and np.array_equal(back[1], rgb) and np.array_equal(back[2], samples), k
+    finally:
+        st.close()
+    assert lib.avl_stream_wait_event(None, None) != 0                 # a null event is an error, not a crash

@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_merge_kernels_gpu.py -m gpu -x -q 2>&1 | tail -15
+timeout 600 python -m pytest tests/test_api_gpu.py -m gpu -x -q -k "failing_rank" 2>&1 | tail -5
