@@ -1,7 +1,10 @@
 // libavlmaps_hip.so -- library / device plumbing entry points (include/avlmaps_hip.h, first block).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
+
+#include <immintrin.h>
 
 #include "avl_common.h"
 
@@ -268,6 +271,146 @@ void run_shuffles(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t* arr)
         }
     }
 }
+
+// AVX2 form of the draw loop (modes 0 and 2).  Inside a constant-mask run eight draws are decided at once: with i the running index
+// before the block, a draw x <= i - 7 is accepted whatever happened to the seven before it, a draw x > i is rejected; only
+// i - 7 < x <= i is ambiguous (probability 7 / (mask + 1) per draw: about once per 10^5 draws for 720x1080) and sends the block
+// through the scalar loop.  The accepted draws are packed with a 256-entry permutation table so that the r-th accepted one lands at
+// arr[i - r], exactly where the scalar loop writes it.  Same draws, same state: tests/test_host_mirror.py pins both forms.
+alignas(32) static uint32_t g_pack_lut[256][8];
+static void build_pack_lut() {
+    for (int a = 0; a < 256; ++a) {
+        int src[8], cnt = 0;
+        for (int b = 0; b < 8; ++b)
+            if (a & (1 << b)) src[cnt++] = b;
+        for (int lane = 0; lane < 8; ++lane) {
+            const int r = 7 - lane;                      // lane 7 holds the first accepted draw (address i), lane 6 the second, ...
+            g_pack_lut[a][lane] = (uint32_t)(r < cnt ? src[r] : 0);
+        }
+    }
+}
+
+// the Mersenne-twister state update, eight words at a time (the recurrence reads key[i + 1] and key[i + 397 mod 624]: distances that
+// leave eight consecutive words independent), and the tempering of the whole block
+__attribute__((target("avx2"))) static inline void mt_step8(uint32_t* key, int i, int j) {     // key[i .. i+7] from key[i .. i+8], key[j .. j+7]
+    const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(key + i));
+    const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(key + i + 1));
+    const __m256i y = _mm256_or_si256(_mm256_and_si256(a, _mm256_set1_epi32((int)0x80000000u)), _mm256_and_si256(b, _mm256_set1_epi32(0x7fffffff)));
+    const __m256i odd = _mm256_sub_epi32(_mm256_setzero_si256(), _mm256_and_si256(y, _mm256_set1_epi32(1)));       // all ones where y is odd
+    const __m256i r = _mm256_xor_si256(_mm256_xor_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(key + j)), _mm256_srli_epi32(y, 1)),
+                                       _mm256_and_si256(odd, _mm256_set1_epi32((int)0x9908b0dfu)));
+    _mm256_storeu_si256(reinterpret_cast<__m256i*>(key + i), r);
+}
+static inline void mt_step1(uint32_t* key, int i, int i1, int j) {
+    const uint32_t y = (key[i] & 0x80000000u) | (key[i1] & 0x7fffffffu);
+    key[i] = key[j] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__attribute__((target("avx2"))) static void mt_regen_avx2(uint32_t* key) {
+    int i = 0;
+    for (; i + 8 <= 227; i += 8) mt_step8(key, i, i + 397);
+    for (; i < 227; ++i) mt_step1(key, i, i + 1, i + 397);
+    for (; i + 8 <= 623; i += 8) mt_step8(key, i, i - 227);
+    for (; i < 623; ++i) mt_step1(key, i, i + 1, i - 227);
+    mt_step1(key, 623, 0, 396);
+}
+__attribute__((target("avx2"))) static void mt_temper_avx2(const uint32_t* key, uint32_t* out) {
+    const __m256i m1 = _mm256_set1_epi32((int)0x9d2c5680u), m2 = _mm256_set1_epi32((int)0xefc60000u);
+    for (int k = 0; k < 624; k += 8) {
+        __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(key + k));
+        y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 11));
+        y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 7), m1));
+        y = _mm256_xor_si256(y, _mm256_and_si256(_mm256_slli_epi32(y, 15), m2));
+        y = _mm256_xor_si256(y, _mm256_srli_epi32(y, 18));
+        _mm256_store_si256(reinterpret_cast<__m256i*>(out + k), y);
+    }
+}
+
+template <int MODE>
+__attribute__((target("avx2,popcnt"))) void run_shuffles_avx2(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t* arr) {
+    alignas(32) uint32_t out[624 + 8];
+    if (g.pos < 624) mt_temper_avx2(g.key, out);
+    for (int64_t s = 0; s < n_shuffles; ++s) {
+        if (n_items < 2) continue;
+        uint32_t i = (uint32_t)(n_items - 1), mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        while (i >= 1) {
+            const uint32_t lo = mask >> 1;
+            const __m256i vmask = _mm256_set1_epi32((int)mask);
+            while (i > lo) {
+                if (g.pos >= 624) {
+                    mt_regen_avx2(g.key);
+                    g.pos = 0;
+                    mt_temper_avx2(g.key, out);
+                }
+                const int avail = 624 - g.pos;
+                const uint32_t* o = out + g.pos;
+                int k = 0;
+                for (;;) {
+                    // 32 draws against ONE broadcast of i: the loop-carried chain (i -> broadcast -> compare -> movemask -> popcount
+                    // -> i, ~15 cycles) is paid once per 32 draws instead of once per 8
+                    while (k + 32 <= avail && i >= lo + 32) {
+                        const __m256i vi = _mm256_set1_epi32((int)i), vlo = _mm256_set1_epi32((int)i - 31);
+                        __m256i x[4];
+                        int rej[4], nacc[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            x[b] = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(o + k + 8 * b)), vmask);
+                            rej[b] = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(x[b], vi)));
+                            nacc[b] = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(x[b], vlo)));
+                        }
+                        if ((rej[0] ^ nacc[0]) | (rej[1] ^ nacc[1]) | (rej[2] ^ nacc[2]) | (rej[3] ^ nacc[3])) break;   // ambiguous: narrower paths
+                        uint32_t ii = i;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int a = (~nacc[b]) & 0xff;
+                            if (MODE == 2) {
+                                const __m256i perm = _mm256_load_si256(reinterpret_cast<const __m256i*>(g_pack_lut[a]));
+                                _mm256_storeu_si256(reinterpret_cast<__m256i*>(arr + (ii - 7)), _mm256_permutevar8x32_epi32(x[b], perm));
+                            }
+                            ii -= (uint32_t)__builtin_popcount((unsigned)a);
+                        }
+                        i = ii;
+                        k += 32;
+                    }
+                    while (k + 8 <= avail && i >= lo + 8) {
+                        const __m256i x = _mm256_and_si256(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(o + k)), vmask);
+                        const int rej = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(x, _mm256_set1_epi32((int)i))));
+                        const int nacc = _mm256_movemask_ps(_mm256_castsi256_ps(_mm256_cmpgt_epi32(x, _mm256_set1_epi32((int)i - 7))));
+                        if (rej != nacc) break;                       // an ambiguous draw: this block goes through the scalar loop
+                        const int a = (~nacc) & 0xff;
+                        if (MODE == 2) {
+                            const __m256i perm = _mm256_load_si256(reinterpret_cast<const __m256i*>(g_pack_lut[a]));
+                            _mm256_storeu_si256(reinterpret_cast<__m256i*>(arr + (i - 7)), _mm256_permutevar8x32_epi32(x, perm));
+                        }
+                        i -= (uint32_t)__builtin_popcount((unsigned)a);
+                        k += 8;
+                        if (k + 32 <= avail && i >= lo + 32) break;      // back to the wide path
+                    }
+                    const int kend = k + 8 < avail ? k + 8 : avail;
+                    for (; k < kend && i > lo; ++k) {
+                        const uint32_t x = o[k] & mask;
+                        if (MODE == 2) arr[i] = (int32_t)x;
+                        i -= x <= i ? 1u : 0u;
+                    }
+                    if (k >= avail || i <= lo) break;
+                }
+                g.pos += k;
+            }
+            mask = lo;
+        }
+    }
+}
+
+template <int MODE>
+void run_shuffles_best(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t* arr) {
+    static const bool avx2 = [] {
+        const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt") && std::getenv("AVL_NO_AVX2") == nullptr;
+        if (ok) build_pack_lut();
+        return ok;
+    }();
+    if (avx2) run_shuffles_avx2<MODE>(g, n_items, n_shuffles, arr);
+    else run_shuffles<MODE>(g, n_items, n_shuffles, arr);
+}
 }  // namespace
 }  // extern "C++"
 
@@ -276,7 +419,7 @@ int avl_mt19937_skip_shuffles(uint32_t* h_key624, int* h_pos, int64_t n_items, i
     AVL_REQUIRE(*h_pos >= 0 && *h_pos <= 624 && n_items >= 0 && n_shuffles >= 0, "avl_mt19937_skip_shuffles: bad arguments");
     AVL_REQUIRE(n_items <= 0x7fffffffll, "avl_mt19937_skip_shuffles: arrays beyond 2^31 items are not supported");
     Mt19937 g{h_key624, *h_pos};
-    run_shuffles<0>(g, n_items, n_shuffles, nullptr);
+    run_shuffles_best<0>(g, n_items, n_shuffles, nullptr);
     *h_pos = g.pos;
     return AVL_OK;
 }
@@ -301,7 +444,7 @@ int avl_mt19937_shuffle_sample(uint32_t* h_key624, int* h_pos, int64_t n_items, 
             owner[(size_t)k] = (int16_t)o;
             h_out[o] = (int32_t)k;
         }
-        run_shuffles<2>(g, n_items, 1, h_scratch);
+        run_shuffles_best<2>(g, n_items, 1, h_scratch);
         int16_t* ow = owner.data();
         for (int64_t i = 1; i < n_items; ++i) {
             const uint32_t j = (uint32_t)h_scratch[i];
