@@ -152,94 +152,34 @@ class DeviceView:
 
 class StagedFrame:
     """one frame's depth / rgb / sample list on the device (views of a FrameStager slot) + the event its copies complete behind"""
-    __slots__ = ("depth", "rgb", "samples", "slot", "ready")
+    __slots__ = ("depth", "rgb", "samples", "slot", "ready", "ring")
 
-    def __init__(self, depth, rgb, samples, slot, ready):
-        self.depth, self.rgb, self.samples, self.slot, self.ready = depth, rgb, samples, slot, ready
+    def __init__(self, depth, rgb, samples, slot, ready, ring):
+        self.depth, self.rgb, self.samples, self.slot, self.ready, self.ring = depth, rgb, samples, slot, ready, ring
 
 
-class FrameStager:
-    """Pinned, asynchronous host-to-device path of the builder's frame loop (VERDICT r3 #5: a frame was 22 us of kernels inside
-    ~1.5 ms of pageable, synchronous copies on the fusing thread).
+class _StageRing:
+    """the slots of one frame layout: page-locked host buffers, their device twins, a `ready` and a `free` event per slot"""
 
-    A ring of slots, each a page-locked host buffer [depth f32 | rgb u8 | samples i32] and its device twin.  A PRODUCER thread
-    (the builder's frame thread) copies a decoded frame into a free slot's pinned buffer and queues ONE asynchronous copy of the
-    whole slot on the stager's own copy stream, followed by an event; the FUSING thread makes its stream wait for that event on
-    the device (avl_stream_wait_event: the host never blocks), launches the frame kernels on views of the slot, and records the
-    slot's `free` event behind them.  A slot is refilled only after its free event has completed.  5.4 MB per 720x1080 frame
-    cross PCIe at the pinned rate (~0.1 ms) while earlier frames are being fused."""
-
-    def __init__(self, slots: int, device=None):
+    def __init__(self, n, layout, offsets):
         lib = _lib.load()
-        self.n = max(2, int(slots))
-        self.device = _lib.current_device() if device is None else int(device)
-        st = C.c_void_p()
-        _lib.check(lib.avl_stream_create(C.byref(st)), "avl_stream_create")
-        self.copy_stream = st
-        self.layout = None            # (depth shape, rgb shape, max samples) the slots were sized for
+        self.layout, self.offsets = layout, offsets
         self.pinned, self.dev, self.ready, self.free_ev, self.free_pending = [], [], [], [], []
-        self.next = 0
-
-    def _event(self):
-        ev = C.c_void_p()
-        _lib.check(_lib.load().avl_event_create(C.byref(ev)), "avl_event_create")
-        return ev
-
-    def _size_for(self, depth, rgb, samples):
-        lay = (tuple(depth.shape), tuple(rgb.shape), int(samples.shape[0]))
-        if self.layout is not None and self.layout[:2] == lay[:2] and self.layout[2] >= lay[2]:
-            return
-        self.close_slots()
-        nd, nr = depth.size * 4, rgb.size
-        off_r = (nd + 255) & ~255
-        off_s = (off_r + nr + 255) & ~255
-        cap_s = max(lay[2], 1) + 64
-        total = off_s + cap_s * 4
-        self.layout = (lay[0], lay[1], cap_s)
-        self.offsets = (0, off_r, off_s, total)
-        for _ in range(self.n):
+        for _ in range(n):
             pb = PinnedBuffer()
-            pb.reserve(total)
+            pb.reserve(offsets[3])
             self.pinned.append(pb)
-            self.dev.append(DeviceArray((total,), np.uint8))
-            self.ready.append(self._event())
-            self.free_ev.append(self._event())
+            self.dev.append(DeviceArray((offsets[3],), np.uint8))
+            evs = []
+            for _e in range(2):
+                ev = C.c_void_p()
+                _lib.check(lib.avl_event_create(C.byref(ev)), "avl_event_create")
+                evs.append(ev)
+            self.ready.append(evs[0])
+            self.free_ev.append(evs[1])
             self.free_pending.append(False)
 
-    def stage(self, depth: np.ndarray, rgb: np.ndarray, samples: np.ndarray) -> StagedFrame:
-        """producer thread: copy the frame into the next slot and start its transfer"""
-        lib = _lib.load()
-        depth = np.asarray(depth, dtype=np.float32)
-        rgb = np.asarray(rgb, dtype=np.uint8)
-        samples = np.asarray(samples, dtype=np.int32).reshape(-1)
-        self._size_for(depth, rgb, samples)
-        k = self.next
-        self.next = (k + 1) % self.n
-        if self.free_pending[k]:
-            _lib.check(lib.avl_event_sync(self.free_ev[k]), "avl_event_sync")      # the launches that read this slot have finished
-            self.free_pending[k] = False
-        _, off_r, off_s, total = self.offsets
-        pb = self.pinned[k]
-        np.copyto(pb.view(0, depth.shape, np.float32), depth)
-        np.copyto(pb.view(off_r, rgb.shape, np.uint8), rgb)
-        ns = int(samples.shape[0])
-        np.copyto(pb.view(off_s, (ns,), np.int32), samples)
-        d = self.dev[k]
-        _lib.check(lib.avl_memcpy_h2d(d.ptr, pb.ptr, off_s + ns * 4, self.copy_stream), "avl_memcpy_h2d")
-        _lib.check(lib.avl_event_record(self.ready[k], self.copy_stream), "avl_event_record")
-        return StagedFrame(DeviceView(d.ptr, depth.shape, np.float32), DeviceView(d.ptr + off_r, rgb.shape, np.uint8),
-                           DeviceView(d.ptr + off_s, (ns,), np.int32), k, self.ready[k])
-
-    def acquire(self, staged: StagedFrame, stream=None) -> None:
-        """fusing thread, before the launches that read the frame: `stream` waits (on the device) for the slot's copies"""
-        _lib.check(_lib.load().avl_stream_wait_event(stream, staged.ready), "avl_stream_wait_event")
-
-    def release(self, staged: StagedFrame, stream=None) -> None:
-        """fusing thread, after the last launch that reads the frame's depth / rgb / samples has been queued on `stream`"""
-        _lib.check(_lib.load().avl_event_record(self.free_ev[staged.slot], stream), "avl_event_record")
-        self.free_pending[staged.slot] = True
-
-    def close_slots(self):
+    def close(self):
         lib = _lib.load()
         for k in range(len(self.dev)):
             if self.free_pending[k]:
@@ -249,15 +189,88 @@ class FrameStager:
             self.dev[k].free()
             self.pinned[k].free()
         self.pinned, self.dev, self.ready, self.free_ev, self.free_pending = [], [], [], [], []
-        self.layout = None
+
+
+class FrameStager:
+    """Pinned, asynchronous host-to-device path of the builder's frame loop (VERDICT r3 #5: a frame was 22 us of kernels inside
+    ~1.5 ms of pageable, synchronous copies on the fusing thread).
+
+    A ring of slots, each a page-locked host buffer [depth f32 | rgb u8 | samples i32] and its device twin.  A PRODUCER thread
+    (the builder's stager thread) copies a decoded frame into a free slot's pinned buffer and queues ONE asynchronous copy of the
+    whole slot on the stager's own copy stream, followed by an event; the FUSING thread makes its stream wait for that event on
+    the device (avl_stream_wait_event: the host never blocks), launches the frame kernels on views of the slot, and records the
+    slot's `free` event behind them.  A slot is refilled only after its free event has completed; the ring must therefore have more
+    slots than frames can be in flight between stage() and release() (the builder sizes it: queue depth + batch + 3).  5.4 MB per
+    720x1080 frame cross PCIe at the pinned rate (~0.1 ms) while earlier frames are being fused.  A change of the frame shape
+    starts a NEW ring; the old one lives until close(), because frames staged in it may still be queued."""
+
+    def __init__(self, slots: int, device=None):
+        lib = _lib.load()
+        self.n = max(2, int(slots))
+        self.device = _lib.current_device() if device is None else int(device)
+        st = C.c_void_p()
+        _lib.check(lib.avl_stream_create(C.byref(st)), "avl_stream_create")
+        self.copy_stream = st
+        self.ring = None
+        self.retired = []
         self.next = 0
+
+    def _ring_for(self, depth, rgb, samples):
+        lay = (tuple(depth.shape), tuple(rgb.shape), int(samples.shape[0]))
+        r = self.ring
+        if r is not None and r.layout[:2] == lay[:2] and r.layout[2] >= lay[2]:
+            return r
+        if r is not None:
+            self.retired.append(r)
+        nd, nr = depth.size * 4, rgb.size
+        off_r = (nd + 255) & ~255
+        off_s = (off_r + nr + 255) & ~255
+        cap_s = max(lay[2], 1) + 64
+        self.ring = _StageRing(self.n, (lay[0], lay[1], cap_s), (0, off_r, off_s, off_s + cap_s * 4))
+        self.next = 0
+        return self.ring
+
+    def stage(self, depth: np.ndarray, rgb: np.ndarray, samples: np.ndarray) -> StagedFrame:
+        """producer thread: copy the frame into the next slot and start its transfer"""
+        lib = _lib.load()
+        depth = np.asarray(depth, dtype=np.float32)
+        rgb = np.asarray(rgb, dtype=np.uint8)
+        samples = np.asarray(samples, dtype=np.int32).reshape(-1)
+        ring = self._ring_for(depth, rgb, samples)
+        k = self.next
+        self.next = (k + 1) % self.n
+        if ring.free_pending[k]:
+            _lib.check(lib.avl_event_sync(ring.free_ev[k]), "avl_event_sync")      # the launches that read this slot have finished
+            ring.free_pending[k] = False
+        _, off_r, off_s, _total = ring.offsets
+        pb = ring.pinned[k]
+        np.copyto(pb.view(0, depth.shape, np.float32), depth)
+        np.copyto(pb.view(off_r, rgb.shape, np.uint8), rgb)
+        ns = int(samples.shape[0])
+        np.copyto(pb.view(off_s, (ns,), np.int32), samples)
+        d = ring.dev[k]
+        _lib.check(lib.avl_memcpy_h2d(d.ptr, pb.ptr, off_s + ns * 4, self.copy_stream), "avl_memcpy_h2d")
+        _lib.check(lib.avl_event_record(ring.ready[k], self.copy_stream), "avl_event_record")
+        return StagedFrame(DeviceView(d.ptr, depth.shape, np.float32), DeviceView(d.ptr + off_r, rgb.shape, np.uint8),
+                           DeviceView(d.ptr + off_s, (ns,), np.int32), k, ring.ready[k], ring)
+
+    def acquire(self, staged: StagedFrame, stream=None) -> None:
+        """fusing thread, before the launches that read the frame: `stream` waits (on the device) for the slot's copies"""
+        _lib.check(_lib.load().avl_stream_wait_event(stream, staged.ready), "avl_stream_wait_event")
+
+    def release(self, staged: StagedFrame, stream=None) -> None:
+        """fusing thread, after the last launch that reads the frame's depth / rgb / samples has been queued on `stream`"""
+        _lib.check(_lib.load().avl_event_record(staged.ring.free_ev[staged.slot], stream), "avl_event_record")
+        staged.ring.free_pending[staged.slot] = True
 
     def close(self):
         try:
             lib = _lib.load()
             if self.copy_stream:
                 lib.avl_stream_sync(self.copy_stream)
-            self.close_slots()
+            for r in self.retired + ([self.ring] if self.ring is not None else []):
+                r.close()
+            self.retired, self.ring = [], None
             if self.copy_stream:
                 lib.avl_stream_destroy(self.copy_stream)
                 self.copy_stream = None

@@ -132,18 +132,22 @@ def test_frame_stager_hands_over_exact_copies_and_follows_shape_changes(env):
     from avlmaps_amd.device import FrameStager
     st = FrameStager(3)
     rng = np.random.default_rng(3)
+    held = []                                                     # frames staged but not yet consumed (a queue between the threads)
     try:
-        for k, (H, W, P) in enumerate([(12, 16, 40), (12, 16, 33), (12, 16, 40), (12, 16, 7), (12, 16, 40), (20, 8, 50), (20, 8, 50)]):
+        for k, (H, W, P) in enumerate([(12, 16, 40), (12, 16, 33), (12, 16, 40), (12, 16, 7), (12, 16, 40), (20, 8, 50), (20, 8, 50), (20, 8, 9)]):
             depth = rng.random((H, W)).astype(np.float32)
             rgb = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
             samples = rng.integers(0, H * W, P).astype(np.int32)
-            sf = st.stage(depth, rgb, samples)
-            st.acquire(sf)                                            # the (null) stream waits for the copies on the device
-            back = [np.empty(v.shape, v.dtype) for v in (sf.depth, sf.rgb, sf.samples)]
-            for b, v in zip(back, (sf.depth, sf.rgb, sf.samples)):
-                _lib.check(lib.avl_memcpy_d2h(b.ctypes.data, v.ptr, v.nbytes, None))
-            st.release(sf)
-            assert np.array_equal(back[0], depth) and np.array_equal(back[1], rgb) and np.array_equal(back[2], samples), k
+            held.append((st.stage(depth, rgb, samples), depth, rgb, samples))
+            while len(held) > (2 if k != 5 else 0):               # consume with a lag of two frames -- also across the change of shape
+                sf, d0, r0, s0 = held.pop(0)                      # at k == 5 (old-ring frames still held when the new ring starts)
+                st.acquire(sf)                                    # the (null) stream waits for the copies on the device
+                back = [np.empty(v.shape, v.dtype) for v in (sf.depth, sf.rgb, sf.samples)]
+                for b, v in zip(back, (sf.depth, sf.rgb, sf.samples)):
+                    _lib.check(lib.avl_memcpy_d2h(b.ctypes.data, v.ptr, v.nbytes, None))
+                st.release(sf)
+                assert np.array_equal(back[0], d0) and np.array_equal(back[1], r0) and np.array_equal(back[2], s0), k
+        assert len(st.retired) == 1                               # the 12 x 16 ring was retired, not freed under the queued frames
     finally:
         st.close()
     assert lib.avl_stream_wait_event(None, None) != 0                 # a null event is an error, not a crash
