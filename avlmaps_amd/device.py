@@ -21,6 +21,7 @@ _POOL_BYTES = [0]
 _POOL_LIMIT = 2 << 30
 _POOL_MAX_ITEM = 256 << 20
 _H2D_PIECE = 64 << 20
+_D2H_PARALLEL_MIN = 256 << 20
 
 
 def _pool_device() -> int:
@@ -90,8 +91,37 @@ class DeviceArray:
 
     def numpy(self, stream=None):
         out = np.empty(self.shape, dtype=self.dtype)
-        if self.nbytes:
-            _lib.check(_lib.load().avl_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, stream), "avl_memcpy_d2h")
+        if not self.nbytes:
+            return out
+        lib = _lib.load()
+        if self.nbytes < _D2H_PARALLEL_MIN:
+            _lib.check(lib.avl_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, stream), "avl_memcpy_d2h")
+            return out
+        # A multi-GB copy into a FRESH host array is bound by the page faults of its first touch, not by PCIe (measured on the GPU
+        # box: 3.2 GB in 0.33 s into np.empty, 0.06 s into memory that has been touched before): several host threads copy -- and
+        # fault in -- disjoint pieces at once.  The map's final save and the first full checkpoint come through here.
+        import threading
+        _lib.check(lib.avl_stream_sync(stream), "avl_stream_sync")
+        dev, dst, errs = self.device, out.ctypes.data, []
+        nthr = min(8, max(2, self.nbytes // (128 << 20)))
+        piece = ((self.nbytes + nthr - 1) // nthr + 4095) & ~4095
+
+        def work(k):
+            try:
+                _lib.set_device(dev)
+                off = k * piece
+                m = min(piece, self.nbytes - off)
+                if m > 0:
+                    _lib.check(lib.avl_memcpy_d2h(dst + off, self.ptr + off, m, None), "avl_memcpy_d2h")
+            except BaseException as e:      # surfaced on the calling thread
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(k,), name="avl-d2h") for k in range(nthr)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
         return out
 
     def free(self):
