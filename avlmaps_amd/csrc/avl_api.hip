@@ -43,6 +43,23 @@ void* scratch(size_t bytes) {
     return s->p;
 }
 
+// The finalisation / replay / merge paths take their temporaries from the device's default stream-ordered pool (hipMallocAsync).
+// HIP's default release threshold is 0: every synchronisation hands the pool's memory back to the driver and the next call maps
+// it again -- tens of ms per GB, which showed as 30-60 ms of "allocation" inside a 30 ms merge (profiles/r04_build_8ranks_*).
+// Keep what the pool has grown to (bounded by what one finalisation needs); once per device and process.
+void keep_mempool_once() {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || done_for == dev) return;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    done_for = dev;
+}
+
 int num_cus() {
     static thread_local int cached_dev = -1;
     static thread_local int cached = 256;

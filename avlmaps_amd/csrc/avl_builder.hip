@@ -1192,27 +1192,10 @@ int avl_builder_destroy(avl_builder* b) {
     return AVL_OK;
 }
 
-// The finalisation / replay / merge paths take their temporaries from the device's default stream-ordered pool (hipMallocAsync).
-// HIP's default release threshold is 0: every synchronisation hands the pool's memory back to the driver and the next call maps
-// it again -- tens of ms per GB, which showed as 30-60 ms of "allocation" inside a 30 ms merge (profiles/r04_build_8ranks_*).
-// Keep what the pool has grown to (bounded by what one finalisation needs); once per device and process.
-static void keep_mempool_once() {
-    static thread_local int done_for = -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || done_for == dev) return;
-    hipMemPool_t pool = nullptr;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-        uint64_t keep = ~0ull;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
-    (void)hipGetLastError();
-    done_for = dev;
-}
-
 int avl_builder_create_grid(avl_builder** h_out, int n0, int gs, int vh, double cs, int D, int64_t capacity) {
     AVL_REQUIRE(h_out, "avl_builder_create: null output");
     *h_out = nullptr;
-    keep_mempool_once();
+    avl::keep_mempool_once();
     AVL_REQUIRE(n0 > 0 && gs > 0 && vh > 0 && D > 0 && cs > 0 && capacity > 0, "avl_builder_create: bad parameters");
     const double ncell_d = (double)n0 * gs * vh;
     AVL_REQUIRE(ncell_d < 2.0e9, "avl_builder_create: gs*gs*vh = %.0f cells exceeds the int32 cell index", ncell_d);

@@ -38,6 +38,9 @@ int num_cus();
 // points that return host scalars (avl_argmax_f32, avl_topk_f32) keep their partial results here instead of allocating on
 // every call.  Valid until the calling thread's next scratch() call; returns nullptr (and sets the error) on failure.
 void* scratch(size_t bytes);
+// keep what the device's default stream-ordered pool (hipMallocAsync) has grown to instead of handing it back at every synchronisation
+// (HIP's default release threshold is 0: tens of ms per GB to map it again); once per device and thread, cheap afterwards
+void keep_mempool_once();
 
 constexpr int kWave = 64;
 

@@ -16,6 +16,7 @@
 //     the (2R+1)^2 columns of its window and finds the nearest set bit of each column with clz / ffs.
 //   * brute force: targets staged through LDS, every thread owns one voxel (used when the window would
 //     be larger than the target list or the dense grid would not fit).
+#include <algorithm>
 #include <climits>
 #include <cstring>
 
@@ -25,7 +26,10 @@
 
 namespace avl {
 
-__global__ void heat_bbox_kernel(const int32_t* __restrict__ pos, int64_t N, int* __restrict__ bbox /* min xyz, max xyz */) {
+// (one atomic per value and WORKGROUP, at most 512 workgroups: the first version issued six atomics per wave on one cache line --
+// 49 k of them at 2 M voxels, and a hot word sustains ~90 atomics per microsecond: 0.6 ms of a 1.8 ms call)
+__global__ __launch_bounds__(256) void heat_bbox_kernel(const int32_t* __restrict__ pos, int64_t N, int* __restrict__ bbox /* min xyz, max xyz */) {
+    __shared__ int red[6][4];
     int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
 #pragma unroll
@@ -42,20 +46,36 @@ __global__ void heat_bbox_kernel(const int32_t* __restrict__ pos, int64_t N, int
             mx[c] = max(mx[c], __shfl_xor(mx[c], off, 64));
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&bbox[c], mn[c]);
-            atomicMax(&bbox[3 + c], mx[c]);
+            red[c][threadIdx.x >> 6] = mn[c];
+            red[3 + c][threadIdx.x >> 6] = mx[c];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int c = threadIdx.x;
+        int v = red[c][0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = c < 3 ? min(v, red[c][w]) : max(v, red[c][w]);
+        if (c < 3) atomicMin(&bbox[c], v);
+        else atomicMax(&bbox[c], v);
     }
 }
 
 // targets as a bit grid: one 64-bit word covers 64 consecutive z cells of an (x, y) column
+// ... and, one level up, a byte per block of kCoarse x kCoarse columns: "some target lives in this block" (round 4).  A voxel whose
+// window touches no occupied block is done after reading <= 9 bytes (from LDS when the coarse grid fits: 16 KB for a 1000 x 1000
+// map) instead of scanning (2R + 1)^2 columns; empty blocks inside a window are stepped over.  Pure pruning: the same bits.
+constexpr int kCoarseShift = 3, kCoarse = 1 << kCoarseShift;
+constexpr int kCoarseLdsBytes = 48 * 1024;
+
 __global__ void heat_scatter_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask, int64_t N, int ox,
-                                    int oy, int oz, int ny, int wz, unsigned long long* __restrict__ grid) {
+                                    int oy, int oz, int ny, int wz, unsigned long long* __restrict__ grid, int cny,
+                                    uint8_t* __restrict__ coarse) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask[i]) {
-            const int z = pos[i * 3 + 2] - oz;
-            const size_t w = ((size_t)(pos[i * 3] - ox) * ny + (pos[i * 3 + 1] - oy)) * wz + (z >> 6);
+            const int x = pos[i * 3] - ox, y = pos[i * 3 + 1] - oy, z = pos[i * 3 + 2] - oz;
+            const size_t w = ((size_t)x * ny + y) * wz + (z >> 6);
             atomicOr(&grid[w], 1ull << (z & 63));
+            coarse[(size_t)(x >> kCoarseShift) * cny + (y >> kCoarseShift)] = 1;      // idempotent plain store
         }
     }
 }
@@ -89,10 +109,28 @@ __device__ __forceinline__ int nearest_bit(unsigned long long word, int wbase, i
     return best;
 }
 
+// The scan of a window used to be ONE dependent load per column: `best` prunes columns, so the compiler cannot hoist a load above
+// the test before it, and every column cost a full L2 round trip -- 121 of them back to back at the reference's decay 0.01
+// (~60 us per wave with a single live lane; 1.0 ms at 2 M voxels).  Now the words of kBatch columns of a window row are loaded
+// together, unconditionally (the address is clamped, the result masked), and only then examined: 11 rows x 2 batches of
+// independent loads.  The visiting order and every comparison are unchanged, so are the results.
+constexpr int kBatch = 8;
+
+template <bool COARSE_LDS>
 __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
                                                           int64_t N, int ox, int oy, int oz, int nx, int ny, int nz, int wz, int R,
-                                                          const unsigned long long* __restrict__ grid, double cell_size,
+                                                          const unsigned long long* __restrict__ grid, int cnx, int cny,
+                                                          const uint8_t* __restrict__ coarse_g, double cell_size,
                                                           double decay, float* __restrict__ heat) {
+    extern __shared__ uint8_t coarse_s[];
+    const uint8_t* coarse = coarse_g;
+    if (COARSE_LDS) {
+        const int nb = cnx * cny;
+        for (int k = threadIdx.x * 4; k < nb; k += blockDim.x * 4)                 // (the buffer is padded to a multiple of 4 bytes)
+            *reinterpret_cast<uint32_t*>(coarse_s + k) = *reinterpret_cast<const uint32_t*>(coarse_g + k);
+        __syncthreads();
+        coarse = coarse_s;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask[i]) {
             heat[i] = 1.0f;
@@ -101,19 +139,53 @@ __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restr
         const int x = pos[i * 3] - ox, y = pos[i * 3 + 1] - oy, z = pos[i * 3 + 2] - oz;
         const int x0 = max(0, x - R), x1 = min(nx - 1, x + R);
         const int y0 = max(0, y - R), y1 = min(ny - 1, y + R);
+        // coarse level: does ANY block of columns that the window touches hold a target?
+        bool any = false;
+        for (int ca = x0 >> kCoarseShift; ca <= (x1 >> kCoarseShift); ++ca)
+            for (int cb = y0 >> kCoarseShift; cb <= (y1 >> kCoarseShift); ++cb) any |= coarse[ca * cny + cb] != 0;
+        if (!any) {
+            heat[i] = 0.0f;      // every target is farther than R >= cell_size / decay: the heat clips to exactly 0
+            continue;
+        }
         const int z0 = max(0, z - R), z1 = min(nz - 1, z + R);
         const int w0 = z0 >> 6, w1 = z1 >> 6;
         int best = INT_MAX;
+        // one word per column (nz <= 64: every map of the reference, vh = 30): the masks that nearest_bit() derives from (z, z0, z1)
+        // are the same for every column of this voxel -- below = bits z0 .. z, above = bits z + 1 .. z1 -- and are built once
+        const unsigned long long upto_z = z >= 63 ? ~0ull : ((1ull << (z + 1)) - 1ull);
+        const unsigned long long m_below = upto_z & ~((1ull << z0) - 1ull);
+        const unsigned long long m_above = ~upto_z & (z1 >= 63 ? ~0ull : ((1ull << (z1 + 1)) - 1ull));
         for (int a = x0; a <= x1; ++a) {
             const int dx2 = (a - x) * (a - x);
             if (dx2 >= best) continue;
-            for (int b = y0; b <= y1; ++b) {
-                const int dxy2 = dx2 + (b - y) * (b - y);
-                if (dxy2 >= best) continue;
-                const unsigned long long* gp = grid + ((size_t)a * ny + b) * wz;
-                for (int w = w0; w <= w1; ++w) {
-                    const int dz = nearest_bit(gp[w], w << 6, z, z0, z1);
-                    if (dz != INT_MAX) best = min(best, dxy2 + dz * dz);
+            const unsigned long long* grow = grid + (size_t)a * ny * wz;
+            for (int b0 = y0; b0 <= y1; b0 += kBatch) {
+                if (wz == 1) {
+                    unsigned long long word[kBatch];
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) word[k] = grow[min(b0 + k, y1)];     // independent loads, issued together
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) {
+                        const int b = b0 + k;
+                        if (b > y1) break;
+                        const int dxy2 = dx2 + (b - y) * (b - y);
+                        if (dxy2 >= best) continue;
+                        const unsigned long long below = word[k] & m_below, above = word[k] & m_above;
+                        int dz = INT_MAX;
+                        if (below) dz = z - (63 - __clzll((long long)below));
+                        if (above) dz = min(dz, (__ffsll((long long)above) - 1) - z);
+                        if (dz != INT_MAX) best = min(best, dxy2 + dz * dz);
+                    }
+                } else {
+                    for (int b = b0; b <= min(b0 + kBatch - 1, y1); ++b) {
+                        const int dxy2 = dx2 + (b - y) * (b - y);
+                        if (dxy2 >= best) continue;
+                        const unsigned long long* gp = grow + (size_t)b * wz;
+                        for (int w = w0; w <= w1; ++w) {
+                            const int dz = nearest_bit(gp[w], w << 6, z, z0, z1);
+                            if (dz != INT_MAX) best = min(best, dxy2 + dz * dz);
+                        }
+                    }
                 }
             }
         }
@@ -184,6 +256,7 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_grid_pos && d_mask && d_heat, "avl_heatmap_from_mask: null pointer");
     hipStream_t st = as_stream(stream);
+    keep_mempool_once();
     int64_t blocks = (N + 255) / 256;
     const int64_t maxb = (int64_t)num_cus() * 8;
     if (blocks > maxb) blocks = maxb;
@@ -204,7 +277,7 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
         const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
         AVL_HIP_CHECK(hipMallocAsync((void**)&d_bbox, sizeof(init), st));
         AVL_HIP_CHECK(hipMemcpyAsync(d_bbox, init, sizeof(init), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(heat_bbox_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, N, d_bbox);
+        hipLaunchKernelGGL(heat_bbox_kernel, dim3((unsigned)std::min<int64_t>(blocks, 512)), dim3(256), 0, st, d_grid_pos, N, d_bbox);
         AVL_HIP_CHECK(hipMemcpyAsync(h_bbox, d_bbox, sizeof(h_bbox), hipMemcpyDeviceToHost, st));
         AVL_HIP_CHECK(hipStreamSynchronize(st));
         (void)hipFreeAsync(d_bbox, st);
@@ -219,12 +292,20 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
         const int wz = (nz + 63) / 64;
         const size_t words = (size_t)nx * ny * wz;
         unsigned long long* grid = nullptr;
-        AVL_HIP_CHECK(hipMallocAsync((void**)&grid, words * sizeof(unsigned long long), st));
-        AVL_HIP_CHECK(hipMemsetAsync(grid, 0, words * sizeof(unsigned long long), st));
+        const int cnx = (nx >> kCoarseShift) + 1, cny = (ny >> kCoarseShift) + 1;
+        const size_t cbytes = ((size_t)cnx * cny + 3) & ~(size_t)3;
+        const size_t gbytes = words * sizeof(unsigned long long);
+        AVL_HIP_CHECK(hipMallocAsync((void**)&grid, gbytes + cbytes, st));          // bit grid | coarse byte grid
+        AVL_HIP_CHECK(hipMemsetAsync(grid, 0, gbytes + cbytes, st));
+        uint8_t* coarse = reinterpret_cast<uint8_t*>(grid) + gbytes;
         hipLaunchKernelGGL(heat_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                           h_bbox[1], h_bbox[2], ny, wz, grid);
-        hipLaunchKernelGGL(heat_window_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                           h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cell_size, decay_rate, d_heat);
+                           h_bbox[1], h_bbox[2], ny, wz, grid, cny, coarse);
+        if (cbytes <= (size_t)kCoarseLdsBytes)
+            hipLaunchKernelGGL(heat_window_kernel<true>, dim3((unsigned)blocks), dim3(256), cbytes, st, d_grid_pos, d_mask, N, h_bbox[0],
+                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat);
+        else
+            hipLaunchKernelGGL(heat_window_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
+                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat);
         (void)hipFreeAsync(grid, st);
     } else {
         int32_t* tpos = nullptr;

@@ -429,7 +429,22 @@ def run_index(args, torch, dist, lib, rank, ws):
             torch.cuda.synchronize()
             ms_heat = float(np.median([timer(heat_step) for _ in range(5)]))
             out["extra"]["heatmap_from_mask"] = dict(ms=ms_heat, voxels=N, targets=int(mask.sum().item()), decay_rate=0.01,
-                                                     nonzero_heat=int((heat > 0).sum().item()))
+                                                     nonzero_heat=int((heat > 0).sum().item()),
+                                                     geometry=f"{side}^3 cube at 7 % occupancy, targets scattered uniformly (5 words per column)")
+            # the reference's map shape: a 1000 x 1000 x 30 grid (one word per column); targets scattered uniformly -- every window
+            # holds some -- and clustered into a few objects, the case index_object meets (most windows are empty: coarse pruning)
+            lin = torch.randperm(1000 * 1000 * 30, device="cuda", generator=g)[:N]
+            pos = torch.stack([lin // 30000, (lin // 30) % 1000, lin % 30], 1).to(torch.int32).contiguous()
+            centres = pos[torch.randint(0, N, (6,), device="cuda", generator=g)]
+            shaped = {}
+            for name, mk in (("uniform_targets", mask), ("clustered_targets",
+                                                         ((pos[:, None, :] - centres[None]).abs().amax(dim=2) <= 12).any(dim=1).to(torch.uint8))):
+                mask = mk
+                heat_step()
+                torch.cuda.synchronize()
+                shaped[name] = dict(ms=float(np.median([timer(heat_step) for _ in range(5)])), targets=int(mk.sum().item()),
+                                    nonzero_heat=int((heat > 0).sum().item()))
+            out["extra"]["heatmap_from_mask"]["map_shaped_1000x1000x30"] = shaped
             del pos, mask, heat, lin
         except Exception as e:  # the extra must never break the benchmark line
             out["extra"]["heatmap_from_mask"] = dict(error=str(e))

@@ -300,6 +300,29 @@ def test_heatmap_matches_reference(ops, golden):
     assert np.array_equal(ti, want) and np.array_equal(tv, heat[want]) and ti[0] == idx
 
 
+def test_heatmap_coarse_pruning_and_batched_column_loads_change_nothing(ops):
+    """round 4: windows that touch no occupied 8 x 8 block of columns are skipped at a coarse level and the columns of a window row
+    are loaded in batches; on a 90 k-voxel map the heat is still the oracle's brute force, bit for bit -- for clustered targets
+    (most windows empty) and for uniformly scattered ones (every block occupied), at two window radii"""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(5)
+    N, side = 90_000, 110
+    lin = rng.choice(side * side * 30, N, replace=False)
+    pos = np.stack([lin // (side * 30) + 400, (lin // 30) % side + 450, lin % 30], 1).astype(np.int32)
+    for kind in ("clustered", "uniform"):
+        if kind == "clustered":
+            centre = pos[rng.integers(0, N, 3)]
+            mask = (np.abs(pos[:, None, :] - centre[None]).max(axis=2) <= 6).any(axis=1)
+        else:
+            mask = rng.random(N) < 0.02
+        for decay in (0.01, 0.004):
+            got = ops.heatmap_from_mask(pos, mask, 0.05, decay)
+            sub = np.concatenate([rng.choice(N, 3000, replace=False), np.flatnonzero(mask)[:50]])
+            want = O.heatmap_from_mask(np.concatenate([pos[sub], pos[mask]]), np.concatenate([mask[sub], np.ones(int(mask.sum()), bool)]), 0.05, decay)
+            assert np.array_equal(got[sub], want[:len(sub)]), (kind, decay)
+            assert (got[mask] == 1.0).all() and (kind == "uniform" or (got == 0).mean() > 0.5)
+
+
 def test_wave_level_topk_orders_like_stable_argsort(ops):
     """avl_topk_f32, k <= 64 (wave-level selection): value descending, ties by ascending index, NaN last, -0.0 == 0.0 --
     np.argsort(-v, kind="stable")[:k]; a heat vector has thousands of exact ties at 1.0"""
