@@ -102,6 +102,9 @@ _SIGS = {
     "avl_obstacle_map": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "avl_obstacle_scatter": (C.c_int, [_vp, _vp, _i64, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "avl_heatmap_from_mask": (C.c_int, [_vp, _vp, _i64, _f64, _f64, _vp, _vp]),
+    "avl_heat_plan_create": (C.c_int, [C.POINTER(_vp), _vp, _i64, _vp]),
+    "avl_heat_plan_destroy": (C.c_int, [_vp]),
+    "avl_heatmap_from_mask_planned": (C.c_int, [_vp, _vp, _f64, _f64, _vp, _vp]),
     "avl_lseg_merge_windows": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
 }
 

@@ -116,12 +116,18 @@ __device__ __forceinline__ int nearest_bit(unsigned long long word, int wbase, i
 // independent loads.  The visiting order and every comparison are unchanged, so are the results.
 constexpr int kBatch = 8;
 
-template <bool COARSE_LDS>
+// PLANNED (avl_heat_plan): the voxels are walked in CELL order -- the plan's one-time radix sort of the map's cells -- instead of in
+// voxel-id order.  Voxel ids are in first-touch order (the sampled pixels of a frame in random order), so the 64 voxels of a wave
+// sit anywhere in the map and each of their column loads is a transaction of its own; in cell order the lanes of a wave are
+// neighbours in z and y, their loads fall on the same or adjacent words (window kernel 3x faster), and a wave is either all near
+// a target or not at all.  Coordinates come out of the sorted cell, the mask is gathered and the heat scattered through `order`.
+template <bool COARSE_LDS, bool PLANNED>
 __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
                                                           int64_t N, int ox, int oy, int oz, int nx, int ny, int nz, int wz, int R,
                                                           const unsigned long long* __restrict__ grid, int cnx, int cny,
                                                           const uint8_t* __restrict__ coarse_g, double cell_size,
-                                                          double decay, float* __restrict__ heat) {
+                                                          double decay, float* __restrict__ heat,
+                                                          const uint32_t* __restrict__ cells, const int32_t* __restrict__ order) {
     extern __shared__ uint8_t coarse_s[];
     const uint8_t* coarse = coarse_g;
     if (COARSE_LDS) {
@@ -131,12 +137,22 @@ __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restr
         __syncthreads();
         coarse = coarse_s;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t;
+        int x, y, z;
+        if (PLANNED) {
+            const uint32_t cell = cells[t];
+            i = order[t];
+            z = (int)(cell % (uint32_t)nz);
+            y = (int)((cell / (uint32_t)nz) % (uint32_t)ny);
+            x = (int)(cell / ((uint32_t)nz * (uint32_t)ny));
+        } else {
+            x = pos[t * 3] - ox, y = pos[t * 3 + 1] - oy, z = pos[t * 3 + 2] - oz;
+        }
         if (mask[i]) {
             heat[i] = 1.0f;
             continue;
         }
-        const int x = pos[i * 3] - ox, y = pos[i * 3 + 1] - oy, z = pos[i * 3 + 2] - oz;
         const int x0 = max(0, x - R), x1 = min(nx - 1, x + R);
         const int y0 = max(0, y - R), y1 = min(ny - 1, y + R);
         // coarse level: does ANY block of columns that the window touches hold a target?
@@ -301,11 +317,11 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
         hipLaunchKernelGGL(heat_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
                            h_bbox[1], h_bbox[2], ny, wz, grid, cny, coarse);
         if (cbytes <= (size_t)kCoarseLdsBytes)
-            hipLaunchKernelGGL(heat_window_kernel<true>, dim3((unsigned)blocks), dim3(256), cbytes, st, d_grid_pos, d_mask, N, h_bbox[0],
-                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat);
+            hipLaunchKernelGGL((heat_window_kernel<true, false>), dim3((unsigned)blocks), dim3(256), cbytes, st, d_grid_pos, d_mask, N, h_bbox[0],
+                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat, nullptr, nullptr);
         else
-            hipLaunchKernelGGL(heat_window_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat);
+            hipLaunchKernelGGL((heat_window_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
+                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat, nullptr, nullptr);
         (void)hipFreeAsync(grid, st);
     } else {
         int32_t* tpos = nullptr;
@@ -319,6 +335,150 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
         (void)hipFreeAsync(tpos, st);
         (void)hipFreeAsync(cnt, st);
     }
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+namespace avl {
+__global__ void heat_cells_kernel(const int32_t* __restrict__ pos, int64_t N, int ox, int oy, int oz, int ny, int nz,
+                                  uint32_t* __restrict__ cells, int32_t* __restrict__ iota) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        cells[i] = ((uint32_t)(pos[i * 3] - ox) * (uint32_t)ny + (uint32_t)(pos[i * 3 + 1] - oy)) * (uint32_t)nz + (uint32_t)(pos[i * 3 + 2] - oz);
+        iota[i] = (int32_t)i;
+    }
+}
+
+// targets into the bit grid + the coarse grid, from the plan's sorted cells (mask gathered through `order`)
+__global__ void heat_scatter_planned_kernel(const uint32_t* __restrict__ cells, const int32_t* __restrict__ order,
+                                            const uint8_t* __restrict__ mask, int64_t N, int ny, int nz, int wz,
+                                            unsigned long long* __restrict__ grid, int cny, uint8_t* __restrict__ coarse) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (int64_t)gridDim.x * blockDim.x) {
+        if (mask[order[t]]) {
+            const uint32_t cell = cells[t];
+            const int z = (int)(cell % (uint32_t)nz), y = (int)((cell / (uint32_t)nz) % (uint32_t)ny), x = (int)(cell / ((uint32_t)nz * (uint32_t)ny));
+            atomicOr(&grid[((size_t)x * ny + y) * wz + (z >> 6)], 1ull << (z & 63));
+            coarse[(size_t)(x >> kCoarseShift) * cny + (y >> kCoarseShift)] = 1;
+        }
+    }
+}
+}  // namespace avl
+
+struct avl_heat_plan {
+    const int32_t* d_grid_pos = nullptr;    // caller-owned, must outlive the plan (the brute-force fall-back reads it)
+    int64_t N = 0;
+    int dev = 0;
+    int bbox[6] = {0, 0, 0, 0, 0, 0};
+    int nx = 0, ny = 0, nz = 0, wz = 0, cnx = 0, cny = 0;
+    size_t gbytes = 0, cbytes = 0;
+    uint32_t* cells = nullptr;               // (N,) linear cells inside the bounding box, ascending
+    int32_t* order = nullptr;                // (N,) voxel id of the t-th cell
+    unsigned long long* grid = nullptr;      // bit grid | coarse byte grid, zeroed per call
+};
+
+extern "C" int avl_heat_plan_destroy(avl_heat_plan* p) {
+    if (!p) return AVL_OK;
+    (void)hipFree(p->cells);
+    (void)hipFree(p->order);
+    (void)hipFree(p->grid);
+    delete p;
+    return AVL_OK;
+}
+
+extern "C" int avl_heat_plan_create(avl_heat_plan** h_out, const int32_t* d_grid_pos, int64_t N, void* stream) {
+    AVL_REQUIRE(h_out, "avl_heat_plan_create: null output");
+    *h_out = nullptr;
+    AVL_REQUIRE(N > 0 && N < (1ll << 31) && d_grid_pos, "avl_heat_plan_create: bad arguments");
+    hipStream_t st = as_stream(stream);
+    keep_mempool_once();
+    int64_t blocks = std::min<int64_t>((N + 255) / 256, (int64_t)num_cus() * 8);
+    const int init[6] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN};
+    int* d_bbox = nullptr;
+    AVL_HIP_CHECK(hipMallocAsync((void**)&d_bbox, sizeof(init), st));
+    AVL_HIP_CHECK(hipMemcpyAsync(d_bbox, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(heat_bbox_kernel, dim3((unsigned)std::min<int64_t>(blocks, 512)), dim3(256), 0, st, d_grid_pos, N, d_bbox);
+    avl_heat_plan* p = new avl_heat_plan();
+    p->d_grid_pos = d_grid_pos;
+    p->N = N;
+    (void)hipGetDevice(&p->dev);
+    hipError_t e = hipMemcpyAsync(p->bbox, d_bbox, sizeof(p->bbox), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFreeAsync(d_bbox, st);
+    if (e != hipSuccess) {
+        delete p;
+        set_error("avl_heat_plan_create: %s", hipGetErrorString(e));
+        return AVL_ERR_HIP;
+    }
+    p->nx = p->bbox[3] - p->bbox[0] + 1, p->ny = p->bbox[4] - p->bbox[1] + 1, p->nz = p->bbox[5] - p->bbox[2] + 1;
+    const double cells_d = (double)p->nx * p->ny * p->nz;
+    if (cells_d >= 4294967296.0) {       // the cell order needs 32-bit cells: the stateless call handles such maps
+        delete p;
+        set_error("avl_heat_plan_create: the map's bounding box has %.0f cells (>= 2^32); use avl_heatmap_from_mask", cells_d);
+        return AVL_ERR_INVALID;
+    }
+    p->wz = (p->nz + 63) / 64;
+    p->cnx = (p->nx >> kCoarseShift) + 1, p->cny = (p->ny >> kCoarseShift) + 1;
+    p->gbytes = (size_t)p->nx * p->ny * p->wz * sizeof(unsigned long long);
+    p->cbytes = ((size_t)p->cnx * p->cny + 3) & ~(size_t)3;
+    uint32_t* unsorted = nullptr;
+    int32_t* iota = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int bits = 1;
+    while (bits < 32 && (double)(1ull << bits) < cells_d) ++bits;
+    e = hipMalloc((void**)&p->cells, (size_t)N * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->order, (size_t)N * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&p->grid, p->gbytes + p->cbytes);
+    if (e == hipSuccess) e = hipMallocAsync((void**)&unsorted, (size_t)N * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipMallocAsync((void**)&iota, (size_t)N * sizeof(int32_t), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(heat_cells_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, N, p->bbox[0], p->bbox[1], p->bbox[2], p->ny,
+                           p->nz, unsorted, iota);
+        e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, unsorted, p->cells, iota, p->order, (size_t)N, 0, bits, st);
+    }
+    if (e == hipSuccess) e = hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, unsorted, p->cells, iota, p->order, (size_t)N, 0, bits, st);
+    (void)hipFreeAsync(tmp, st);
+    (void)hipFreeAsync(iota, st);
+    (void)hipFreeAsync(unsorted, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)avl_heat_plan_destroy(p);
+        set_error("avl_heat_plan_create: %s", hipGetErrorString(e));
+        return AVL_ERR_HIP;
+    }
+    *h_out = p;
+    return AVL_OK;
+}
+
+extern "C" int avl_heatmap_from_mask_planned(avl_heat_plan* p, const uint8_t* d_mask, double cell_size, double decay_rate, float* d_heat,
+                                             void* stream) {
+    AVL_REQUIRE(p, "avl_heatmap_from_mask_planned: null plan");
+    AVL_REQUIRE(cell_size > 0 && d_mask && d_heat, "avl_heatmap_from_mask_planned: bad arguments");
+    hipStream_t st = as_stream(stream);
+    int R = 0;
+    bool windowed = false;
+    if (decay_rate > 0) {
+        const double r = cell_size / decay_rate;
+        if (r < 64.0) {
+            R = (int)ceil(r);
+            windowed = (2.0 * R + 1) * (2.0 * R + 1) * (2.0 * R + 1) <= 40000.0;
+        }
+    }
+    if (!windowed)      // a window larger than the target list: the stateless call's brute force over LDS-staged targets
+        return avl_heatmap_from_mask(p->d_grid_pos, d_mask, p->N, cell_size, decay_rate, d_heat, stream);
+    const int64_t blocks = std::min<int64_t>((p->N + 255) / 256, (int64_t)num_cus() * 8);
+    AVL_HIP_CHECK(hipMemsetAsync(p->grid, 0, p->gbytes + p->cbytes, st));
+    uint8_t* coarse = reinterpret_cast<uint8_t*>(p->grid) + p->gbytes;
+    hipLaunchKernelGGL(heat_scatter_planned_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p->cells, p->order, d_mask, p->N, p->ny, p->nz,
+                       p->wz, p->grid, p->cny, coarse);
+    if (p->cbytes <= (size_t)kCoarseLdsBytes)
+        hipLaunchKernelGGL((heat_window_kernel<true, true>), dim3((unsigned)blocks), dim3(256), p->cbytes, st, nullptr, d_mask, p->N, p->bbox[0],
+                           p->bbox[1], p->bbox[2], p->nx, p->ny, p->nz, p->wz, R, p->grid, p->cnx, p->cny, coarse, cell_size, decay_rate, d_heat,
+                           p->cells, p->order);
+    else
+        hipLaunchKernelGGL((heat_window_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, nullptr, d_mask, p->N, p->bbox[0],
+                           p->bbox[1], p->bbox[2], p->nx, p->ny, p->nz, p->wz, R, p->grid, p->cnx, p->cny, coarse, cell_size, decay_rate, d_heat,
+                           p->cells, p->order);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }

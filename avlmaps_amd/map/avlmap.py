@@ -40,10 +40,10 @@ class AVLMap:
             mask = vm._score(q, want_scores=False)[1] == 0
             if not mask.any():
                 raise ValueError("attempt to get argmin of an empty sequence")
-            return ops.heatmap_from_mask(vm._device_pos(), mask.astype(np.uint8), cs, decay_rate).numpy()
+            return vm.heatmap_from_mask(mask.astype(np.uint8), cs, decay_rate).numpy()
         _, am, _ = ops.sim_scores(feat, q, want_scores=False, want_argmax=True, precision=vm._sim_precision)
         mask = ops.mask_from_argmax(am, 0)
-        heat = ops.heatmap_from_mask(vm._device_pos(), mask, cs, decay_rate)
+        heat = vm.heatmap_from_mask(mask, cs, decay_rate)
         if vm.grid_pos.shape[0] and ops.argmax_f32(heat)[1] < 1.0:      # a target voxel has heat exactly 1
             raise ValueError("attempt to get argmin of an empty sequence")   # what np.argmin raises upstream (no voxel matched)
         return heat.numpy()

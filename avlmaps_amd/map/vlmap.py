@@ -170,6 +170,27 @@ class VLMap(Map):
             self._dev_pos_src = self.grid_pos
         return self._dev_pos
 
+    def _heat_plan(self):
+        """ops.HeatPlan of this map's voxel positions (cell order + grid buffers), rebuilt only when the positions change; None
+        for a map whose bounding box is too large for one (callers then use the stateless ops.heatmap_from_mask)."""
+        from .. import ops
+        pos = self._device_pos()
+        if getattr(self, "_heat_plan_src", None) is not pos:
+            old = getattr(self, "_heat_plan_obj", None)
+            if old is not None:
+                old.close()
+            self._heat_plan_obj = ops.HeatPlan.for_positions(pos) if len(self.grid_pos) else None
+            self._heat_plan_src = pos
+        return self._heat_plan_obj
+
+    def heatmap_from_mask(self, mask, cell_size, decay_rate):
+        """visualize_utils.py:29-49 for this map's voxels: mask (N,) host/device -> device heat (planned when possible)"""
+        from .. import ops
+        plan = self._heat_plan()
+        if plan is not None:
+            return plan(mask, cell_size, decay_rate)
+        return ops.heatmap_from_mask(self._device_pos(), mask, cell_size, decay_rate)
+
     def adopt_device_shard(self, shard) -> bool:
         """Take this rank's block of a freshly merged map (VLMapBuilder.map_shard: device tensors of
         parallel.merge_accumulator_sharded) as the resident copy the index kernels read -- no 4 GB host round trip after a

@@ -662,6 +662,68 @@ def heatmap_from_mask(grid_pos, mask, cell_size=0.05, decay_rate=0.01, stream=No
     return heat.numpy(stream) if isinstance(grid_pos, np.ndarray) else heat
 
 
+class HeatPlan:
+    """The part of heatmap_from_mask that depends on the voxel positions only, kept for a map that is queried repeatedly
+    (avl_heat_plan: bounding box, voxels in cell order, zeroed grid buffers).  plan(mask, cell_size, decay_rate) returns the same
+    bits as heatmap_from_mask(grid_pos, mask, ...), ~3x sooner.  grid_pos: DeviceArray or CUDA tensor (N,3) int32, kept alive here.
+    HeatPlan.for_positions returns None when the map's bounding box is too large for a plan (>= 2^32 cells)."""
+
+    def __init__(self, grid_pos, stream=None):
+        lib = _lib.load()
+        _lib.require_gpu()
+        if isinstance(grid_pos, np.ndarray):
+            grid_pos = DeviceArray.from_numpy(np.ascontiguousarray(grid_pos, dtype=np.int32))
+        pp, pshape, self._keep = as_device(grid_pos, np.int32, stream)
+        self.grid_pos, self.N = grid_pos, int(pshape[0])
+        self._torch = _is_torch(grid_pos)
+        h = C.c_void_p()
+        _lib.check(lib.avl_heat_plan_create(C.byref(h), pp, self.N, stream), "avl_heat_plan_create")
+        self._h, self._lib = h, lib
+
+    @classmethod
+    def for_positions(cls, grid_pos, stream=None):
+        try:
+            return cls(grid_pos, stream)
+        except _lib.AvlError as e:
+            if "2^32" in str(e):
+                return None
+            raise
+
+    def __call__(self, mask, cell_size=0.05, decay_rate=0.01, stream=None):
+        if self._h is None:
+            raise RuntimeError("HeatPlan used after close()")
+        if _is_torch(mask):
+            import torch
+            if mask.dtype == torch.bool:
+                mask = mask.to(torch.uint8)
+        elif isinstance(mask, np.ndarray):
+            mask = mask.astype(np.uint8)
+        mp, mshape, keep = as_device(mask, np.uint8, stream)
+        if int(np.prod(mshape)) != self.N:
+            raise ValueError(f"mask has {int(np.prod(mshape))} entries, the plan {self.N} voxels")
+        if self._torch:
+            import torch
+            heat = torch.empty((self.N,), dtype=torch.float32, device=self.grid_pos.device)
+            hp = heat.data_ptr()
+        else:
+            heat = DeviceArray((self.N,), np.float32)
+            hp = heat.ptr
+        _lib.check(self._lib.avl_heatmap_from_mask_planned(self._h, mp, float(cell_size), float(decay_rate), hp, stream),
+                   "avl_heatmap_from_mask_planned")
+        return heat
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None:
+            self._lib.avl_heat_plan_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---------------------------------------------------------------------------------------- top-down 2-D products
 def _dev_u8(x, stream):
     """bool / uint8 host array, DeviceArray or torch tensor -> uint8 device pointer"""

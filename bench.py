@@ -437,6 +437,14 @@ def run_index(args, torch, dist, lib, rank, ws):
             pos = torch.stack([lin // 30000, (lin // 30) % 1000, lin % 30], 1).to(torch.int32).contiguous()
             centres = pos[torch.randint(0, N, (6,), device="cuda", generator=g)]
             shaped = {}
+            plan = C.c_void_p()                             # what AVLMap.index_object keeps per map: the voxels' cell order
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _lib.check(lib.avl_heat_plan_create(C.byref(plan), pos.data_ptr(), N, None))
+            shaped["plan_build_ms"] = (time.perf_counter() - t0) * 1e3
+
+            def planned_step():
+                _lib.check(lib.avl_heatmap_from_mask_planned(plan, mask.data_ptr(), 0.05, 0.01, heat.data_ptr(), None))
             for name, mk in (("uniform_targets", mask), ("clustered_targets",
                                                          ((pos[:, None, :] - centres[None]).abs().amax(dim=2) <= 12).any(dim=1).to(torch.uint8))):
                 mask = mk
@@ -444,6 +452,12 @@ def run_index(args, torch, dist, lib, rank, ws):
                 torch.cuda.synchronize()
                 shaped[name] = dict(ms=float(np.median([timer(heat_step) for _ in range(5)])), targets=int(mk.sum().item()),
                                     nonzero_heat=int((heat > 0).sum().item()))
+                want = heat.clone()
+                planned_step()
+                torch.cuda.synchronize()
+                shaped[name]["planned_ms"] = float(np.median([timer(planned_step) for _ in range(5)]))
+                shaped[name]["planned_same_bits"] = bool(torch.equal(want, heat))
+            lib.avl_heat_plan_destroy(plan)
             out["extra"]["heatmap_from_mask"]["map_shaped_1000x1000x30"] = shaped
             del pos, mask, heat, lin
         except Exception as e:  # the extra must never break the benchmark line

@@ -420,6 +420,18 @@ AVL_API int avl_rows_add_f64_async(int64_t n, int cols, const int64_t* d_rows, i
  * ------------------------------------------------------------------------------------------------ */
 AVL_API int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d_mask, int64_t N, double cell_size,
                                   double decay_rate, float* d_heat, void* stream);
+/* The same heat for a map that is queried again and again (AVLMap.index_object on one map, many object names): a PLAN holds what
+ * depends on the voxel positions only -- the bounding box, the voxels in CELL order (one radix sort) and the zeroed bit-grid
+ * buffers -- so that a call is a memset, a scatter of the targets and the window scan walked in cell order (the lanes of a wave
+ * are then spatial neighbours and their column loads coalesce: the scan is 3x faster than in voxel-id order, and no host
+ * round trip for the bounding box remains).  Results are the same bits as avl_heatmap_from_mask.  d_grid_pos is caller-owned
+ * and must outlive the plan; one plan = one device = one host thread at a time.  AVL_ERR_INVALID when the bounding box has
+ * >= 2^32 cells (use the stateless call). */
+typedef struct avl_heat_plan avl_heat_plan;
+AVL_API int avl_heat_plan_create(avl_heat_plan** h_out, const int32_t* d_grid_pos, int64_t N, void* stream);
+AVL_API int avl_heat_plan_destroy(avl_heat_plan* plan);
+AVL_API int avl_heatmap_from_mask_planned(avl_heat_plan* plan, const uint8_t* d_mask, double cell_size, double decay_rate,
+                                          float* d_heat, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (4) top-down 2-D products of the voxel map (the consumers that loop over all N voxels in Python upstream).

@@ -194,6 +194,9 @@ def test_vlmap_index_and_avlmap_index_object(golden):
     heat = av.index_object("sofa", decay_rate=0.01)
     assert heat.shape == (n,) and heat.dtype == np.float32
     assert np.array_equal(heat, O.heatmap_from_mask(vm.grid_pos, mask, 0.05, 0.01))
+    plan = vm._heat_plan()                       # the map's cell order is computed once and answers the next query too
+    assert plan is not None and np.array_equal(av.index_object("sofa", decay_rate=0.1), O.heatmap_from_mask(vm.grid_pos, mask, 0.05, 0.1))
+    assert vm._heat_plan() is plan
     for fn in (av.index_sound, av.index_area, av.index_image):
         with pytest.raises(NotImplementedError):
             fn("x")

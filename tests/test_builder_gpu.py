@@ -323,6 +323,43 @@ def test_heatmap_coarse_pruning_and_batched_column_loads_change_nothing(ops):
             assert (got[mask] == 1.0).all() and (kind == "uniform" or (got == 0).mean() > 0.5)
 
 
+def test_heat_plan_gives_the_stateless_call_bit_for_bit(ops, golden):
+    """avl_heat_plan: the cell order and grid buffers of a map kept across calls.  One plan answers many masks (clustered, uniform,
+    empty, all-set), window radii and the brute-force fall-back with the bits of avl_heatmap_from_mask; a map taller than one grid
+    word (nz > 64) and the golden map are covered too"""
+    rng = np.random.default_rng(11)
+    g = golden("g4_heatmap.npz")
+    plan = ops.HeatPlan(g["grid_pos"])
+    for decay in (0.01, 0.1, 0.003):
+        h = plan(g["mask"], 0.05, decay).numpy()
+        assert np.array_equal(h, ops.heatmap_from_mask(g["grid_pos"], g["mask"], 0.05, decay)), decay
+        if decay != 0.003:
+            assert np.array_equal(h, g[f"heat_{decay}"])
+    plan.close()
+    with pytest.raises(RuntimeError):
+        plan(g["mask"])
+    for nz, side in ((30, 110), (150, 60)):
+        N = 90_000
+        lin = rng.choice(side * side * nz, N, replace=False)
+        pos = np.stack([lin // (side * nz) + 400, (lin // nz) % side + 450, lin % nz - 3], 1).astype(np.int32)
+        plan = ops.HeatPlan(pos)
+        centre = pos[rng.integers(0, N, 3)]
+        masks = dict(clustered=(np.abs(pos[:, None, :] - centre[None]).max(axis=2) <= 6).any(axis=1), uniform=rng.random(N) < 0.02,
+                     empty=np.zeros(N, bool), full=np.ones(N, bool), one=np.arange(N) == 777)
+        for name, mask in masks.items():
+            for decay in (0.01, 0.004, 0.05):
+                got = plan(mask, 0.05, decay).numpy()
+                assert np.array_equal(got, ops.heatmap_from_mask(pos, mask, 0.05, decay)), (nz, name, decay)
+        got = plan(masks["one"], 0.05, 0.0005).numpy()                     # window too large: brute force behind the same entry
+        assert np.array_equal(got, ops.heatmap_from_mask(pos, masks["one"], 0.05, 0.0005))
+        with pytest.raises(ValueError):
+            plan(masks["one"][:-1])
+    # a bounding box of >= 2^32 cells has no plan: for_positions says so and callers keep the stateless call
+    far = np.array([[0, 0, 0], [70000, 70000, 3]], np.int32)
+    assert ops.HeatPlan.for_positions(far) is None
+    assert np.array_equal(ops.heatmap_from_mask(far, np.array([1, 0], np.uint8), 0.05, 0.01), np.array([1, 0], np.float32))
+
+
 def test_wave_level_topk_orders_like_stable_argsort(ops):
     """avl_topk_f32, k <= 64 (wave-level selection): value descending, ties by ascending index, NaN last, -0.0 == 0.0 --
     np.argsort(-v, kind="stable")[:k]; a heat vector has thousands of exact ties at 1.0"""

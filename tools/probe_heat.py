@@ -28,12 +28,27 @@ if kind == "uniform":
 else:
     c = pos[torch.randint(0, N, (6,), device="cuda", generator=g)]
     mask = ((pos[:, None, :] - c[None]).abs().amax(dim=2) <= 12).any(dim=1).to(torch.uint8)
-for _ in range(3):
-    _lib.check(lib.avl_heatmap_from_mask(pos.data_ptr(), mask.data_ptr(), N, 0.05, 0.01, heat.data_ptr(), None))
+def timed(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps * 1e3
+
+
+ms = timed(lambda: _lib.check(lib.avl_heatmap_from_mask(pos.data_ptr(), mask.data_ptr(), N, 0.05, 0.01, heat.data_ptr(), None)))
+ref = heat.clone()
+print(f"{kind} targets ({int(mask.sum())} of {N}), stateless call: {ms:.3f} ms, nonzero heat {int((heat > 0).sum())}")
+import ctypes as C  # noqa: E402
+h = C.c_void_p()
 torch.cuda.synchronize()
 t = time.perf_counter()
-for _ in range(reps):
-    _lib.check(lib.avl_heatmap_from_mask(pos.data_ptr(), mask.data_ptr(), N, 0.05, 0.01, heat.data_ptr(), None))
-torch.cuda.synchronize()
-print(f"{kind} targets ({int(mask.sum())} of {N}), {'plain' if os.environ.get('AVL_HEAT_UNSORTED') else 'cell-ordered'} walk: "
-      f"{(time.perf_counter() - t) / reps * 1e3:.3f} ms per call, nonzero heat {int((heat > 0).sum())}")
+_lib.check(lib.avl_heat_plan_create(C.byref(h), pos.data_ptr(), N, None))
+t_plan = (time.perf_counter() - t) * 1e3
+heat.zero_()
+ms = timed(lambda: _lib.check(lib.avl_heatmap_from_mask_planned(h, mask.data_ptr(), 0.05, 0.01, heat.data_ptr(), None)))
+print(f"{kind} targets, planned call: {ms:.3f} ms (plan built once in {t_plan:.2f} ms), same bits: {bool(torch.equal(ref, heat))}")
+lib.avl_heat_plan_destroy(h)
