@@ -174,6 +174,12 @@ def aux_case(i):
     heat = heat.numpy() if not isinstance(heat, np.ndarray) else heat
     if not np.array_equal(heat, O.heatmap_from_mask(pos, mask, cs, decay)):
         fails.append((cfg, "heat differs"))
+    plan = ops.HeatPlan(pos)                       # the map's cached cell order must give the same bits, also on a second mask
+    mask2 = np.roll(mask, 1)
+    for mk in (mask, mask2):
+        if not np.array_equal(plan(mk, cs, decay).numpy(), heat if mk is mask else ops.heatmap_from_mask(pos, mk, cs, decay)):
+            fails.append((cfg, "planned heat differs"))
+    plan.close()
     idx, val = ops.argmax_f32(heat)
     if idx != int(np.argmax(heat)) or val != heat[idx]:
         fails.append((cfg, "argmax_f32 differs"))
