@@ -418,6 +418,120 @@ __attribute__((target("avx2,popcnt"))) void run_shuffles_avx2(Mt19937& g, int64_
     }
 }
 
+// AVX-512 form (Zen 4/5, recent Xeons): the same scheme sixteen words at a time -- the twister's recurrence leaves sixteen
+// consecutive words independent too (distances 1 and 397 / -227) -- with the compares landing in mask registers.  64 draws are
+// decided against one broadcast of i (ambiguous only for i - 63 < x <= i).  MODE 2 packs the accepted draws of a 16-block with
+// vpcompressd on the lane-reversed block (register form + masked store: the r-th accepted draw lands at arr[i - r], nothing above
+// arr[i] is touched).  Same draws, same state as the scalar loop; AVL_NO_AVX512=1 falls back to the AVX2 form.
+#define AVL_T512 __attribute__((target("avx512f,avx512vl,avx512bw,avx512dq,popcnt")))
+AVL_T512 static inline void mt_step16(uint32_t* key, int i, int j) {
+    const __m512i a = _mm512_loadu_si512(key + i), b = _mm512_loadu_si512(key + i + 1);
+    const __m512i y = _mm512_or_si512(_mm512_and_si512(a, _mm512_set1_epi32((int)0x80000000u)), _mm512_and_si512(b, _mm512_set1_epi32(0x7fffffff)));
+    const __mmask16 odd = _mm512_test_epi32_mask(y, _mm512_set1_epi32(1));
+    __m512i r = _mm512_xor_si512(_mm512_loadu_si512(key + j), _mm512_srli_epi32(y, 1));
+    r = _mm512_mask_xor_epi32(r, odd, r, _mm512_set1_epi32((int)0x9908b0dfu));
+    _mm512_storeu_si512(key + i, r);
+}
+AVL_T512 static void mt_regen_avx512(uint32_t* key) {
+    int i = 0;
+    for (; i + 16 <= 227; i += 16) mt_step16(key, i, i + 397);
+    for (; i < 227; ++i) mt_step1(key, i, i + 1, i + 397);
+    for (; i + 16 <= 623; i += 16) mt_step16(key, i, i - 227);
+    for (; i < 623; ++i) mt_step1(key, i, i + 1, i - 227);
+    mt_step1(key, 623, 0, 396);
+}
+AVL_T512 static void mt_temper_avx512(const uint32_t* key, uint32_t* out) {
+    const __m512i m1 = _mm512_set1_epi32((int)0x9d2c5680u), m2 = _mm512_set1_epi32((int)0xefc60000u);
+    for (int k = 0; k < 624; k += 16) {
+        __m512i y = _mm512_loadu_si512(key + k);
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), m1));
+        y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), m2));
+        y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+        _mm512_store_si512(out + k, y);
+    }
+}
+AVL_T512 static inline unsigned rev16(unsigned m) {       // bit-reverse a 16-bit mask
+    m = ((m & 0x5555u) << 1) | ((m >> 1) & 0x5555u);
+    m = ((m & 0x3333u) << 2) | ((m >> 2) & 0x3333u);
+    m = ((m & 0x0f0fu) << 4) | ((m >> 4) & 0x0f0fu);
+    return ((m & 0x00ffu) << 8) | ((m >> 8) & 0x00ffu);
+}
+
+// accepted draws of one 16-block (mask acc over the draws in order) -> arr[i], arr[i - 1], ...; returns how many
+template <int MODE>
+AVL_T512 static inline uint32_t pack16(__m512i x, unsigned acc, uint32_t i, int32_t* arr) {
+    const uint32_t cnt = (uint32_t)__builtin_popcount(acc);
+    if (MODE == 2) {
+        const __m512i vrev = _mm512_set_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);   // lane l <- lane 15 - l
+        const __m512i packed = _mm512_maskz_compress_epi32((__mmask16)rev16(acc), _mm512_permutexvar_epi32(vrev, x));
+        _mm512_mask_storeu_epi32(arr + ((int64_t)i - cnt + 1), (__mmask16)((1u << cnt) - 1u), packed);   // last accepted ... first accepted
+    }
+    return cnt;
+}
+
+template <int MODE>
+AVL_T512 void run_shuffles_avx512(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t* arr) {
+    alignas(64) uint32_t out[624 + 16];
+    if (g.pos < 624) mt_temper_avx512(g.key, out);
+    for (int64_t s = 0; s < n_shuffles; ++s) {
+        if (n_items < 2) continue;
+        uint32_t i = (uint32_t)(n_items - 1), mask = i;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        while (i >= 1) {
+            const uint32_t lo = mask >> 1;
+            const __m512i vmask = _mm512_set1_epi32((int)mask);
+            while (i > lo) {
+                if (g.pos >= 624) {
+                    mt_regen_avx512(g.key);
+                    g.pos = 0;
+                    mt_temper_avx512(g.key, out);
+                }
+                const int avail = 624 - g.pos;
+                const uint32_t* o = out + g.pos;
+                int k = 0;
+                for (;;) {
+                    while (k + 64 <= avail && i >= lo + 64) {
+                        const __m512i vi = _mm512_set1_epi32((int)i), vlo = _mm512_set1_epi32((int)i - 63);
+                        __m512i x[4];
+                        unsigned rej[4], nacc[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            x[b] = _mm512_and_si512(_mm512_loadu_si512(o + k + 16 * b), vmask);
+                            rej[b] = _mm512_cmpgt_epu32_mask(x[b], vi);
+                            nacc[b] = _mm512_cmpgt_epu32_mask(x[b], vlo);
+                        }
+                        if ((rej[0] ^ nacc[0]) | (rej[1] ^ nacc[1]) | (rej[2] ^ nacc[2]) | (rej[3] ^ nacc[3])) break;   // ambiguous: narrower paths
+                        uint32_t ii = i;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) ii -= pack16<MODE>(x[b], (~nacc[b]) & 0xffffu, ii, arr);
+                        i = ii;
+                        k += 64;
+                    }
+                    while (k + 16 <= avail && i >= lo + 16) {
+                        const __m512i x = _mm512_and_si512(_mm512_loadu_si512(o + k), vmask);
+                        const unsigned rej = _mm512_cmpgt_epu32_mask(x, _mm512_set1_epi32((int)i));
+                        const unsigned nacc = _mm512_cmpgt_epu32_mask(x, _mm512_set1_epi32((int)i - 15));
+                        if (rej != nacc) break;                       // an ambiguous draw: this block goes through the scalar loop
+                        i -= pack16<MODE>(x, (~nacc) & 0xffffu, i, arr);
+                        k += 16;
+                        if (k + 64 <= avail && i >= lo + 64) break;      // back to the wide path
+                    }
+                    const int kend = k + 16 < avail ? k + 16 : avail;
+                    for (; k < kend && i > lo; ++k) {
+                        const uint32_t x = o[k] & mask;
+                        if (MODE == 2) arr[i] = (int32_t)x;
+                        i -= x <= i ? 1u : 0u;
+                    }
+                    if (k >= avail || i <= lo) break;
+                }
+                g.pos += k;
+            }
+            mask = lo;
+        }
+    }
+}
+
 template <int MODE>
 void run_shuffles_best(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t* arr) {
     static const bool avx2 = [] {
@@ -425,7 +539,10 @@ void run_shuffles_best(Mt19937& g, int64_t n_items, int64_t n_shuffles, int32_t*
         if (ok) build_pack_lut();
         return ok;
     }();
-    if (avx2) run_shuffles_avx2<MODE>(g, n_items, n_shuffles, arr);
+    static const bool avx512 = avx2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+                               __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512dq") && std::getenv("AVL_NO_AVX512") == nullptr;
+    if (avx512) run_shuffles_avx512<MODE>(g, n_items, n_shuffles, arr);
+    else if (avx2) run_shuffles_avx2<MODE>(g, n_items, n_shuffles, arr);
     else run_shuffles<MODE>(g, n_items, n_shuffles, arr);
 }
 }  // namespace

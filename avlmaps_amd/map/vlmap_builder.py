@@ -70,13 +70,20 @@ class VLMapBuilder:
         self.incremental_checkpoints = True        # periodic saves write only the rows that changed + the new rows
                                                    # (utils.mapping_utils.MapFileWriter); False = full rewrite like upstream
         self.pixel_sampling = "reference"          # "reference": np.random.shuffle(arange(H*W))[::rate] on the global RNG, the pixels a
-                                                   # seeded upstream run samples (serial by nature; 2 ms per 720x1080 frame through
-                                                   # avl_mt19937_shuffle_sample, 6.6 ms in NumPy: it caps a pixel-faithful pipeline
-                                                   # at ~400 frames/s); "uniform": the same distribution -- an
+                                                   # seeded upstream run samples (its draws are serial by nature: 0.3-0.5 ms per
+                                                   # 720x1080 frame through avl_mt19937_skip_shuffles, see sampler_workers; NumPy's
+                                                   # shuffle takes 6.6 ms); "uniform": the same distribution -- an
                                                    # ordered uniform sample without replacement -- from a per-frame generator
                                                    # seeded by ONE draw of the global RNG and the frame index (0.25 ms; not the
                                                    # reference's pixels, but reproducible under np.random.seed and independent
                                                    # of how the frames are sharded over ranks)
+        self.sampler_workers = "auto"              # "reference" sampling with prefetch_frames > 0: the serial part of a frame's
+                                                   # shuffle is only its DRAWS (how far the RNG moves: avl_mt19937_skip_shuffles,
+                                                   # half the cost of the sample).  The sampler thread walks the RNG frame by frame
+                                                   # and hands a snapshot of the state to this many worker threads, which compute
+                                                   # the pixel lists of different frames side by side (same lists, same final RNG
+                                                   # state).  "auto" = 3 when the host has >= 6 cores, else 0 (= sample in the
+                                                   # sampler thread as before)
         self.merge_mode = "sharded"                # several ranks: "sharded" = one all_to_all of every rank's OWN voxel rows to the
                                                    # owners of their final rows, finalised where they land (bytes ~ what a rank
                                                    # holds; the map stays row-sharded for the index kernels); "reduce" = ONE
@@ -135,8 +142,34 @@ class VLMapBuilder:
         return shuffle_mask[::depth_sample_rate].astype(np.int32)
 
     @staticmethod
+    def _sample_from_state(key: np.ndarray, pos: int, n_pix: int, depth_sample_rate: int) -> np.ndarray:
+        """sample_pixels for an explicit MT19937 state (a worker's private copy: the global RNG is not touched)"""
+        import ctypes as C
+        from .. import _lib
+        lib = _lib.load()
+        cpos = C.c_int(int(pos))
+        scratch = _SCRATCH.__dict__.get("buf")
+        if scratch is None or scratch.shape[0] < n_pix:
+            scratch = _SCRATCH.buf = np.empty(n_pix, np.int32)
+        out = np.empty((n_pix + depth_sample_rate - 1) // depth_sample_rate, np.int32)
+        _lib.check(lib.avl_mt19937_shuffle_sample(key.ctypes.data, C.byref(cpos), int(n_pix), int(depth_sample_rate), scratch.ctypes.data,
+                                                  out.ctypes.data), "avl_mt19937_shuffle_sample")
+        return out
+
+    def _n_sampler_workers(self) -> int:
+        w = self.sampler_workers
+        if w == "auto":
+            import os
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except Exception:
+                cores = os.cpu_count() or 1
+            return 3 if cores >= 6 else 0
+        return max(0, int(w or 0))
+
+    @staticmethod
     def _announce_skip(n_frames: int, n_pix: int) -> None:
-        est = n_frames * n_pix * 2.2e-9                          # ~2.2 ns per index of a skipped shuffle
+        est = n_frames * n_pix * 0.7e-9                          # 0.4-0.7 ns per index of a skipped shuffle (AVX-512 / AVX2)
         if est > 5.0:
             print(f"[avlmaps_amd] fast-forwarding the NumPy RNG past {n_frames} frames of the ranks before this one (~{est:.0f} s) so "
                   "that this seeded run samples the reference's pixels; pixel_sampling='uniform' or shard_sampling='independent' "
@@ -243,13 +276,39 @@ class VLMapBuilder:
                         self._announce_skip(skip_shuffles, depth.shape[0] * depth.shape[1])
                         self.skip_pixel_shuffles(skip_shuffles, depth.shape[0] * depth.shape[1])
                     t_ = time.perf_counter()
-                    smp = self._draw_samples(i, depth.shape[0] * depth.shape[1], depth_sample_rate)
+                    n_pix = depth.shape[0] * depth.shape[1]
+                    smp = None
+                    if workers is not None and 0 < n_pix < (1 << 31):
+                        st = np.random.get_state()
+                        if st[0] == "MT19937":
+                            # the frame's pixel list is computed from a snapshot by a worker; this thread only moves the RNG on
+                            key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+                            smp = workers.submit(timed_sample, key, int(st[2]), n_pix, depth_sample_rate)
+                            self.skip_pixel_shuffles(1, n_pix)
+                    if smp is None:
+                        smp = self._draw_samples(i, n_pix, depth_sample_rate)
                     st_["sampler_busy_s"] += time.perf_counter() - t_
                     if not put(sampled, (i, rgb, depth, smp, None)):
                         return
                 put(sampled, None)
             except BaseException as e:     # surfaced on the consuming thread
                 put(sampled, e)
+
+        def timed_sample(key, pos, n_pix, rate):
+            t_ = time.perf_counter()
+            smp = self._sample_from_state(key, pos, n_pix, rate)
+            with st_lock:
+                st_["sampler_workers_busy_s"] += time.perf_counter() - t_
+            return smp
+
+        def resolved(item):
+            """the sample list of a queued frame: wait for the worker that computes it (frames stay in order)"""
+            if item is None or isinstance(item, BaseException) or isinstance(item[3], np.ndarray):
+                return item
+            try:
+                return item[:3] + (item[3].result(),) + item[4:]
+            except BaseException as e:
+                return e
 
         def stage_frames():
             try:
@@ -260,6 +319,7 @@ class VLMapBuilder:
                         item = sampled.get(timeout=0.1)
                     except queue.Empty:
                         continue
+                    item = resolved(item)
                     if item is None or isinstance(item, BaseException):
                         put(out, item)
                         return
@@ -272,6 +332,11 @@ class VLMapBuilder:
             except BaseException as e:
                 put(out, e)
 
+        nw = self._n_sampler_workers() if self.pixel_sampling == "reference" else 0
+        st_["sampler_workers"] = nw
+        st_["sampler_workers_busy_s"] = 0.0
+        st_lock = threading.Lock()
+        workers = ThreadPoolExecutor(max_workers=nw, thread_name_prefix="avl-sample") if nw > 0 else None
         with ThreadPoolExecutor(max_workers=min(n, 8), thread_name_prefix="avl-frame") as ex:
             threads = [threading.Thread(target=sampler, args=(ex,), name="avl-sampler", daemon=True)]
             if stage:
@@ -282,6 +347,8 @@ class VLMapBuilder:
                 while True:
                     t_ = time.perf_counter()
                     item = out.get()
+                    if not stage:
+                        item = resolved(item)
                     st_["fuse_thread_wait_s"] += time.perf_counter() - t_
                     if item is None:
                         break
@@ -293,6 +360,8 @@ class VLMapBuilder:
                 stop.set()
                 for th in threads:
                     th.join()
+                if workers is not None:
+                    workers.shutdown(wait=True, cancel_futures=True)
 
     def _init_lseg(self):
         """Reference: vlmap_builder.py:226-264 builds LSegEncNet from demo_e200.ckpt.  The model is not part of this

@@ -346,6 +346,45 @@ def test_sample_pixels_is_numpys_shuffle():
     assert 0.0 <= np.random.rand() < 1.0                                            # the global RNG still works afterwards
 
 
+def test_every_simd_form_of_the_shuffle_draws_numpys_numbers():
+    """avl_mt19937_shuffle_sample / avl_mt19937_skip_shuffles dispatch on the host's instruction set (AVX-512, AVX2, scalar); each
+    form, forced through AVL_NO_AVX512 / AVL_NO_AVX2 in a fresh process, must produce NumPy's samples and leave NumPy's state --
+    full 720 x 1080 frames included (every constant-mask run, block edges at the 624-word refills, ambiguous blocks)"""
+    import hashlib
+    import subprocess
+    import sys
+    cases = ((777600, 100, 3), (70001, 7, 2), (1 << 16, 3, 2), ((1 << 16) + 1, 1, 2), (1000, 1, 5), (65, 2, 4), (17, 1, 4))
+    h = hashlib.sha256()
+    np.random.seed(3)
+    for n_pix, rate, k in cases:
+        for _ in range(k):
+            m = np.arange(n_pix)
+            np.random.shuffle(m)
+            h.update(np.ascontiguousarray(m[::rate], dtype=np.int32).tobytes())
+        for _ in range(2):                                     # two more shuffles, skipped by the draws-only entry
+            np.random.shuffle(np.arange(n_pix))
+        st = np.random.get_state()
+        h.update(st[1].tobytes() + bytes([st[2] & 0xff, st[2] >> 8]))
+    want = h.hexdigest()
+    prog = (
+        "import hashlib, sys, numpy as np\n"
+        f"sys.path.insert(0, {str(Path(__file__).resolve().parent.parent)!r})\n"
+        "from avlmaps_amd.map.vlmap_builder import VLMapBuilder\n"
+        "h = hashlib.sha256(); np.random.seed(3)\n"
+        f"for n_pix, rate, k in {cases!r}:\n"
+        "    for _ in range(k):\n"
+        "        h.update(VLMapBuilder.sample_pixels(n_pix, rate).tobytes())\n"
+        "    VLMapBuilder.skip_pixel_shuffles(2, n_pix)\n"
+        "    st = np.random.get_state()\n"
+        "    h.update(st[1].tobytes() + bytes([st[2] & 0xff, st[2] >> 8]))\n"
+        "print(h.hexdigest())\n")
+    import os
+    for form, env in (("widest", {}), ("avx2", {"AVL_NO_AVX512": "1"}), ("scalar", {"AVL_NO_AVX512": "1", "AVL_NO_AVX2": "1"})):
+        r = subprocess.run([sys.executable, "-c", prog], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.stdout.strip().splitlines()[-1] == want, form
+
+
 def test_lseg_window_plan_reproduces_the_reference_windows(golden):
     """WindowPlan + window_batch (the geometry of lseg_utils.py:36-96 as one canvas and one batch of views) with the reference's
     accumulation done in torch on the CPU: the reference run's feature maps (g5) bit for bit -- so what is left for the GPU

@@ -307,7 +307,27 @@ def test_frame_stream_skips_and_never_hangs_on_a_full_queue(tmp_path):
         assert [g[0] for g in got] == [4, 5, 6, 7]
         for i, _, depth, s, staged in got:
             assert depth[0, 0] == i and np.array_equal(s, whole[i]) and staged is None
-    b.prefetch_frames = 1
+    # the sampler thread walking the RNG (draws only) while workers compute the lists from snapshots of the state: the same
+    # lists in the same order, and the global RNG ends where the serial loop leaves it
+    H2, W2 = 90, 121
+    b.load_frame = lambda i: (np.zeros((H2, W2, 3), np.uint8), np.full((H2, W2), float(i), np.float32))
+    np.random.seed(11)
+    want = []
+    for _ in range(n):
+        m = np.arange(H2 * W2)
+        np.random.shuffle(m)                      # the reference's loop itself (vlmap_builder.py:275-277)
+        want.append(m[::rate])
+    end_state = np.random.get_state()
+    for workers in (0, 2, "auto"):
+        b.prefetch_frames, b.sampler_workers = 3, workers
+        np.random.seed(11)
+        got = list(b._frame_stream(0, n, rate))
+        assert len(got) == n and all(np.array_equal(g[3], want[g[0]]) for g in got), workers
+        st = np.random.get_state()
+        assert st[2] == end_state[2] and np.array_equal(st[1], end_state[1]), workers
+        assert b.pipeline_stats["sampler_workers"] == (b._n_sampler_workers() if workers == "auto" else workers)
+    b.load_frame = lambda i: (np.zeros((H, W, 3), np.uint8), np.full((H, W), float(i), np.float32))
+    b.prefetch_frames, b.sampler_workers = 1, 2
     before = threading.active_count()
     gen = b._frame_stream(0, n, rate)
     next(gen)

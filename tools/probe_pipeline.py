@@ -46,6 +46,8 @@ for sampling, deferred, save_every in CASES:
         b = VLMapBuilder(tmp, cfg, pose_path, [None] * n, [None] * n, m.base2cam_tf, m.base_transform, feat_extractor=extractor)
         b.load_frame = lambda i: (rgbs_h[i % nbuf], depths_h[i % nbuf])
         b.pixel_sampling, b.deferred_fuse, b.save_every = sampling, deferred, save_every      # (the product default is deferred_fuse = "auto")
+        if os.environ.get("AVL_SAMPLER_WORKERS"):
+            b.sampler_workers = int(os.environ["AVL_SAMPLER_WORKERS"])
         np.random.seed(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
