@@ -11,7 +11,8 @@ def get_heatmap_from_mask_3d(pc: np.ndarray, mask: np.ndarray, cell_size: float 
     mask = np.asarray(mask)
     if mask.sum() == 0:
         raise ValueError("attempt to get argmin of an empty sequence")   # what np.argmin raises upstream
-    return ops.heatmap_from_mask(np.ascontiguousarray(pc, dtype=np.int32), mask.astype(np.uint8), cell_size, decay_rate)
+    # the same grid_pos array comes back on every query of a map: its device copy and cell order are kept between calls
+    return ops.heatmap_from_mask(np.ascontiguousarray(pc, dtype=np.int32), mask.astype(np.uint8), cell_size, decay_rate, reuse_plan=True)
 
 
 def pool_3d_label_to_2d(mask_3d: np.ndarray, grid_pos: np.ndarray, gs: int) -> np.ndarray:

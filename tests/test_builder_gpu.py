@@ -360,6 +360,35 @@ def test_heat_plan_gives_the_stateless_call_bit_for_bit(ops, golden):
     assert np.array_equal(ops.heatmap_from_mask(far, np.array([1, 0], np.uint8), 0.05, 0.01), np.array([1, 0], np.float32))
 
 
+def test_host_position_arrays_keep_their_heat_plan_between_queries(ops, golden):
+    """get_heatmap_from_mask_3d(grid_pos, mask) is called with the SAME host array on every query of a map (avlmap.py:67-76): the
+    device copy and the cell order are kept per array object (ops.heatmap_from_mask(reuse_plan=True)), dropped when the array
+    dies, rebuilt when it is edited in place; results are the stateless call's bits throughout"""
+    import gc
+    from avlmaps_amd.utils.visualize_utils import get_heatmap_from_mask_3d
+    g = golden("g4_heatmap.npz")
+    pos = np.ascontiguousarray(g["grid_pos"], dtype=np.int32)
+    ops._HOST_PLANS.clear()
+    h1 = get_heatmap_from_mask_3d(pos, g["mask"], 0.05, 0.01)
+    assert np.array_equal(h1, g["heat_0.01"]) and len(ops._HOST_PLANS) == 1
+    plan = ops._HOST_PLANS[0][2]
+    h2 = get_heatmap_from_mask_3d(pos, np.roll(g["mask"], 3), 0.05, 0.1)
+    assert ops._HOST_PLANS[0][2] is plan and np.array_equal(h2, ops.heatmap_from_mask(pos, np.roll(g["mask"], 3), 0.05, 0.1))
+    pos[:, 0] += 1                                              # edited in place: every sampled row changes -> a new plan
+    h3 = get_heatmap_from_mask_3d(pos, g["mask"], 0.05, 0.01)
+    assert ops._HOST_PLANS[0][2] is not plan and len(ops._HOST_PLANS) == 1 and np.array_equal(h3, g["heat_0.01"])
+    others = [pos + k for k in (10, 20, 30)]                      # at most two maps are kept
+    for o in others:
+        assert np.array_equal(get_heatmap_from_mask_3d(o, g["mask"], 0.05, 0.01), g["heat_0.01"])
+    assert len(ops._HOST_PLANS) == 2 and ops._HOST_PLANS[0][0]() is others[2]
+    del others, o
+    gc.collect()
+    get_heatmap_from_mask_3d(pos, g["mask"], 0.05, 0.01)
+    assert len(ops._HOST_PLANS) == 1                            # the dead arrays' plans went with them
+    with pytest.raises(ValueError):
+        get_heatmap_from_mask_3d(pos, np.zeros(len(pos), bool))
+
+
 def test_wave_level_topk_orders_like_stable_argsort(ops):
     """avl_topk_f32, k <= 64 (wave-level selection): value descending, ties by ascending index, NaN last, -0.0 == 0.0 --
     np.argsort(-v, kind="stable")[:k]; a heat vector has thousands of exact ties at 1.0"""
