@@ -64,17 +64,18 @@ __global__ __launch_bounds__(256) void heat_bbox_kernel(const int32_t* __restric
 // ... and, one level up, a byte per block of kCoarse x kCoarse columns: "some target lives in this block" (round 4).  A voxel whose
 // window touches no occupied block is done after reading <= 9 bytes (from LDS when the coarse grid fits: 16 KB for a 1000 x 1000
 // map) instead of scanning (2R + 1)^2 columns; empty blocks inside a window are stepped over.  Pure pruning: the same bits.
-constexpr int kCoarseShift = 3, kCoarse = 1 << kCoarseShift;
+constexpr int kCoarseShift = 3;   // blocks of 8 x 8 columns
 constexpr int kCoarseLdsBytes = 48 * 1024;
 
 __global__ void heat_scatter_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask, int64_t N, int ox,
                                     int oy, int oz, int ny, int wz, unsigned long long* __restrict__ grid, int cny,
-                                    uint8_t* __restrict__ coarse) {
+                                    uint8_t* __restrict__ coarse, unsigned long long* __restrict__ colmap, int cwy) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         if (mask[i]) {
             const int x = pos[i * 3] - ox, y = pos[i * 3 + 1] - oy, z = pos[i * 3 + 2] - oz;
             const size_t w = ((size_t)x * ny + y) * wz + (z >> 6);
             atomicOr(&grid[w], 1ull << (z & 63));
+            atomicOr(&colmap[(size_t)x * cwy + (y >> 6)], 1ull << (y & 63));
             coarse[(size_t)(x >> kCoarseShift) * cny + (y >> kCoarseShift)] = 1;      // idempotent plain store
         }
     }
@@ -109,12 +110,13 @@ __device__ __forceinline__ int nearest_bit(unsigned long long word, int wbase, i
     return best;
 }
 
-// The scan of a window used to be ONE dependent load per column: `best` prunes columns, so the compiler cannot hoist a load above
-// the test before it, and every column cost a full L2 round trip -- 121 of them back to back at the reference's decay 0.01
-// (~60 us per wave with a single live lane; 1.0 ms at 2 M voxels).  Now the words of kBatch columns of a window row are loaded
-// together, unconditionally (the address is clamped, the result masked), and only then examined: 11 rows x 2 batches of
-// independent loads.  The visiting order and every comparison are unchanged, so are the results.
-constexpr int kBatch = 8;
+// Between the coarse bytes and the bit grid sits a COLUMN MAP (round 4): one bit per (x, y) column, "some target lives in this
+// column", 64 columns of a grid row per word (128 KB for a 1000 x 1000 map).  A voxel reads the one or two words that cover its
+// window in a grid row and visits only the columns whose bit is set -- with 28 k targets scattered over a million columns that is
+// 3 of the 121 columns of the reference's window (decay 0.01) instead of all of them; the first version loaded every column's word
+// (one dependent L2 round trip each, 1.0 ms at 2 M voxels; then in batches of 8).  Rows are taken from the voxel's own row outwards
+// and the scan stops at the first |dx| whose dx^2 cannot beat the best distance found: the minimum over the window is unchanged,
+// so are the results.
 
 // PLANNED (avl_heat_plan): the voxels are walked in CELL order -- the plan's one-time radix sort of the map's cells -- instead of in
 // voxel-id order.  Voxel ids are in first-touch order (the sampled pixels of a frame in random order), so the 64 voxels of a wave
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restr
                                                           const unsigned long long* __restrict__ grid, int cnx, int cny,
                                                           const uint8_t* __restrict__ coarse_g, double cell_size,
                                                           double decay, float* __restrict__ heat,
-                                                          const uint32_t* __restrict__ cells, const int32_t* __restrict__ order) {
+                                                          const uint32_t* __restrict__ cells, const int32_t* __restrict__ order,
+                                                          const unsigned long long* __restrict__ colmap, int cwy) {
     extern __shared__ uint8_t coarse_s[];
     const uint8_t* coarse = coarse_g;
     if (COARSE_LDS) {
@@ -171,31 +174,39 @@ __global__ __launch_bounds__(256) void heat_window_kernel(const int32_t* __restr
         const unsigned long long upto_z = z >= 63 ? ~0ull : ((1ull << (z + 1)) - 1ull);
         const unsigned long long m_below = upto_z & ~((1ull << z0) - 1ull);
         const unsigned long long m_above = ~upto_z & (z1 >= 63 ? ~0ull : ((1ull << (z1 + 1)) - 1ull));
-        for (int a = x0; a <= x1; ++a) {
-            const int dx2 = (a - x) * (a - x);
-            if (dx2 >= best) continue;
-            const unsigned long long* grow = grid + (size_t)a * ny * wz;
-            for (int b0 = y0; b0 <= y1; b0 += kBatch) {
-                if (wz == 1) {
-                    unsigned long long word[kBatch];
+        // window bits of a grid row: bit k = column y0 + k holds a target (the window is at most 33 columns wide)
+        const int cw0 = y0 >> 6, cw1 = y1 >> 6, csh = y0 & 63;
+        const unsigned long long wmask = (1ull << (y1 - y0 + 1)) - 1ull;
+        auto row_bits = [&](int a) -> unsigned long long {
+            const unsigned long long* cm = colmap + (size_t)a * cwy;
+            unsigned long long bits = cm[cw0] >> csh;
+            if (cw1 != cw0) bits |= cm[cw1] << (64 - csh);      // csh > 0 whenever the window straddles two words
+            return bits & wmask;
+        };
+        for (int da = 0; da <= R; ++da) {
+            const int dx2 = da * da;
+            if (dx2 >= best) break;                             // rows farther out cannot hold a nearer target
+            const int a_lo = x - da, a_hi = x + da;
+            // both rows at this |dx|: their column words are requested together
+            const unsigned long long bits_lo = a_lo >= 0 ? row_bits(a_lo) : 0ull;
+            const unsigned long long bits_hi = (da > 0 && a_hi < nx) ? row_bits(a_hi) : 0ull;
 #pragma unroll
-                    for (int k = 0; k < kBatch; ++k) word[k] = grow[min(b0 + k, y1)];     // independent loads, issued together
-#pragma unroll
-                    for (int k = 0; k < kBatch; ++k) {
-                        const int b = b0 + k;
-                        if (b > y1) break;
-                        const int dxy2 = dx2 + (b - y) * (b - y);
-                        if (dxy2 >= best) continue;
-                        const unsigned long long below = word[k] & m_below, above = word[k] & m_above;
+            for (int side = 0; side < 2; ++side) {
+                unsigned long long bits = side ? bits_hi : bits_lo;
+                const unsigned long long* grow = grid + (size_t)(side ? a_hi : a_lo) * ny * wz;
+                while (bits) {
+                    const int b = y0 + __ffsll((long long)bits) - 1;
+                    bits &= bits - 1ull;
+                    const int dxy2 = dx2 + (b - y) * (b - y);
+                    if (dxy2 >= best) continue;
+                    if (wz == 1) {
+                        const unsigned long long word = grow[b];
+                        const unsigned long long below = word & m_below, above = word & m_above;
                         int dz = INT_MAX;
                         if (below) dz = z - (63 - __clzll((long long)below));
                         if (above) dz = min(dz, (__ffsll((long long)above) - 1) - z);
                         if (dz != INT_MAX) best = min(best, dxy2 + dz * dz);
-                    }
-                } else {
-                    for (int b = b0; b <= min(b0 + kBatch - 1, y1); ++b) {
-                        const int dxy2 = dx2 + (b - y) * (b - y);
-                        if (dxy2 >= best) continue;
+                    } else {
                         const unsigned long long* gp = grow + (size_t)b * wz;
                         for (int w = w0; w <= w1; ++w) {
                             const int dz = nearest_bit(gp[w], w << 6, z, z0, z1);
@@ -311,17 +322,22 @@ extern "C" int avl_heatmap_from_mask(const int32_t* d_grid_pos, const uint8_t* d
         const int cnx = (nx >> kCoarseShift) + 1, cny = (ny >> kCoarseShift) + 1;
         const size_t cbytes = ((size_t)cnx * cny + 3) & ~(size_t)3;
         const size_t gbytes = words * sizeof(unsigned long long);
-        AVL_HIP_CHECK(hipMallocAsync((void**)&grid, gbytes + cbytes, st));          // bit grid | coarse byte grid
-        AVL_HIP_CHECK(hipMemsetAsync(grid, 0, gbytes + cbytes, st));
-        uint8_t* coarse = reinterpret_cast<uint8_t*>(grid) + gbytes;
+        const int cwy = (ny + 63) / 64;
+        const size_t colbytes = (size_t)nx * cwy * sizeof(unsigned long long);
+        AVL_HIP_CHECK(hipMallocAsync((void**)&grid, gbytes + colbytes + cbytes, st));          // bit grid | column map | coarse byte grid
+        AVL_HIP_CHECK(hipMemsetAsync(grid, 0, gbytes + colbytes + cbytes, st));
+        unsigned long long* colmap = grid + words;
+        uint8_t* coarse = reinterpret_cast<uint8_t*>(grid) + gbytes + colbytes;
         hipLaunchKernelGGL(heat_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                           h_bbox[1], h_bbox[2], ny, wz, grid, cny, coarse);
+                           h_bbox[1], h_bbox[2], ny, wz, grid, cny, coarse, colmap, cwy);
         if (cbytes <= (size_t)kCoarseLdsBytes)
             hipLaunchKernelGGL((heat_window_kernel<true, false>), dim3((unsigned)blocks), dim3(256), cbytes, st, d_grid_pos, d_mask, N, h_bbox[0],
-                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat, nullptr, nullptr);
+                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat, nullptr, nullptr,
+                               colmap, cwy);
         else
             hipLaunchKernelGGL((heat_window_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, d_grid_pos, d_mask, N, h_bbox[0],
-                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat, nullptr, nullptr);
+                               h_bbox[1], h_bbox[2], nx, ny, nz, wz, R, grid, cnx, cny, coarse, cell_size, decay_rate, d_heat, nullptr, nullptr,
+                               colmap, cwy);
         (void)hipFreeAsync(grid, st);
     } else {
         int32_t* tpos = nullptr;
@@ -351,12 +367,14 @@ __global__ void heat_cells_kernel(const int32_t* __restrict__ pos, int64_t N, in
 // targets into the bit grid + the coarse grid, from the plan's sorted cells (mask gathered through `order`)
 __global__ void heat_scatter_planned_kernel(const uint32_t* __restrict__ cells, const int32_t* __restrict__ order,
                                             const uint8_t* __restrict__ mask, int64_t N, int ny, int nz, int wz,
-                                            unsigned long long* __restrict__ grid, int cny, uint8_t* __restrict__ coarse) {
+                                            unsigned long long* __restrict__ grid, int cny, uint8_t* __restrict__ coarse,
+                                            unsigned long long* __restrict__ colmap, int cwy) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N; t += (int64_t)gridDim.x * blockDim.x) {
         if (mask[order[t]]) {
             const uint32_t cell = cells[t];
             const int z = (int)(cell % (uint32_t)nz), y = (int)((cell / (uint32_t)nz) % (uint32_t)ny), x = (int)(cell / ((uint32_t)nz * (uint32_t)ny));
             atomicOr(&grid[((size_t)x * ny + y) * wz + (z >> 6)], 1ull << (z & 63));
+            atomicOr(&colmap[(size_t)x * cwy + (y >> 6)], 1ull << (y & 63));
             coarse[(size_t)(x >> kCoarseShift) * cny + (y >> kCoarseShift)] = 1;
         }
     }
@@ -368,11 +386,11 @@ struct avl_heat_plan {
     int64_t N = 0;
     int dev = 0;
     int bbox[6] = {0, 0, 0, 0, 0, 0};
-    int nx = 0, ny = 0, nz = 0, wz = 0, cnx = 0, cny = 0;
-    size_t gbytes = 0, cbytes = 0;
+    int nx = 0, ny = 0, nz = 0, wz = 0, cnx = 0, cny = 0, cwy = 0;
+    size_t gbytes = 0, colbytes = 0, cbytes = 0;
     uint32_t* cells = nullptr;               // (N,) linear cells inside the bounding box, ascending
     int32_t* order = nullptr;                // (N,) voxel id of the t-th cell
-    unsigned long long* grid = nullptr;      // bit grid | coarse byte grid, zeroed per call
+    unsigned long long* grid = nullptr;      // bit grid | column map | coarse byte grid, zeroed per call
 };
 
 extern "C" int avl_heat_plan_destroy(avl_heat_plan* p) {
@@ -419,6 +437,8 @@ extern "C" int avl_heat_plan_create(avl_heat_plan** h_out, const int32_t* d_grid
     p->cnx = (p->nx >> kCoarseShift) + 1, p->cny = (p->ny >> kCoarseShift) + 1;
     p->gbytes = (size_t)p->nx * p->ny * p->wz * sizeof(unsigned long long);
     p->cbytes = ((size_t)p->cnx * p->cny + 3) & ~(size_t)3;
+    p->cwy = (p->ny + 63) / 64;
+    p->colbytes = (size_t)p->nx * p->cwy * sizeof(unsigned long long);
     uint32_t* unsorted = nullptr;
     int32_t* iota = nullptr;
     void* tmp = nullptr;
@@ -427,7 +447,7 @@ extern "C" int avl_heat_plan_create(avl_heat_plan** h_out, const int32_t* d_grid
     while (bits < 32 && (double)(1ull << bits) < cells_d) ++bits;
     e = hipMalloc((void**)&p->cells, (size_t)N * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&p->order, (size_t)N * sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&p->grid, p->gbytes + p->cbytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->grid, p->gbytes + p->colbytes + p->cbytes);
     if (e == hipSuccess) e = hipMallocAsync((void**)&unsorted, (size_t)N * sizeof(uint32_t), st);
     if (e == hipSuccess) e = hipMallocAsync((void**)&iota, (size_t)N * sizeof(int32_t), st);
     if (e == hipSuccess) {
@@ -467,18 +487,19 @@ extern "C" int avl_heatmap_from_mask_planned(avl_heat_plan* p, const uint8_t* d_
     if (!windowed)      // a window larger than the target list: the stateless call's brute force over LDS-staged targets
         return avl_heatmap_from_mask(p->d_grid_pos, d_mask, p->N, cell_size, decay_rate, d_heat, stream);
     const int64_t blocks = std::min<int64_t>((p->N + 255) / 256, (int64_t)num_cus() * 8);
-    AVL_HIP_CHECK(hipMemsetAsync(p->grid, 0, p->gbytes + p->cbytes, st));
-    uint8_t* coarse = reinterpret_cast<uint8_t*>(p->grid) + p->gbytes;
+    AVL_HIP_CHECK(hipMemsetAsync(p->grid, 0, p->gbytes + p->colbytes + p->cbytes, st));
+    unsigned long long* colmap = p->grid + p->gbytes / sizeof(unsigned long long);
+    uint8_t* coarse = reinterpret_cast<uint8_t*>(p->grid) + p->gbytes + p->colbytes;
     hipLaunchKernelGGL(heat_scatter_planned_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p->cells, p->order, d_mask, p->N, p->ny, p->nz,
-                       p->wz, p->grid, p->cny, coarse);
+                       p->wz, p->grid, p->cny, coarse, colmap, p->cwy);
     if (p->cbytes <= (size_t)kCoarseLdsBytes)
         hipLaunchKernelGGL((heat_window_kernel<true, true>), dim3((unsigned)blocks), dim3(256), p->cbytes, st, nullptr, d_mask, p->N, p->bbox[0],
                            p->bbox[1], p->bbox[2], p->nx, p->ny, p->nz, p->wz, R, p->grid, p->cnx, p->cny, coarse, cell_size, decay_rate, d_heat,
-                           p->cells, p->order);
+                           p->cells, p->order, colmap, p->cwy);
     else
         hipLaunchKernelGGL((heat_window_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, nullptr, d_mask, p->N, p->bbox[0],
                            p->bbox[1], p->bbox[2], p->nx, p->ny, p->nz, p->wz, R, p->grid, p->cnx, p->cny, coarse, cell_size, decay_rate, d_heat,
-                           p->cells, p->order);
+                           p->cells, p->order, colmap, p->cwy);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
