@@ -836,11 +836,13 @@ def run_pipeline_probe(torch, frames=300):
                                                      # checkpoints' share of the fusing thread) and the final save of the whole map
                                                      frame_loop_frames_per_s=frames / bt["frame_loop_s"], final_save_s=bt["final_save_s"],
                                                      checkpoints_skipped_writer_busy=bt.get("checkpoints_skipped", 0),
-                                                     host_threads={k: bt.get(k) for k in ("sampler_busy_s", "stager_busy_s", "fuse_thread_wait_s",
+                                                     host_threads={k: bt.get(k) for k in ("sampler_busy_s", "sampler_workers", "sampler_workers_busy_s",
+                                                                                          "stager_busy_s", "fuse_thread_wait_s",
                                                                                           "checkpoints_on_fusing_thread_s")})
     res["what"] = (f"VLMapBuilder.create_mobile_base_map over {frames} in-memory 720x1080 frames, free feature extractor, checkpoints every "
                    "100 frames, one process; reference sampling = the permutation np.random.shuffle(arange(H*W)) draws per frame from the global RNG "
-                   "(serial; computed by the library's host C code, NumPy's samples and RNG state)")
+                   "(its DRAWS are serial: the sampler thread moves the RNG on with the library's host C code, worker threads compute the lists from "
+                   "snapshots of the state -- NumPy's samples and RNG state)")
     return res
 
 

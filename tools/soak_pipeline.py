@@ -65,7 +65,8 @@ while time.time() < t_end:
     with tempfile.TemporaryDirectory() as t0, tempfile.TemporaryDirectory() as t1:
         ref, _ = build(Path(t0), prefetch_frames=0, deferred_fuse=False, save_every=0)
         opts = dict(prefetch_frames=int(rng.integers(1, 7)), batch_frames=int(rng.choice([1, 1, 2, 4])), deferred_fuse=rng.choice(["auto", False, True]).item(),
-                    stage_frames=bool(rng.random() < 0.8), save_every=int(rng.choice([0, 7, 25])), skip_busy_checkpoints=bool(rng.random() < 0.7))
+                    stage_frames=bool(rng.random() < 0.8), save_every=int(rng.choice([0, 7, 25])), skip_busy_checkpoints=bool(rng.random() < 0.7),
+                    sampler_workers=int(rng.choice([0, 1, 3, 5])))
         if opts["deferred_fuse"] in ("True", "False"):
             opts["deferred_fuse"] = opts["deferred_fuse"] == "True"
         got, b = build(Path(t1), **opts)
