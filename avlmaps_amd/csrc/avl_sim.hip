@@ -845,6 +845,178 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-swap variant of the resident kernel for feature widths of TWO LDS-sized K chunks (512 < D <= 1024, <= 64 query rows: the
+// 1024-column audio block of BASELINE config 5, CLIP ViT-L widths).  The query image of ONE chunk (hi | lo, 133 KB at 64 x 512) is
+// resident; a workgroup carries T voxel tiles through it with their accumulators in registers (16 QT VGPRs per tile), swaps the
+// image for the other chunk, finishes the T tiles, and swaps back for its next T tiles: two LDS refills of half the image per T
+// tiles, against a refill of the whole image per TB = 2 tiles in the streamed kernel, whose per-chunk staging traffic and
+// barriers were 9 % of its time.  A voxel row is read in two visits of 2 KB.
+// image layout = the resident kernel's [kc][hi, lo][Qtot][KC + pad] (sim_prep_queries_kernel, interleaved = 0).
+// ------------------------------------------------------------------------------------------------
+template <int QT, int T, int NS, bool PRE, bool QM = false, bool P24 = false>
+__global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
+    const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
+    const float* __restrict__ inv_scale, int Qtot, int KC, int q_base, int rows, int Q, float* __restrict__ scores,
+    int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
+    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, kg = lane >> 5;
+    const int row_b = (KC + kRowPadHalves) * 2;
+    const int zrow = rows < 32 * QT ? 1 : 0;
+    const int img_b = (rows + zrow) * row_b;
+    float* isc = reinterpret_cast<float*>(smem + 2 * img_b);
+    int32_t* qml = reinterpret_cast<int32_t*>(isc + QT * 32);
+    if constexpr (QM) {
+        if (threadIdx.x < QT * 32) qml[threadIdx.x] = threadIdx.x < rows ? qmap[q_base + threadIdx.x] : INT_MAX;
+    }
+    if (threadIdx.x < QT * 32) isc[threadIdx.x] = threadIdx.x < rows ? inv_scale[q_base + threadIdx.x] : 0.f;
+    // the image of chunk kc -> LDS with direct global-to-LDS loads (global_load_lds_dwordx4: a wave instruction lands 64 x 16 B
+    // at a wave-uniform LDS address; no staging registers -- the T tiles' accumulators are live across a swap -- and all of a
+    // wave's pieces are in flight at once instead of a chain of load/store round trips)
+    auto fill_lds = [&](int kc) {
+        using gptr = const __attribute__((address_space(1))) void*;
+        using lptr = __attribute__((address_space(3))) void*;
+        const char* hi = reinterpret_cast<const char*>(img) + ((int64_t)(kc * 2) * Qtot + q_base) * row_b;
+        const char* lo = hi + (int64_t)Qtot * row_b;
+        const int nb = rows * row_b;                       // bytes per half, a multiple of 16
+        for (int c = wave * 1024; c < nb; c += (kSplitThreads / 64) * 1024) {
+            if (c + lane * 16 < nb) {
+                __builtin_amdgcn_global_load_lds((gptr)(hi + c + lane * 16), (lptr)(smem + c), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr)(lo + c + lane * 16), (lptr)(smem + img_b + c), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (zrow)
+        for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
+            reinterpret_cast<uint32_t*>(smem + rows * row_b)[i] = 0u;
+            reinterpret_cast<uint32_t*>(smem + img_b + rows * row_b)[i] = 0u;
+        }
+    fill_lds(0);
+    __syncthreads();
+
+    const char* a_base[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) a_base[t] = smem + min(t * 32 + j, rows - 1 + zrow) * row_b + kg * 64;
+
+    // work split as in the resident kernel: full rounds of interleaved 256-row tiles, then one tail round in 32-row units
+    const int64_t G = gridDim.x;
+    const int64_t R = N / (G * kTileRows);
+    const int64_t tail_row0 = R * G * kTileRows;
+    const int64_t tail_units = (N - tail_row0 + 31) / 32;
+    const int64_t tu0 = tail_units * blockIdx.x / G, tu1 = tail_units * (blockIdx.x + 1) / G;
+    const int64_t n_it = R + (tu0 < tu1 ? 1 : 0);                  // iterations of this workgroup (workgroup-uniform)
+    constexpr int kElB = P24 ? 3 : 4, kLaneB = P24 ? 96 : 128, kStepB = 2 * kLaneB, kLoads = P24 ? 6 : 8;
+
+    for (int64_t it0 = 0; it0 < n_it; it0 += T) {
+        // slot b of this group = iteration it0 + b of the workgroup; its row / activity are recomputed where they are needed (three
+        // places) instead of being kept in registers next to the T accumulator sets
+        auto slot_row = [&](int b, bool& act) -> int64_t {
+            const int64_t it = it0 + b;
+            const bool tail = it == R;
+            act = it < n_it && (!tail || tu0 + wave < tu1);
+            return !act ? N : (tail ? tail_row0 + (tu0 + wave) * 32 + j : (it * G + blockIdx.x) * kTileRows + wave * 32 + j);
+        };
+        // every row is contracted chunk 0 first, then chunk 1 -- whatever tile group it falls into -- so that its scores do not
+        // depend on where it sits in the launch (a band of rows == the same rows of the whole map, bit for bit)
+        if (it0 > 0) {
+            __syncthreads();                    // every wave is done with chunk 1 of the previous group
+            fill_lds(0);
+            __syncthreads();
+        }
+        f32x16 acc[T][QT][1];
+        float rmax[T];
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            rmax[b] = 0.f;
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][t][0][e] = 0.f;
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+                __syncthreads();                // every wave is done with chunk 0
+                fill_lds(1);
+                __syncthreads();
+            }
+            const int klen = min(KC, D - pass * KC);
+            const int nsteps = NS > 0 ? NS : (klen >> 6);
+#pragma unroll
+            for (int b = 0; b < T; ++b) {
+                bool act;
+                const int64_t row = slot_row(b, act);
+                if (!act) continue;             // wave-uniform; idle slots are the last ones of a workgroup's last group
+                const char* p = reinterpret_cast<const char*>(feat) + (row < N ? row : N - 1) * (ld * kElB) + kLaneB * kg + (int64_t)pass * KC * kElB;
+                auto load = [&](f32x4(&buf)[8], int s) {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(p + kStepB * s);
+#pragma unroll
+                    for (int t = 0; t < kLoads; ++t) buf[t] = g[t];
+                };
+                auto compute = [&](const f32x4(&buf)[8], int s) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        half8 bh, bl;
+                        map_operands<PRE, P24>(buf, m, bh, bl, rmax[b]);
+                        const int off = (s * 64 + 8 * m) * 2;
+                        half8 ah[QT], al[QT];
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) {
+                            ah[t] = *reinterpret_cast<const half8*>(a_base[t] + off);
+                            al[t] = *reinterpret_cast<const half8*>(a_base[t] + off + img_b);
+                        }
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[b][t][0], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[b][t][0], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[b][t][0], 0, 0, 0);
+                    }
+                };
+                if constexpr (NS > 0) {
+                    // (carrying the register buffer of a slot's first step over from the previous slot's last step, and across the
+                    // image swap, was measured: no gain on prepared / compact maps -- 1.635 vs 1.621 ms, 1.258 vs 1.239 ms at
+                    // 2 M x 1024 x 64 -- and 25-29 spills on raw ones; every slot restarts its two-buffer ring)
+                    f32x4 ring[2][8];
+                    load(ring[0], 0);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        if (s + 1 < NS) load(ring[(s + 1) & 1], s + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute(ring[s & 1], s);
+                    }
+                } else {
+                    f32x4 buf0[8], buf1[8];
+                    load(buf0, 0);
+                    for (int s = 0; s < nsteps; s += 2) {
+                        if (s + 1 < nsteps) load(buf1, s + 1);
+                        compute(buf0, s);
+                        if (s + 1 < nsteps) {
+                            if (s + 2 < nsteps) load(buf0, s + 2);
+                            compute(buf1, s + 1);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < T; ++b) {
+            bool act;
+            const int64_t row = slot_row(b, act);
+            if (!act) continue;
+            float rscale = 1.f;
+            if constexpr (PRE) {
+                if (row_scale) rscale = row_scale[row < N ? row : N - 1];
+            }
+            split_epilogue<QT, 1>(acc[b], isc, q_base, rows, Q, scores, argmax, best, row, N, kg, first_chunk, rscale, PRE ? nullptr : flags,
+                                  rmax[b], QM ? qml : nullptr);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // streaming variant of the split kernel for query sets that do not fit LDS whole (Q > 78 at D = 512, or D > 512):
 // ONE pass over the map for up to 128 queries (QT <= 4 MFMA tiles, one accumulator set each).  The query image streams
 // through LDS in K chunks of KS = 64 * SPC columns, double buffered: while the eight waves contract chunk c out of one
@@ -1438,6 +1610,7 @@ struct SplitChunk {
 struct SplitPlan {
     int Qtot, KC, nkc, nchunks, max_rows;
     bool stream;   // sim_stream_f16_kernel: KC = 64 * SPC columns per LDS buffer, nkc chunks streamed per tile
+    bool kswap;    // sim_kswap_f16_kernel: two resident K chunks, swapped once per T tiles
     int SPC;
     SplitChunk chunks[64];
     size_t hdr_bytes, ws_bytes;
@@ -1463,6 +1636,7 @@ static bool stream_fits(int rows, int KS) {
 static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true) {
     if (D % 64 != 0 || D <= 0 || Q <= 0) return false;
     p.stream = false;
+    p.kswap = false;
     p.SPC = 0;
     p.Qtot = (Q + 31) / 32 * 32;
     // rows that fit next to a <=512-wide K chunk: up to 3 MFMA tiles (96 rows) in one pass, e.g. the reference's
@@ -1490,6 +1664,10 @@ static bool make_split_plan(int D, int Q, SplitPlan& p, bool allow_stream = true
     p.nkc = (D + p.KC - 1) / p.KC;
     p.hdr_bytes = (((size_t)p.Qtot * sizeof(float)) + kHdrAlign - 1) / kHdrAlign * kHdrAlign;
     p.ws_bytes = p.hdr_bytes + (size_t)p.nkc * 2 * p.Qtot * (p.KC + kRowPadHalves) * sizeof(_Float16);
+    // exactly two LDS-sized K chunks and at most two MFMA tiles of queries in one pass: the K-swap kernel (T tiles per image swap)
+    static const bool kswap_on = [] { const char* e = std::getenv("AVL_SIM_KSWAP"); return !(e && e[0] == '0'); }();
+    p.kswap = kswap_on && allow_stream && p.nkc == 2 && p.nchunks == 1 && p.max_rows <= 64;
+    if (p.kswap) return true;
     // one streamed pass handles up to 128 queries at any D: take it when it saves map passes (Q > 78 at D = 512) or when
     // the resident plan would have to refill LDS per K chunk anyway (D > 512)
     if (allow_stream && D % 128 == 0) {
@@ -1576,6 +1754,17 @@ static const void* pick_stream_kernel_spc(int SPC, int QT, bool tile_block) {
     return SPC == 4 ? pick_stream_kernel<4, PRE, QM, P24>(QT, tile_block) : pick_stream_kernel<2, PRE, QM, P24>(QT, tile_block);
 }
 
+#ifndef AVL_KSWAP_T
+#define AVL_KSWAP_T 3
+#endif
+template <bool PRE, bool QM, bool P24>
+static const void* pick_kswap_kernel(int QT, bool s8) {
+    if (QT == 2) return s8 ? reinterpret_cast<const void*>(sim_kswap_f16_kernel<2, AVL_KSWAP_T, 8, PRE, QM, P24>)
+                           : reinterpret_cast<const void*>(sim_kswap_f16_kernel<2, AVL_KSWAP_T, 0, PRE, QM, P24>);
+    return s8 ? reinterpret_cast<const void*>(sim_kswap_f16_kernel<1, AVL_KSWAP_T, 8, PRE, QM, P24>)
+              : reinterpret_cast<const void*>(sim_kswap_f16_kernel<1, AVL_KSWAP_T, 0, PRE, QM, P24>);
+}
+
 static bool split_plan_is_fused(const SplitPlan& p, int D) { return !p.stream && p.nkc == 1 && D <= 512; }
 
 template <int QT, bool QM>
@@ -1649,6 +1838,26 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
                             &d_row_scale, &d_flags, &d_qmap};
             AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
         }
+        AVL_HIP_CHECK(hipGetLastError());
+        return AVL_OK;
+    }
+    if (p.kswap) {
+        const SplitChunk& c = p.chunks[0];
+        const bool s8 = p.KC == 512 && D == 1024;
+        const void* kern = nullptr;
+        if constexpr (PRE) {
+            if (p24) kern = d_qmap ? pick_kswap_kernel<true, true, true>(c.QT, s8) : pick_kswap_kernel<true, false, true>(c.QT, s8);
+        }
+        if (!kern) kern = d_qmap ? pick_kswap_kernel<PRE, true, false>(c.QT, s8) : pick_kswap_kernel<PRE, false, false>(c.QT, s8);
+        const size_t lds = p.lds_bytes(c);
+        int rc = ensure_dynamic_lds(kern, lds);
+        if (rc != AVL_OK) return rc;
+        const _Float16* img_c = img;
+        const float* isc_c = inv_scale;
+        int Qtot = p.Qtot, KC = p.KC, q_base = c.q_base, rows = c.rows, first = first_launch ? 1 : 0;
+        void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &KC, &q_base, &rows, &Qs, &d_scores, &d_argmax, &d_best, &first,
+                        &d_row_scale, &d_flags, &d_qmap};
+        AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
         AVL_HIP_CHECK(hipGetLastError());
         return AVL_OK;
     }

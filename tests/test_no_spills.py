@@ -36,9 +36,10 @@ def test_similarity_variants_are_all_there_and_fit(reports):
     prepared / compact, dense / column-block) exists and stays inside the 256-register budget of 8 waves per CU"""
     rows = reports["avl_sim.hip"]
     names = [r["mangled"] for r in rows]
-    for frag in ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel", "sim_mfma_f32_kernel",
+    for frag in ("sim_split_f16_kernel", "sim_kswap_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel", "sim_mfma_f32_kernel",
                  "sim_fixup_rows_kernel", "sim_prepare_map24_kernel"):
         assert any(frag in n for n in names), frag
     assert sum("sim_split_f16_kernel" in n for n in names) >= 40
+    assert sum("sim_kswap_f16_kernel" in n for n in names) == 24      # {1, 2} query tiles x {unrolled, generic} x {raw, prepared, compact} x {dense, column block}
     for r in rows:
         assert r["vgpr"] + r["agpr"] <= 256, r
