@@ -143,7 +143,10 @@ def builder_case(i):
         if not (np.array_equal(out["grid_pos"], ref["grid_pos"]) and np.array_equal(out["occupied_ids"], ref["occupied_ids"])):
             fails.append((c, "voxel ids differ"))
         drgb = np.abs(out["grid_rgb"].astype(int) - ref["grid_rgb"].astype(int))
-        if drgb.max() > 1 or (drgb != 0).mean() > 0.01:
+        # the reference's own knife edge: when the incoming colour equals the stored one, (c w + c a) / (w + a) is c or
+        # c - 1 ulp depending on the last bit of exp(); the device and host exp differ by an ulp now and then -> at most 1 LSB, in at
+        # most 1 % of the bytes -- or ONE byte of a map of a few dozen voxels (all-pixel sampling into a 20-cell grid)
+        if drgb.max() > 1 or (drgb != 0).sum() > max(1, 0.01 * drgb.size):
             fails.append((c, f"rgb differs: max {drgb.max()}, frac {(drgb != 0).mean():.4f}"))
         if not np.allclose(out["weight"], ref["weight"].astype(np.float32), rtol=3e-6, atol=0):
             fails.append((c, "weight differs"))
