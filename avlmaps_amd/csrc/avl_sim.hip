@@ -886,14 +886,15 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
                 __builtin_amdgcn_global_load_lds((gptr)(lo + c + lane * 16), (lptr)(smem + img_b + c), 16, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    auto fill_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     if (zrow)
         for (int i = threadIdx.x; i < row_b / 4; i += kSplitThreads) {
             reinterpret_cast<uint32_t*>(smem + rows * row_b)[i] = 0u;
             reinterpret_cast<uint32_t*>(smem + img_b + rows * row_b)[i] = 0u;
         }
     fill_lds(0);
+    fill_wait();
     __syncthreads();
 
     const char* a_base[QT];
@@ -920,9 +921,8 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
         };
         // every row is contracted chunk 0 first, then chunk 1 -- whatever tile group it falls into -- so that its scores do not
         // depend on where it sits in the launch (a band of rows == the same rows of the whole map, bit for bit)
-        if (it0 > 0) {
-            __syncthreads();                    // every wave is done with chunk 1 of the previous group
-            fill_lds(0);
+        if (it0 > 0) {                          // chunk 0 was requested before the previous group's epilogue (below)
+            fill_wait();
             __syncthreads();
         }
         f32x16 acc[T][QT][1];
@@ -940,6 +940,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
             if (pass == 1) {
                 __syncthreads();                // every wave is done with chunk 0
                 fill_lds(1);
+                fill_wait();
                 __syncthreads();
             }
             const int klen = min(KC, D - pass * KC);
@@ -1000,6 +1001,15 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
                     }
                 }
             }
+        }
+        // the swap back to chunk 0 for the next group travels while this group's scores are reduced and stored (the epilogue reads the
+        // per-query tables behind the images, not the images)
+        if (it0 + T < n_it) {
+            __syncthreads();                    // every wave is done with chunk 1
+            fill_lds(0);
+#ifdef AVL_ABL_KSWAP_SYNCSWAP
+            fill_wait();
+#endif
         }
 #pragma unroll
         for (int b = 0; b < T; ++b) {
