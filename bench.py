@@ -295,9 +295,11 @@ def run_index(args, torch, dist, lib, rank, ws):
                                                                          "timing all-reduce cross ranks; the exchange-bearing numbers are extra.map_build_strong*)",
                     settle_steps=args.settle_steps,
                     kernel=("column-block launches (avl_sim_scores_blocks): sim_split_f16_kernel on the 512 visual columns + "
-                            "sim_stream_f16_kernel on the audio columns, each for its own queries" if use_blocks else
+                            "sim_kswap_f16_kernel on the audio columns, each for its own queries" if use_blocks else
                             "sim_split_f16_kernel (fp16 hi/lo split MFMA, fp32 accumulate, query image resident in LDS)"
                             if D <= 512 and Q <= 78 else
+                            "sim_kswap_f16_kernel (fp16 hi/lo split MFMA, fp32 accumulate, half the query image resident, swapped per 3 voxel tiles)"
+                            if D <= 1024 and Q <= 64 else
                             "sim_stream_f16_kernel (fp16 hi/lo split MFMA, fp32 accumulate, query image streamed through LDS)")),
     )
     out["roofline"] = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
@@ -540,7 +542,7 @@ def run_index(args, torch, dist, lib, rank, ws):
                             argmax_agreement_vs_fp64_sample=ok5, max_abs_err_best_vs_fp64_sample=err5, tolerance=1e-4),
                         dense_single_pass_ms=ms5_dense,
                         kernel="column-block launches: 64 text queries x 512 visual columns (resident kernel) + 64 audio queries x 1024 "
-                               "audio columns (streamed kernel); the map is read once")
+                               "audio columns (K-swap kernel: half the query image resident, swapped per 3 voxel tiles); the map is read once")
                     del m5, rs5
                     del f5, q5, ws5
                 except Exception as e:
@@ -970,7 +972,7 @@ def measure_traffic_in_run(argv_shape, kernels=("sim_",), timeout=120):
             for f in Path(td).rglob("*counter_collection.csv"):
                 for row in csv.DictReader(open(f)):
                     k = row.get("Kernel_Name") or row.get("Kernel Name") or ""
-                    if ("sim_split" in k or "sim_stream" in k) and "prepare_map" not in k:
+                    if ("sim_split" in k or "sim_stream" in k or "sim_kswap" in k) and "prepare_map" not in k:
                         agg[k][row.get("Counter_Name")].append(float(row["Counter_Value"]))
             if r.returncode == 0 and agg:
                 busy = {}

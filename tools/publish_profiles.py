@@ -67,7 +67,7 @@ def busy(d, match):
     out = {}
     for k, v in d.items():
         if any(m in k for m in match) and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]["mean"] > 0:
-            short = "split" if "sim_split" in k else ("stream" if "sim_stream" in k else k[:40])
+            short = "split" if "sim_split" in k else ("stream" if "sim_stream" in k else ("kswap" if "sim_kswap" in k else k[:40]))
             out[short] = v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (1024.0 * v["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
     return out
 
@@ -75,7 +75,7 @@ def busy(d, match):
 # FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream
 # (/opt/skills/guides/MI355X_MICROARCH.md, HBM section) -> doubled.  WRITE_SIZE is uncalibrated (atomics inflate it).
 entries = []
-SIM = ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel", "sim_fixup_rows_kernel", "sim_gather_queries_kernel", "sim_prep_queries_kernel")
+SIM = ("sim_split_f16_kernel", "sim_kswap_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel", "sim_fixup_rows_kernel", "sim_gather_queries_kernel", "sim_prep_queries_kernel")
 for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64, resident="raw"), "index_bench"),
                           ("pmc_config5", dict(N=2000000, D=1536, Q=128, resident="raw"), "config5_bench"),
                           ("pmc_index_compact", dict(N=2000000, D=512, Q=64, resident="compact"), "index_compact_bench"),
@@ -85,7 +85,7 @@ for stem, shape, line in (("pmc_index", dict(N=2000000, D=512, Q=64, resident="r
     f, names = per_step(pmc[stem], SIM, "FETCH_SIZE")
     w, _ = per_step(pmc[stem], SIM, "WRITE_SIZE")
     if f:
-        b = busy(pmc[stem], ("sim_split_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel"))
+        b = busy(pmc[stem], ("sim_split_f16_kernel", "sim_kswap_f16_kernel", "sim_stream_f16_kernel", "sim_stream_tb_f16_kernel"))
         entries.append(dict(workload="index", shape=shape, kernel=" + ".join(sorted(set(names)))[:300],
                             read_bytes=2 * f * 1024, write_bytes=w * 1024, total_bytes=2 * f * 1024 + w * 1024,
                             mfma_busy_frac=(list(b.values())[0] if len(b) == 1 else (b or None)),
