@@ -1771,8 +1771,9 @@ template <bool PRE, bool QM, bool P24>
 static const void* pick_kswap_kernel(int QT, bool s8) {
     if (QT == 2) return s8 ? reinterpret_cast<const void*>(sim_kswap_f16_kernel<2, AVL_KSWAP_T, 8, PRE, QM, P24>)
                            : reinterpret_cast<const void*>(sim_kswap_f16_kernel<2, AVL_KSWAP_T, 0, PRE, QM, P24>);
-    return s8 ? reinterpret_cast<const void*>(sim_kswap_f16_kernel<1, AVL_KSWAP_T, 8, PRE, QM, P24>)
-              : reinterpret_cast<const void*>(sim_kswap_f16_kernel<1, AVL_KSWAP_T, 0, PRE, QM, P24>);
+    // one query tile: twice the voxel tiles per image swap in the same 96 accumulator registers
+    return s8 ? reinterpret_cast<const void*>(sim_kswap_f16_kernel<1, 2 * AVL_KSWAP_T, 8, PRE, QM, P24>)
+              : reinterpret_cast<const void*>(sim_kswap_f16_kernel<1, 2 * AVL_KSWAP_T, 0, PRE, QM, P24>);
 }
 
 static bool split_plan_is_fused(const SplitPlan& p, int D) { return !p.stream && p.nkc == 1 && D <= 512; }
