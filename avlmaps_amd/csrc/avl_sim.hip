@@ -438,6 +438,9 @@ __global__ __launch_bounds__(256) void sim_prepare_map_kernel(float* __restrict_
 // exponent is implied by hi, so all 8 bits are significand: an element is within 2^-19 of its value (hi's 11 bits + 8), against
 // 2^-22 for the 4-byte forms; elements below 2^-11 of the row's maximum (E < 4) keep hi only.  Rows with a non-finite element
 // get row_scale = NaN like sim_prepare_map_kernel.
+// byte of column c inside the residual plane of a compact row (layout: see compact_load_step below)
+__host__ __device__ __forceinline__ int compact_lo_offset(int c) { return 128 * (c >> 7) + 64 * ((c >> 5) & 1) + 32 * ((c >> 6) & 1) + (c & 31); }
+
 __global__ __launch_bounds__(256) void sim_prepare_map24_kernel(const float* __restrict__ feat, int64_t N, int D, int64_t ld,
                                                                 unsigned char* __restrict__ out, float* __restrict__ row_scale) {
     const int lane = threadIdx.x & 63;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(256) void sim_prepare_map24_kernel(const float* __r
         const float scale = ldexpf(1.f, sh);
         if (lane == 0) row_scale[row] = mb >= 0x7f800000u ? __uint_as_float(0x7fc00000u) : ldexpf(1.f, -sh);
         unsigned char* orow = out + row * ((int64_t)D * 3);
-        for (int g = lane; g < g8; g += 64) {           // 8 columns: 16 B of hi and 8 B of lo inside the 96-byte block of 32 columns
+        for (int g = lane; g < g8; g += 64) {           // 8 columns: 16 B in the hi plane, 8 B in the residual plane
             const f32x4 v0 = p[2 * g], v1 = p[2 * g + 1];
             const float x[8] = {v0.x * scale, v0.y * scale, v0.z * scale, v0.w * scale, v1.x * scale, v1.y * scale, v1.z * scale, v1.w * scale};
             half8 hi;
@@ -474,9 +477,8 @@ __global__ __launch_bounds__(256) void sim_prepare_map24_kernel(const float* __r
             }
             const int w0 = (int)(u[0] | (u[1] << 8) | (u[2] << 16) | (u[3] << 24));
             const int w1 = (int)(u[4] | (u[5] << 8) | (u[6] << 16) | (u[7] << 24));
-            unsigned char* blk = orow + (g >> 2) * 96;
-            *reinterpret_cast<half8*>(blk + (g & 3) * 16) = hi;
-            *reinterpret_cast<int2*>(blk + 64 + (g & 3) * 8) = int2{w0, w1};
+            *reinterpret_cast<half8*>(orow + (size_t)g * 16) = hi;                                     // hi plane: column c at 2 c
+            *reinterpret_cast<int2*>(orow + 2 * (size_t)D + compact_lo_offset(8 * g)) = int2{w0, w1};  // residual plane
         }
     }
 }
@@ -551,6 +553,27 @@ __global__ __launch_bounds__(256) void sim_gather_queries_kernel(const float* __
 // the hi value it belongs to.  Two of them -> packed fp16: v_perm_b32 builds the fp16 bit patterns 0x6400 | u = 1024 + u, a packed add
 // of -1152 gives k exactly, and the packed fp16 2^(E - 18) comes from hi's own exponent field (saturating subtract: 0 below
 // E = 4, where the residual is dropped).  Five vector-ALU instructions per two elements.
+// ---- the COMPACT resident form (3 bytes per element, D a multiple of 128), round-4 layout: two planes per row.
+//   hi plane   [0, 2 D):   fp16 hi of column c at 2 c -- the 128-byte line of a 64-column step is consumed by the two lane halves
+//                          of a wave in the same group of loads;
+//   residuals  [2 D, 3 D): one byte per column, arranged per block of 128 columns (one line) so that the 32 + 32 bytes lane half kg
+//                          needs in the block's two steps are contiguous: byte of column c at 128 (c >> 7) + 64 ((c >> 5) & 1) +
+//                          32 ((c >> 6) & 1) + (c & 31).
+// The first compact layout interleaved hi[32] | residuals[32] per 96 bytes: a step was 192 B = one and a half lines, every other step
+// boundary fell inside a line, and that line was requested twice (L1 -> L2 requests 1.2 x the lines, profiles/r04_tcc_requests_raw_vs_compact.txt;
+// a timing ablation of this layout: 0.617 -> 0.542 ms at 2 M x 512 x 64).
+
+// one 64-column step of a compact row for lane half kg: 4 x 16 B of hi -> b[0..3], its 32 residual bytes -> b[4..5].
+// row = first byte of the map row, ld = columns of a full row, sa = the step's index in the row (column / 64)
+__device__ __forceinline__ void compact_load_step(f32x4 (&b)[8], const char* row, int64_t ld, int kg, int sa) {
+    const f32x4* gh = reinterpret_cast<const f32x4*>(row + 128 * sa + 64 * kg);
+    const f32x4* gl = reinterpret_cast<const f32x4*>(row + 2 * ld + 128 * (sa >> 1) + 64 * kg + 32 * (sa & 1));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = gh[t];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b[4 + t] = gl[t];
+}
+
 template <int PAIR>
 __device__ __forceinline__ half2 residual_pair(unsigned w, unsigned hi2) {
     using ushort2v = __attribute__((ext_vector_type(2))) unsigned short;
@@ -563,19 +586,24 @@ __device__ __forceinline__ half2 residual_pair(unsigned w, unsigned hi2) {
 
 // B operands (voxel side) of the m-th 8-column group of a 64-column step from the registers one lane loaded for it:
 // raw float32 (guard + on-the-fly split), prepared hi[8] | lo[8], or the compact form (hi[32] | residual bytes[32] per 96 B)
+// compact form: the 8 hi values of one k group (16 B) and the 16-byte register that holds their residual bytes (second = which half)
+__device__ __forceinline__ void compact_operands(const f32x4& hi, const f32x4& lo, int second, half8& bh, half8& bl) {
+    bh = __builtin_bit_cast(half8, hi);
+    // (bit-casting ONE element of a float ext_vector to int folded every element to element 0 in this compiler;
+    // cast the whole vector first)
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const u32x4 hw = __builtin_bit_cast(u32x4, hi);                       // the 8 hi values, two per word
+    const u32x4 lw = __builtin_bit_cast(u32x4, lo);
+    const unsigned w0 = lw[second * 2], w1 = lw[second * 2 + 1];          // their 8 residual bytes
+    const half2 l0 = residual_pair<0>(w0, hw[0]), l1 = residual_pair<1>(w0, hw[1]);
+    const half2 l2 = residual_pair<0>(w1, hw[2]), l3 = residual_pair<1>(w1, hw[3]);
+    bl = half8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
+}
+
 template <bool PRE, bool P24>
 __device__ __forceinline__ void map_operands(const f32x4 (&b)[8], int m, half8& bh, half8& bl, float& rmax) {
     if constexpr (P24) {
-        bh = __builtin_bit_cast(half8, b[m]);
-        // (bit-casting ONE element of a float ext_vector to int folded every element to element 0 in this compiler;
-        // cast the whole vector first)
-        using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-        const u32x4 hw = __builtin_bit_cast(u32x4, b[m]);                 // the 8 hi values, two per word
-        const u32x4 lw = __builtin_bit_cast(u32x4, b[4 + (m >> 1)]);
-        const unsigned w0 = lw[(m & 1) * 2], w1 = lw[(m & 1) * 2 + 1];    // their 8 residual bytes
-        const half2 l0 = residual_pair<0>(w0, hw[0]), l1 = residual_pair<1>(w0, hw[1]);
-        const half2 l2 = residual_pair<0>(w1, hw[2]), l3 = residual_pair<1>(w1, hw[3]);
-        bl = half8{l0[0], l0[1], l1[0], l1[1], l2[0], l2[1], l3[0], l3[1]};
+        compact_operands(b[m], b[4 + (m >> 1)], m & 1, bh, bl);
     } else if constexpr (PRE) {
         bh = __builtin_bit_cast(half8, b[2 * m]);
         bl = __builtin_bit_cast(half8, b[2 * m + 1]);
@@ -599,7 +627,8 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, const float* __restrict__ q_raw, int64_t ldq, int Qtot, int KC, int nkc, int q_base,
     int rows, int Q, float* __restrict__ scores, int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk,
-    const float* __restrict__ row_scale, uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
+    const float* __restrict__ row_scale, uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap, int col0) {
+    // col0 (P24 only): first column of the window this launch contracts; a compact map's `feat` is never offset by a window (two planes)
     // row_scale (PRE only, nullable): per-row 2^-s of a map prepared with scaling.  flags (!PRE): range-guard words, see kGuardLo.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NA = QT == 1 ? 3 : (QT == 2 ? 2 : 1);   // accumulator sets per tile (register budget: 16 VGPRs each)
@@ -722,7 +751,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
         const int64_t row = !active ? N : (tail ? tail_row0 + (tu0 + wave) * 32 + j : (it * G + blockIdx.x) * kTileRows + wave * 32 + j);
         const int64_t rowc = row < N ? row : N - 1;
         const float* rp = feat + rowc * ld + 32 * kg;
-        const char* rp24 = reinterpret_cast<const char*>(feat) + rowc * (ld * 3) + 96 * kg;   // P24: 96 B per 32 columns, ld = columns of a full row
+        const char* rp24 = reinterpret_cast<const char*>(feat) + rowc * (ld * 3);   // P24: first byte of the row, ld = columns of a full row
 
         // NA independent accumulator sets per query tile (hi*hi | cross terms) so that back-to-back MFMAs never wait on
         // each other's result: a dependent 32x32x16 MFMA cannot issue until its predecessor retires
@@ -745,25 +774,24 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             const int klen = min(KC, D - kc * KC);
             const int nsteps = klen >> 6;
             const float* p = rp + kc * KC;
-            const char* p24 = rp24 + (int64_t)kc * KC * 3;
+            const int sa0 = (col0 + kc * KC) >> 6;          // P24: index of this chunk's first step in the row
 
             f32x4 buf0[8], buf1[8];
             auto load = [&](f32x4(&b)[8], int s) {
                 if constexpr (P24) {
-                    const f32x4* g = reinterpret_cast<const f32x4*>(p24 + 192 * s);   // hi[32] (4 x 16 B) | lo[32] (2 x 16 B)
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) b[t] = g[t];
+                    compact_load_step(b, rp24, ld, kg, sa0 + s);
                 } else {
                     const f32x4* g = reinterpret_cast<const f32x4*>(p + 64 * s);
 #pragma unroll
                     for (int t = 0; t < 8; ++t) b[t] = g[t];
                 }
             };
-            auto compute = [&](const f32x4(&b)[8], int s) {
+            // operands(m, bh, bl): the voxel-side fragments of the m-th 8-column group of step s
+            auto compute_with = [&](auto&& operands, int s) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     half8 bh, bl;
-                    map_operands<PRE, P24>(b, m, bh, bl, rmax);
+                    operands(m, bh, bl);
                     const int off = (s * 64 + 8 * m) * 2;
                     half8 ah[QT], al[QT];
 #pragma unroll
@@ -807,7 +835,40 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
                     }
                 }
             };
-            if constexpr (NSTEPS > 0) {
+            auto compute = [&](const f32x4(&b)[8], int s) {
+                compute_with([&](int m, half8& bh, half8& bl) { map_operands<PRE, P24>(b, m, bh, bl, rmax); }, s);
+            };
+            if constexpr (P24 && NSTEPS > 0) {
+                // Compact map, compile-time trip count, window starting on a 128-column block (the launcher checks): the residual line
+                // of a block serves its two steps and is requested ONCE, with the even step -- 64 B per lane half into a buffer of its
+                // own (two, by block parity: the odd step still reads one while the next block's is in flight); hi: two buffers by
+                // step parity.  One step ahead, like the ring below.
+                static_assert(NSTEPS % 2 == 0, "whole 128-column blocks");
+                f32x4 hb[2][4], lb[2][4];
+                auto load_hi = [&](int st) {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(rp24 + 128 * (sa0 + st) + 64 * kg);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) hb[st & 1][t] = g[t];
+                };
+                auto load_lo = [&](int blk) {
+                    const f32x4* g = reinterpret_cast<const f32x4*>(rp24 + 2 * ld + 128 * ((sa0 >> 1) + blk) + 64 * kg);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) lb[blk & 1][t] = g[t];
+                };
+                load_hi(0);
+                load_lo(0);
+#pragma unroll
+                for (int st = 0; st < NSTEPS; ++st) {
+                    if (st + 1 < NSTEPS) {
+                        load_hi(st + 1);
+                        if (((st + 1) & 1) == 0) load_lo((st + 1) >> 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_with([&](int m, half8& bh, half8& bl) {
+                        compact_operands(hb[st & 1][m], lb[(st >> 1) & 1][2 * (st & 1) + (m >> 1)], m & 1, bh, bl);
+                    }, st);
+                }
+            } else if constexpr (NSTEPS > 0) {
                 // compile-time trip count, ring of kRing register buffers: the loads of the next kRing - 1 steps are in flight
                 // while step s is computed, all waits are counted vmcnt (depth per variant: RingDepth)
                 constexpr int kRing = RingDepth<PRE, XR, QM>::value;
@@ -858,7 +919,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int KC, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
-    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
+    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap, int col0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kg = lane >> 5;
@@ -950,17 +1011,24 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
                 bool act;
                 const int64_t row = slot_row(b, act);
                 if (!act) continue;             // wave-uniform; idle slots are the last ones of a workgroup's last group
-                const char* p = reinterpret_cast<const char*>(feat) + (row < N ? row : N - 1) * (ld * kElB) + kLaneB * kg + (int64_t)pass * KC * kElB;
+                // P24: p = first byte of the (compact, two-plane) row, sa0 = index of the chunk's first 64-column step in the row
+                const char* p = reinterpret_cast<const char*>(feat) + (row < N ? row : N - 1) * (ld * kElB) +
+                                (P24 ? 0 : kLaneB * kg + (int64_t)pass * KC * kElB);
+                const int sa0 = (col0 + pass * KC) >> 6;
                 auto load = [&](f32x4(&buf)[8], int s) {
-                    const f32x4* g = reinterpret_cast<const f32x4*>(p + kStepB * s);
+                    if constexpr (P24) {
+                        compact_load_step(buf, p, ld, kg, sa0 + s);
+                    } else {
+                        const f32x4* g = reinterpret_cast<const f32x4*>(p + kStepB * s);
 #pragma unroll
-                    for (int t = 0; t < kLoads; ++t) buf[t] = g[t];
+                        for (int t = 0; t < kLoads; ++t) buf[t] = g[t];
+                    }
                 };
-                auto compute = [&](const f32x4(&buf)[8], int s) {
+                auto compute_with = [&](auto&& operands, int s) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         half8 bh, bl;
-                        map_operands<PRE, P24>(buf, m, bh, bl, rmax[b]);
+                        operands(m, bh, bl);
                         const int off = (s * 64 + 8 * m) * 2;
                         half8 ah[QT], al[QT];
 #pragma unroll
@@ -976,7 +1044,38 @@ __global__ __launch_bounds__(kSplitThreads) void sim_kswap_f16_kernel(
                         for (int t = 0; t < QT; ++t) acc[b][t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[b][t][0], 0, 0, 0);
                     }
                 };
-                if constexpr (NS > 0) {
+                auto compute = [&](const f32x4(&buf)[8], int s) {
+                    compute_with([&](int m, half8& bh, half8& bl) { map_operands<PRE, P24>(buf, m, bh, bl, rmax[b]); }, s);
+                };
+                if constexpr (NS > 0 && P24) {
+                    // compact map, window on a 128-column block: the residual line of a block is requested once, with its even step
+                    // (see the resident kernel)
+                    static_assert(NS % 2 == 0, "whole 128-column blocks");
+                    f32x4 hb[2][4], lb[2][4];
+                    auto load_hi = [&](int st) {
+                        const f32x4* g = reinterpret_cast<const f32x4*>(p + 128 * (sa0 + st) + 64 * kg);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) hb[st & 1][t] = g[t];
+                    };
+                    auto load_lo = [&](int blk) {
+                        const f32x4* g = reinterpret_cast<const f32x4*>(p + 2 * ld + 128 * ((sa0 >> 1) + blk) + 64 * kg);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) lb[blk & 1][t] = g[t];
+                    };
+                    load_hi(0);
+                    load_lo(0);
+#pragma unroll
+                    for (int st = 0; st < NS; ++st) {
+                        if (st + 1 < NS) {
+                            load_hi(st + 1);
+                            if (((st + 1) & 1) == 0) load_lo((st + 1) >> 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        compute_with([&](int m, half8& bh, half8& bl) {
+                            compact_operands(hb[st & 1][m], lb[(st >> 1) & 1][2 * (st & 1) + (m >> 1)], m & 1, bh, bl);
+                        }, st);
+                    }
+                } else if constexpr (NS > 0) {
                     // (carrying the register buffer of a slot's first step over from the previous slot's last step, and across the
                     // image swap, was measured: no gain on prepared / compact maps -- 1.635 vs 1.621 ms, 1.258 vs 1.239 ms at
                     // 2 M x 1024 x 64 -- and 25-29 spills on raw ones; every slot restarts its two-buffer ring)
@@ -1045,7 +1144,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
-    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
+    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap, int col0) {
     static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = 64 * SPC;
@@ -1096,15 +1195,19 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
     constexpr int kElB = P24 ? 3 : 4, kLaneB = P24 ? 96 : 128, kStepB = 2 * kLaneB, kLoads = P24 ? 6 : 8;
     auto tile_ptr = [&](int64_t tile) {
         const int64_t r = tile * kTileRows + wave * 32 + j;
-        return reinterpret_cast<const char*>(feat) + (r < N ? r : N - 1) * (ld * kElB) + kLaneB * kg;
+        return reinterpret_cast<const char*>(feat) + (r < N ? r : N - 1) * (ld * kElB) + (P24 ? 0 : kLaneB * kg);   // P24: first byte of the row
     };
     f32x4 ring[2][8];
-    auto load = [&](f32x4(&b)[8], const char* src) {
-        const f32x4* g = reinterpret_cast<const f32x4*>(src);
+    auto load = [&](f32x4(&b)[8], const char* src, int step) {     // step `step` of the window whose row (lane line) starts at src
+        if constexpr (P24) {
+            compact_load_step(b, src, ld, kg, (col0 >> 6) + step);
+        } else {
+            const f32x4* g = reinterpret_cast<const f32x4*>(src + kStepB * step);
 #pragma unroll
-        for (int t = 0; t < kLoads; ++t) b[t] = g[t];
+            for (int t = 0; t < kLoads; ++t) b[t] = g[t];
+        }
     };
-    load(ring[0], tile_ptr(blockIdx.x));   // first tile, step 0: in flight while chunk 0 is brought in
+    load(ring[0], tile_ptr(blockIdx.x), 0);   // first tile, step 0: in flight while chunk 0 is brought in
 #pragma unroll
     for (int s = 0; s < SPC; ++s) {
         stage_load(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
@@ -1139,13 +1242,12 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 #ifndef AVL_ABL_NOSTAGE
                 stage_load(cn, i0, i1);               // issued ahead of this step's voxel prefetch (older in vmcnt order)
 #endif
-                const char* nxt = rp + kStepB * (c * SPC + s + 1);
                 if (s + 1 < SPC) {
-                    load(ring[(s + 1) & 1], nxt);
+                    load(ring[(s + 1) & 1], rp, c * SPC + s + 1);
                 } else if (c + 1 < nch) {
-                    load(ring[0], nxt);
+                    load(ring[0], rp, c * SPC + s + 1);
                 } else if (has_next) {
-                    load(ring[0], p_next);
+                    load(ring[0], p_next, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const f32x4(&b)[8] = ring[s & 1];
@@ -1235,7 +1337,7 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
     const float* __restrict__ inv_scale, int Qtot, int nch, int q_base, int rows, int Q, float* __restrict__ scores,
     int32_t* __restrict__ argmax, float* __restrict__ best, int first_chunk, const float* __restrict__ row_scale,
-    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap) {
+    uint32_t* __restrict__ flags, const int32_t* __restrict__ qmap, int col0) {
     static_assert(SPC % 2 == 0, "the register buffer of a chunk's first step must not move between chunks");
     constexpr int TB = StreamTB<QT, P24, PRE>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1301,19 +1403,23 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
     constexpr int kElB = P24 ? 3 : 4, kLaneB = P24 ? 96 : 128, kStepB = 2 * kLaneB, kLoads = P24 ? 6 : 8;   // see sim_stream_f16_kernel
     auto tile_ptr = [&](int64_t tile) {
         const int64_t r = tile * (NT / 64 * 32) + wave * 32 + j;
-        return reinterpret_cast<const char*>(feat) + (r < N ? r : N - 1) * (ld * kElB) + kLaneB * kg;
+        return reinterpret_cast<const char*>(feat) + (r < N ? r : N - 1) * (ld * kElB) + (P24 ? 0 : kLaneB * kg);   // P24: first byte of the row
     };
     f32x4 ring[2][8];
-    auto load = [&](f32x4(&b)[8], const char* src) {
-        const f32x4* g = reinterpret_cast<const f32x4*>(src);
+    auto load = [&](f32x4(&b)[8], const char* src, int step) {     // step `step` of the window whose row (lane line) starts at src
+        if constexpr (P24) {
+            compact_load_step(b, src, ld, kg, (col0 >> 6) + step);
+        } else {
+            const f32x4* g = reinterpret_cast<const f32x4*>(src + kStepB * step);
 #pragma unroll
-        for (int t = 0; t < kLoads; ++t) b[t] = g[t];
+            for (int t = 0; t < kLoads; ++t) b[t] = g[t];
+        }
     };
     int64_t tile0;
     int cnt;
     block_of(0, tile0, cnt);
     if (cnt == 0) return;   // kernel-uniform per workgroup, before any barrier
-    load(ring[0], tile_ptr(tile0));   // first tile, step 0: in flight while chunk 0 is brought in
+    load(ring[0], tile_ptr(tile0), 0);   // first tile, step 0: in flight while chunk 0 is brought in
 #pragma unroll
     for (int s = 0; s < SPC; ++s) {
         stage_load(0, (s * kStreamFill) / SPC, ((s + 1) * kStreamFill) / SPC);
@@ -1363,12 +1469,13 @@ __global__ __launch_bounds__(NT) void sim_stream_tb_f16_kernel(
                         // (the address is selected, the load itself is unconditional: a load inside a branch makes the compiler's
                         // s_waitcnt bookkeeping fall back to vmcnt(0); the very last step of a workgroup re-reads its own line)
                         if (s + 1 < SPC) {
-                            load(ring[(s + 1) & 1], rp[b] + kStepB * (c * SPC + s + 1));
+                            load(ring[(s + 1) & 1], rp[b], c * SPC + s + 1);
                         } else {
                             const char* nxt = p_next;
-                            if (b + 1 < TB && b + 1 < cnt) nxt = rp[b + 1 < TB ? b + 1 : b] + kStepB * (c * SPC);
-                            else if (c + 1 < nch) nxt = rp[0] + kStepB * ((c + 1) * SPC);
-                            load(ring[0], nxt);
+                            int nstep = 0;
+                            if (b + 1 < TB && b + 1 < cnt) { nxt = rp[b + 1 < TB ? b + 1 : b]; nstep = c * SPC; }
+                            else if (c + 1 < nch) { nxt = rp[0]; nstep = (c + 1) * SPC; }
+                            load(ring[0], nxt, nstep);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         const f32x4(&v)[8] = ring[s & 1];
@@ -1820,7 +1927,9 @@ static int run_fixup(const float* d_feat, int64_t N, int D, int64_t ld, const fl
 template <bool PRE>
 static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const float* d_q, int Qg, int64_t ldq, int Qs,
                      float* d_scores, int32_t* d_argmax, float* d_best, const SplitPlan& p, void* d_ws, const float* d_row_scale,
-                     uint32_t* d_flags, const int32_t* d_qmap, bool first_launch, hipStream_t st, bool p24 = false) {
+                     uint32_t* d_flags, const int32_t* d_qmap, bool first_launch, hipStream_t st, bool p24 = false, int col0 = 0) {
+    // col0 (compact maps only): first column of the window; d_feat then is the map's first byte (two planes per row: a window is no
+    // pointer offset), and the compile-time-unrolled variants, which pair the steps of a 128-column block, need col0 % 128 == 0
     float* inv_scale = reinterpret_cast<float*>(d_ws);
     _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(d_ws) + p.hdr_bytes);
     const bool fq = split_plan_is_fused(p, D);   // resident image built inside the kernel: no prep launch, no workspace
@@ -1846,7 +1955,7 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
             const float* isc_c = inv_scale;
             int Qtot = p.Qtot, nch = p.nkc, q_base = c.q_base, rows = c.rows, first = (ci == 0 && first_launch) ? 1 : 0;
             void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &nch, &q_base, &rows, &Qs, &d_scores, &d_argmax, &d_best, &first,
-                            &d_row_scale, &d_flags, &d_qmap};
+                            &d_row_scale, &d_flags, &d_qmap, &col0};
             AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
         }
         AVL_HIP_CHECK(hipGetLastError());
@@ -1854,7 +1963,7 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
     }
     if (p.kswap) {
         const SplitChunk& c = p.chunks[0];
-        const bool s8 = p.KC == 512 && D == 1024;
+        const bool s8 = p.KC == 512 && D == 1024 && (!p24 || col0 % 128 == 0);
         const void* kern = nullptr;
         if constexpr (PRE) {
             if (p24) kern = d_qmap ? pick_kswap_kernel<true, true, true>(c.QT, s8) : pick_kswap_kernel<true, false, true>(c.QT, s8);
@@ -1867,14 +1976,14 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
         const float* isc_c = inv_scale;
         int Qtot = p.Qtot, KC = p.KC, q_base = c.q_base, rows = c.rows, first = first_launch ? 1 : 0;
         void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &Qtot, &KC, &q_base, &rows, &Qs, &d_scores, &d_argmax, &d_best, &first,
-                        &d_row_scale, &d_flags, &d_qmap};
+                        &d_row_scale, &d_flags, &d_qmap, &col0};
         AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
         AVL_HIP_CHECK(hipGetLastError());
         return AVL_OK;
     }
     for (int ci = 0; ci < p.nchunks; ++ci) {
         const SplitChunk& c = p.chunks[ci];
-        const bool s8 = (p.nkc == 1 && D == 512);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
+        const bool s8 = (p.nkc == 1 && D == 512) && (!p24 || col0 % 128 == 0);   // the LSeg / CLIP ViT-B feature width: fully unrolled k loop
         // "N categories + other": 1..4 rows beyond full 32-row tiles go to the 4x4x4 MFMA path instead of a padded tile
         const int xr = c.rows % 32;
         // (same-box A/B at 2 M voxels: 65 rows 0.753 -> 0.726 ms raw, 0.758 -> 0.718 prepared, 0.645 -> 0.624 compact; 33 rows on a raw
@@ -1896,7 +2005,7 @@ static int run_split(const float* d_feat, int64_t N, int D, int64_t ld, const fl
         const float* isc_c = inv_scale;
         int Qtot = p.Qtot, KC = p.KC, nkc = p.nkc, q_base = c.q_base, rows = c.rows, first = (ci == 0 && first_launch) ? 1 : 0;
         void* args[] = {&d_feat, &N, &D, &ld, &img_c, &isc_c, &d_q, &ldq, &Qtot, &KC, &nkc, &q_base, &rows, &Qs,
-                        &d_scores, &d_argmax, &d_best, &first, &d_row_scale, &d_flags, &d_qmap};
+                        &d_scores, &d_argmax, &d_best, &first, &d_row_scale, &d_flags, &d_qmap, &col0};
         AVL_HIP_CHECK(hipLaunchKernel(kern, dim3((unsigned)blocks), dim3(kSplitThreads), args, lds, st));
     }
     AVL_HIP_CHECK(hipGetLastError());
@@ -1996,8 +2105,8 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
     AVL_REQUIRE(precision >= AVL_SIM_AUTO && precision <= AVL_SIM_PREPARED24, "avl_sim_scores: bad precision %d", precision);
     const bool p24 = precision == AVL_SIM_PREPARED24;
     if (p24) {   // compact prepared map: 3 bytes per element, dense rows (resident, streamed and column-block kernels)
-        AVL_REQUIRE(D % 64 == 0 && ld_feat == D && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0,
-                    "avl_sim_scores_prepared24: needs D %% 64 == 0 and dense 16-byte aligned rows (D=%d)", D);
+        AVL_REQUIRE(D % 128 == 0 && ld_feat == D && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0,
+                    "avl_sim_scores_prepared24: needs D %% 128 == 0 and dense 16-byte aligned rows (D=%d)", D);
         AVL_REQUIRE(d_row_scale, "avl_sim_scores_prepared24: the compact form always has row scales");
         precision = AVL_SIM_PREPARED;
     }
@@ -2096,10 +2205,11 @@ static int sim_scores_impl(const float* d_feat, const float* d_row_scale, int64_
                 const int32_t* qmap_g = qmap + row_off;
                 hipLaunchKernelGGL(sim_gather_queries_kernel, dim3((unsigned)Qg), dim3(256), 0, st, d_queries, ld_q, qmap_g, Qg, cg.col0,
                                    cg.cols, qg_g);
-                // the column window of every row: 4 B per column, 3 B in the compact form (96 B per 32 columns; windows are 128-aligned)
-                const float* feat_g = p24 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_feat) + (size_t)cg.col0 * 3) : d_feat + cg.col0;
+                // the column window of every row: a pointer offset of 4 B per column; a compact map has two planes per row and its window
+                // travels as col0 (windows are 128-aligned: whole residual lines)
+                const float* feat_g = p24 ? d_feat : d_feat + cg.col0;
                 rc = prepared ? run_split<true>(feat_g, N, cg.cols, ld_feat, qg_g, Qg, cg.cols, Q, d_scores, amax, best, gplans[g], ws,
-                                                d_row_scale, nullptr, qmap_g, g == 0, st, p24)
+                                                d_row_scale, nullptr, qmap_g, g == 0, st, p24, p24 ? cg.col0 : 0)
                               : run_split<false>(feat_g, N, cg.cols, ld_feat, qg_g, Qg, cg.cols, Q, d_scores, amax, best, gplans[g], ws, nullptr,
                                                  flags, qmap_g, g == 0, st);
                 row_off += (size_t)Qg;
@@ -2149,9 +2259,10 @@ int avl_sim_scores_prepared24(const void* d_map24, const float* d_row_scale, int
 
 int avl_sim_prepare_map24(const float* d_feat, int64_t N, int D, int64_t ld_feat, void* d_map24, float* d_row_scale, void* stream) {
     AVL_REQUIRE(N >= 0 && D > 0 && ld_feat >= D, "avl_sim_prepare_map24: bad shape");
-    AVL_REQUIRE(D % 64 == 0 && ld_feat % 4 == 0 && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0 &&
+    AVL_REQUIRE(D % 128 == 0 && ld_feat % 4 == 0 && (reinterpret_cast<uintptr_t>(d_feat) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(d_map24) & 15) == 0,
-                "avl_sim_prepare_map24: needs D %% 64 == 0 and 16-byte aligned rows (D=%d ld=%lld)", D, (long long)ld_feat);
+                "avl_sim_prepare_map24: needs D %% 128 == 0 (whole 128-column residual lines) and 16-byte aligned rows (D=%d ld=%lld)", D,
+                (long long)ld_feat);
     if (N == 0) return AVL_OK;
     AVL_REQUIRE(d_feat && d_map24 && d_row_scale, "avl_sim_prepare_map24: null pointer");
     int64_t blocks = (N + 3) / 4;

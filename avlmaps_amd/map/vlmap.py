@@ -150,9 +150,9 @@ class VLMap(Map):
             self._dev_feat_src = self.grid_feat
             self._sim_precision = "auto"
             if dev.shape[1] % 64 == 0 and dev.shape[0] > 0:
-                # the compact form is read by every matrix-core kernel (resident, streamed, column-block); widths the streamed
-                # kernels cannot take (D > 512 and not a multiple of 128) keep the 4-byte copy
-                if self.compact_map and (dev.shape[1] <= 512 or dev.shape[1] % 128 == 0):
+                # the compact form is read by every matrix-core kernel (resident, K-swap, streamed, column-block); its residual plane
+                # is laid out in lines of 128 columns, other widths keep the 4-byte copy
+                if self.compact_map and dev.shape[1] % 128 == 0:
                     raw = dev
                     dev = ops.prepare_map(raw, compact=True)
                     raw.free()                                        # the float32 device copy is not needed any more
@@ -209,7 +209,7 @@ class VLMap(Map):
             self._sim_precision = "auto"
             dev = feat
             if D % 64 == 0 and feat.shape[0] > 0:
-                if self.compact_map and (D <= 512 or D % 128 == 0):
+                if self.compact_map and D % 128 == 0:
                     dev = ops.prepare_map(feat, compact=True)
                 else:
                     dev = ops.prepare_map(feat.clone(), scaled=True)

@@ -179,10 +179,9 @@ def prepare_map(feat_dev, scaled=True, stream=None, compact=False):
     PreparedMap for sim_scores.  scaled=True (default): every row gets its own power-of-two scale, so rows of any magnitude
     -- e.g. voxels observed once from far away, feat * exp(-r^2/1.2) -- score with float32-class accuracy.  scaled=False:
     scores bit-identical to the on-the-fly split of the raw map.  feat_dev: DeviceArray or torch CUDA tensor (N, D), D % 64 == 0.
-    compact=True: out of place into the 3-byte form (avl_sim_prepare_map24: fp16 hi + the residual in units of ulp(hi)/256, always
-    row-scaled): a quarter less HBM traffic per query pass, max score error 2.3e-6 instead of 1.4e-6 (float32-class; pays for
-    D <= 512); the float32
-    map is left untouched and can be freed by the caller."""
+    compact=True (D % 128 == 0): out of place into the 3-byte form (avl_sim_prepare_map24: a plane of fp16 hi values + a plane of
+    residual bytes in units of ulp(hi)/256 per row, always row-scaled): a quarter less HBM traffic per query pass, max score error
+    2.3e-6 instead of 1.4e-6 (float32-class); the float32 map is left untouched and can be freed by the caller."""
     lib = _lib.load()
     if isinstance(feat_dev, np.ndarray):
         raise TypeError("prepare_map works on a device-resident map (DeviceArray / torch CUDA tensor), not a host array")
@@ -192,6 +191,8 @@ def prepare_map(feat_dev, scaled=True, stream=None, compact=False):
     fptr, fshape, _ = as_device(feat_dev, np.float32, stream)
     if compact:
         N, D = fshape
+        if D % 128:
+            raise ValueError(f"the compact form needs a feature width that is a multiple of 128 (D = {D}); use the 4-byte prepared form")
         if _is_torch(feat_dev):
             import torch
             buf = torch.empty((N, 3 * D), dtype=torch.uint8, device=feat_dev.device)

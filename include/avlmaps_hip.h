@@ -167,16 +167,19 @@ AVL_API int avl_sim_scores_prepared(const float* d_feat, const float* d_row_scal
                                     const float* d_queries, int Q, int64_t ld_q, float* d_scores, int32_t* d_argmax,
                                     float* d_best, void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* COMPACT resident copy of a map that is indexed many times (VLMap.compact_map, its default for D <= 512): 3 bytes per element
- * instead of 4 -- per 32 columns fp16 hi[32] (round to nearest) then one byte per element holding the residual x - hi in units of
- * ulp(hi) / 256, every row scaled by a power of two (d_row_scale out, N floats).
+/* COMPACT resident copy of a map that is indexed many times (VLMap.compact_map, its default when D % 128 == 0): 3 bytes per element
+ * instead of 4 -- fp16 hi (round to nearest) and one byte per element holding the residual x - hi in units of ulp(hi) / 256, every row
+ * scaled by a power of two (d_row_scale out, N floats).  Row layout (round 4; opaque to callers, it only has to come from this
+ * function): a plane of hi values [0, 2 D) -- column c at byte 2 c -- then a plane of residual bytes [2 D, 3 D), column c at
+ * 128 (c >> 7) + 64 ((c >> 5) & 1) + 32 ((c >> 6) & 1) + (c & 31): every load of the kernels' walk is a whole cache line shared by the
+ * two halves of a wave (the first layout interleaved hi[32] | residuals[32] per 96 bytes and requested every third line twice).
  * d_map24: N * D * 3 bytes, out of place (the float32 map is left alone).  A query pass then reads a quarter less HBM; the
  * residuals are rebuilt as fp16 in registers (five vector-ALU instructions per two elements) and the arithmetic is the same three
  * fp16 MFMAs.  Accuracy: 19 significant bits per element (hi's 11 + 8: the residual's exponent is implied by hi) instead of 22 --
  * max |score - float64| 2.3e-6 on LSeg-scale rows against 1.4e-6 for the 4-byte forms (tests/test_sim_gpu.py): still float32-class.
- * Elements below 2^-11 of their row's maximum keep hi only.  D % 64 == 0.  Every matrix-core kernel reads this form: the
- * resident-query kernel (D <= 512, up to ~78 queries per pass: 0.70 -> 0.61 ms at 2 M x 512 x 64), the streamed kernels (any
- * D % 128 == 0, up to 128 queries per pass) and the column-block launches of avl_sim_scores_blocks (precision
+ * Elements below 2^-11 of their row's maximum keep hi only.  D % 128 == 0.  Every matrix-core kernel reads this form: the
+ * resident-query kernel (D <= 512, up to ~78 queries per pass: 0.70 -> 0.57 ms at 2 M x 512 x 64), the K-swap kernel (D <= 1024),
+ * the streamed kernels (up to 128 queries per pass) and the column-block launches of avl_sim_scores_blocks (precision
  * AVL_SIM_PREPARED24; BASELINE config 5's fused 1536-column map is 9.2 GB instead of 12.3 GB per pass). */
 AVL_API int avl_sim_prepare_map24(const float* d_feat, int64_t N, int D, int64_t ld_feat, void* d_map24, float* d_row_scale,
                                   void* stream);

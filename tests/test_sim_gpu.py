@@ -489,8 +489,8 @@ def test_column_windows_with_ties_zero_queries_and_bad_rows(ops, windows, counts
         assert am[7] == Q - 1 and np.isnan(sc[17]).all() and am[17] == 0, name       # np.argmax of an all-NaN row is 0
 
 
-@pytest.mark.parametrize("N,D,Q", [(3000, 512, 64), (2500, 512, 65), (1000, 512, 1), (1500, 64, 9), (1200, 1024, 40), (900, 512, 170),
-                                   (700, 1536, 33)])
+@pytest.mark.parametrize("N,D,Q", [(3000, 512, 64), (2500, 512, 65), (1000, 512, 1), (1500, 128, 9), (1200, 1024, 40), (900, 512, 170),
+                                   (700, 1536, 33), (800, 640, 50), (600, 256, 96), (900, 768, 64), (500, 896, 64), (700, 384, 130)])
 def test_compact_prepared_map(ops, N, D, Q):
     """prepare_map(compact=True): 3 bytes per element (fp16 hi + the residual in units of ulp(hi)/256, per-row power-of-two scale).
     Scores stay float32-class (19 significant bits per element instead of 22: 1e-5 of the row's size is asserted, ~2e-6 measured), argmax /
@@ -509,6 +509,8 @@ def test_compact_prepared_map(ops, N, D, Q):
     want = f.astype(np.float64) @ q.astype(np.float64).T
     pm = ops.prepare_map(DeviceArray.from_numpy(f), compact=True)
     assert pm.compact and pm.feat.shape == (N, 3 * D)
+    with pytest.raises(ValueError):                           # the residual plane is laid out in lines of 128 columns
+        ops.prepare_map(DeviceArray.from_numpy(np.ascontiguousarray(f[:, :64])), compact=True)
     sc, am, best = ops.sim_scores(pm, q, want_best=True)
     sc, am, best = sc.numpy(), am.numpy(), best.numpy()
     ok = np.ones(N, bool)

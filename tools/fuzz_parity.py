@@ -42,7 +42,8 @@ def sim_case(i):
         q[Q - 1] = q[0]                                              # exact tie: lowest index must win
     want = f.astype(np.float64) @ q.astype(np.float64).T
     tol = 2e-5 * max(1.0, float(np.abs(want).max()))
-    mode = str(rng.choice(["raw", "prepared", "prepared_unscaled", "exact", "compact"] if D % 64 == 0 else ["raw", "exact"]))
+    mode = str(rng.choice(["raw", "prepared", "prepared_unscaled", "exact", "compact"] if D % 128 == 0 else
+                          (["raw", "prepared", "prepared_unscaled", "exact"] if D % 64 == 0 else ["raw", "exact"])))
     src = f
     kw = {}
     if mode == "prepared":
