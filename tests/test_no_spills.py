@@ -40,6 +40,6 @@ def test_similarity_variants_are_all_there_and_fit(reports):
                  "sim_fixup_rows_kernel", "sim_prepare_map24_kernel"):
         assert any(frag in n for n in names), frag
     assert sum("sim_split_f16_kernel" in n for n in names) >= 40
-    assert sum("sim_kswap_f16_kernel" in n for n in names) == 24      # {1, 2} query tiles x {unrolled, generic} x {raw, prepared, compact} x {dense, column block}
+    assert sum("sim_kswap_f16_kernel" in n for n in names) == 24      # (two query tiles x {8, 6, run-time steps} + one tile, run-time steps) x {raw, prepared, compact} x {dense, column block}
     for r in rows:
         assert r["vgpr"] + r["agpr"] <= 256, r
