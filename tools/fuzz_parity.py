@@ -42,6 +42,10 @@ def sim_case(i):
         q[Q - 1] = q[0]                                              # exact tie: lowest index must win
     want = f.astype(np.float64) @ q.astype(np.float64).T
     tol = 2e-5 * max(1.0, float(np.abs(want).max()))
+    # the split's own error scale: 2^-22 per product, summed over D products of random sign -- ~2.4e-7 |row| |query| / sqrt(D).  It only
+    # exceeds the line above when every score of a case is small by cancellation (seen once: N = Q = 1, rows of norm 7 600, score 2.7,
+    # error 7e-5 = 9e-9 of |row| |query|; NumPy's own float32 product is off by 1e-4 there)
+    tol = max(tol, 1e-6 * float(np.linalg.norm(f, axis=1).max()) * float(np.linalg.norm(q, axis=1).max()) / np.sqrt(D))
     mode = str(rng.choice(["raw", "prepared", "prepared_unscaled", "exact", "compact"] if D % 128 == 0 else
                           (["raw", "prepared", "prepared_unscaled", "exact"] if D % 64 == 0 else ["raw", "exact"])))
     src = f
@@ -146,8 +150,8 @@ def builder_case(i):
         drgb = np.abs(out["grid_rgb"].astype(int) - ref["grid_rgb"].astype(int))
         # the reference's own knife edge: when the incoming colour equals the stored one, (c w + c a) / (w + a) is c or
         # c - 1 ulp depending on the last bit of exp(); the device and host exp differ by an ulp now and then -> at most 1 LSB, in at
-        # most 1 % of the bytes -- or ONE byte of a map of a few dozen voxels (all-pixel sampling into a 20-cell grid)
-        if drgb.max() > 1 or (drgb != 0).sum() > max(1, 0.01 * drgb.size):
+        # most 1 % of the bytes -- or the three channels of ONE voxel of a map of a few dozen voxels (dense sampling into a 20-cell grid)
+        if drgb.max() > 1 or (drgb != 0).sum() > max(3, 0.01 * drgb.size):      # (3: the channels of one voxel)
             fails.append((c, f"rgb differs: max {drgb.max()}, frac {(drgb != 0).mean():.4f}"))
         if not np.allclose(out["weight"], ref["weight"].astype(np.float32), rtol=3e-6, atol=0):
             fails.append((c, "weight differs"))
