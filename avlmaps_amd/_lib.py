@@ -88,6 +88,7 @@ _SIGS = {
     "avl_builder_capacity": (C.c_int, [_vp, C.POINTER(_i64)]),
     "avl_builder_set_deferred_fuse": (C.c_int, [_vp, C.c_int, _vp]),
     "avl_builder_flush": (C.c_int, [_vp, _vp]),
+    "avl_builder_release_scratch": (C.c_int, [_vp, _i64, _vp]),
     "avl_builder_scatter_merge": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "avl_finalize_merged": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),

@@ -85,7 +85,8 @@ def _navigator_adapter(module):
         predict = np.argmax(self.map.scores_mat, axis=1)
         i = module.find_similar_category_id(name, self.map.categories)
         sim = predict == i
-        heat = ops.heatmap_from_mask(np.ascontiguousarray(self.map.grid_pos, dtype=np.int32), sim, 1.0, decay_rate, reuse_plan=True).astype(np.float32)
+        pos = np.ascontiguousarray(self.map.grid_pos, dtype=np.int32)
+        heat = ops.heatmap_from_mask(pos, sim, 1.0, decay_rate, reuse_plan=pos is self.map.grid_pos).astype(np.float32)
         cfg = getattr(self, "config", None)
         try:
             if cfg is not None and cfg["nav"]["vis"]:

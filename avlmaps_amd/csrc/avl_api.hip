@@ -46,18 +46,35 @@ void* scratch(size_t bytes) {
 // The finalisation / replay / merge paths take their temporaries from the device's default stream-ordered pool (hipMallocAsync).
 // HIP's default release threshold is 0: every synchronisation hands the pool's memory back to the driver and the next call maps
 // it again -- tens of ms per GB, which showed as 30-60 ms of "allocation" inside a 30 ms merge (profiles/r04_build_8ranks_*).
-// Keep what the pool has grown to (bounded by what one finalisation needs); once per device and process.
+// Keep a BOUNDED amount between calls (AVLMAPS_MEMPOOL_KEEP_MB, default 1024: the temporaries of a checkpoint finalisation of a
+// 2 M-voxel map); what a one-off merge grew beyond that goes back at the next synchronisation, and avl_release_scratch trims the
+// pool on request (an unbounded threshold kept GBs outside torch's allocator next to a feature extractor).
+static uint64_t mempool_keep_bytes() {
+    const char* e = getenv("AVLMAPS_MEMPOOL_KEEP_MB");
+    long long mb = e ? atoll(e) : 1024;
+    if (mb < 0) mb = 0;
+    return (uint64_t)mb << 20;
+}
+
 void keep_mempool_once() {
     static thread_local int done_for = -1;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || done_for == dev) return;
     hipMemPool_t pool = nullptr;
     if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-        uint64_t keep = ~0ull;
+        uint64_t keep = mempool_keep_bytes();
         (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
     }
     (void)hipGetLastError();
     done_for = dev;
+}
+
+void trim_mempool(uint64_t keep) {
+    int dev = 0;
+    hipMemPool_t pool = nullptr;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool)
+        (void)hipMemPoolTrimTo(pool, (size_t)keep);
+    (void)hipGetLastError();
 }
 
 int num_cus() {

@@ -380,7 +380,16 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
 
     auto add = [&](int cur, double alpha, int32_t fpix, uint32_t rgbv) {
         const float* f = (batch ? batch[cur / P_frame].feat : feat) + (size_t)fpix * D;
+        // The first-touch sample of a voxel BORN in this launch is kept OUT of the sum: sum_feat = sum over all OTHER samples of
+        // alpha f, and the finalisation adds a1^2 f1 (the reference stores feat * alpha with weight alpha for a new voxel and
+        // treats it as a mean afterwards, vlmap_builder.py:166-174).  The earlier form sum(alpha f) - a1 (1 - a1) f1 cancels
+        // catastrophically for a voxel touched once from far away (alpha = exp(-r^2 / 1.2) < 1e-13 beyond ~6 m: 1 - a1 rounds to
+        // 1 and the row came out as ZERO instead of a1 f1).  Members arrive in ascending sample order (up to 64 per launch), so
+        // `first` normally fires once; if a smaller sample index turns up later the previous candidate rejoins the sum.
         const bool first = cur < min_s;  // wave-uniform
+        const bool hold = first && is_new;
+        const bool rejoin = hold && min_s != INT_MAX;
+        const double a_prev = a1;
         if (first) { min_s = cur; a1 = alpha; }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
@@ -396,7 +405,8 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[c][e] += alpha * (double)v[e];
+                    if (rejoin) acc[c][e] += a_prev * (double)f1[c][e];
+                    if (!hold) acc[c][e] += alpha * (double)v[e];
                     if (first) f1[c][e] = v[e];
                 }
             }
@@ -549,8 +559,8 @@ __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigne
         float f1 = 0.f;
         for (int cur = h0; cur >= 0; cur = recs.next[cur]) {
             const float v = (batch ? batch[cur / P_frame].feat : feat)[(size_t)recs.fpix[cur] * D + d];
-            acc += recs.alpha[cur] * (double)v;
             if (cur == min_s) f1 = v;
+            if (!(is_new && cur == min_s)) acc += recs.alpha[cur] * (double)v;   // the first touch of a new voxel stays out of the sum (fuse_body)
         }
         sf[d] = is_new ? acc : sf[d] + acc;
         if (is_new) ff[d] = f1;
@@ -590,10 +600,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
             const double* s = sum_feat + sl * ld_sf;
             float* o = grid_feat + r * D;
             if (first_feat) {
+                // reference closed form (a1^2 f1 + sum_{i >= 2} alpha_i f_i) / sum alpha; sum_feat excludes the first touch
                 const double a1 = first_alpha[sl];
-                const double corr = a1 * (1.0 - a1);
+                const double a1sq = a1 * a1;
                 const float* f1 = first_feat + sl * D;
-                for (int c = lane; c < D; c += 64) o[c] = (float)((s[c] - corr * (double)f1[c]) / w);
+                for (int c = lane; c < D; c += 64) o[c] = (float)((a1sq * (double)f1[c] + s[c]) / w);
             } else {
                 for (int c = lane; c < D; c += 64) o[c] = (float)(s[c] / w);
             }
@@ -620,7 +631,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
 // Multi-GPU merge, step "scatter" (avlmaps_amd/parallel.py): wave per local slot s.  The slot's accumulators go to row
 // row_of_slot[s] of the dense (M, D + 4) float64 buffer every rank reduces -- straight from the builder's own arrays, no
 // export copy.  The rank that OWNS the voxel's global first touch (its slot_key equals the all-reduced MIN key) subtracts the
-// reference's first-touch term a1 (1 - a1) f1 here (vlmap_builder.py:166-174 closed form), so that the
+// first touch with the reference's weight a1^2 (every other rank: a1; vlmap_builder.py:166-174 closed form), so that the
 // reduced rows only need dividing by sum alpha: ONE sum-reduce carries the whole merge.
 __global__ __launch_bounds__(256) void scatter_merge_kernel(int64_t n, int D, const int64_t* __restrict__ row_of_slot,
                                                             const unsigned long long* __restrict__ global_key,
@@ -634,22 +645,20 @@ __global__ __launch_bounds__(256) void scatter_merge_kernel(int64_t n, int D, co
     for (int64_t s = wave0; s < n; s += nwaves) {
         const int64_t row = row_of_slot[s];
         const bool owner = slot_key[s] == global_key[row];
+        // sum_feat leaves the slot's LOCAL first touch out (fuse_body): the rank that holds the GLOBAL first touch contributes it
+        // with the reference's a1^2, every other rank with its plain weight a1
         const double a1 = first_alpha[s];
-        const double corr = a1 * (1.0 - a1);
+        const double wf = owner ? a1 * a1 : a1;
         const double* sf = sum_feat + s * D;
         const float* f1 = first_feat + s * D;
         double* o = acc + row * ld;
-        if (owner && corr != 0.0) {
-            for (int c = lane; c < D; c += 64) o[c] = sf[c] - corr * (double)f1[c];
-        } else {
-            for (int c = lane; c < D; c += 64) o[c] = sf[c];
-        }
+        for (int c = lane; c < D; c += 64) o[c] = wf * (double)f1[c] + sf[c];
         if (lane < 4) o[D + lane] = sum_w4[s * 4 + lane];
     }
 }
 
 // Row-sharded merge with the mixed payload (avlmaps_amd/parallel.py, round 4).  A voxel that only ONE rank ever touched needs no
-// float64 exchange: its finished float32 feature row (sum - a1 (1 - a1) f1) / sum alpha is computed where the accumulators live --
+// float64 exchange: its finished float32 feature row (a1^2 f1 + sum) / sum alpha is computed where the accumulators live --
 // the same float64 expression finalize_kernel evaluates, so the row is bit-identical to the single-process map -- and travels as
 // 4 B per element.  Only voxels that several ranks touched ship float64 partial sums (own != 0: this rank holds the global first
 // touch and folds the reference's first-touch term in).  Wave per listed slot; output row i belongs to slot slots[i].
@@ -664,11 +673,11 @@ __global__ __launch_bounds__(256) void export_rows_f32_kernel(int64_t k, int D, 
         const int64_t sl = slots[i];
         const double w = sum_w4[sl * 4];
         const double a1 = first_alpha[sl];
-        const double corr = a1 * (1.0 - a1);
+        const double a1sq = a1 * a1;
         const double* s = sum_feat + sl * D;
         const float* f1 = first_feat + sl * D;
         float* o = out + i * ld;
-        for (int c = lane; c < D; c += 64) o[c] = (float)((s[c] - corr * (double)f1[c]) / w);
+        for (int c = lane; c < D; c += 64) o[c] = (float)((a1sq * (double)f1[c] + s[c]) / w);   // finalize_kernel's expression
     }
 }
 
@@ -682,15 +691,11 @@ __global__ __launch_bounds__(256) void export_rows_f64_kernel(int64_t k, int D, 
     for (int64_t i = wave0; i < k; i += nwaves) {
         const int64_t sl = slots[i];
         const double a1 = first_alpha[sl];
-        const double corr = a1 * (1.0 - a1);
+        const double wf = own[i] ? a1 * a1 : a1;   // global first touch: a1^2 f1 (reference closed form); else the sample's plain weight
         const double* s = sum_feat + sl * D;
         const float* f1 = first_feat + sl * D;
         double* o = out + i * ld;
-        if (own[i] && corr != 0.0) {
-            for (int c = lane; c < D; c += 64) o[c] = s[c] - corr * (double)f1[c];
-        } else {
-            for (int c = lane; c < D; c += 64) o[c] = s[c];
-        }
+        for (int c = lane; c < D; c += 64) o[c] = wf * (double)f1[c] + s[c];
     }
 }
 
@@ -866,7 +871,7 @@ __global__ __launch_bounds__(256) void import_map_kernel(int64_t n, int D, int n
                 slot_cell[r] = cell;
             }
             slot_key[r] = (unsigned long long)r;                        // imported voxels order before any new one
-            first_alpha[r] = 1.0;                                       // a1*(1-a1) == 0: no further correction
+            first_alpha[r] = 0.0;                                       // no first-touch term: it is baked into the imported row
             sum_w4[r * 4] = w;
             for (int c = 0; c < 3; ++c) sum_w4[r * 4 + 1 + c] = (grid_rgb ? (double)grid_rgb[r * 3 + c] : 0.0) * w;
         }
@@ -1399,6 +1404,16 @@ int avl_builder_set_deferred_fuse(avl_builder* b, int on, void* stream) {
 int avl_builder_flush(avl_builder* b, void* stream) {
     AVL_REQUIRE(b, "avl_builder_flush: null handle");
     return flush_pending(b, as_stream(stream));
+}
+
+int avl_builder_release_scratch(avl_builder* b, int64_t keep_bytes, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_release_scratch: null handle");
+    AVL_REQUIRE(keep_bytes >= 0, "avl_builder_release_scratch: keep_bytes < 0");
+    hipStream_t st = as_stream(stream);
+    drop_log_segments(b, st);                       // the slot-sorted replay log cached between the two replay calls of a merge
+    AVL_HIP_CHECK(hipStreamSynchronize(st));        // the pool only gives back what no stream still uses
+    avl::trim_mempool((uint64_t)keep_bytes);
+    return AVL_OK;
 }
 
 int avl_builder_integrate_frame(avl_builder* b, const float* d_depth, int H, int W, const double* h_calib,

@@ -41,6 +41,7 @@ void* scratch(size_t bytes);
 // keep what the device's default stream-ordered pool (hipMallocAsync) has grown to instead of handing it back at every synchronisation
 // (HIP's default release threshold is 0: tens of ms per GB to map it again); once per device and thread, cheap afterwards
 void keep_mempool_once();
+void trim_mempool(uint64_t keep_bytes);   // hipMemPoolTrimTo on the device's default pool
 
 constexpr int kWave = 64;
 

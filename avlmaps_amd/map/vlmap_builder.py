@@ -69,7 +69,11 @@ class VLMapBuilder:
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
         self.incremental_checkpoints = True        # periodic saves write only the rows that changed + the new rows
                                                    # (utils.mapping_utils.MapFileWriter); False = full rewrite like upstream
-        self.pixel_sampling = "reference"          # "reference": np.random.shuffle(arange(H*W))[::rate] on the global RNG, the pixels a
+        self.pixel_sampling = "auto"               # "auto" (default): "reference" in a single process, "uniform" with several ranks
+                                                   # (the reference's sampling is ONE serial random stream: the last of 8 ranks of a
+                                                   # 40 k-frame build would fast-forward ~10 s before its first frame; a line on
+                                                   # stdout says so, ask for "reference" explicitly to prove N ranks == 1 rank).
+                                                   # "reference": np.random.shuffle(arange(H*W))[::rate] on the global RNG, the pixels a
                                                    # seeded upstream run samples (its draws are serial by nature: 0.3-0.5 ms per
                                                    # 720x1080 frame through avl_mt19937_skip_shuffles, see sampler_workers; NumPy's
                                                    # shuffle takes 6.6 ms); "uniform": the same distribution -- an
@@ -405,6 +409,12 @@ class VLMapBuilder:
 
         self._init_lseg()
         rank, ws = _dist_rank_ws()
+        if self.pixel_sampling == "auto":
+            self.pixel_sampling = "uniform" if ws > 1 else "reference"
+            if ws > 1 and rank == 0:
+                print(f"[avlmaps_amd] {ws} ranks: pixel_sampling defaults to 'uniform' (per-frame generators seeded by one draw of the "
+                      "global NumPy RNG: reproducible, independent of the sharding, no serial RNG fast-forward); set "
+                      "pixel_sampling='reference' for the pixels a seeded single-process / upstream run samples", flush=True)
         n_frames = min(len(self.rgb_paths), len(self.depth_paths), len(self.base_poses))
         lo, hi = parallel.shard_frames(n_frames, rank, ws)
 
@@ -419,10 +429,17 @@ class VLMapBuilder:
         except _RanksAborted:
             raise
         except BaseException as e:
-            # several ranks: the others are (or will be) waiting in the next checkpoint / merge collective -- tell them, so that
-            # every rank fails now instead of hanging until the RCCL timeout
+            # several ranks: the others are (or will be) waiting in a collective -- make every rank fail now instead of hanging
+            # until the RCCL timeout.  WHICH collective decides how: between rounds the peers reach the
+            # status all-reduce that opens the next round, and this rank joins it with its failure flag set; a rank that fails
+            # INSIDE a round (the merge's all_to_alls / all_gathers, rank 0's file write before the round's last collective) has
+            # peers sitting in a collective of another kind -- a mismatched all_reduce would hang or exchange garbage on RCCL --
+            # so the job is torn down instead.
             if ws > 1:
-                self._announce_failure(rank, e)
+                if getattr(self, "_in_round", False):
+                    self._abort_ranks(rank, e)
+                else:
+                    self._announce_failure(rank, e)
             raise
 
     def _build_loop(self, lo, hi, depth_sample_rate, skip, rank, ws, gs, cs, vh, calib_mat, calib_inv, transforms, rounds_total):
@@ -431,6 +448,7 @@ class VLMapBuilder:
         pending = []
         rounds_done = 0
         probation = None
+        pending_storage = None
         self.deferred_fuse_active = self.deferred_fuse is True and self.batch_frames <= 1
         import time
         stage = bool(self.stage_frames and (self.prefetch_frames or 0) > 0)
@@ -471,6 +489,12 @@ class VLMapBuilder:
                 if len(pending) >= self.batch_frames:
                     self._flush(acc, pending, calib_mat, calib_inv, transforms)
             else:
+                if self.deferred_fuse_active and pending_storage is not None and _storage_key(feat) == pending_storage:
+                    # the extractor wrote this frame into the storage in which the PREVIOUS frame's features still wait to be
+                    # fused (probation saw fresh storage for the first two frames; the extractor started recycling later).  That
+                    # frame's features are gone -- fail loudly instead of fusing the wrong bytes
+                    raise RuntimeError(f"frame {frame_i}: the feature extractor reused the storage of the previous frame's features "
+                                       "before they were fused (deferred fuse); build with deferred_fuse=False for this extractor")
                 acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
                                     calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,
                                     sigma_sq=self.sigma_sq)
@@ -478,14 +502,17 @@ class VLMapBuilder:
                     self._stager.release(staged)          # depth / rgb / samples are read by this launch only (features: deferred)
                 if probation is not None:
                     # deferred fuse on probation: does the extractor hand out fresh storage while the previous tensor is alive?
+                    # Compared by STORAGE, not by data pointer: two views at different offsets of one persistent buffer are
+                    # the same memory being refilled
                     probation.append(feat)
                     if len(probation) == 2:
-                        ptrs = [f.data_ptr() if hasattr(f, "data_ptr") else id(f) for f in probation]
-                        fresh = not hasattr(feat, "data_ptr") or ptrs[0] != ptrs[1]     # NumPy features are staged by us: always fresh
+                        keys = [_storage_key(f) for f in probation]
+                        fresh = keys[0] is None or keys[0] != keys[1]     # NumPy features are staged by us: always fresh
                         if fresh:
                             acc.set_deferred_fuse(True)
                         self.deferred_fuse_active = bool(fresh)
                         probation = None
+                pending_storage = _storage_key(feat)
             mapped_iter_set.add(frame_i)
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
@@ -525,6 +552,7 @@ class VLMapBuilder:
         self.build_times.update(frame_loop_s=t_fin - t_loop, checkpoints_skipped=getattr(self, "checkpoints_skipped", 0), **self.pipeline_stats)
         self._finish(acc, mapped_iter_set, rank, ws, gs, vh)
         self.build_times["final_save_s"] = time.perf_counter() - t_fin
+        acc.release_scratch()       # sorted replay log + pool memory of the final merge / finalisation go back to the driver
 
     def _flush(self, acc, pending, calib_mat, calib_inv, transforms):
         """fuse the buffered frames (consecutive indices, equal shapes) with one launch pair"""
@@ -577,11 +605,16 @@ class VLMapBuilder:
             import torch.distributed as dist
             info = [None]
             if rank == 0:
-                exists = bool(map_file_exists(self.map_save_path))
-                iters = read_map_dataset(self.map_save_path, "mapped_iter_list") if exists else None
-                info = [(exists, [] if iters is None else np.asarray(iters).tolist(),
-                         bool(map_checkpoint_complete(self.map_save_path)) if exists else True)]
+                try:
+                    exists = bool(map_file_exists(self.map_save_path))
+                    iters = read_map_dataset(self.map_save_path, "mapped_iter_list") if exists else None
+                    info = [(exists, [] if iters is None else np.asarray(iters).tolist(),
+                             bool(map_checkpoint_complete(self.map_save_path)) if exists else True)]
+                except Exception as e:      # the peers wait in the broadcast below: they must hear about it THERE
+                    info = [("error", f"{type(e).__name__}: {e}")]
             dist.broadcast_object_list(info, src=0)
+            if info[0][0] == "error":
+                raise _RanksAborted(f"multi-rank build aborted: rank 0 could not read {self.map_save_path}: {info[0][1]}")
             exists, iters, complete = info[0]
             if not exists:
                 return set()
@@ -618,14 +651,40 @@ class VLMapBuilder:
         except BaseException:      # the process group itself is gone: nothing more to do
             pass
 
+    def _abort_ranks(self, rank, exc) -> None:
+        """a rank that failed INSIDE a collective round cannot be matched by its peers' next collective: abort the process group
+        (peers blocked in RCCL return with an error) and, unless AVLMAPS_ABORT_EXITS=0, leave the process with a non-zero status
+        so that torchrun tears the job down at once.  The exception is printed first; with AVLMAPS_ABORT_EXITS=0 it propagates."""
+        import sys
+        import traceback
+        print(f"[avlmaps_amd] rank {rank}: {type(exc).__name__}: {exc} inside a collective round -- aborting the job", flush=True)
+        traceback.print_exception(type(exc), exc, exc.__traceback__)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        try:
+            import torch.distributed as dist
+            abort = getattr(dist.distributed_c10d, "_abort_process_group", None)
+            if abort is not None:
+                abort()
+        except BaseException:
+            pass
+        if os.environ.get("AVLMAPS_ABORT_EXITS", "1") != "0":
+            os._exit(70)
+
     def _finish(self, acc, mapped_iter_set, rank, ws, gs, vh):
         if ws == 1:
             self._checkpoint(acc, mapped_iter_set, background=False)
             return
+        import torch
         import torch.distributed as dist
         self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=True)
         self._join_save()
-        dist.barrier()
+        # closing status all-reduce (same [busy, failed] shape as the one that opens a round) instead of a bare barrier: if rank 0's
+        # final file write raised, its _announce_failure is THIS collective for the peers, and they raise too
+        flags = torch.zeros(2, dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        if int(flags[1].item()):
+            raise _RanksAborted("multi-rank build aborted: another rank reported a failure (see its traceback)")
 
     def _checkpoint_ranks(self, acc, mapped_iter_set, rank, ws, final: bool) -> None:
         """One merge of the ranks' accumulators (a collective) + the map file written by rank 0.  Non-destructive: frames keep
@@ -649,6 +708,8 @@ class VLMapBuilder:
         if int(flags[0].item()):
             self.checkpoints_skipped = getattr(self, "checkpoints_skipped", 0) + 1
             return
+        # from here to the round's last collective a local failure cannot be announced by an all-reduce (see create_mobile_base_map)
+        self._in_round = True
         self.merge_timings = {}
         if self.merge_mode == "reduce":
             fin = parallel.merge_accumulator(acc, dst=0, exact_rgb=self.exact_rgb, timings=self.merge_timings)
@@ -661,6 +722,7 @@ class VLMapBuilder:
             raise ValueError(f"merge_mode must be 'sharded' or 'reduce', not {self.merge_mode!r}")
         sets = [None] * ws
         dist.all_gather_object(sets, sorted(mapped_iter_set))
+        self._in_round = False      # the round's collectives are done: what fails now (rank 0's file write) is announced at the next status all-reduce
         if rank != 0:
             return
         iters = set(i for s in sets for i in s)
@@ -755,6 +817,18 @@ class VLMapBuilder:
 import threading as _threading
 
 _SCRATCH = _threading.local()
+
+
+def _storage_key(feat):
+    """identity of the memory a feature tensor lives in: (device, start of its untyped storage) for torch tensors, None for
+    anything the builder stages itself (NumPy arrays are copied into fresh device buffers)"""
+    st = getattr(feat, "untyped_storage", None)
+    if st is None:
+        return None
+    try:
+        return (str(feat.device), int(st().data_ptr()))
+    except Exception:
+        return (str(getattr(feat, "device", "")), int(feat.data_ptr()))
 
 
 class _RanksAborted(RuntimeError):

@@ -343,6 +343,12 @@ class VoxelAccumulator:
         _lib.check(_lib.load().avl_builder_flush(self._h, stream), "avl_builder_flush")
         return self
 
+    def release_scratch(self, keep_bytes=0, stream=None):
+        """drop the cached sorted replay log and trim the library's stream-ordered pool to keep_bytes (after the last merge /
+        save of a build that shares the GPU with a feature extractor)"""
+        _lib.check(_lib.load().avl_builder_release_scratch(self._h, int(keep_bytes), stream), "avl_builder_release_scratch")
+        return self
+
     @property
     def capacity(self):
         c = C.c_int64()
@@ -641,21 +647,37 @@ def finalize_merged(merged, D, gs, vh, stream=None, n_rows=None):
 _HOST_PLANS = []          # [(weakref to the host array, fingerprint, HeatPlan)]: most recent first, at most two maps
 
 
+def _fingerprint(a: np.ndarray) -> int:
+    """hash of the WHOLE array (a fingerprint of sampled rows misses an in-place edit elsewhere and the stale cell order
+    gives a silently wrong heat).  xxh3 runs at ~10 GB/s (2 ms for a 2 M-voxel map's 24 MB); zlib.crc32 is the fall-back."""
+    buf = memoryview(a).cast("B")
+    try:
+        import xxhash
+        return xxhash.xxh3_64_intdigest(buf)
+    except ImportError:
+        import zlib
+        return zlib.crc32(buf)
+
+
 def _host_heat_plan(grid_pos: np.ndarray, stream=None):
     """HeatPlan for a HOST position array that is passed again and again (upstream's AVLMap.index_object and the navigator hand
-    the map's grid_pos to get_heatmap_from_mask_3d on every query): kept per array object, checked against a fingerprint of
-    its contents (1 024 sampled rows) so that an array edited in place gets a new plan.  None if the map cannot have one."""
+    the map's grid_pos to get_heatmap_from_mask_3d on every query): kept per array object, checked against a hash of ALL of
+    its contents so that an array edited in place gets a new plan.  Only for arrays that reach the library unchanged (int32,
+    C-contiguous): a converted temporary is a new object on every call and would build -- and keep alive -- a plan per query.
+    None if the map cannot have one."""
     import weakref
-    import zlib
-    n = len(grid_pos)
-    fp = (n, grid_pos.__array_interface__["data"][0], zlib.crc32(np.ascontiguousarray(grid_pos[::max(1, n // 1024)]).tobytes()))
+    fp = (len(grid_pos), grid_pos.__array_interface__["data"][0], _fingerprint(grid_pos))
     for k, (ref, f, plan) in enumerate(_HOST_PLANS):
         if ref() is grid_pos and f == fp:
             if k:
                 _HOST_PLANS.insert(0, _HOST_PLANS.pop(k))
             return plan
+    stale = [e for e in _HOST_PLANS if e[0]() is None or e[0]() is grid_pos]
     _HOST_PLANS[:] = [e for e in _HOST_PLANS if e[0]() is not None and e[0]() is not grid_pos]
-    plan = HeatPlan.for_positions(DeviceArray.from_numpy(np.ascontiguousarray(grid_pos, dtype=np.int32)), stream)
+    for _, _, old in stale:                    # the array died or was edited in place: its plan's device buffers go now
+        if old is not None:
+            old.close()
+    plan = HeatPlan.for_positions(DeviceArray.from_numpy(grid_pos), stream)
     try:
         _HOST_PLANS.insert(0, (weakref.ref(grid_pos), fp, plan))
     except TypeError:
@@ -669,11 +691,14 @@ def _host_heat_plan(grid_pos: np.ndarray, stream=None):
 
 def heatmap_from_mask(grid_pos, mask, cell_size=0.05, decay_rate=0.01, stream=None, reuse_plan=False):
     """visualize_utils.py:29-49 on the GPU.  grid_pos (N,3) int32, mask (N,) bool/uint8 -> (N,) float32.
-    reuse_plan (host grid_pos only): keep the map's positions and their cell order on the device between calls (HeatPlan) --
-    the second query on the same array uploads the mask alone and runs the 3-4x faster planned kernel; same bits."""
+    reuse_plan (host grid_pos only, int32 and C-contiguous, i.e. the SAME array object on every call): keep the map's positions
+    and their cell order on the device between calls (HeatPlan) -- the second query on the same array uploads the mask alone and
+    runs the 3-4x faster planned kernel; same bits.  The whole array is hashed per call (~2 ms at 2 M voxels), so an in-place
+    edit gets a fresh plan; VLMap / AVLMap.index_object hold their own plan and skip the hash."""
     lib = _lib.load()
     _lib.require_gpu()
-    if reuse_plan and isinstance(grid_pos, np.ndarray) and grid_pos.ndim == 2 and len(grid_pos) > 0 and grid_pos.dtype == np.int32:
+    if (reuse_plan and isinstance(grid_pos, np.ndarray) and grid_pos.ndim == 2 and len(grid_pos) > 0 and grid_pos.dtype == np.int32
+            and grid_pos.flags.c_contiguous):
         plan = _host_heat_plan(grid_pos, stream)
         if plan is not None:
             return plan(np.asarray(mask), cell_size, decay_rate, stream).numpy(stream)

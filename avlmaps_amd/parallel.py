@@ -14,8 +14,9 @@ VoxelAccumulator, with no communication while frames stream in.  At the end ONE 
          for the index kernels.  A gather of the finished float32 rows to one rank is optional (file save).
      (b) ONE reduce(SUM) of a dense (M, D+4) float64 buffer to the destination rank (merge_accumulator; north_star's
          "single RCCL reduce"): simple, but every rank allocates and moves the whole map (9.3 GB at M = 2.25 M).
-     Either way the rank that owns a voxel's global first touch (its key == the MIN) subtracts the reference's first-touch
-     term a1 (1 - a1) f1 (vlmap_builder.py:166-174 closed form) from its own contribution first, so no first-touch rows
+     Either way every rank folds its LOCAL first-touch sample (which the accumulators keep out of sum_feat) into its own
+     contribution first -- with the reference's weight a1^2 on the rank that owns the voxel's global first touch (its key ==
+     the MIN; vlmap_builder.py:166-174 closed form), with the plain weight a1 elsewhere -- so no first-touch rows
      are exchanged and the summed rows only need dividing by sum alpha.
   4. (optional, exact weight / grid_rgb) the sequential uint8 colour replay is a CHAIN over ranks: 24 B of state per
      voxel travel rank 0 -> 1 -> ... -> ws-1 (point-to-point), each rank continuing it with its own sample log.
@@ -316,8 +317,8 @@ def merge_raw(raw: Dict[str, "torch.Tensor"], dst: int = 0, group=None):
     acc = torch.zeros((plan.M, D + 4), dtype=torch.float64, device=raw["cell"].device)
     a1 = raw["first_alpha"]
     own = raw["first_key"].to(torch.int64) == plan.key[rows]
-    corr = torch.where(own, a1 * (1.0 - a1), torch.zeros_like(a1))
-    acc[rows, :D] = raw["sum_feat"] - corr[:, None] * raw["first_feat"].double()
+    wf = torch.where(own, a1 * a1, a1)          # sum_feat leaves the local first touch out: a1^2 f1 for the global owner, a1 f1 otherwise
+    acc[rows, :D] = wf[:, None] * raw["first_feat"].double() + raw["sum_feat"]
     acc[rows, D:] = raw["sum_w4"]
     if plan.coll is not None:
         import torch.distributed as dist
@@ -364,8 +365,8 @@ def _merge_raw_sharded_general(raw: Dict[str, "torch.Tensor"], group=None):
     ex = ShardExchange(plan)
     a1 = raw["first_alpha"]
     own = raw["first_key"].to(torch.int64) == plan.key[plan.row_of_slot]
-    corr = torch.where(own, a1 * (1.0 - a1), torch.zeros_like(a1))
-    contrib = torch.cat([raw["sum_feat"] - corr[:, None] * raw["first_feat"].double(), raw["sum_w4"]], dim=1)[ex.order].contiguous()
+    wf = torch.where(own, a1 * a1, a1)
+    contrib = torch.cat([wf[:, None] * raw["first_feat"].double() + raw["sum_feat"], raw["sum_w4"]], dim=1)[ex.order].contiguous()
     rows = ex.rows_sorted
     if plan.coll is not None:
         got_rows = plan.coll.all_to_all(rows, ex.send_counts, ex.recv_counts)
@@ -836,15 +837,21 @@ class MixedExchange:
 
 def _fold_mixed(plan, ex, D, side, done, part, rows_add):
     """owner side of the mixed exchange, shared by the device path and its torch twin: returns (own_cell, w4 (n_own, 4) f64,
-    state (n_own, 3) i64, done_rows, done_feat, part_rows (k,), part_acc (k, D) f64) -- rows relative to this rank's block"""
+    state (n_own, 3) i64, done_rows, done_feat, part_rows (k,), part_acc (k, D) f64, bad_rows (1,) int32 = some received row
+    index lay outside the block) -- rows relative to this rank's block"""
     import torch
     i64 = torch.int64
     dev = side.device
     n_own = ex.r1 - ex.r0
     word = side[:, 0]
     rows = (word & 0xFFFFFFFF) - ex.r0
-    own_cell = torch.zeros(n_own, dtype=torch.int32, device=dev)
+    # a row outside this rank's block would be a plan / exchange bug: never index with it (a device-side assert would take the
+    # process down before anybody could report it) -- clamp, and let the caller raise on EVERY rank (bad_rows; ADVICE r4)
+    bad_rows = ((rows < 0) | (rows >= n_own)).any().reshape(1).to(torch.int32) if rows.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+    rows = rows.clamp(0, max(n_own - 1, 0))
+    own_cell = torch.zeros(max(n_own, 1), dtype=torch.int32, device=dev)
     own_cell[rows] = ((word >> 32) & 0x7FFFFFFF).to(torch.int32)
+    own_cell = own_cell[:n_own]
     w4 = torch.zeros((max(n_own, 1), 4), dtype=torch.float64, device=dev)
     o = 0
     for c in ex.recv_all:                           # peer by peer, in rank order: a reproducible float64 sum
@@ -866,7 +873,7 @@ def _fold_mixed(plan, ex, D, side, done, part, rows_add):
         if c:
             rows_add(inv[o:o + c], part[o:o + c], acc)
         o += c
-    return own_cell, w4, state, done_rows, done, part_rows, acc
+    return own_cell, w4, state, done_rows, done, part_rows, acc, bad_rows
 
 
 def merge_raw_sharded(raw: Dict[str, "torch.Tensor"], group=None, replay_fn=None, gs2: Optional[int] = None):
@@ -892,8 +899,8 @@ def merge_raw_sharded(raw: Dict[str, "torch.Tensor"], group=None, replay_fn=None
     ex = MixedExchange(plan)
     n = plan.n
     a1 = raw["first_alpha"]
-    corr = torch.where(plan.is_new, a1 * (1.0 - a1), torch.zeros_like(a1))
-    contrib = raw["sum_feat"] - corr[:, None] * raw["first_feat"].double()
+    wf = torch.where(plan.is_new, a1 * a1, a1)
+    contrib = wf[:, None] * raw["first_feat"].double() + raw["sum_feat"]
     o = ex.order
     single = ex.single_sorted
     done = (contrib[o][single] / raw["sum_w4"][o][single][:, :1]).float().contiguous()
@@ -915,7 +922,9 @@ def merge_raw_sharded(raw: Dict[str, "torch.Tensor"], group=None, replay_fn=None
 
     def rows_add(rows, src, dst):
         dst.index_add_(0, rows, src)
-    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc, bad_rows = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    if int(bad_rows.item()):
+        raise RuntimeError("multi-rank merge: a received row index lies outside its owner's block of final rows")
     n_own = ex.r1 - ex.r0
     grid_feat = torch.zeros((n_own, D), dtype=torch.float32, device=dev)
     grid_feat[done_rows] = done_feat
@@ -1085,9 +1094,14 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
         _lib.check(lib.avl_rows_add_f64_async(int(rows.shape[0]), int(src.shape[1]), rows.data_ptr(), 0, int(dst.shape[0]), src.data_ptr(),
                                               int(src.shape[1]), dst.data_ptr(), int(dst.shape[1]), err_flag.data_ptr(), st), "avl_rows_add_f64_async")
     tr3 = _Trace('fold', dev)
-    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc, bad_rows = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    # every rank learns whether ANY rank saw a bad row and raises with it: a rank raising alone would leave the others in
+    # gather_row_shards' collectives
+    err_flag = torch.maximum(err_flag, bad_rows.to(err_flag.device))
+    if coll is not None:
+        err_flag = coll.all_reduce(err_flag, coll.dist.ReduceOp.MAX)
     if int(err_flag.item()):
-        raise RuntimeError("multi-rank merge: a received row index lies outside this rank's block of final rows")
+        raise RuntimeError("multi-rank merge: a received row index lies outside its owner's block of final rows")
     tr3('fold lists')
     out = dict(M=M, rows=(ex.r0, ex.r1), cell=own_cell,
                grid_feat=torch.empty((n_own, D), dtype=torch.float32, device=dev),
@@ -1188,8 +1202,8 @@ def merge_raw_local(raws):
     for r, idx in zip(raws, idxs):
         own = r["first_key"].to(torch.int64) == gkey[idx]
         a1 = r["first_alpha"]
-        corr = torch.where(own, a1 * (1.0 - a1), torch.zeros_like(a1))
-        acc[idx, :D] += r["sum_feat"] - corr[:, None] * r["first_feat"].double()
+        wf = torch.where(own, a1 * a1, a1)
+        acc[idx, :D] += wf[:, None] * r["first_feat"].double() + r["sum_feat"]
         acc[idx, D:] += r["sum_w4"]
     order = torch.argsort(gkey)
     return dict(cell=union[order].to(torch.int32), first_key=gkey[order], acc=acc[order].contiguous())

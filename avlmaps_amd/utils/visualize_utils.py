@@ -11,8 +11,10 @@ def get_heatmap_from_mask_3d(pc: np.ndarray, mask: np.ndarray, cell_size: float 
     mask = np.asarray(mask)
     if mask.sum() == 0:
         raise ValueError("attempt to get argmin of an empty sequence")   # what np.argmin raises upstream
-    # the same grid_pos array comes back on every query of a map: its device copy and cell order are kept between calls
-    return ops.heatmap_from_mask(np.ascontiguousarray(pc, dtype=np.int32), mask.astype(np.uint8), cell_size, decay_rate, reuse_plan=True)
+    # the same grid_pos array comes back on every query of a map: its device copy and cell order are kept between calls --
+    # only when the array reaches the library as it is (a converted temporary is a new object every time: stateless path)
+    pos = np.ascontiguousarray(pc, dtype=np.int32)
+    return ops.heatmap_from_mask(pos, mask.astype(np.uint8), cell_size, decay_rate, reuse_plan=pos is pc)
 
 
 def pool_3d_label_to_2d(mask_3d: np.ndarray, grid_pos: np.ndarray, gs: int) -> np.ndarray:

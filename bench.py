@@ -468,7 +468,8 @@ def run_index(args, torch, dist, lib, rank, ws):
             feat_h, q_h = feat.cpu().numpy(), q.cpu().numpy()
             t_cpu, threads, am_cpu = cpu_index_baseline(feat_h, q_h)
             agree = float(np.mean(am_cpu == am.cpu().numpy()))
-            out["cpu_baseline"] = dict(value=N * Q / t_cpu, unit="similarities/s", cores=threads, kind="port",
+            out["cpu_baseline"] = dict(value=N * Q / t_cpu, unit="similarities/s", cores=threads, kind="reference",
+                                       kind_note="the reference's OWN op on the host cores (NumPy / OpenBLAS sgemm + np.argmax), not a port",
                                        sample=f"full workload ({N}x{D} @ {D}x{Q} numpy/OpenBLAS sgemm + np.argmax, best of 3, "
                                               f"{t_cpu * 1e3:.0f} ms; the op at clip_utils.py:229 + vlmap.py:123)",
                                        argmax_agreement_with_gpu=agree)
@@ -649,7 +650,7 @@ def merge_ranks(parallel, acc, mode, exact_rgb, timings=None):
 
 
 def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, batch=1, exact_rgb=True, feature_standin=None,
-                   deferred=False, solo=False):
+                   deferred=False, solo=False, merge_mode=None):
     """STRONG scaling of map creation: `total_frames` frames of one sequence are sharded contiguously over the ranks; the
     timed region is everything between the first fused frame and the finished map resident in HBM:
         fuse own shard (K1/K2/K3 per launch)  ->  [ws > 1: plan + scatter + ONE all_to_all of the ranks' own voxel rows to the
@@ -708,7 +709,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         fuse(lo, lo + warmup)           # untimed: code objects loaded, pools warm; then start from an empty map
     # the warm-up covers the tail of the path too: the first merge of a process pays for torch's sort / unique kernels, RCCL's
     # lazily created point-to-point communicators and the allocator's first large blocks (tens to hundreds of ms, once)
-    mode = getattr(args, "merge_mode", "sharded")
+    mode = merge_mode or getattr(args, "merge_mode", "sharded")
     if ws > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1":
         # torch's large-size sort / unique code objects (lazy, per process) and the allocator's first exchange-sized blocks
         parallel.warm_up_merge(1 << 20, D=D, n_exchange=cap)
@@ -875,7 +876,7 @@ def run_build(args, torch, dist, lib, rank, ws):
     return out
 
 
-def cpu_build_baseline(frames=12):
+def cpu_build_baseline(frames=64):
     """sequential C port of the reference loop (oracle) on one core; the reference itself is a Python loop (~5 frames/s)"""
     from oracle import avl_oracle as O
     H, W, Hf, Wf, D, rate = 720, 1080, 347, 520, 512, 100
@@ -1080,6 +1081,11 @@ def main():
                 # fusion.  NOT LSeg (no weights here): a random-weight ViT-L/16-shaped encoder, 2 crops x 900 tokens, bf16
                 nst = max(args.standin_frames, 2 * ws)
                 rv = run_build_core(args, torch, dist, lib, rank, ws, total_frames=nst, batch=1, feature_standin="vit-l16")
+                # north_star's wording is "a single RCCL reduce over xGMI": the same frames once more with the OTHER merge mode
+                # (dense (M, D + 4) float64 sum-reduce to rank 0 when the default is the row-sharded all_to_all, and vice versa),
+                # so that one --gpus N run exercises both collectives on the hardware
+                other = "reduce" if getattr(args, "merge_mode", "sharded") != "reduce" else "sharded"
+                ro = run_build_core(args, torch, dist, lib, rank, ws, total_frames=args.build_frames, batch=1, merge_mode=other)
                 # the single-GPU reference of the SAME sequences, measured in this run by rank 0 alone while the others wait:
                 # the top-level `build` block then answers north_star's strong-scaling question without a second command
                 s1 = sv = None
@@ -1104,6 +1110,12 @@ def main():
                                                                 "in_collectives_total_s", "merged_voxels", "local_voxels", "single_rank_voxels",
                                                                 "shared_voxels_local", "payload_bytes_sent", "payload_bytes_fp64_form",
                                                                 "bytes_sent_per_rank", "world_size", "backend")},
+                        other_merge_mode=dict(merge_mode=ro["merge_mode"], frames_per_s=ro["frames_per_s"], seconds=ro["seconds"],
+                                              merge_finalize_seconds=ro["merge_finalize_seconds"], voxels_merged=ro["voxels_merged"],
+                                              speedup_vs_single_gpu=ro["frames_per_s"] / s1["frames_per_s"],
+                                              breakdown={k: (ro.get("merge_breakdown") or {}).get(k) for k in
+                                                         ("mode", "plan_s", "scatter_s", "reduce_s", "exchange_s", "replay_chain_s", "accumulate_s",
+                                                          "finalize_s", "dense_reduce_payload_bytes", "bytes_sent_per_rank")}),
                         with_extractor_standin=dict(
                             note="a random-weight ViT-L/16-shaped encoder (2 crops x 900 tokens, bf16) runs before every frame: a stand-in "
                                  "for LSeg's per-frame cost, NOT LSeg -- the regime north_star's >= 6x at 8 GPUs is about",

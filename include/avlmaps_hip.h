@@ -241,6 +241,11 @@ AVL_API int avl_builder_capacity(avl_builder* b, int64_t* h_capacity);
  * produced, then fused, one frame at a time. */
 AVL_API int avl_builder_set_deferred_fuse(avl_builder* b, int on, void* stream);
 AVL_API int avl_builder_flush(avl_builder* b, void* stream);
+/* Give back what the builder's finalisation / replay / merge temporaries left cached: the slot-sorted replay log kept between the
+ * two replay calls of a merge, and everything above keep_bytes in the device's stream-ordered pool (hipMemPoolTrimTo).  The
+ * library keeps AVLMAPS_MEMPOOL_KEEP_MB (default 1024) MB of that pool between calls; call this after the last merge / final
+ * save of a build that shares the GPU with a feature extractor.  Synchronises the stream. */
+AVL_API int avl_builder_release_scratch(avl_builder* b, int64_t keep_bytes, void* stream);
 
 /* Optional: keep a 24-byte log entry per sampled pixel (up to max_samples in total) so that avl_builder_finalize can
  * REPLAY the reference's sequential weight / grid_rgb updates exactly -- float32 weight accumulation and the truncating
@@ -369,9 +374,11 @@ AVL_API int avl_finalize_raw(int64_t n, int D, int gs, int vh, const int32_t* d_
  * Multi-GPU merge on the device (avlmaps_amd/parallel.py drives the RCCL calls).  After the ranks have agreed
  * on the union of occupied cells and all-reduced (MIN) the first-touch keys, every rank scatters its accumulators into a
  * zero-initialised dense (M, ld_acc >= D + 4) float64 buffer that is then sum-reduced ONCE:
- *   row d_row_of_slot[s] <- [sum_feat[s] - own * a1 (1 - a1) first_feat[s]  |  sum alpha, sum alpha * (r, g, b)]
- * where own = (this rank's first-touch key of the voxel == d_global_key[row]): the owner of the global first touch folds
- * the reference's first-touch term in locally, so no first_feat / first_alpha exchange is needed.
+ *   row d_row_of_slot[s] <- [sum_feat[s] + (own ? a1^2 : a1) first_feat[s]  |  sum alpha, sum alpha * (r, g, b)]
+ * where sum_feat[s] sums alpha f over every sample of the slot EXCEPT its local first touch (a1, first_feat) and
+ * own = (this rank's first-touch key of the voxel == d_global_key[row]): the owner of the global first touch contributes it
+ * with the reference's weight a1^2 (vlmap_builder.py:166-174), every other rank with a1, so no first_feat / first_alpha
+ * exchange is needed.
  * n must equal avl_builder_num_voxels().  d_row_of_slot (n,) int64, d_global_key (M,) uint64.
  */
 AVL_API int avl_builder_scatter_merge(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, const uint64_t* d_global_key,
@@ -393,10 +400,10 @@ AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d
                                      void* stream);
 AVL_API int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream);
 /* Mixed payload of the row-sharded merge (round 4).  A voxel only ONE rank touched is finished where its accumulators live:
- * d_out[i, :D] = (float)((sum_feat[s] - a1 (1 - a1) first_feat[s]) / sum alpha), s = d_slots[i] -- the float64 expression of the
+ * d_out[i, :D] = (float)((a1^2 first_feat[s] + sum_feat[s]) / sum alpha), s = d_slots[i] -- the float64 expression of the
  * single-process finalisation (vlmap_builder.py:166-178 closed form), so the row is bit-identical to the single-process map and
- * travels as 4 B per element.  Voxels several ranks touched ship float64 partial sums: d_out[i, :D] = sum_feat[s] - d_own[i] *
- * a1 (1 - a1) first_feat[s] (d_own[i] != 0: this rank holds the voxel's global first touch).  d_slots (k,) int32 distinct slots. */
+ * travels as 4 B per element.  Voxels several ranks touched ship float64 partial sums: d_out[i, :D] = sum_feat[s] +
+ * (d_own[i] ? a1^2 : a1) first_feat[s] (d_own[i] != 0: this rank holds the voxel's global first touch).  d_slots (k,) int32 distinct slots. */
 AVL_API int avl_builder_export_rows_f32(avl_builder* b, int64_t k, const int32_t* d_slots, float* d_out, int64_t ld, void* stream);
 AVL_API int avl_builder_export_rows_f64(avl_builder* b, int64_t k, const int32_t* d_slots, const uint8_t* d_own, double* d_out,
                                         int64_t ld, void* stream);

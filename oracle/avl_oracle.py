@@ -169,11 +169,12 @@ class OracleMap:
             lib().avlo_map_destroy(self._h)
             self._h = None
 
-    def integrate(self, depth, calib, pc_transform, sample_idx, feat_chw, rgb, min_depth=0.1, max_depth=6.0):
+    def integrate(self, depth, calib, pc_transform, sample_idx, feat_chw, rgb, min_depth=0.1, max_depth=6.0, calib_inv=None):
         depth = np.ascontiguousarray(depth, dtype=np.float32)
         H, W = depth.shape
         K = np.ascontiguousarray(np.asarray(calib, dtype=np.float64).reshape(3, 3))
-        Kinv = np.ascontiguousarray(np.linalg.inv(K))           # mapping_utils.py:237
+        # mapping_utils.py:237; tests may inject an exact camera-frame point through the inverse (tests/test_geometry_gpu.py)
+        Kinv = np.ascontiguousarray(np.linalg.inv(K) if calib_inv is None else np.asarray(calib_inv, dtype=np.float64).reshape(3, 3))
         feat = np.ascontiguousarray(feat_chw, dtype=np.float32)
         if feat.ndim == 4:
             feat = feat[0]

@@ -141,6 +141,57 @@ def test_builder_vs_sequential_oracle_medium(ops):
     assert np.mean(out2["grid_feat"] == out["grid_feat"]) > 0.9999
 
 
+@pytest.mark.parametrize("mode", ["frames", "deferred", "batch"])
+def test_far_voxels_keep_their_direction(ops, mode):
+    """A voxel first touched from far away stores feat * alpha with alpha = exp(-r^2 / 1.2) down to 1e-30 (image corners at 5-6 m,
+    vlmap_builder.py:156-168): tiny rows, but index_map's argmax only sees their DIRECTION.  Every row must match the sequential
+    oracle RELATIVE TO ITS OWN MAGNITUDE -- the closed form's first-touch term must not cancel (round 5: the earlier form
+    sum - a1 (1 - a1) f1 returned all-zero rows below alpha ~ 1e-16) -- in every fusion mode."""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(31)
+    H, W, Hf, Wf, D, nfr, rate = 72, 108, 35, 52, 32, 3, 2
+    gs, cs, cam_h = 1000, 0.05, 1.5
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    yy, xx = np.meshgrid(np.linspace(-1, 1, H), np.linspace(-1, 1, W), indexing="ij")
+    depths = np.stack([(5.2 + 0.7 * np.cos(1.3 * xx + 0.4 * i) * np.cos(yy)).astype(np.float32) for i in range(nfr)])
+    rgbs = rng.integers(0, 256, (nfr, H, W, 3), dtype=np.uint8)
+    feats = rng.standard_normal((nfr, D, Hf, Wf)).astype(np.float32)
+    feats = (feats / np.linalg.norm(feats, axis=1, keepdims=True) * 14.2857).astype(np.float32)
+    # the camera looks along the floor (pitch ~ 0) from 1.4 m below the ceiling of the grid so that far points stay inside 0 <= h < 30
+    poses = np.array([[0.02 * i, 0.0, 0.0, 0.0, np.sin(0.01 * i), 0.0, np.cos(0.01 * i)] for i in range(nfr)])
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(5)
+    samples = [O.sample_indices(rs, H * W, rate) for _ in range(nfr)]
+    om = O.OracleMap(gs, cs, cam_h, D)
+    for i in range(nfr):
+        om.integrate(depths[i], calib, Ts[i], samples[i], feats[i], rgbs[i])
+    ref = om.export()
+    w = ref["weight"].astype(np.float64)
+    assert len(w) > 500 and (w < 1e-16).sum() > 50 and (w < 1e-12).mean() > 0.3, (len(w), (w < 1e-16).sum())
+    if mode == "batch":
+        acc = ops.VoxelAccumulator(gs, cs, int(cam_h / cs), D, capacity=50_000)
+        fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
+        acc.integrate_batch(list(depths), calib, Ts, samples, fs, list(rgbs), frame_idx0=0)
+    else:
+        acc = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=50_000, deferred=mode == "deferred")
+    out = acc.finalize()
+    assert np.array_equal(out["grid_pos"], ref["grid_pos"])
+    np.testing.assert_allclose(out["weight"], ref["weight"], rtol=3e-6, atol=0)
+    scale = np.abs(ref["grid_feat"]).max(axis=1, keepdims=True)
+    assert scale.min() > 0                                              # the reference has no all-zero row here
+    rel = np.abs(out["grid_feat"].astype(np.float64) - ref["grid_feat"]) / scale
+    assert rel.max() < 1e-5, (rel.max(), float(w[np.argmax(rel.max(axis=1))]))
+    # and what index_map sees: the class of every voxel against 9 random unit queries, through the HIP similarity kernel
+    q = rng.standard_normal((9, D)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    want = ref["grid_feat"].astype(np.float64) @ q.T.astype(np.float64)
+    srt = np.sort(want, axis=1)
+    clear = (srt[:, -1] - srt[:, -2]) > 1e-4 * np.abs(srt[:, -1])
+    _, am, _ = ops.sim_scores(np.ascontiguousarray(out["grid_feat"]), q)
+    assert clear.mean() > 0.99 and np.array_equal(am[clear], np.argmax(want, axis=1)[clear])
+
+
 @pytest.mark.parametrize("D", [5, 30, 257, 768, 1024, 1536])
 def test_builder_feature_widths(ops, D):
     """every register-chunk variant of K3 (D <= 256 / 512 / 1024), rows that are not 16-byte multiples, and the generic kernel
@@ -704,7 +755,7 @@ def test_full_size_build_properties(ops):
     sel = order[pick]
     sf, sw = raw["sum_feat"][sel], raw["sum_w4"][sel][:, 0:1]
     a1, f1 = raw["first_alpha"][sel][:, None], raw["first_feat"][sel].double()
-    want = ((sf - a1 * (1.0 - a1) * f1) / sw).cpu().numpy()
+    want = ((a1 * a1 * f1 + sf) / sw).cpu().numpy()          # sum_feat leaves the first touch out; the reference weighs it a1^2
     got = out["grid_feat"][pick.cpu().numpy()]
     np.testing.assert_allclose(got, want.astype(np.float32), rtol=2e-6, atol=1e-6)
     # batched fusion: identical ids / colour / weight, features to rounding

@@ -46,12 +46,12 @@ def test_export_rows_match_the_single_process_finalisation(env, golden):
     row_of_slot[order] = np.arange(n)
     assert np.array_equal(rows32, fin["grid_feat"][row_of_slot[slots]])           # bit-identical to the single-process map
     a1 = raw["first_alpha"][slots]
-    want32 = ((raw["sum_feat"][slots] - (a1 * (1 - a1))[:, None] * raw["first_feat"][slots].astype(np.float64)) / raw["sum_w4"][slots, :1])
+    want32 = (((a1 * a1)[:, None] * raw["first_feat"][slots].astype(np.float64) + raw["sum_feat"][slots]) / raw["sum_w4"][slots, :1])
     assert np.array_equal(rows32, want32.astype(np.float32))
     own = (rng.random(len(slots)) < 0.5).astype(np.uint8)
     out64 = DeviceArray((len(slots), D), np.float64)
     _lib.check(lib.avl_builder_export_rows_f64(acc._h, len(slots), d_slots.ptr, DeviceArray.from_numpy(own).ptr, out64.ptr, D, None), "export_rows_f64")
-    want64 = raw["sum_feat"][slots] - (own * a1 * (1 - a1))[:, None] * raw["first_feat"][slots].astype(np.float64)
+    want64 = np.where(own != 0, a1 * a1, a1)[:, None] * raw["first_feat"][slots].astype(np.float64) + raw["sum_feat"][slots]
     assert np.array_equal(out64.numpy(), want64)
     # argument checks: more slots than voxels, a row stride below D
     assert lib.avl_builder_export_rows_f32(acc._h, n + 1, d_slots.ptr, out32.ptr, D + 8, None) != 0

@@ -117,6 +117,30 @@ def test_similarity_matches_reference(golden):
     assert np.array_equal(am, g["tie_argmax"])
     assert g["tie_argmax"][200] == 0
 
+def config1_map():
+    """BASELINE config 1's map: 50 000 x 512 standard normal float32 from seed 0 (tools/gen_golden.py:config1_inputs)"""
+    return np.random.default_rng(0).standard_normal((50_000, 512)).astype(np.float32)
+
+
+def test_config1_at_its_stated_size(golden):
+    """BASELINE config 1 (50 000 x 512, one landmark + "other"; clip_utils.py:196-242, vlmap.py:104-125): the oracle against
+    what the reference returned for the SAME seeded map (g9), at the size the config states -- the CPU plumbing case."""
+    g = golden("g9_config1.npz")
+    feat = config1_map()
+    assert np.array_equal(feat[::997].sum(axis=1), g["feat_crc_rows"])          # the seed still produces the map g9 was made from
+    assert np.array_equal(O.template_mean(g["template_feats"]), g["mean_feats"])
+    sc = O.sim_scores(feat, g["mean_feats"])
+    assert sc.shape == (50_000, 2) and sc.dtype == np.float32
+    np.testing.assert_allclose(sc, g["scores"], rtol=0, atol=1e-6)
+    mask, ids = O.argmax_mask(sc, 0)
+    assert np.array_equal(mask, g["index_map_mask"]) and np.array_equal(ids, np.argmax(g["scores"], axis=1))
+    np.testing.assert_allclose(O.sim_scores(feat, g["single_feats"]), g["single_scores"], rtol=0, atol=1e-5)
+    sc2, am2 = O.sim_scores_scalar(feat, g["mean_feats"])
+    np.testing.assert_allclose(sc2, g["scores"], rtol=0, atol=2e-6)
+    gap = np.abs(g["scores"][:, 0] - g["scores"][:, 1])
+    assert np.array_equal(am2[gap > 4e-6], ids[gap > 4e-6])
+
+
 
 def test_heatmap_matches_reference(golden):
     g = golden("g4_heatmap.npz")

@@ -45,8 +45,13 @@ def expected_merge(raws):
             e = table.setdefault(c, dict(key=parallel.I64_MAX, sf=np.zeros(D), w4=np.zeros(4), ff=None, fa=None))
             e["sf"] = e["sf"] + r["sum_feat"][i].numpy()
             e["w4"] = e["w4"] + r["sum_w4"][i].numpy()
+            e.setdefault("firsts", []).append((int(r["first_key"][i]), float(r["first_alpha"][i]), r["first_feat"][i].numpy().astype(np.float64)))
             if int(r["first_key"][i]) < e["key"]:
                 e["key"], e["ff"], e["fa"] = int(r["first_key"][i]), r["first_feat"][i].numpy(), float(r["first_alpha"][i])
+    for e in table.values():
+        # sum_feat leaves every rank's LOCAL first touch out: the global first touch counts with the reference's a1^2
+        # (vlmap_builder.py:166-174), the local first touches of the other ranks with their plain weight
+        e["want"] = e["sf"] + sum((a * a if k == e["key"] else a) * f for k, a, f in e["firsts"])
     cells = sorted(table, key=lambda c: table[c]["key"])
     return cells, table
 
@@ -74,8 +79,8 @@ def _worker(rank, ws, port, tmpdir):
         for i, c in enumerate(cells):
             e = table[c]
             assert int(merged["first_key"][i]) == e["key"]
-            # ONE reduce: the owner of the global first touch has already subtracted a1 (1 - a1) f1
-            want = e["sf"] - e["fa"] * (1.0 - e["fa"]) * e["ff"].astype(np.float64)
+            # ONE reduce: every rank has already folded its first-touch sample in (a1^2 f1 for the global owner)
+            want = e["want"]
             np.testing.assert_allclose(merged["acc"][i, :D].numpy(), want, rtol=1e-13, atol=1e-13)
             np.testing.assert_allclose(merged["acc"][i, D:].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
         # rank 0's frames precede rank 1's: shared voxels must be owned by rank 0
@@ -173,7 +178,7 @@ def _sharded_worker(rank, ws, port, tmpdir, monotone=True):
     part = {int(r): i for i, r in enumerate(sh["part_rows"].tolist())}
     for i in range(r0, r1):
         e = table[cells[i]]
-        want = e["sf"] - e["fa"] * (1.0 - e["fa"]) * e["ff"].astype(np.float64)
+        want = e["want"]
         np.testing.assert_allclose(sh["w4"][i - r0].numpy(), e["w4"], rtol=1e-15, atol=1e-15)
         assert int(sh["first_key"][i - r0]) == e["key"]
         if monotone and len(holders[cells[i]]) == 1:
@@ -270,7 +275,7 @@ def test_single_process_merge_is_a_sort():
     merged = parallel.merge_raw(shuffled)
     assert torch.equal(merged["cell"], raw["cell"]) and torch.equal(merged["first_key"], raw["first_key"])
     a1 = raw["first_alpha"]
-    want = raw["sum_feat"] - (a1 * (1 - a1))[:, None] * raw["first_feat"].double()
+    want = (a1 * a1)[:, None] * raw["first_feat"].double() + raw["sum_feat"]
     assert torch.equal(merged["acc"][:, :4], want) and torch.equal(merged["acc"][:, 4:], raw["sum_w4"])
 
 

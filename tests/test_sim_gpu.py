@@ -50,9 +50,45 @@ def test_golden_wide_queries(ops, golden, tag, precision):
     assert np.abs(sc - ref).max() < 3e-5                               # what the kernels actually achieve vs the sgemm result
     rows = np.arange(len(ref))
     assert np.all(ref[rows, am] >= ref.max(axis=1) - 6e-5)
-    agree = np.mean(am == g[f"{tag}_argmax"])
-    assert agree > 0.99, agree                                         # the rest are float32 near-ties of the reference itself
+    # every row on which the fused argmax differs from the reference's is a near-tie OF THE REFERENCE ITSELF: the top-2
+    # gap of its own float32 sgemm scores is below 6e-5 there (and the column we picked is one of those two)
+    bad = np.nonzero(am != g[f"{tag}_argmax"])[0]
+    if len(bad):
+        top2 = np.sort(ref[bad], axis=1)[:, -2:]
+        assert np.all(top2[:, 1] - top2[:, 0] < 6e-5), (bad, top2)
+        assert np.all(ref[bad, am[bad]] >= top2[:, 0])
     assert np.array_equal(am, np.argmax(sc, axis=1))                   # fused argmax == argmax of the returned scores
+
+
+@pytest.mark.parametrize("precision", ["exact", "exact_valu", "split_f16", "auto", "prepared", "compact"])
+def test_config1_at_its_stated_size(ops, golden, precision):
+    """BASELINE config 1 at the size it states -- 50 000 voxels x 512, ONE landmark + "other" (Q = 2) -- against what the
+    reference itself returned for the same seeded map (g9: clip_utils.py:196-242 get_lseg_score, vlmap.py:104-125
+    VLMap.index_map(with_init_cat=False)), against the oracle and against np.argmax."""
+    from avlmaps_amd.device import DeviceArray
+    from oracle import avl_oracle as O
+    g = golden("g9_config1.npz")
+    feat = np.random.default_rng(0).standard_normal((50_000, 512)).astype(np.float32)
+    assert np.array_equal(feat[::997].sum(axis=1), g["feat_crc_rows"])
+    q, ref = g["mean_feats"], g["scores"]
+    src = feat
+    if precision in ("prepared", "compact"):
+        src = ops.prepare_map(DeviceArray.from_numpy(feat), compact=precision == "compact")
+    sc, am, best = ops.sim_scores(src, q, want_best=True, precision="auto" if precision in ("prepared", "compact") else precision)
+    sc, am, best = (x.numpy() if hasattr(x, "numpy") and not isinstance(x, np.ndarray) else x for x in (sc, am, best))
+    assert sc.shape == (50_000, 2)
+    np.testing.assert_allclose(sc, ref, rtol=0, atol=1e-4)                       # north_star's tolerance
+    assert np.abs(sc - ref).max() < 1e-5                                         # what the kernels achieve (scores are O(1) here)
+    np.testing.assert_allclose(sc, O.sim_scores(feat, q), rtol=0, atol=1e-5)     # the oracle on the same inputs
+    ref_am = np.argmax(ref, axis=1)
+    clear = np.abs(ref[:, 0] - ref[:, 1]) > 2e-5
+    assert clear.mean() > 0.999
+    assert np.array_equal(am[clear], ref_am[clear])                              # np.argmax of the reference's scores
+    assert np.array_equal(am, np.argmax(sc, axis=1))                             # fused argmax == argmax of the returned scores
+    np.testing.assert_allclose(best, ref.max(axis=1), rtol=0, atol=1e-5)
+    mask = ops.mask_from_argmax(am, 0)
+    mask = mask.numpy() if hasattr(mask, "numpy") and not isinstance(mask, np.ndarray) else np.asarray(mask)
+    assert np.array_equal(mask.astype(bool)[clear], g["index_map_mask"][clear])  # the reference's index_map mask
 
 
 @pytest.mark.parametrize("precision", ["exact", "exact_valu", "split_f16"])

@@ -17,6 +17,8 @@ Reference entry points exercised (file:line in /root/reference):
       avlmaps/map/map.py:79-113 Map.generate_obstacle_map / generate_cropped_obstacle_map / generate_rgb_topdown_map,
       avlmaps/utils/index_utils.py:138-184 get_dynamic_obstacles_map_3d, avlmaps/map/vlmap.py:158-187 VLMap.get_pos
       (up to the cv2.findContours call, which is stubbed: its input mask is recorded)
+  G9  BASELINE config 1 at its stated size (50 000 x 512, one landmark + "other"): clip_utils.py:196-242 get_lseg_score and
+      vlmap.py:104-125 VLMap.index_map(with_init_cat=False); the map is regenerated from its seed, outputs only are stored
 """
 import os
 import sys
@@ -468,6 +470,9 @@ def main():
     if "--only-g7" in sys.argv:
         gen_g7_wide(import_reference(), np.random.default_rng(77))
         return
+    if "--only-g9" in sys.argv:
+        gen_g9_config1(import_reference(), np.random.default_rng(99))
+        return
     m = import_reference()
     gen_g1(m, np.random.default_rng(11))
     gen_g2(m, np.random.default_rng(22))
@@ -479,6 +484,8 @@ def main():
     gen_g6_multi_floor(np.random.default_rng(66))
     if "--only-g7" in sys.argv or "--all" in sys.argv or not (OUT / "g7_similarity_wide.npz").exists():
         gen_g7_wide(import_reference(), np.random.default_rng(77))
+    if "--only-g9" in sys.argv or "--all" in sys.argv or not (OUT / "g9_config1.npz").exists():
+        gen_g9_config1(import_reference(), np.random.default_rng(99))
     os.system(f"ls -la {OUT}")
 
 
@@ -518,6 +525,46 @@ def gen_g7_wide(m, rng):
         out[f"{tag}_argmax"] = np.argmax(sc, axis=1).astype(np.int32)
     np.savez_compressed(OUT / "g7_similarity_wide.npz", **out)
     print("G7 written", {k: v.shape for k, v in out.items() if k.endswith("scores")})
+
+
+def config1_inputs():
+    """BASELINE config 1 / SURVEY 8(d): 50 000 x 512 standard-normal map from seed 0 (the tests regenerate it from the seed,
+    only the reference's outputs are stored)"""
+    return np.random.default_rng(0).standard_normal((50_000, 512)).astype(np.float32)
+
+
+def gen_g9_config1(m, rng):
+    """BASELINE config 1 AT ITS STATED SIZE through the reference itself: avlmaps/utils/clip_utils.py:196-242 get_lseg_score
+    and avlmaps/map/vlmap.py:104-125 VLMap.index_map(with_init_cat=False) on the 50 000 x 512 map, one landmark (+ "other")."""
+    cu = m["clip_utils"]
+    VLMap = m["vlmap"].VLMap
+    D = 512
+    feat = config1_inputs()
+    table = {}
+    for lm in ("sofa", "other"):
+        for t in list(cu.multiple_templates) + ["{}"]:
+            v = rng.standard_normal(D).astype(np.float32)
+            table[t.format(lm)] = v / np.linalg.norm(v)
+
+    def fake_text_feats(in_text, clip_model, clip_feat_dim, batch_size=64):
+        return np.stack([table[t] for t in in_text]).astype(np.float32)
+
+    cu.get_text_feats = fake_text_feats
+    m["vlmap"].get_lseg_score = cu.get_lseg_score
+    out = {"feat_seed": 0, "feat_shape": np.array(feat.shape), "feat_crc_rows": feat[::997].sum(axis=1)}
+    tf = np.stack([np.stack([table[t.format(lm)] for t in cu.multiple_templates]) for lm in ("sofa", "other")])
+    out["template_feats"] = tf.astype(np.float32)
+    out["mean_feats"] = np.mean(tf.astype(np.float32), axis=1)
+    out["scores"] = cu.get_lseg_score(None, ["sofa"], feat, D, use_multiple_templates=True, add_other=True)
+    out["single_feats"] = np.stack([table["sofa"], table["other"]]).astype(np.float32)
+    out["single_scores"] = cu.get_lseg_score(None, ["sofa"], feat, D, use_multiple_templates=False, add_other=True)
+    cfg = make_map_config(1000, 0.05, 1.5, [540, 0, 540, 0, 540, 360, 0, 0, 1], 100)
+    vm = VLMap(cfg)
+    vm.grid_feat, vm.clip_model, vm.clip_feat_dim = feat, None, D
+    out["index_map_mask"] = vm.index_map("sofa", with_init_cat=False)
+    assert out["scores"].shape == (50_000, 2) and out["scores"].dtype == np.float32
+    np.savez_compressed(OUT / "g9_config1.npz", **out)
+    print("G9 written", out["scores"].shape, "mask true", int(out["index_map_mask"].sum()))
 
 
 def gen_templates_hash(m):
