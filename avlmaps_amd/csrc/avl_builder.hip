@@ -620,8 +620,10 @@ __global__ __launch_bounds__(256) void finalize_kernel(int64_t n, int D, int gs,
             if (occupied) occupied[cl] = (int32_t)(row0 + r);
         }
         if (grid_rgb && lane < 3) {
-            // running mean stored into a uint8 array (truncating cast); we truncate the exact weighted mean
-            double m = sum_w4[sl * ld_w4 + 1 + lane] / w;
+            // running mean stored into a uint8 array (truncating cast); we truncate the exact weighted mean.  (sum alpha c) / (sum
+            // alpha) of samples that all have the colour c is c or c - 1 ulp: the 1e-9 keeps that from truncating to c - 1 (a voxel
+            // touched once stores its pixel's colour exactly, vlmap_builder.py:167)
+            double m = sum_w4[sl * ld_w4 + 1 + lane] / w + 1e-9;
             m = fmin(fmax(m, 0.0), 255.0);
             grid_rgb[r * 3 + lane] = (uint8_t)m;
         }
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(256) void finalize_side_kernel(int64_t n, int gs, i
         if (occupied) occupied[cl] = (int32_t)(row0 + r);
         if (grid_rgb)
             for (int k = 0; k < 3; ++k) {
-                double m = w4[r * 4 + 1 + k] / w;
+                double m = w4[r * 4 + 1 + k] / w + 1e-9;   // as finalize_kernel
                 m = fmin(fmax(m, 0.0), 255.0);
                 grid_rgb[r * 3 + k] = (uint8_t)m;
             }

@@ -747,10 +747,31 @@ class VLMapBuilder:
         writer = getattr(self, "_map_writer", None)
         lean_ok = (self.incremental_checkpoints and h5lite.available() and writer is not None and writer.n_saved is not None
                    and writer.mirror is not None and writer.path == Path(self.map_save_path) and writer.path.exists())
+        import time
+        t0 = time.perf_counter()
+        log = self.build_times.setdefault("checkpoint_log", []) if hasattr(self, "build_times") else []
         if not lean_ok:
+            if background and self.prefetch_frames:
+                # the first (full) checkpoint of a build: finalise on the device (ms) and let the WRITER thread bring the map to the
+                # host -- a fresh multi-hundred-MB host array is bound by its first-touch page faults (0.1-0.3 s per GB), and on a
+                # cold process the HDF5 library, the writer and the staging buffers are created here too: none of it on the
+                # fusing thread (0.95 s of a 1.35 s build on the driver's box)
+                from .. import _lib
+                dev_arrays = acc.finalize(as_numpy=False, want_dirty=self.incremental_checkpoints)
+                dev = _lib.current_device()
+
+                def to_host():
+                    if dev is not None:
+                        _lib.set_device(dev)
+                    return {k: (v.numpy() if v is not None else None) for k, v in dev_arrays.items()}
+                self._save_3d_map(to_host, mapped_iter_set, background=True)
+                log.append(("full, host copy on the writer thread", time.perf_counter() - t0))
+                return
             self._save_3d_map(acc.finalize(want_dirty=self.incremental_checkpoints), mapped_iter_set, background=background)
+            log.append(("full", time.perf_counter() - t0))
             return
         lean = acc.finalize_rows(writer.n_saved)
+        log.append(("changed rows", time.perf_counter() - t0))
         iters = list(mapped_iter_set)
 
         def write():
