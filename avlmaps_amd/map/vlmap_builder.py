@@ -179,6 +179,19 @@ class VLMapBuilder:
                   "that this seeded run samples the reference's pixels; pixel_sampling='uniform' or shard_sampling='independent' "
                   "start at once (same distribution, other pixels)", flush=True)
 
+    def _resolve_pixel_sampling(self) -> None:
+        """pixel_sampling = "auto" (the default) becomes "reference" in a single process -- the pixels of a seeded upstream run,
+        vlmap_builder.py:275-277 -- and "uniform" with several ranks, where the reference's one serial random stream would make
+        the last rank fast-forward past every other rank's frames before its first one."""
+        if self.pixel_sampling != "auto":
+            return
+        rank, ws = _dist_rank_ws()
+        self.pixel_sampling = "uniform" if ws > 1 else "reference"
+        if ws > 1 and rank == 0:
+            print(f"[avlmaps_amd] {ws} ranks: pixel_sampling defaults to 'uniform' (per-frame generators seeded by one draw of the "
+                  "global NumPy RNG: reproducible, independent of the sharding, no serial RNG fast-forward); set "
+                  "pixel_sampling='reference' for the pixels a seeded single-process / upstream run samples", flush=True)
+
     def _draw_samples(self, frame_i: int, n_pix: int, depth_sample_rate: int) -> np.ndarray:
         if self.pixel_sampling == "reference":
             return self.sample_pixels(n_pix, depth_sample_rate)
@@ -228,6 +241,7 @@ class VLMapBuilder:
             waits for.  staged is None otherwise (the arrays are copied synchronously by the fusing thread, as before).
         Pillow, np.load, the shuffle (host C) and large NumPy copies release the GIL."""
         n = int(self.prefetch_frames or 0)
+        self._resolve_pixel_sampling()
         if self.pixel_sampling not in ("reference", "uniform"):
             raise ValueError(f"pixel_sampling must be 'reference' or 'uniform', not {self.pixel_sampling!r}")
         if self.pixel_sampling == "uniform":
@@ -409,12 +423,7 @@ class VLMapBuilder:
 
         self._init_lseg()
         rank, ws = _dist_rank_ws()
-        if self.pixel_sampling == "auto":
-            self.pixel_sampling = "uniform" if ws > 1 else "reference"
-            if ws > 1 and rank == 0:
-                print(f"[avlmaps_amd] {ws} ranks: pixel_sampling defaults to 'uniform' (per-frame generators seeded by one draw of the "
-                      "global NumPy RNG: reproducible, independent of the sharding, no serial RNG fast-forward); set "
-                      "pixel_sampling='reference' for the pixels a seeded single-process / upstream run samples", flush=True)
+        self._resolve_pixel_sampling()
         n_frames = min(len(self.rgb_paths), len(self.depth_paths), len(self.base_poses))
         lo, hi = parallel.shard_frames(n_frames, rank, ws)
 
