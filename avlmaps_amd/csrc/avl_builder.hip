@@ -331,12 +331,17 @@ __global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, cons
 // The owner sample s0 is the wave's own index and the TAIL of the LIFO list, so its record is fetched (scalar loads, the
 // index is wave-uniform) together with the owner flag, and its feature row, the list head and the accumulator row go out in
 // the next round trip; the rest of the list (1.3 samples per group on average) is walked from the head down to s0.
-template <int CH>
-__device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
-                                          int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
-                                          double* __restrict__ sum_feat, double* __restrict__ sum_w4,
-                                          float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                          unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+// FULL: D == 256 CH exactly (D = 512 at CH = 2, the LSeg width): every row access is an unconditional 16-byte vector access.
+// With a run-time width the per-lane "does my piece of the row exist" tests are branches around the loads, and the compiler's
+// s_waitcnt bookkeeping falls back to vmcnt(0) where they merge: the accumulator row, the owner's feature row and every
+// member's row then arrive one after the other instead of together.
+template <int CH, bool FULL>
+__device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                               int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
+                                               double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                               float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                               unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+    const int D = FULL ? 256 * CH : D_rt;
     const int lane = threadIdx.x & 63;
     const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
     if (s0 >= P) return;
@@ -366,7 +371,7 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int d = c * 256 + lane * 4;
-            if (d + 3 < D && (D & 1) == 0) {   // 16-byte aligned rows
+            if (FULL || (d + 3 < D && (D & 1) == 0)) {   // 16-byte aligned rows
                 const double2 q0 = *reinterpret_cast<const double2*>(sf + d), q1 = *reinterpret_cast<const double2*>(sf + d + 2);
                 old[c][0] = q0.x; old[c][1] = q0.y; old[c][2] = q1.x; old[c][3] = q1.y;
             } else {
@@ -375,11 +380,24 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
                     if (d + e < D) old[c][e] = sf[d + e];
             }
         }
-        if (lane < 4) w4_old = sum_w4[(size_t)slot * 4 + lane];
     }
+    if (lane < 4) w4_old = is_new ? 0.0 : sum_w4[(size_t)slot * 4 + lane];
 
-    auto add = [&](int cur, double alpha, int32_t fpix, uint32_t rgbv) {
-        const float* f = (batch ? batch[cur / P_frame].feat : feat) + (size_t)fpix * D;
+    auto row_of = [&](int cur, int32_t fpix) { return (batch ? batch[cur / P_frame].feat : feat) + (size_t)fpix * D; };
+    auto load_row = [&](float (&v)[CH][4], const float* f) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int d = c * 256 + lane * 4;
+            if (FULL || (d + 3 < D && (D & 3) == 0)) {
+                const float4 q = *reinterpret_cast<const float4*>(f + d);
+                v[c][0] = q.x; v[c][1] = q.y; v[c][2] = q.z; v[c][3] = q.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[c][e] = d + e < D ? f[d + e] : 0.f;
+            }
+        }
+    };
+    auto add = [&](int cur, double alpha, uint32_t rgbv, const float (&v)[CH][4]) {
         // The first-touch sample of a voxel BORN in this launch is kept OUT of the sum: sum_feat = sum over all OTHER samples of
         // alpha f, and the finalisation adds a1^2 f1 (the reference stores feat * alpha with weight alpha for a new voxel and
         // treats it as a mean afterwards, vlmap_builder.py:166-174).  The earlier form sum(alpha f) - a1 (1 - a1) f1 cancels
@@ -393,36 +411,22 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
         if (first) { min_s = cur; a1 = alpha; }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int d = c * 256 + lane * 4;
-            if (d < D) {
-                float v[4];
-                if (d + 3 < D && (D & 3) == 0) {
-                    const float4 q = *reinterpret_cast<const float4*>(f + d);
-                    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = d + e < D ? f[d + e] : 0.f;
-                }
+            if (FULL || c * 256 + lane * 4 < D) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (rejoin) acc[c][e] += a_prev * (double)f1[c][e];
-                    if (!hold) acc[c][e] += alpha * (double)v[e];
-                    if (first) f1[c][e] = v[e];
+                    if (!hold) acc[c][e] += alpha * (double)v[c][e];
+                    if (first) f1[c][e] = v[c][e];
                 }
             }
         }
         if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
     };
-#ifdef AVL_ABL_K3_LIST_ORDER   // ablation: sum the members in list (= atomic arrival) order, as before round 2
-    add(s0, alpha0, fpix0, rgb0);
-    for (int cur = h0, steps = 0; cur != s0 && (unsigned)cur < (unsigned)P && steps < P; ++steps) {
-        const int nxt = recs.next[cur];
-        add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
-        cur = nxt;
-    }
-#else
+    const float* feat0 = row_of(s0, fpix0);
     if (h0 == s0) {
-        add(s0, alpha0, fpix0, rgb0);   // one sample for this voxel in this launch: 70 % of the groups of a single frame
+        float v[CH][4];
+        load_row(v, feat0);
+        add(s0, alpha0, rgb0, v);   // one sample for this voxel in this launch: 70 % of the groups of a single frame
     } else {
         // Several samples: sum them in ASCENDING SAMPLE ORDER (the reference's order), not in the order in which their atomics
         // happened to arrive -- fp64 addition is not associative, and with the arrival order two runs of the same build could
@@ -449,37 +453,65 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(my, j) < my ? 1 : 0;
         const int a_lo = __double2loint(a_l), a_hi = __double2hiint(a_l);
-        for (int k = 0; k < n; ++k) {
-            const unsigned long long m = __ballot(lane < n && rank == k);
-            const int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-            const double al = __hiloint2double(__builtin_amdgcn_readlane(a_hi, l), __builtin_amdgcn_readlane(a_lo, l));
-            add(__builtin_amdgcn_readlane(my, l), al, __builtin_amdgcn_readlane(fp_l, l), (uint32_t)__builtin_amdgcn_readlane((int)rgb_l, l));
+        // The rows of MR members (ranks k0 .. k0 + MR - 1) are requested TOGETHER, and unconditionally: until round 5 every member's
+        // row was loaded inside its add -- one HBM round trip (1.3-1.7 us) per member -- and a load inside a branch would not do
+        // either: the compiler's s_waitcnt bookkeeping falls back to vmcnt(0) where the branches merge.  Ranks beyond the group
+        // re-read the owner's row (a cache hit) and are not added.  Two at a time: 73 % of the multi-sample groups of a frame are
+        // pairs, and four in flight cost 16 more registers and 5-9 % in 16- / 64-frame launches, where most groups are large
+        // (profiles/r05_ab_builder_k3.txt).
+#ifndef AVL_K3_MR
+#define AVL_K3_MR 2
+#endif
+        constexpr int MR = CH <= 4 ? AVL_K3_MR : 1;
+        for (int k0 = 0; k0 < n; k0 += MR) {
+            float v[MR][CH][4];
+            int cj[MR], lj[MR];
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                const unsigned long long m = __ballot(lane < n && rank == k0 + j);
+                lj[j] = m ? __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1) : 0;
+                cj[j] = m ? __builtin_amdgcn_readlane(my, lj[j]) : -1;
+                load_row(v[j], cj[j] >= 0 ? row_of(cj[j], __builtin_amdgcn_readlane(fp_l, lj[j])) : feat0);
+            }
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
+                if (cj[j] >= 0) {
+                    const double al = __hiloint2double(__builtin_amdgcn_readlane(a_hi, lj[j]), __builtin_amdgcn_readlane(a_lo, lj[j]));
+                    add(cj[j], al, (uint32_t)__builtin_amdgcn_readlane((int)rgb_l, lj[j]), v[j]);
+                }
+            }
         }
         for (int steps = 0; cur != s0 && (unsigned)cur < (unsigned)P && steps < P; ++steps) {   // members beyond the 64th
             const int nxt = recs.next[cur];
-            add(cur, recs.alpha[cur], recs.fpix[cur], recs.rgb[cur]);
+            float v[CH][4];
+            load_row(v, row_of(cur, recs.fpix[cur]));
+            add(cur, recs.alpha[cur], recs.rgb[cur], v);
             cur = nxt;
         }
     }
-#endif
 
+    float* ff = first_feat + (size_t)slot * D;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         const int d = c * 256 + lane * 4;
+        double r[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (d + e < D) sf[d + e] = is_new ? acc[c][e] : old[c][e] + acc[c][e];
-    }
-    if (lane < 4) sum_w4[(size_t)slot * 4 + lane] = is_new ? w4 : w4_old + w4;
-    if (is_new) {
-        float* ff = first_feat + (size_t)slot * D;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int d = c * 256 + lane * 4;
+        for (int e = 0; e < 4; ++e) r[e] = is_new ? acc[c][e] : old[c][e] + acc[c][e];
+        if constexpr (FULL) {
+            *reinterpret_cast<double2*>(sf + d) = double2{r[0], r[1]};
+            *reinterpret_cast<double2*>(sf + d + 2) = double2{r[2], r[3]};
+            if (is_new) *reinterpret_cast<float4*>(ff + d) = float4{f1[c][0], f1[c][1], f1[c][2], f1[c][3]};
+        } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (d + e < D) ff[d + e] = f1[c][e];
+                if (d + e < D) {
+                    sf[d + e] = r[e];
+                    if (is_new) ff[d + e] = f1[c][e];
+                }
         }
+    }
+    if (lane < 4) sum_w4[(size_t)slot * 4 + lane] = w4_old + w4;
+    if (is_new) {
         if (lane == 0) {
             first_alpha[slot] = a1;
             slot_key[slot] = batch ? (batch[min_s / P_frame].frame_key | (unsigned)(min_s % P_frame)) : (frame_key | (unsigned)min_s);
@@ -489,6 +521,18 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
         head[slot] = -1;  // ready for the next launch
         dirty[slot] = 1;  // changed since the last checkpoint (avl_builder_finalize_ex)
     }
+}
+
+template <int CH>
+__device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                          int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
+                                          double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                          float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                          unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+    if (D == 256 * CH)
+        fuse_body_impl<CH, true>(blk, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty);
+    else
+        fuse_body_impl<CH, false>(blk, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty);
 }
 
 template <int CH>
