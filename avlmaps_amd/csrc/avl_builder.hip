@@ -149,6 +149,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         ok = (pl2 > fp.min_depth) && (pl2 < fp.max_depth);  // strict on both sides, NaN fails
     }
     long long row = 0, col = 0, h = 0;
+    size_t rgb_off = 0;
     if (ok) {
         // transform_pc: pose @ [pc; 1]  (dgemm FMA chain k = 0..3)
         const double g0 = fma(T[3], 1.0, fma(T[2], pl2, fma(T[1], pl1, T[0] * pl0)));
@@ -180,8 +181,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
             atomicOr(err_flags, 2);  // the reference raises IndexError here; we drop the point and flag it
             ok = false;
         } else {
-            const uint8_t* c = rgb + ((size_t)py * fp.W + px) * 3;
-            rgbv = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
+            rgb_off = ((size_t)py * fp.W + px) * 3;
         }
         // project_point(get_sim_cam_mat(Hf, Wf), p_local) -> feature pixel, bounds-checked (vlmap_builder.py:161)
         q0 = gemv3(fp.kf + 0, pl0, pl1, pl2);
@@ -202,10 +202,16 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     // cell states only move forward (empty -> pending -> slot), so a slot read here is final even if the line is old
     int32_t known = -1;
     bool creator = false;
+    // The colour gather and the cell's slot are requested TOGETHER, in straight-line code (a sample that dropped out reads
+    // element 0 of both): inside the `ok` branches the three colour bytes had to arrive before the cell_slot load was issued --
+    // one round trip of this kernel's dependent chain for a value that is only stored at the end.
+    const uint8_t* c = ok ? rgb + rgb_off : reinterpret_cast<const uint8_t*>(cell_slot);   // (batched launches carry no frame-level rgb pointer)
+    const uint8_t c0 = c[0], c1 = c[1], c2 = c[2];
+    const int32_t seen = cell_slot[ok ? cell : 0];
     if (ok) {
-        const int32_t seen = cell_slot[cell];
         if (seen == kEmpty) creator = atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
         else if (seen >= 0) known = seen;
+        rgbv = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
     }
     const unsigned long long cmask = __ballot(creator);
     const int lane = threadIdx.x & 63;
