@@ -1844,6 +1844,64 @@ int avl_builder_export_raw(avl_builder* b, int64_t n, int32_t* d_cell, uint64_t*
     return AVL_OK;
 }
 
+// values of the sort below: 0, 1, 2, ...
+__global__ void iota64_kernel(int64_t* __restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v[i] = i;
+}
+
+}  // extern "C"
+
+template <typename K>
+static hipError_t argsort_bits_impl(void* tmp, size_t& tmp_bytes, const void* keys, void* keys_out, const int64_t* iota, int64_t* perm,
+                                    int64_t n, int bits, hipStream_t st) {
+    // LSD radix sort over the low `bits` bits only (the keys are non-negative and smaller than 2^bits): stable
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, reinterpret_cast<const K*>(keys), reinterpret_cast<K*>(keys_out), iota, perm,
+                                     (size_t)n, 0, bits, st);
+}
+
+static size_t argsort_align(size_t b) { return (b + 255) / 256 * 256; }
+
+extern "C" {
+
+int avl_argsort_bits_work_bytes(int64_t n, int key_bytes, int bits, size_t* h_bytes) {
+    AVL_REQUIRE(h_bytes && n >= 0 && n < (1ll << 31) && (key_bytes == 4 || key_bytes == 8) && bits >= 1 && bits <= 8 * key_bytes - 1,
+                "avl_argsort_bits_work_bytes: bad arguments");
+    size_t tmp_bytes = 0;
+    const hipError_t e = key_bytes == 8 ? argsort_bits_impl<uint64_t>(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, n ? n : 1, bits, nullptr)
+                                        : argsort_bits_impl<uint32_t>(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, n ? n : 1, bits, nullptr);
+    AVL_HIP_CHECK(e);
+    // [values 0..n-1 | sorted keys | rocPRIM's own storage (its size depends on the bit range: rocPRIM picks the passes by it)]
+    *h_bytes = argsort_align((size_t)n * 8) + argsort_align((size_t)n * key_bytes) + argsort_align(tmp_bytes) + 256;
+    return AVL_OK;
+}
+
+int avl_argsort_bits(int64_t n, const void* d_keys, int key_bytes, int bits, int64_t* d_perm, void* d_work, size_t work_bytes,
+                     void* stream) {
+    AVL_REQUIRE(n >= 0 && n < (1ll << 31), "avl_argsort_bits: bad n");
+    AVL_REQUIRE(key_bytes == 4 || key_bytes == 8, "avl_argsort_bits: keys are int32 or int64");
+    AVL_REQUIRE(bits >= 1 && bits <= 8 * key_bytes - 1, "avl_argsort_bits: bits must be in [1, %d]", 8 * key_bytes - 1);
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_keys && d_perm && d_work, "avl_argsort_bits: null pointer");
+    size_t need = 0;
+    int rc = avl_argsort_bits_work_bytes(n, key_bytes, bits, &need);
+    if (rc != AVL_OK) return rc;
+    AVL_REQUIRE(work_bytes >= need, "avl_argsort_bits: work buffer of %zu bytes, %zu needed (avl_argsort_bits_work_bytes)", work_bytes, need);
+    hipStream_t st = as_stream(stream);
+    char* w = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(d_work) + 255) / 256 * 256);
+    int64_t* iota = reinterpret_cast<int64_t*>(w);
+    void* keys_out = w + argsort_align((size_t)n * 8);
+    void* tmp = reinterpret_cast<char*>(keys_out) + argsort_align((size_t)n * key_bytes);
+    size_t tmp_bytes = need - 256 - argsort_align((size_t)n * 8) - argsort_align((size_t)n * key_bytes);
+    hipLaunchKernelGGL(iota64_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, iota, n);
+    const hipError_t e = key_bytes == 8 ? argsort_bits_impl<uint64_t>(tmp, tmp_bytes, d_keys, keys_out, iota, d_perm, n, bits, st)
+                                        : argsort_bits_impl<uint32_t>(tmp, tmp_bytes, d_keys, keys_out, iota, d_perm, n, bits, st);
+    if (e != hipSuccess) {
+        set_error("avl_argsort_bits: %s", hipGetErrorString(e));
+        return AVL_ERR_HIP;
+    }
+    return AVL_OK;
+}
+
 int avl_points_bbox(const void* d_depth, int depth_is_u16, double depth_div, int H, int W, const double* h_calib_inv,
                     const double* h_transform, const int32_t* d_sample_idx, int P, double min_depth, double max_depth,
                     double* h_minmax, void* stream) {

@@ -340,7 +340,7 @@ class ShardExchange:
         ws, M = plan.ws, plan.M
         self.per = max(1, (M + ws - 1) // ws)
         self.r0, self.r1 = shard_rows(M, plan.rank, ws)
-        self.order = torch.argsort(rows)                            # local slots in final-row order
+        self.order = _argsort_bits(rows, max(1, int(M).bit_length()))   # local slots in final-row order (rows are distinct)
         self.rows_sorted = rows[self.order].contiguous()
         self.send_pos = torch.empty_like(self.order)
         self.send_pos[self.order] = torch.arange(rows.shape[0], device=dev)
@@ -523,6 +523,52 @@ def _merge_accumulator_sharded_general(acc, group=None, exact_rgb: bool = True, 
 U64_ALL_ONES = (1 << 64) - 1
 
 
+def _mask_idx(mask, size):
+    """Indices of the set elements of a boolean vector whose COUNT the host already knows (it rode on one of the plan's tiny
+    all_gathers): torch.nonzero / boolean-mask indexing would read that count back from the device -- a host synchronisation
+    per mask, a dozen per merge plan, each ~80-150 us (profiles/r05_merge_plan_ops.txt)"""
+    import torch
+    return torch.nonzero_static(mask, size=int(size)).reshape(-1)
+
+
+def _argsort_bits(t, bits: int):
+    """torch.argsort(t, stable=True) of non-negative integers below 2^bits.  On the GPU: the library's radix sort over just those
+    bits (avl_argsort_bits) -- torch sorts every int64 vector with all 64 bits, eight passes where the merge plan's 3-bit
+    destination ranks need one and its row numbers three."""
+    import torch
+    n = int(t.numel())
+    if not t.is_cuda or n < 8192 or t.dtype not in (torch.int64, torch.int32):
+        return torch.argsort(t, stable=True)
+    from . import _lib
+    from .device import torch_stream_ptr
+    import ctypes as C
+    lib = _lib.load()
+    t = t.contiguous()
+    perm = torch.empty(n, dtype=torch.int64, device=t.device)
+    nb = C.c_size_t()
+    bits = int(min(max(bits, 1), 8 * t.element_size() - 1))
+    _lib.check(lib.avl_argsort_bits_work_bytes(n, t.element_size(), bits, C.byref(nb)), "avl_argsort_bits_work_bytes")
+    work = torch.empty(int(nb.value), dtype=torch.uint8, device=t.device)      # torch's caching allocator: no hipMalloc per sort
+    _lib.check(lib.avl_argsort_bits(n, t.data_ptr(), t.element_size(), bits, perm.data_ptr(), work.data_ptr(), int(nb.value),
+                                    torch_stream_ptr()), "avl_argsort_bits")
+    return perm
+
+
+def _group_counts(sorted_ids, k: int, masks=()):
+    """Histogram of a SORTED vector of group ids in [0, k) -- and, per boolean mask, how many of each group's elements have it
+    set -- from the groups' boundaries (one searchsorted, a running sum per mask).  torch.bincount reads the largest value back
+    to size its result: a host synchronisation per histogram; scatter_add would be millions of atomics on a handful of words."""
+    import torch
+    i64 = torch.int64
+    dev = sorted_ids.device
+    edges = torch.searchsorted(sorted_ids, torch.arange(k + 1, dtype=sorted_ids.dtype, device=dev))
+    out = [edges[1:] - edges[:-1]]
+    for m in masks:
+        run = torch.cat([torch.zeros(1, dtype=i64, device=dev), torch.cumsum(m.to(i64), 0)])
+        out.append(run[edges[1:]] - run[edges[:-1]])
+    return out
+
+
 def _dir_owner(cell64, ws: int):
     """directory rank of a linear cell: a multiplicative hash, so a map that occupies one corner of the grid still spreads evenly"""
     return (((cell64 * 2654435761) & 0xFFFFFFFF) >> 12) % ws
@@ -611,17 +657,19 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     tr('to i64')
     dest = _dir_owner(cell64, ws)
     tr('hash')
-    ordd = torch.argsort(dest, stable=True)                       # local slots grouped by directory rank
+    ordd = _argsort_bits(dest, max(1, (ws - 1).bit_length()))     # local slots grouped by directory rank (stable)
     tr('argsort')
     dest_o = dest[ordd]
-    sc = torch.bincount(dest, minlength=ws)[:ws]
+    sc, = _group_counts(dest_o, ws)
     tr('bincount')
     kmin = key.min().reshape(1) if n else torch.full((1,), I64_MAX, dtype=i64, device=dev)
     kmax = key.max().reshape(1) if n else torch.full((1,), -1, dtype=i64, device=dev)
     tr('minmax')
-    head = torch.cat([sc, torch.tensor([n], dtype=i64, device=dev), kmin, kmax, torch.tensor([int(a) for a in aux], dtype=i64, device=dev)])
+    hv = torch.tensor([n] + [int(a) for a in aux], dtype=i64).to(dev)          # one small upload
+    head = torch.cat([sc, hv[:1], kmin, kmax, hv[1:]])
     tr('hash+sort+head')
-    allh = torch.stack(gather(head)).cpu()
+    allh_d = torch.stack(gather(head))
+    allh = allh_d.cpu()
     tr('gather head')
     plan.aux_all = allh[:, ws + 3:].numpy()
     last = -1
@@ -640,7 +688,9 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     R = int(recv.shape[0])
     plan.dir_entries = R
     tr('a2a cells')
-    src = torch.repeat_interleave(torch.arange(ws, dtype=i64, device=dev), torch.tensor(rc_l, dtype=i64, device=dev))
+    # source rank of every arrival (arrivals are grouped by source): a search in the running sum of the counts, which are on the
+    # device already (repeat_interleave with a host-side count list cost 0.9 ms of a 4 ms plan at 2.25 M entries)
+    src = torch.bucketize(torch.arange(R, dtype=i64, device=dev), torch.cumsum(allh_d[:, rank], 0), right=True)
     perm = torch.argsort(recv, stable=True)                      # arrival order is by source rank: stable = (cell, rank) order
     cs, ss = recv[perm], src[perm]
     first = torch.ones(R, dtype=torch.bool, device=dev)
@@ -662,17 +712,16 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     nxt[ordd] = (back >> 16) - 1
     # 2. new voxels in key order; row bases
     is_new = prev < 0
-    idx_new = torch.nonzero(is_new).reshape(-1)
-    idx_new = idx_new[torch.argsort(key[idx_new])]
-    c = int(idx_new.shape[0])
-    # the counts of the two directory round trips below ride on the same tiny all_gather
+    # The size of EVERY data-dependent list below -- my new voxels, the directory's distinct cells, the four lists of the two
+    # directory round trips -- rides on one tiny all_gather, so that no boolean mask is ever counted on the host (_mask_idx).
+    # The per-rank list sizes come from the group boundaries of the (sorted) rank vectors (_group_counts), not from histograms.
     m3 = (is_new & (nxt >= 0))[ordd]                             # my new voxels that others share, in sending order
     m4 = (~is_new)[ordd]                                         # my voxels whose row somebody else assigns
     m3r = (prev_r < 0) & (next_r >= 0)
     m4r = prev_r >= 0
-    cnt = torch.cat([torch.tensor([c], dtype=i64, device=dev), torch.bincount(dest_o[m3], minlength=ws)[:ws],
-                     torch.bincount(src[m3r], minlength=ws)[:ws], torch.bincount(src[m4r], minlength=ws)[:ws],
-                     torch.bincount(dest_o[m4], minlength=ws)[:ws]])
+    _, n3, n4 = _group_counts(dest_o, ws, (m3, m4))              # my entries are grouped by directory rank,
+    _, n3r, n4r = _group_counts(src, ws, (m3r, m4r))             # the directory's arrivals by source rank
+    cnt = torch.cat([is_new.sum().reshape(1), first.sum().reshape(1), n3, n3r, n4r, n4]).to(i64)
     tr('new voxels + counts')
     allc = torch.stack(gather(cnt)).cpu()
     tr('gather counts')
@@ -681,21 +730,25 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     for r in range(1, ws):
         bases[r] = bases[r - 1] + counts[r - 1]
     plan.M, plan.bases, plan.counts = int(sum(counts)), bases, counts
-    s3, r3, s4, r4 = (allc[rank, 1 + k * ws:1 + (k + 1) * ws].tolist() for k in range(4))
+    n_first = int(allc[rank, 1])
+    s3, r3, s4, r4 = (allc[rank, 2 + k * ws:2 + (k + 1) * ws].tolist() for k in range(4))
+    c = int(counts[rank])
+    idx_new = _mask_idx(is_new, c)
+    idx_new = idx_new[torch.argsort(key[idx_new])]
     row = torch.full((n,), -1, dtype=i64, device=dev)
     row[idx_new] = bases[rank] + torch.arange(c, dtype=i64, device=dev)
     # 3. rows of shared voxels: first contributor -> directory -> the other contributors
-    recv3 = a2a(row[ordd][m3].contiguous(), s3, r3)
+    recv3 = a2a(row[ordd[_mask_idx(m3, sum(s3))]].contiguous(), s3, r3)
     tr('a2a first rows')
     rowfirst_r = torch.full((R,), -1, dtype=i64, device=dev)
-    rowfirst_r[m3r] = recv3                                      # both sides keep the order of the first all_to_all
+    rowfirst_r[_mask_idx(m3r, sum(r3))] = recv3                  # both sides keep the order of the first all_to_all
     seg = torch.cumsum(first.to(i64), 0) - 1
-    row_s = rowfirst_r[perm][first][seg] if R else rowfirst_r
+    row_s = rowfirst_r[perm[_mask_idx(first, n_first)]][seg] if R else rowfirst_r
     row_r = torch.empty(R, dtype=i64, device=dev)
     row_r[perm] = row_s
     tr('propagate')
-    recv4 = a2a(row_r[m4r].contiguous(), s4, r4)
-    row[ordd[m4]] = recv4
+    recv4 = a2a(row_r[_mask_idx(m4r, sum(s4))].contiguous(), s4, r4)
+    row[ordd[_mask_idx(m4, sum(r4))]] = recv4
     tr('a2a other rows')
     plan.row_of_slot, plan.is_new, plan.prev, plan.next = row, is_new, prev, nxt
     # the key after which the reference's arrays have their post-growth dtypes (vlmap_builder.py:286-311)
@@ -818,13 +871,13 @@ class MixedExchange:
         ws, M = plan.ws, plan.M
         self.per = max(1, (M + ws - 1) // ws)
         self.r0, self.r1 = shard_rows(M, plan.rank, ws)
-        self.order = torch.argsort(rows)
+        self.order = _argsort_bits(rows, max(1, int(M).bit_length()))   # rows are distinct: any sort is the stable one
         self.rows_sorted = rows[self.order].contiguous()
         single = (plan.prev < 0) & (plan.next < 0)
         self.single_sorted = single[self.order]
         dest = torch.clamp(self.rows_sorted // self.per, max=ws - 1)
-        cnt = torch.stack([torch.bincount(dest, minlength=ws)[:ws], torch.bincount(dest[self.single_sorted], minlength=ws)[:ws],
-                           torch.bincount(dest[~self.single_sorted], minlength=ws)[:ws]]).to(i64)
+        n_all, n_single = _group_counts(dest, ws, (self.single_sorted,))      # rows are sorted, so their destinations are
+        cnt = torch.stack([n_all, n_single, n_all - n_single]).to(i64)
         if plan.coll is not None:
             allc = torch.stack(plan.coll.all_gather(cnt)).cpu()                         # (ws, 3, ws): [sender, list, receiver]
             recv = allc[:, :, plan.rank]
@@ -860,11 +913,14 @@ def _fold_mixed(plan, ex, D, side, done, part, rows_add):
         o += c
     st = side[:, 5:8]
     fin = (st[:, 2] >> 32) != 0                     # `started` of the 24-byte state: only a voxel's LAST contributor sends it
-    state = torch.zeros((max(n_own, 1), 3), dtype=i64, device=dev)
-    state[rows[fin]] = st[fin]
+    # (no boolean-mask indexing here: every mask would be counted on the host.  States that are not final land in one spare row)
+    state = torch.zeros((max(n_own, 1) + 1, 3), dtype=i64, device=dev)
+    state[torch.where(fin, rows, torch.full_like(rows, max(n_own, 1)))] = st
+    state = state[:max(n_own, 1)]
     # rows of the two feature lists: the side list of a peer is in final-row order, and so are its done / part sublists
     single_flag = (word >> 63) != 0                 # bit 63 of the word: the voxel travelled as a finished row
-    done_rows, part_rows_all = rows[single_flag], rows[~single_flag]
+    done_rows = rows[_mask_idx(single_flag, sum(ex.recv_done))]
+    part_rows_all = rows[_mask_idx(~single_flag, sum(ex.recv_part))]
     part_rows, inv = (torch.unique(part_rows_all, return_inverse=True) if part_rows_all.numel() else
                       (part_rows_all, part_rows_all))
     acc = torch.zeros((max(int(part_rows.shape[0]), 1), D), dtype=torch.float64, device=dev)
@@ -1037,13 +1093,14 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
     # ---- local rows -> the three send lists (final-row order = destination order)
     o32 = ex.order.to(torch.int32)
     single = ex.single_sorted
-    slots_done = o32[single].contiguous()
-    slots_part = o32[~single].contiguous()
-    n_done, n_part = int(slots_done.shape[0]), int(slots_part.shape[0])
+    n_done, n_part = int(sum(ex.send_done)), int(sum(ex.send_part))     # known on the host: no mask is counted there (_mask_idx)
+    i_part = _mask_idx(~single, n_part)
+    slots_done = o32[_mask_idx(single, n_done)].contiguous()
+    slots_part = o32[i_part].contiguous()
     done = torch.empty((max(n_done, 1), D), dtype=torch.float32, device=dev)
     part = torch.empty((max(n_part, 1), D), dtype=torch.float64, device=dev)
     _lib.check(lib.avl_builder_export_rows_f32(acc._h, n_done, slots_done.data_ptr(), done.data_ptr(), D, st), "avl_builder_export_rows_f32")
-    own_part = plan.is_new[ex.order][~single].to(torch.uint8).contiguous()
+    own_part = plan.is_new[ex.order[i_part]].to(torch.uint8).contiguous()
     _lib.check(lib.avl_builder_export_rows_f64(acc._h, n_part, slots_part.data_ptr(), own_part.data_ptr(), part.data_ptr(), D, st),
                "avl_builder_export_rows_f64")
     torch.cuda.synchronize()

@@ -75,6 +75,13 @@ AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* s
 /* dst row i = src row d_rows[i] (rows of row_bytes bytes, int64 indices): packs the rows an incremental checkpoint has to
  * write (the changed and the new voxels, avl_builder_finalize_ex's d_row_dirty) so that only they cross PCIe -- the reference
  * rewrites the whole map file every 100 frames (vlmap_builder.py:180-183). */
+/* Stable argsort of n NON-NEGATIVE integer keys smaller than 2^bits: d_perm[i] = position of the i-th smallest key, ties in
+ * position order (an LSD radix sort over the low `bits` bits only).  d_keys int32 or int64 (key_bytes 4 / 8), d_perm int64[n].
+ * The multi-GPU merge plan sorts 3-bit destination ranks and 22-bit row numbers held in int64 tensors (avlmaps_amd/parallel.py:
+ * the bookkeeping around vlmap_builder.py:163-170's voxel ids); a generic 64-bit sort makes eight passes where one or three do. */
+AVL_API int avl_argsort_bits_work_bytes(int64_t n, int key_bytes, int bits, size_t* h_bytes);
+AVL_API int avl_argsort_bits(int64_t n, const void* d_keys, int key_bytes, int bits, int64_t* d_perm, void* d_work, size_t work_bytes,
+                             void* stream);
 AVL_API int avl_gather_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, void* stream);
 /* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32.
  * pattern bit 0: 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk;

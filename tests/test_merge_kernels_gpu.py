@@ -151,3 +151,31 @@ def test_frame_stager_hands_over_exact_copies_and_follows_shape_changes(env):
     finally:
         st.close()
     assert lib.avl_stream_wait_event(None, None) != 0                 # a null event is an error, not a crash
+
+
+def test_argsort_bits_is_torchs_stable_argsort(env):
+    """avl_argsort_bits (the merge plan's narrow-key sorts, parallel._argsort_bits): the permutation of torch.argsort(stable=True)
+    for int64 and int32 keys, few and many bits, ties in position order; and the plan built with it equals the plan built with
+    torch's own sorts"""
+    import torch
+    from avlmaps_amd import parallel
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for dtype, bits, n in ((torch.int64, 3, 100_001), (torch.int64, 22, 300_000), (torch.int32, 25, 250_000), (torch.int64, 1, 50_000),
+                           (torch.int64, 40, 65_537)):
+        t = torch.randint(0, 1 << min(bits, 62), (n,), generator=g, dtype=torch.int64).to(dtype).cuda()
+        got = parallel._argsort_bits(t, bits)
+        want = torch.argsort(t, stable=True)
+        assert got.dtype == torch.int64 and torch.equal(got, want), (dtype, bits, n)
+    n = 200_000
+    cell = torch.randperm(4 * n, generator=g)[:n].to(torch.int32).cuda()
+    key = torch.randperm(n, generator=g).cuda()
+    a = parallel.plan_merge_directory(cell, key, local=True)
+    small = parallel._argsort_bits
+    try:
+        parallel._argsort_bits = lambda t, bits: torch.argsort(t, stable=True)
+        b = parallel.plan_merge_directory(cell, key, local=True)
+    finally:
+        parallel._argsort_bits = small
+    assert a.M == b.M == n and torch.equal(a.row_of_slot, b.row_of_slot) and torch.equal(a.prev, b.prev) and torch.equal(a.next, b.next)
+    assert torch.equal(torch.sort(a.row_of_slot).values, torch.arange(n, device="cuda"))
+    assert torch.equal(a.row_of_slot[torch.argsort(key)], torch.arange(n, device="cuda"))       # one rank: rows in key order
