@@ -690,6 +690,37 @@ int avl_gather_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows,
     return AVL_OK;
 }
 
+// dst row rows[i] = src row i (rows distinct and in [0, n_dst): an out-of-range row is skipped and raises the flag)
+__global__ __launch_bounds__(256) void scatter_rows16_kernel(const uint4* __restrict__ src, int64_t row_u4, const int64_t* __restrict__ rows,
+                                                             int64_t n, int64_t n_dst, uint4* __restrict__ dst, int* __restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < n; i += nwaves) {
+        const int64_t r = rows[i];
+        if (r < 0 || r >= n_dst) {
+            if (lane == 0 && err_flag) atomicOr(err_flag, 1);
+            continue;
+        }
+        const uint4* s = src + i * row_u4;
+        uint4* d = dst + r * row_u4;
+        for (int64_t k = lane; k < row_u4; k += 64) d[k] = s[k];
+    }
+}
+
+int avl_scatter_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, int64_t n_dst, int32_t* d_err_flag,
+                     void* stream) {
+    AVL_REQUIRE(row_bytes > 0 && row_bytes % 16 == 0 && n >= 0 && n_dst >= 0, "avl_scatter_rows: rows must be multiples of 16 bytes");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_src && d_rows && d_dst, "avl_scatter_rows: null pointer");
+    AVL_REQUIRE((reinterpret_cast<uintptr_t>(d_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0, "avl_scatter_rows: 16-byte aligned bases");
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > (int64_t)avl::num_cus() * 16) blocks = (int64_t)avl::num_cus() * 16;
+    hipLaunchKernelGGL(scatter_rows16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const uint4*>(d_src),
+                       row_bytes / 16, d_rows, n, n_dst, reinterpret_cast<uint4*>(d_dst), reinterpret_cast<int*>(d_err_flag));
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
 int avl_hbm_read_probe(const void* d_buf, int64_t rows, int row_floats, int pattern, int iters, float* h_best_gbs, void* stream) {
     AVL_REQUIRE(d_buf && rows > 0 && row_floats > 0 && iters > 0 && h_best_gbs, "avl_hbm_read_probe: bad arguments");
     AVL_REQUIRE(pattern >= 0 && pattern <= 15, "avl_hbm_read_probe: pattern must be 0..15");

@@ -1167,7 +1167,14 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
                grid_rgb=torch.empty((n_own, 3), dtype=torch.uint8, device=dev))
     tr3('alloc out')
     if n_own:
-        out["grid_feat"].index_copy_(0, done_rows, done_feat)
+        if D % 4 == 0 and done_rows.numel():
+            # the finished rows that arrived, to their final positions: one pass at the copy rate (torch's index_copy_ took 3.3 ms
+            # for the 4.6 GB of a 2.25 M-voxel map, this kernel 1.6)
+            df = done_feat.contiguous()
+            _lib.check(lib.avl_scatter_rows(df.data_ptr(), D * 4, done_rows.contiguous().data_ptr(), int(done_rows.shape[0]),
+                                            out["grid_feat"].data_ptr(), n_own, err_flag.data_ptr(), st), "avl_scatter_rows")
+        else:
+            out["grid_feat"].index_copy_(0, done_rows, done_feat)
         tr3('copy done rows')
         if part_rows.numel():
             out["grid_feat"].index_copy_(0, part_rows, (part_acc / w4[part_rows, :1]).float())

@@ -82,6 +82,11 @@ AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* s
 AVL_API int avl_argsort_bits_work_bytes(int64_t n, int key_bytes, int bits, size_t* h_bytes);
 AVL_API int avl_argsort_bits(int64_t n, const void* d_keys, int key_bytes, int bits, int64_t* d_perm, void* d_work, size_t work_bytes,
                              void* stream);
+/* The reverse: row d_rows[i] of d_dst (n_dst rows) = row i of d_src; rows distinct, 16-byte multiples at 16-byte aligned bases.
+ * A row index outside [0, n_dst) is skipped and sets bit 0 of *d_err_flag (nullable).  The owner side of the multi-GPU merge places
+ * the finished float32 rows it received at their final positions with it (avlmaps_amd/parallel.py). */
+AVL_API int avl_scatter_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, int64_t n_dst,
+                             int32_t* d_err_flag, void* stream);
 AVL_API int avl_gather_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, void* stream);
 /* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32.
  * pattern bit 0: 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk;
