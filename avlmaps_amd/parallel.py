@@ -614,12 +614,13 @@ class ShardPlan:
         prev / next (n,) int64  the neighbouring contributors of the voxel in rank order, -1 if none: the colour replay of a
                                 voxel runs prev -> this rank -> next; a voxel with prev == next == -1 belongs to this rank alone
         M, bases, counts        merged voxel count, and per rank the first row / the number of its new voxels
+        n_prev / n_next         per rank r: how many local voxels have prev == r / next == r (host lists: chain_replay's hop sizes)
         grow_key                first-touch key of row `grow_row` (plan_merge_directory(grow_row=...)), all ones if M is smaller
         aux_all                 (ws, k) the `aux` integers of every rank (rides on the plan's first all_gather)
         monotone                False: the first-touch keys are not ordered by rank (frames were not sharded contiguously);
                                 only aux_all is valid and the caller falls back to the general plan (plan_merge)"""
     __slots__ = ("M", "n", "row_of_slot", "is_new", "prev", "next", "bases", "counts", "grow_key", "aux_all", "monotone", "rank", "ws",
-                 "coll", "dir_entries")
+                 "coll", "dir_entries", "n_prev", "n_next")
 
 
 def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=None, grow_row: Optional[int] = None, aux=(),
@@ -721,7 +722,9 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     m4r = prev_r >= 0
     _, n3, n4 = _group_counts(dest_o, ws, (m3, m4))              # my entries are grouped by directory rank,
     _, n3r, n4r = _group_counts(src, ws, (m3r, m4r))             # the directory's arrivals by source rank
-    cnt = torch.cat([is_new.sum().reshape(1), first.sum().reshape(1), n3, n3r, n4r, n4]).to(i64)
+    ranks = torch.arange(ws, dtype=i64, device=dev)
+    cnt = torch.cat([is_new.sum().reshape(1), first.sum().reshape(1), n3, n3r, n4r, n4,
+                     (prev[:, None] == ranks).sum(0), (nxt[:, None] == ranks).sum(0)]).to(i64)   # ... and the replay's hop sizes
     tr('new voxels + counts')
     allc = torch.stack(gather(cnt)).cpu()
     tr('gather counts')
@@ -731,7 +734,7 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
         bases[r] = bases[r - 1] + counts[r - 1]
     plan.M, plan.bases, plan.counts = int(sum(counts)), bases, counts
     n_first = int(allc[rank, 1])
-    s3, r3, s4, r4 = (allc[rank, 2 + k * ws:2 + (k + 1) * ws].tolist() for k in range(4))
+    s3, r3, s4, r4, plan.n_prev, plan.n_next = (allc[rank, 2 + k * ws:2 + (k + 1) * ws].tolist() for k in range(6))
     c = int(counts[rank])
     idx_new = _mask_idx(is_new, c)
     idx_new = idx_new[torch.argsort(key[idx_new])]
@@ -823,15 +826,14 @@ def chain_replay(plan: ShardPlan, cell: "torch.Tensor", replay_fn, tr=None) -> "
         return state
     # ONE sort per direction groups the shared voxels by neighbour rank, in cell order inside a group (the same order on both
     # sides of a hop, so no indices travel); the per-rank lists are slices
-    def grouped(which):
-        idx = torch.nonzero(which >= 0).reshape(-1)
-        idx = idx[torch.argsort((which[idx] << 32) | cell[idx].to(i64))]
-        return idx, torch.bincount(which[idx], minlength=ws)[:ws]
-    idx_p, cnt_p = grouped(plan.prev)
-    idx_n, cnt_n = grouped(plan.next)
-    both = torch.stack([cnt_p, cnt_n]).cpu()
+    # (the list sizes came with the plan: nothing is counted on the host here; voxels without a neighbour sort behind rank ws - 1)
+    def grouped(which, total):
+        k = (torch.where(which >= 0, which, torch.full_like(which, ws)) << 32) | cell.to(i64)
+        return _argsort_bits(k, 32 + max(1, int(ws).bit_length()))[:int(total)]
+    n_prev, n_next = [int(v) for v in plan.n_prev], [int(v) for v in plan.n_next]
+    idx_p = grouped(plan.prev, sum(n_prev))
+    idx_n = grouped(plan.next, sum(n_next))
     tr('group by neighbour')
-    n_prev, n_next = both[0].tolist(), both[1].tolist()
     if sum(n_prev):
         buf = torch.empty((int(idx_p.shape[0]), 3), dtype=i64, device=dev)
         o = 0
