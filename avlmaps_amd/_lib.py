@@ -76,6 +76,8 @@ _SIGS = {
                                               C.c_int, _vp, _i64, _f64, _f64, _f64, _vp]),
     "avl_builder_integrate_batch": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int,
                                               _vp, _i64, _f64, _f64, _f64, _vp]),
+    "avl_builder_integrate_frames": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int,
+                                               _vp, _i64, _f64, _f64, _f64, _vp]),
     "avl_builder_integrate_frame_global": (C.c_int, [_vp, _vp, C.c_int, _f64, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp,
                                                      C.c_int, C.c_int, _vp, _i64, _f64, _f64, _f64, _vp, _vp]),
     "avl_points_bbox": (C.c_int, [_vp, C.c_int, _f64, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, _f64, _f64, _vp, _vp]),

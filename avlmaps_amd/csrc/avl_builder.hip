@@ -1497,6 +1497,20 @@ int avl_builder_integrate_batch(avl_builder* b, int B, const float* const* h_dep
                           h_sample_ptrs, h_feat_ptrs, h_rgb_ptrs);
 }
 
+int avl_builder_integrate_frames(avl_builder* b, int n_frames, const float* const* h_depth_ptrs, int H, int W, const double* h_calib,
+                                 const double* h_calib_inv, const double* h_pc_transforms, const int32_t* const* h_sample_ptrs, int P,
+                                 const float* const* h_feat_ptrs, int Hf, int Wf, const uint8_t* const* h_rgb_ptrs, int64_t frame_idx0,
+                                 double min_depth, double max_depth, double sigma_sq, void* stream) {
+    AVL_REQUIRE(n_frames > 0, "avl_builder_integrate_frames: n_frames must be positive");
+    AVL_REQUIRE(h_depth_ptrs && h_sample_ptrs && h_feat_ptrs && h_rgb_ptrs && h_pc_transforms, "avl_builder_integrate_frames: null pointer table");
+    for (int i = 0; i < n_frames; ++i) {
+        const int rc = integrate_impl(b, h_depth_ptrs[i], 0, 1.0, H, W, h_calib, h_calib_inv, h_pc_transforms + 16 * i, h_sample_ptrs[i], P,
+                                      h_feat_ptrs[i], Hf, Wf, h_rgb_ptrs[i], frame_idx0 + i, min_depth, max_depth, sigma_sq, nullptr, stream);
+        if (rc != AVL_OK) return rc;
+    }
+    return AVL_OK;
+}
+
 int avl_builder_num_voxels(avl_builder* b, int64_t* h_n, void* stream) {
     AVL_REQUIRE(b && h_n, "avl_builder_num_voxels: null argument");
     int rc = flush_pending(b, as_stream(stream));

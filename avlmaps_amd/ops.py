@@ -410,6 +410,22 @@ class VoxelAccumulator:
             plan = self.make_batch_plan(depths, sample_idxs, feats_hwc, rgbs, stream)
         return self._integrate_plan(plan, calib, pc_transforms, frame_idx0, calib_inv, min_depth, max_depth, sigma_sq, stream)
 
+    def integrate_frames(self, plan, calib, pc_transforms, frame_idx0=0, calib_inv=None, min_depth=0.1, max_depth=6.0, sigma_sq=0.6,
+                         stream=None):
+        """The frame-by-frame loop from C (avl_builder_integrate_frames): the frames of `plan` (make_batch_plan) one after the other,
+        one launch pair -- with deferred fuse one launch -- per frame, exactly like len(plan) integrate_frame calls without the
+        ~12 us of Python / ctypes per call.  Not a batch: no two frames share a launch."""
+        lib = _lib.load()
+        B = plan.B
+        K, Kinv = self._calib_pair(calib, calib_inv)
+        T = np.ascontiguousarray(np.asarray(pc_transforms, dtype=np.float64).reshape(B, 16))
+        rc = lib.avl_builder_integrate_frames(self._h, B, plan.depth, plan.H, plan.W, K.ctypes.data, Kinv.ctypes.data, T.ctypes.data,
+                                              plan.samples, plan.P, plan.feat, plan.Hf, plan.Wf, plan.rgb, int(frame_idx0),
+                                              float(min_depth), float(max_depth), float(sigma_sq), stream)
+        _lib.check(rc, "avl_builder_integrate_frames")
+        self._retain(plan.keep, stream)
+        return self
+
     def make_batch_plan(self, depths, sample_idxs, feats_hwc, rgbs, stream=None):
         """Resolve the per-frame device pointers of a batch once.  A pipeline that cycles through a ring of frame buffers can
         keep the plan and pass it as `depths` to integrate_batch (sample_idxs / feats_hwc / rgbs are then ignored)."""

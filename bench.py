@@ -684,7 +684,23 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
 
     extract = make_vit_standin(torch) if feature_standin == "vit-l16" else None
 
+    # frame-by-frame launches with the frames resident: the LOOP runs in C (avl_builder_integrate_frames, 64 frames per call; one
+    # launch pair -- deferred: one launch -- per frame, exactly what 64 integrate_frame calls issue).  A Python call costs 12.4 us
+    # of host time, more than the 11.9 us pipe_kernel it launches (tools/probe_frame_loop.py); --python-frame-loop keeps it in Python
+    c_loop = BATCH == 1 and extract is None and not getattr(args, "python_frame_loop", False)
+    SEQ = 64
+
     def fuse(i0, i1):
+        if c_loop:
+            for j0 in range(i0, i1, SEQ):
+                j1 = min(i1, j0 + SEQ)
+                idx = tuple(i % nbuf for i in range(j0, j1))
+                plan = plans.get(idx)
+                if plan is None:
+                    plan = plans[idx] = acc.make_batch_plan([depths[b] for b in idx], [samples[b] for b in idx], [feats[b] for b in idx],
+                                                            [rgbs[b] for b in idx])
+                acc.integrate_frames(plan, calib, Ts[j0:j1], frame_idx0=j0)
+            return
         if BATCH == 1:
             for i in range(i0, i1):
                 b = i % nbuf
@@ -773,6 +789,8 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     pts_per_frame, groups, newv = npts / nfr, ngroups / nfr, nvox / nfr
     alg_frame = P * (4 + 4 + 25) + pts_per_frame * (3 + D * 4 + 25) + groups * D * 8 + (groups - newv) * D * 8 + newv * D * 4
     res = dict(total_frames=total_frames, frames_per_gpu=nloc, frames_per_launch=BATCH, deferred_fuse=bool(deferred) and BATCH == 1,
+               host_loop=("C: avl_builder_integrate_frames, 64 frames per call -- one launch pair (deferred: one launch) per frame, no frames share a launch"
+                          if c_loop else "Python: one integrate call per frame / batch"),
                frames_per_s=total_frames / dt,
                seconds=dt, fuse_seconds_max_rank=fuse_s, merge_finalize_seconds=dt - fuse_s, exact_rgb_replay=bool(exact_rgb),
                feature_standin=feature_standin, trajectory=getattr(args, "trajectory", "loop"),
@@ -1048,6 +1066,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run a few steps under rocprofv3 --pmc to measure HBM traffic in the run")
     ap.add_argument("--no-build-extra", action="store_true")
+    ap.add_argument("--python-frame-loop", action="store_true",
+                    help="build workload, one frame per launch: call integrate_frame from Python per frame (12.4 us of host time per call) "
+                         "instead of running the frame loop in C (avl_builder_integrate_frames)")
     ap.add_argument("--profile-run", action="store_true",
                     help="only the timed kernel launches (no scores_mat variant, CPU baseline or build extra): used under rocprofv3 "
                          "so that the trace's per-kernel average is the benchmarked launch")

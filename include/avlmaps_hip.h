@@ -301,6 +301,19 @@ AVL_API int avl_builder_integrate_batch(avl_builder* b, int B, const float* cons
                                         double max_depth, double sigma_sq, void* stream);
 
 /*
+ * The frame-by-frame loop itself (vlmap_builder.py:102-183's `for frame_i in ...`), for callers whose frames are already resident:
+ * exactly n_frames calls of avl_builder_integrate_frame -- one launch pair per frame, or one launch with deferred fuse; NOT a
+ * batch: no two frames share a launch or a list -- issued from C.  A call through a language binding costs more host time than the
+ * frame's kernels take (12.4 us per ctypes call against 11.9 us of pipe_kernel, tools/probe_frame_loop.py).  Arguments as for
+ * avl_builder_integrate_batch; with deferred fuse the LAST frame's features are still to be fused when the call returns.
+ */
+AVL_API int avl_builder_integrate_frames(avl_builder* b, int n_frames, const float* const* h_depth_ptrs, int H, int W,
+                                        const double* h_calib, const double* h_calib_inv, const double* h_pc_transforms,
+                                        const int32_t* const* h_sample_ptrs, int P, const float* const* h_feat_ptrs, int Hf,
+                                        int Wf, const uint8_t* const* h_rgb_ptrs, int64_t frame_idx0, double min_depth,
+                                        double max_depth, double sigma_sq, void* stream);
+
+/*
  * Global (multi-floor) variant of the frame fusion: replaces vlmap_builder_multi_floor.py:137-199.
  *   voxel index = np.round((p_global - pcd_min) / cs) per axis, (row, height, col) = (x, y, z) (:146);
  *   d_depth is float32 metres, or uint16 with metres = value / depth_div (depth PNGs / 1000.0, :105);

@@ -670,6 +670,11 @@ def test_deferred_fuse_heavy_collisions_and_mixed_calls(ops):
             elif step == 1:
                 acc.integrate_frame(depths[i], calib, Ts[i], samples[i], fs[i], rgbs[i], frame_idx=i)
                 i += 1
+            elif isinstance(step, tuple):        # ("seq", k): the frame-by-frame loop from C (avl_builder_integrate_frames)
+                sl = slice(i, i + step[1])
+                bp = acc.make_batch_plan(list(depths[sl]), samples[sl], fs[sl], list(rgbs[sl]))
+                acc.integrate_frames(bp, calib, Ts[sl], frame_idx0=i)
+                i += step[1]
             else:
                 sl = slice(i, i + step)
                 acc.integrate_batch(list(depths[sl]), calib, Ts[sl], samples[sl], fs[sl], list(rgbs[sl]), frame_idx0=i)
@@ -681,10 +686,12 @@ def test_deferred_fuse_heavy_collisions_and_mixed_calls(ops):
     n, pts = ref.num_voxels(), ref.num_points()
     assert pts > 10 * n > 0
     want = ref.finalize()
-    for plan in ([1] * nfr, [1, 1, "flush", 1, 1, 1, "flush", "flush", 1, 1, 1, 1], [1, 1, 1, "off", 1, 1, "on", 1, 1, 1, 1]):
+    for plan in ([1] * nfr, [1, 1, "flush", 1, 1, 1, "flush", "flush", 1, 1, 1, 1], [1, 1, 1, "off", 1, 1, "on", 1, 1, 1, 1],
+                 [("seq", nfr)], [1, ("seq", 4), "flush", ("seq", 3), 1]):
         acc = build(plan, True)
         assert acc.num_voxels() == n and acc.num_points() == pts
         _same_map(acc.finalize(), want)
+    _same_map(build([("seq", 5), 1, ("seq", 3)], False).finalize(), want)      # ... and frame-at-once: the same launches as nfr calls
     # a batched call in the middle groups the samples of its frames per voxel: same ids / colour / weight, features to rounding
     acc = build([1, 1, 3, 1, 2, 1], True)
     out = acc.finalize()
