@@ -468,7 +468,7 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
 #ifndef AVL_K3_MR
 #define AVL_K3_MR 2
 #endif
-        constexpr int MR = CH <= 4 ? AVL_K3_MR : 1;
+        constexpr int MR = CH <= 4 ? AVL_K3_MR : 1;   // (CH = 6: 219 VGPRs already)
         for (int k0 = 0; k0 < n; k0 += MR) {
             float v[MR][CH][4];
             int cj[MR], lj[MR];
@@ -1183,6 +1183,9 @@ static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, cons
     else if (b->D <= 512)
         hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    else if (b->D == 768)    // CLIP ViT-L: three full chunks (the full-width path: unconditional row accesses)
+        hipLaunchKernelGGL(fuse_kernel<3>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
+                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
     else if (b->D <= 1024)
         hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
                            b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
@@ -1424,6 +1427,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         const FusePrev prev{b->pend.P, b->pend.frame_key, b->recs_alt, b->head_alt, b->pend.feat};
         if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        else if (b->D == 768) launch_pipe<3>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         else if (b->D <= 1024) launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         else launch_pipe<6>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         if (b->log.slot) b->log_used += P;
