@@ -890,13 +890,14 @@ class MixedExchange:
         self.recv_all, self.recv_done, self.recv_part = (recv[:, k].tolist() for k in range(3))
 
 
-def _fold_mixed(plan, ex, D, side, done, part, rows_add):
+def _fold_mixed(plan, ex, D, side, done, part, rows_add, tr=None):
     """owner side of the mixed exchange, shared by the device path and its torch twin: returns (own_cell, w4 (n_own, 4) f64,
     state (n_own, 3) i64, done_rows, done_feat, part_rows (k,), part_acc (k, D) f64, bad_rows (1,) int32 = some received row
     index lay outside the block) -- rows relative to this rank's block"""
     import torch
     i64 = torch.int64
     dev = side.device
+    tr = tr or (lambda label: None)
     n_own = ex.r1 - ex.r0
     word = side[:, 0]
     rows = (word & 0xFFFFFFFF) - ex.r0
@@ -907,12 +908,14 @@ def _fold_mixed(plan, ex, D, side, done, part, rows_add):
     own_cell = torch.zeros(max(n_own, 1), dtype=torch.int32, device=dev)
     own_cell[rows] = ((word >> 32) & 0x7FFFFFFF).to(torch.int32)
     own_cell = own_cell[:n_own]
+    tr('rows + cells')
     w4 = torch.zeros((max(n_own, 1), 4), dtype=torch.float64, device=dev)
     o = 0
     for c in ex.recv_all:                           # peer by peer, in rank order: a reproducible float64 sum
         if c:
             rows_add(rows[o:o + c], side[o:o + c, 1:5].view(torch.float64), w4)
         o += c
+    tr('w4 adds')
     st = side[:, 5:8]
     fin = (st[:, 2] >> 32) != 0                     # `started` of the 24-byte state: only a voxel's LAST contributor sends it
     # (no boolean-mask indexing here: every mask would be counted on the host.  States that are not final land in one spare row)
@@ -923,14 +926,17 @@ def _fold_mixed(plan, ex, D, side, done, part, rows_add):
     single_flag = (word >> 63) != 0                 # bit 63 of the word: the voxel travelled as a finished row
     done_rows = rows[_mask_idx(single_flag, sum(ex.recv_done))]
     part_rows_all = rows[_mask_idx(~single_flag, sum(ex.recv_part))]
+    tr('state + lists')
     part_rows, inv = (torch.unique(part_rows_all, return_inverse=True) if part_rows_all.numel() else
                       (part_rows_all, part_rows_all))
+    tr('unique')
     acc = torch.zeros((max(int(part_rows.shape[0]), 1), D), dtype=torch.float64, device=dev)
     o = 0
     for c in ex.recv_part:
         if c:
             rows_add(inv[o:o + c], part[o:o + c], acc)
         o += c
+    tr('part adds')
     return own_cell, w4, state, done_rows, done, part_rows, acc, bad_rows
 
 
@@ -1152,8 +1158,8 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
         rows = rows.contiguous()
         _lib.check(lib.avl_rows_add_f64_async(int(rows.shape[0]), int(src.shape[1]), rows.data_ptr(), 0, int(dst.shape[0]), src.data_ptr(),
                                               int(src.shape[1]), dst.data_ptr(), int(dst.shape[1]), err_flag.data_ptr(), st), "avl_rows_add_f64_async")
-    tr3 = _Trace('fold', dev)
-    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc, bad_rows = _fold_mixed(plan, ex, D, side, done, part, rows_add)
+    tr3 = _Trace('fold', dev, coll)
+    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc, bad_rows = _fold_mixed(plan, ex, D, side, done, part, rows_add, tr3)
     # every rank learns whether ANY rank saw a bad row and raises with it: a rank raising alone would leave the others in
     # gather_row_shards' collectives
     err_flag = torch.maximum(err_flag, bad_rows.to(err_flag.device))
