@@ -51,6 +51,18 @@
 
 namespace avl {
 
+#ifdef AVL_PROBE_CHAIN
+// tools/probe_chain.py: per-work-item timestamps (s_memrealtime, 100 MHz) of the dependent-load chains of K1 + K2 and K3, taken
+// AFTER the loads before them have landed.  Never compiled into the shipped library (tools/build_variant.py -DAVL_PROBE_CHAIN).
+__device__ unsigned long long* g_probe = nullptr;
+constexpr int kProbeK12Row0 = 16384;
+#define AVL_STAMP(var)                                                                                             \
+    unsigned long long var;                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define AVL_STAMP(var)
+#endif
+
 // one frame of a batch (avl_builder_integrate_batch): what differs between the frames of one launch
 struct BatchEntry {
     double t[16];                 // pc_transform of the frame
@@ -126,6 +138,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     __syncthreads();
     const int s = blk * blockDim.x + threadIdx.x;   // global sample index: frame-major within a batch
     const bool valid = s < fp.P;
+    AVL_STAMP(pt0);
     double alpha = 0.0;
     int32_t cell = -1, fpix = 0;
     uint32_t rgbv = 0;
@@ -138,6 +151,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     }
     const int pix = !valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]);
     bool ok = pix >= 0 && pix < fp.H * fp.W;
+    AVL_STAMP(pt1);
     double pl0 = 0, pl1 = 0, pl2 = 0;
     if (ok) {
         // depth2pc: p_2d = (u + 0.5, v + 0.5, 1); pc = Kinv @ p_2d (dgemm: FMA chain over k); pc *= z
@@ -148,6 +162,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
         ok = (pl2 > fp.min_depth) && (pl2 < fp.max_depth);  // strict on both sides, NaN fails
     }
+    AVL_STAMP(pt2);
     long long row = 0, col = 0, h = 0;
     size_t rgb_off = 0;
     if (ok) {
@@ -205,6 +220,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     // The colour gather and the cell's slot are requested TOGETHER, in straight-line code (a sample that dropped out reads
     // element 0 of both): inside the `ok` branches the three colour bytes had to arrive before the cell_slot load was issued --
     // one round trip of this kernel's dependent chain for a value that is only stored at the end.
+    AVL_STAMP(pt3);
     const uint8_t* c = ok ? rgb + rgb_off : reinterpret_cast<const uint8_t*>(cell_slot);   // (batched launches carry no frame-level rgb pointer)
     const uint8_t c0 = c[0], c1 = c[1], c2 = c[2];
     const int32_t seen = cell_slot[ok ? cell : 0];
@@ -213,6 +229,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         else if (seen >= 0) known = seen;
         rgbv = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
     }
+    AVL_STAMP(pt4);
     const unsigned long long cmask = __ballot(creator);
     const int lane = threadIdx.x & 63;
     unsigned long long base = 0;
@@ -249,6 +266,15 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         recs.fpix[s] = fpix;
         recs.rgb[s] = rgbv;
     }
+#ifdef AVL_PROBE_CHAIN
+    {
+        AVL_STAMP(pt5);
+        if (g_probe && valid && fp.P < kProbeK12Row0) {
+            unsigned long long* q = g_probe + (size_t)(kProbeK12Row0 + s) * 8;
+            q[0] = pt0; q[1] = pt1; q[2] = pt2; q[3] = pt3; q[4] = pt4; q[5] = pt5;
+        }
+    }
+#endif
     return SampleRec{alpha, cell, fpix, rgbv, known};
 }
 
@@ -318,6 +344,12 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
             log.rgb[i] = in.rgbv;
         }
     }
+#ifdef AVL_PROBE_CHAIN
+    {
+        AVL_STAMP(pt7);
+        if (g_probe && valid && P < kProbeK12Row0) g_probe[(size_t)(kProbeK12Row0 + s) * 8 + 7] = pt7 | ((unsigned long long)(slot >= 0) << 63);
+    }
+#endif
     __syncthreads();
     if (threadIdx.x < 2 && blk_cnt[threadIdx.x]) atomicAdd(&counters[1 + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
 }
@@ -351,15 +383,28 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
     const int lane = threadIdx.x & 63;
     const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
     if (s0 >= P) return;
+    AVL_STAMP(pt0);
     const uint8_t own = recs.owner[s0];
     const int32_t slot = recs.slot[s0];
     const double alpha0 = recs.alpha[s0];
     const int32_t fpix0 = recs.fpix[s0];
     const uint32_t rgb0 = recs.rgb[s0];
+#ifdef AVL_PROBE_CHAIN
+    {
+        AVL_STAMP(ptn);
+        if (!own && g_probe && lane == 0 && P < kProbeK12Row0) { g_probe[(size_t)s0 * 8] = pt0; g_probe[(size_t)s0 * 8 + 1] = ptn; g_probe[(size_t)s0 * 8 + 7] = 0; }
+    }
+#endif
     if (!own) return;
+    AVL_STAMP(pt1);
     const bool is_new = slot_key[slot] == kNoKey;  // born in this launch: accumulators hold nothing yet
     const int h0 = head[slot];
     double* sf = sum_feat + (size_t)slot * D;
+    AVL_STAMP(pt2);
+#ifdef AVL_PROBE_CHAIN
+    int probe_n = 1;
+    unsigned long long pt3 = 0, pt4 = 0;
+#endif
 
     double acc[CH][4], old[CH][4];
     float f1[CH][4];
@@ -433,6 +478,9 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
         float v[CH][4];
         load_row(v, feat0);
         add(s0, alpha0, rgb0, v);   // one sample for this voxel in this launch: 70 % of the groups of a single frame
+#ifdef AVL_PROBE_CHAIN
+        { AVL_STAMP(ptx); pt3 = pt4 = ptx; }
+#endif
     } else {
         // Several samples: sum them in ASCENDING SAMPLE ORDER (the reference's order), not in the order in which their atomics
         // happened to arrive -- fp64 addition is not associative, and with the arrival order two runs of the same build could
@@ -448,6 +496,9 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
             ++n;
             cur = recs.next[cur];
         }
+#ifdef AVL_PROBE_CHAIN
+        { AVL_STAMP(ptx); pt3 = ptx; probe_n = n; }
+#endif
         double a_l = 0.0;
         int32_t fp_l = 0;
         uint32_t rgb_l = 0;
@@ -456,6 +507,9 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
             fp_l = recs.fpix[my];
             rgb_l = recs.rgb[my];
         }
+#ifdef AVL_PROBE_CHAIN
+        { AVL_STAMP(ptx); pt4 = ptx; }
+#endif
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += __builtin_amdgcn_readlane(my, j) < my ? 1 : 0;
         const int a_lo = __double2loint(a_l), a_hi = __double2hiint(a_l);
@@ -496,6 +550,7 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
         }
     }
 
+    AVL_STAMP(pt5);
     float* ff = first_feat + (size_t)slot * D;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -527,6 +582,16 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
         head[slot] = -1;  // ready for the next launch
         dirty[slot] = 1;  // changed since the last checkpoint (avl_builder_finalize_ex)
     }
+#ifdef AVL_PROBE_CHAIN
+    {
+        AVL_STAMP(pt6);
+        if (g_probe && lane == 0 && P < kProbeK12Row0) {
+            unsigned long long* q = g_probe + (size_t)s0 * 8;
+            q[0] = pt0; q[1] = pt1; q[2] = pt2; q[3] = pt3; q[4] = pt4; q[5] = pt5; q[6] = pt6;
+            q[7] = (unsigned long long)probe_n | (is_new ? 1ull << 32 : 0ull);
+        }
+    }
+#endif
 }
 
 template <int CH>
@@ -1217,6 +1282,15 @@ static void launch_pipe(avl_builder* b, const FrameParams& fp, unsigned pb, cons
 }
 
 extern "C" {
+
+#ifdef AVL_PROBE_CHAIN
+__attribute__((visibility("default"))) int avl_debug_set_probe(void* d_buf) {
+    AVL_HIP_CHECK(hipDeviceSynchronize());
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(d_buf);
+    AVL_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(avl::g_probe), &p, sizeof(p)));
+    return AVL_OK;
+}
+#endif
 
 int avl_builder_reset(avl_builder* b, void* stream) {
     AVL_REQUIRE(b, "avl_builder_reset: null handle");

@@ -64,14 +64,13 @@ for deferred in (False, True):
         end12 = (a[:, 7] & np.uint64((1 << 63) - 1)).max()
         print(f" K1+K2: {live12.sum()} samples; span first start -> last end {10.0 * float(end12 - start):.0f} ns")
         pct(a[:, 0] - start, "start skew")
-        pct(a[:, 1] - a[:, 0], "hop: sample index")
-        pct(a[:, 2] - a[:, 1], "hop: depth (+ geometry)")
-        pct(a[:, 3] - a[:, 2], "geometry + rgb gather")
-        pct(a[:, 4] - a[:, 3], "hop: cell_slot read")
-        pct(a[:, 5] - a[:, 4], "hop: CAS (creators' waves)")
-        pct(a[:, 6] - a[:, 5], "counter atomic + publish + rec stores")
+        pct(a[:, 1] - a[:, 0], "hop: kernel arguments + sample index")
+        pct(a[:, 2] - a[:, 1], "hop: depth")
+        pct(a[:, 3] - a[:, 2], "geometry (fp64 divides, exp)")
+        pct(a[:, 4] - a[:, 3], "hop: colour + cell_slot (+ CAS)")
+        pct(a[:, 5] - a[:, 4], "counter atomic + publish + rec stores")
         e = a[:, 7] & np.uint64((1 << 63) - 1)
-        pct(e - a[:, 6], "K2: poll + exch + stores")
+        pct(e - a[:, 5], "K2: poll + exch + stores")
         pct(e - a[:, 0], "whole chain")
         live3 = k3[:, 0] != 0
         c = k3[live3]
