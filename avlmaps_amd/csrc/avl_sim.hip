@@ -748,7 +748,17 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
             if (!active) continue;   // no barrier inside the tile loop when the whole image is resident
         }
         // inactive waves of a K-chunked launch (barriers in the loop) idle on row N-1 and write nothing
-        const int64_t row = !active ? N : (tail ? tail_row0 + (tu0 + wave) * 32 + j : (it * G + blockIdx.x) * kTileRows + wave * 32 + j);
+        // Complete rounds: workgroup b takes tile it * G + b -- all workgroups sweep one compact window of the map.  With a row stride
+        // that is a multiple of 4 KiB (512 columns of a 1024- or 2048-float row) that window camps on a few HBM channels (0.79 / 0.77
+        // ms against 0.72 contiguous, profiles/r04_row_stride_probe.txt): there a workgroup takes kRun CONSECUTIVE tiles of every
+        // super-round of G * kRun tiles, as the K-swap kernel does, so that at any moment the workgroups are spread over the map.
+        constexpr int64_t kRun = 4;
+#ifndef AVL_SPREAD_MODE
+#define AVL_SPREAD_MODE 0
+#endif
+        const bool spread = !P24 && (AVL_SPREAD_MODE == 2 || (ld != D && (AVL_SPREAD_MODE == 1 || ((ld * 4) & 4095) == 0))) && it < (R / kRun) * kRun;
+        const int64_t tile = spread ? (it / kRun) * (G * kRun) + (int64_t)blockIdx.x * kRun + (it % kRun) : it * G + blockIdx.x;
+        const int64_t row = !active ? N : (tail ? tail_row0 + (tu0 + wave) * 32 + j : tile * kTileRows + wave * 32 + j);
         const int64_t rowc = row < N ? row : N - 1;
         const float* rp = feat + rowc * ld + 32 * kg;
         const char* rp24 = reinterpret_cast<const char*>(feat) + rowc * (ld * 3);   // P24: first byte of the row, ld = columns of a full row

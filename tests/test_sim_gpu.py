@@ -604,3 +604,36 @@ def test_packed_mask_rows_add_and_window_merge_edge_cases(ops):
     cols = out[0, :, 0].cpu().numpy()
     assert np.array_equal(cols[:6], np.zeros(6)) and np.array_equal(cols[6:8], [0.5, 0.5]) and np.array_equal(cols[8:12], np.ones(4))
     assert np.array_equal(cols[12:14], [1.5, 1.5]) and np.array_equal(cols[14:], 2 * np.ones(6))
+
+
+def test_power_of_two_row_stride_scores_like_a_contiguous_copy(ops):
+    """512 columns of rows with a 4 KiB / 8 KiB stride (a column window of a wider map, avl_sim_scores' ld_feat): the resident
+    kernel deals the tiles of such a view out in runs of consecutive tiles per workgroup (HBM channel camping otherwise: -9 %);
+    every row must score exactly as it does in a contiguous copy of the window -- enough rows for complete super-rounds and a
+    ragged tail, both windows of the row"""
+    import ctypes as C
+    import torch
+    from avlmaps_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, D, Q = 4 * 256 * 256 * 2 + 12_345, 512, 64
+    q = torch.randn((Q, D), device="cuda", generator=g)
+    wsb = C.c_size_t()
+    _lib.check(lib.avl_sim_workspace_bytes_n(N, D, Q, C.byref(wsb)))
+    ws = torch.empty((max(wsb.value, 64),), dtype=torch.uint8, device="cuda")
+
+    def run(ptr, ld):
+        am = torch.empty((N,), dtype=torch.int32, device="cuda")
+        best = torch.empty((N,), dtype=torch.float32, device="cuda")
+        _lib.check(lib.avl_sim_scores_ws(ptr, N, D, ld, q.data_ptr(), Q, D, None, am.data_ptr(), best.data_ptr(), 0, ws.data_ptr(), wsb.value, None))
+        torch.cuda.synchronize()
+        return am, best
+    for ld in (1024, 2048):
+        wide = torch.randn((N, ld), device="cuda", generator=g)
+        for off in (0, ld - D):
+            am_v, best_v = run(wide.data_ptr() + 4 * off, ld)
+            tight = wide[:, off:off + D].contiguous()
+            am_c, best_c = run(tight.data_ptr(), D)
+            assert torch.equal(am_v, am_c) and torch.equal(best_v, best_c), (ld, off)
+            del tight
+        del wide
