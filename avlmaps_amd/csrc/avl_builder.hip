@@ -1187,34 +1187,42 @@ struct LogSegments {
     int32_t *active = nullptr, *order = nullptr;
     long long *seg_start = nullptr, *seg_end = nullptr, *d_count = nullptr;
     void *tmp = nullptr, *tmp_sel = nullptr;
+    char *block1 = nullptr, *block2 = nullptr;   // TWO pool allocations hold all of the above (a hipMallocAsync / hipFreeAsync pair costs
+                                                 // ~90 us of host time: nine of them were most of a small rank's replay)
+    static size_t al(size_t bytes) { return (bytes + 255) / 256 * 256; }
     int build(avl_builder* b, int64_t n, hipStream_t st) {
         const long long L = b->log_used;
         size_t sel_bytes = 0, tmp_bytes = 0;
-        AVL_HIP_CHECK(hipMallocAsync((void**)&active, (size_t)L * sizeof(int32_t), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&d_count, sizeof(long long), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_start, (size_t)n * sizeof(long long), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&seg_end, (size_t)n * sizeof(long long), st));
-        AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, (size_t)n * sizeof(long long), st));
-        AVL_HIP_CHECK(hipMemsetAsync(seg_end, 0, (size_t)n * sizeof(long long), st));
         const LogActive pred{b->log.slot};
         rocprim::counting_iterator<int32_t> first(0);
-        AVL_HIP_CHECK(rocprim::select(nullptr, sel_bytes, first, active, d_count, (size_t)L, pred, st));
-        AVL_HIP_CHECK(hipMallocAsync(&tmp_sel, sel_bytes ? sel_bytes : 16, st));
+        AVL_HIP_CHECK(rocprim::select(nullptr, sel_bytes, first, (int32_t*)nullptr, (long long*)nullptr, (size_t)L, pred, st));
+        const size_t b_active = al((size_t)L * sizeof(int32_t)), b_seg = al((size_t)n * sizeof(long long)), b_sel = al(sel_bytes ? sel_bytes : 16);
+        AVL_HIP_CHECK(hipMallocAsync((void**)&block1, b_active + 256 + 2 * b_seg + b_sel, st));
+        active = reinterpret_cast<int32_t*>(block1);
+        d_count = reinterpret_cast<long long*>(block1 + b_active);
+        seg_start = reinterpret_cast<long long*>(block1 + b_active + 256);
+        seg_end = reinterpret_cast<long long*>(block1 + b_active + 256 + b_seg);
+        tmp_sel = block1 + b_active + 256 + 2 * b_seg;
+        AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, 2 * b_seg, st));
         AVL_HIP_CHECK(rocprim::select(tmp_sel, sel_bytes, first, active, d_count, (size_t)L, pred, st));
         long long La = 0;
         AVL_HIP_CHECK(hipMemcpyAsync(&La, d_count, sizeof(La), hipMemcpyDeviceToHost, st));
         AVL_HIP_CHECK(hipStreamSynchronize(st));
         const size_t Ls = (size_t)(La > 0 ? La : 1);
-        AVL_HIP_CHECK(hipMallocAsync((void**)&active_slot, Ls * sizeof(uint32_t), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&sorted_slot, Ls * sizeof(uint32_t), st));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&order, Ls * sizeof(int32_t), st));
+        int bits = 1;
+        while (bits < 32 && (1ll << bits) <= (long long)n) ++bits;      // slots are < n
+        if (La > 0)
+            AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                                    (size_t)La, 0, bits, st));
+        const size_t b_ls = al(Ls * sizeof(uint32_t));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&block2, 3 * b_ls + al(tmp_bytes ? tmp_bytes : 16), st));
+        active_slot = reinterpret_cast<uint32_t*>(block2);
+        sorted_slot = reinterpret_cast<uint32_t*>(block2 + b_ls);
+        order = reinterpret_cast<int32_t*>(block2 + 2 * b_ls);
+        tmp = block2 + 3 * b_ls;
         if (La > 0) {
             hipLaunchKernelGGL(gather_u32_kernel, dim3((unsigned)std::min<long long>((La + 255) / 256, 8192)), dim3(256), 0, st, b->log.slot,
                                active, La, active_slot);
-            int bits = 1;
-            while (bits < 32 && (1ll << bits) <= (long long)n) ++bits;      // slots are < n
-            AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, active_slot, sorted_slot, active, order, (size_t)La, 0, bits, st));
-            AVL_HIP_CHECK(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, active_slot, sorted_slot, active, order, (size_t)La, 0, bits, st));
             hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((La + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
                                La, (long long)n, seg_start, seg_end);
@@ -1223,9 +1231,9 @@ struct LogSegments {
         return AVL_OK;
     }
     void release(hipStream_t st) {
-        (void)hipFreeAsync(tmp, st); (void)hipFreeAsync(tmp_sel, st); (void)hipFreeAsync(seg_end, st); (void)hipFreeAsync(seg_start, st);
-        (void)hipFreeAsync(order, st); (void)hipFreeAsync(active, st); (void)hipFreeAsync(sorted_slot, st);
-        (void)hipFreeAsync(active_slot, st); (void)hipFreeAsync(d_count, st);
+        (void)hipFreeAsync(block2, st);
+        (void)hipFreeAsync(block1, st);
+        block1 = block2 = nullptr;
     }
 };
 
@@ -1736,12 +1744,16 @@ int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32
     int32_t *iota = nullptr, *perm = nullptr;
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
-    AVL_HIP_CHECK(hipMallocAsync((void**)&keys_out, (size_t)n * sizeof(unsigned long long), st));
-    AVL_HIP_CHECK(hipMallocAsync((void**)&iota, (size_t)n * sizeof(int32_t), st));
-    AVL_HIP_CHECK(hipMallocAsync((void**)&perm, (size_t)n * sizeof(int32_t), st));
-    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, iota, n);
+    // one pool allocation for the four temporaries (each hipMallocAsync / hipFreeAsync pair is ~90 us of host time)
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
-    AVL_HIP_CHECK(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, st));
+    const size_t b_keys = ((size_t)n * sizeof(unsigned long long) + 255) / 256 * 256, b_idx = ((size_t)n * sizeof(int32_t) + 255) / 256 * 256;
+    char* block = nullptr;
+    AVL_HIP_CHECK(hipMallocAsync((void**)&block, b_keys + 2 * b_idx + (tmp_bytes ? tmp_bytes : 16), st));
+    keys_out = reinterpret_cast<unsigned long long*>(block);
+    iota = reinterpret_cast<int32_t*>(block + b_keys);
+    perm = reinterpret_cast<int32_t*>(block + b_keys + b_idx);
+    tmp = block + b_keys + 2 * b_idx;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, st, iota, n);
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, b->slot_key, keys_out, iota, perm, (size_t)n, 0, 64, st));
     rc = launch_finalize(n, b->D, b->gs, b->vh, 0, perm, b->slot_cell, b->sum_feat, b->D, b->sum_w4, 4, b->first_feat, b->first_alpha,
                          d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, st);
@@ -1761,10 +1773,7 @@ int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32
                            d_row_dirty, clear_dirty);
         if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
     }
-    (void)hipFreeAsync(tmp, st);
-    (void)hipFreeAsync(perm, st);
-    (void)hipFreeAsync(iota, st);
-    (void)hipFreeAsync(keys_out, st);
+    (void)hipFreeAsync(block, st);
     if (rc != AVL_OK) return rc;
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     return AVL_OK;

@@ -616,7 +616,7 @@ def test_power_of_two_row_stride_scores_like_a_contiguous_copy(ops):
     from avlmaps_amd import _lib
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(5)
-    N, D, Q = 4 * 256 * 256 * 2 + 12_345, 512, 64
+    N, D, Q = 4 * 256 * 256 + 70_001, 512, 64   # one complete super-round of 4 tiles x 256 workgroups, one interleaved round, a ragged tail
     q = torch.randn((Q, D), device="cuda", generator=g)
     wsb = C.c_size_t()
     _lib.check(lib.avl_sim_workspace_bytes_n(N, D, Q, C.byref(wsb)))
