@@ -99,6 +99,19 @@ struct Recs {
     int32_t* next;    // next sample of the same voxel in this frame, -1 = end
     uint8_t* owner;   // 1 = this sample found its voxel's list empty: it is the list's TAIL and its wave fuses the list
 };
+// The owners of a BATCHED launch compacted per K2 workgroup (no atomics: a ballot and four LDS words): entry 256 b + k is owner k of
+// workgroup b, ocnt[b] of them.  K3 then runs kFuseWaves waves per K2 workgroup over them instead of one wave per SAMPLE, most of
+// which load a flag and leave: half the workgroups to dispatch, +3 % / +6 % at 16 / 64 frames per launch.  Single-frame launches keep
+// the wave-per-sample form (the compacted one measured 11.2 -> 12.0 us there), and these pointers stay out of their kernel arguments.
+struct OwnerList {
+    double* o_alpha;
+    int32_t* o_s;
+    int32_t* o_slot;
+    int32_t* o_fpix;
+    uint32_t* o_rgb;
+    int32_t* ocnt;
+};
+constexpr int kFuseWaves = 128;   // K3 waves per K2 workgroup of 256 samples (more owners than that: a wave takes several)
 
 constexpr int kEmpty = -1, kPending = -2;
 constexpr int kAggregateSamples = 32768;   // launches at least this large allocate slots per workgroup instead of per wave
@@ -289,13 +302,15 @@ struct ReplayLog {
 // K2 body.  Runs right behind K1 in the same kernel: the sample comes in registers, and a cell another workgroup is still
 // creating (kPending) is waited for.  That cannot deadlock: a creator publishes its slot without waiting for anybody but
 // its own workgroup's barrier (batched launches), which every wave of the workgroup reaches before it spins.
+template <bool MAY_COMPACT = true>
 __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
                                           const Recs& recs, unsigned long long* __restrict__ counters, const ReplayLog& log,
                                           long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
-                                          int P_frame, const SampleRec& in, int* __restrict__ err_flags) {
+                                          int P_frame, const SampleRec& in, int* __restrict__ err_flags, const OwnerList& ol = OwnerList{}) {
     // statistics counters are aggregated per workgroup in LDS: a single hot device word sustains only ~90 atomics/us,
     // which at one atomic per wave was most of this kernel's time in batched launches
     __shared__ unsigned blk_cnt[2];
+    __shared__ unsigned sh_own[4];
     if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int s = blk * blockDim.x + threadIdx.x;
@@ -332,6 +347,7 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
         atomicAdd(&blk_cnt[0], (unsigned)__popcll(amask));
         if (omask) atomicAdd(&blk_cnt[1], (unsigned)__popcll(omask));
     }
+    if (MAY_COMPACT && (threadIdx.x & 63) == 0) sh_own[threadIdx.x >> 6] = (unsigned)__popcll(omask);
     if (valid) {
         recs.slot[s] = slot;
         recs.next[s] = next;
@@ -351,6 +367,17 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
     }
 #endif
     __syncthreads();
+    if (MAY_COMPACT && owner && P >= kAggregateSamples) {   // (kernel-uniform: only batched launches fuse from the compacted owners, see fuse_body)
+        unsigned pos = (unsigned)__popcll(omask & ((1ull << (threadIdx.x & 63)) - 1ull));
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pos += sh_own[w];
+        const size_t o = (size_t)blk * 256 + pos;
+        ol.o_s[o] = s;
+        ol.o_slot[o] = slot;
+        ol.o_alpha[o] = in.alpha;
+        ol.o_fpix[o] = in.fpix;
+        ol.o_rgb[o] = in.rgbv;
+    }
+    if (MAY_COMPACT && P >= kAggregateSamples && threadIdx.x == 0) ol.ocnt[blk] = (int32_t)(sh_own[0] + sh_own[1] + sh_own[2] + sh_own[3]);
     if (threadIdx.x < 2 && blk_cnt[threadIdx.x]) atomicAdd(&counters[1 + threadIdx.x], (unsigned long long)blk_cnt[threadIdx.x]);
 }
 
@@ -360,9 +387,9 @@ __global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, cons
                                                             const uint8_t* rgb, int32_t* __restrict__ cell_slot,
                                                             int32_t* __restrict__ slot_cell, Recs recs, int32_t* __restrict__ head,
                                                             unsigned long long* __restrict__ counters, int* __restrict__ err_flags,
-                                                            ReplayLog log, long long log_base, unsigned long long frame_key) {
+                                                            ReplayLog log, long long log_base, unsigned long long frame_key, OwnerList ol) {
     const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
-    link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags);
+    link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags, ol);
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
@@ -374,28 +401,14 @@ __global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, cons
 // s_waitcnt bookkeeping falls back to vmcnt(0) where they merge: the accumulator row, the owner's feature row and every
 // member's row then arrive one after the other instead of together.
 template <int CH, bool FULL>
-__device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
-                                               int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
-                                               double* __restrict__ sum_feat, double* __restrict__ sum_w4,
-                                               float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                               unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+__device__ __forceinline__ void fuse_group_impl(int s0, int32_t slot, double alpha0, int32_t fpix0, uint32_t rgb0, int P, int D_rt, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+                                                int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
+                                                double* __restrict__ sum_feat, double* __restrict__ sum_w4,
+                                                float* __restrict__ first_feat, double* __restrict__ first_alpha,
+                                                unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
     const int D = FULL ? 256 * CH : D_rt;
     const int lane = threadIdx.x & 63;
-    const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
-    if (s0 >= P) return;
     AVL_STAMP(pt0);
-    const uint8_t own = recs.owner[s0];
-    const int32_t slot = recs.slot[s0];
-    const double alpha0 = recs.alpha[s0];
-    const int32_t fpix0 = recs.fpix[s0];
-    const uint32_t rgb0 = recs.rgb[s0];
-#ifdef AVL_PROBE_CHAIN
-    {
-        AVL_STAMP(ptn);
-        if (!own && g_probe && lane == 0 && P < kProbeK12Row0) { g_probe[(size_t)s0 * 8] = pt0; g_probe[(size_t)s0 * 8 + 1] = ptn; g_probe[(size_t)s0 * 8 + 7] = 0; }
-    }
-#endif
-    if (!own) return;
     AVL_STAMP(pt1);
     const bool is_new = slot_key[slot] == kNoKey;  // born in this launch: accumulators hold nothing yet
     const int h0 = head[slot];
@@ -594,25 +607,63 @@ __device__ __forceinline__ void fuse_body_impl(int blk, int P, int D_rt, unsigne
 #endif
 }
 
-template <int CH>
+template <int CH, bool COMPACT = false>
 __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
                                           int P_frame, const Recs& recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                           double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                           float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                          unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
-    if (D == 256 * CH)
-        fuse_body_impl<CH, true>(blk, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty);
-    else
-        fuse_body_impl<CH, false>(blk, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty);
+                                          unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty,
+                                          const OwnerList& ol = OwnerList{}) {
+    auto group = [&](int s0, int32_t slot, double alpha0, int32_t fpix0, uint32_t rgb0) {
+        if (D == 256 * CH)
+            fuse_group_impl<CH, true>(s0, slot, alpha0, fpix0, rgb0, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat,
+                                      first_alpha, slot_key, dirty);
+        else
+            fuse_group_impl<CH, false>(s0, slot, alpha0, fpix0, rgb0, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat,
+                                       first_alpha, slot_key, dirty);
+    };
+    if constexpr (!COMPACT) {
+        // a single frame (and every launch below kAggregateSamples samples): wave per SAMPLE, the owner flag fetched with the record (72 % of the waves leave here).  The compacted
+        // form below measured slower at this size -- pipe_kernel 11.2 -> 12.0 us, fuse_kernel 10.35 -> 10.7 (profiles/r05_ab_builder_k3.txt s27)
+        const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
+        if (s0 >= P) return;
+        const uint8_t own = recs.owner[s0];
+        const int32_t slot = recs.slot[s0];
+        const double alpha0 = recs.alpha[s0];
+        const int32_t fpix0 = recs.fpix[s0];
+        const uint32_t rgb0 = recs.rgb[s0];
+        if (!own) return;
+        group(s0, slot, alpha0, fpix0, rgb0);
+        return;
+    } else {
+    // Batched launches (a kernel of their own, so that the single-frame kernels keep their 80 registers): K3 runs over the owners K2 compacted -- half the workgroups, and +7 % at 64 frames per launch.  Wave i of
+    // workgroup j takes owner entry t = i * nblk + j of the launch's nb * kFuseWaves entries (K2 workgroup t / kFuseWaves, its owner
+    // t % kFuseWaves): the owners of a K2 workgroup are a PREFIX of its entries and consecutive entries go to different workgroups,
+    // so every workgroup -- every CU -- gets the same mix of live and idle waves.
+    const int nb = (P + 255) / 256;
+    const int nblk = nb * (kFuseWaves / 4);
+    const int t = (int)(threadIdx.x >> 6) * nblk + blk;
+    const int b = __builtin_amdgcn_readfirstlane(t / kFuseWaves);
+    if (b >= nb) return;
+    const int n_own = __builtin_amdgcn_readfirstlane(ol.ocnt[b]);
+    for (int k = t % kFuseWaves; k < n_own; k += kFuseWaves) {
+        const int oi = __builtin_amdgcn_readfirstlane(b * 256 + k);
+        // (oi is wave-uniform: scalar registers whatever kind of load the compiler picks)
+        const double a0 = ol.o_alpha[oi];
+        group(__builtin_amdgcn_readfirstlane(ol.o_s[oi]), __builtin_amdgcn_readfirstlane(ol.o_slot[oi]),
+              __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(a0)), __builtin_amdgcn_readfirstlane(__double2loint(a0))),
+              __builtin_amdgcn_readfirstlane(ol.o_fpix[oi]), (uint32_t)__builtin_amdgcn_readfirstlane((int)ol.o_rgb[oi]));
+    }
+    }
 }
 
-template <int CH>
+template <int CH, bool COMPACT>
 __global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                                    double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
-    fuse_body<CH>(blockIdx.x, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty);
+                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty, OwnerList ol) {
+    fuse_body<CH, COMPACT>(blockIdx.x, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty, ol);
 }
 
 // Deferred-fuse launch (avl_builder_set_deferred_fuse): ONE kernel per frame.  Workgroups [0, pb) run K1 + K2 of the NEW frame
@@ -638,7 +689,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(FrameParams fp, int pb, const
                                                    uint8_t* __restrict__ dirty) {
     if ((int)blockIdx.x < pb) {
         const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
-        link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
+        link_body<false>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
     } else {
         fuse_body<CH>((int)blockIdx.x - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
                       first_feat, first_alpha, slot_key, dirty);
@@ -1047,6 +1098,7 @@ struct avl_builder {
     unsigned long long* counters = nullptr;  // [0] slots handed out, [1] samples fused, [2] per-frame voxel groups fused
     int* err_flags = nullptr;
     char* recs_mem = nullptr;
+    OwnerList owners{};                      // batched launches only (see struct OwnerList)
     Recs recs{}, recs_alt{};                 // recs_alt: records of the pending frame (deferred fuse), swapped like head
     int recs_cap = 0;
     // deferred fuse (avl_builder_set_deferred_fuse): K3 of a frame runs inside the NEXT frame's launch
@@ -1106,9 +1158,10 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     AVL_HIP_CHECK(hipStreamSynchronize(st));
     if (b->recs_mem) AVL_HIP_CHECK(hipFree(b->recs_mem));
     b->recs_mem = nullptr;
-    const size_t cap = ((size_t)P + P / 4 + 1024 + 63) / 64 * 64;
+    const size_t cap = ((size_t)P + P / 4 + 1024 + 255) / 256 * 256;
     const size_t one = (cap * (8 + 4 * 4 + 1) + 255) / 256 * 256;
-    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one));
+    const size_t own = (cap * (8 + 4 * 4) + (cap / 256 + 1) * 4 + 255) / 256 * 256;
+    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one + own));
     auto carve = [&](Recs& r, char* p) {
         r.alpha = reinterpret_cast<double*>(p); p += cap * 8;
         r.slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
@@ -1119,6 +1172,16 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     };
     carve(b->recs, b->recs_mem);
     carve(b->recs_alt, b->recs_mem + one);
+    {
+        char* p = b->recs_mem + 2 * one;
+        OwnerList& o = b->owners;
+        o.o_alpha = reinterpret_cast<double*>(p); p += cap * 8;
+        o.o_s = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        o.o_slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        o.o_fpix = reinterpret_cast<int32_t*>(p); p += cap * 4;
+        o.o_rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
+        o.ocnt = reinterpret_cast<int32_t*>(p);
+    }
     b->recs_cap = (int)cap;
     return AVL_OK;
 }
@@ -1249,25 +1312,27 @@ static void drop_log_segments(avl_builder* b, hipStream_t st) {
 // K3 over one launch's records (CH = 256-float register chunks of a feature row)
 static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, const BatchEntry* batch, int P_frame, const Recs& recs,
                        int32_t* head, const float* d_feat, hipStream_t st) {
-    const unsigned wb = (unsigned)((P + 3) / 4);
-    if (b->D <= 256)
-        hipLaunchKernelGGL(fuse_kernel<1>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else if (b->D <= 512)
-        hipLaunchKernelGGL(fuse_kernel<2>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else if (b->D == 768)    // CLIP ViT-L: three full chunks (the full-width path: unconditional row accesses)
-        hipLaunchKernelGGL(fuse_kernel<3>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else if (b->D <= 1024)
-        hipLaunchKernelGGL(fuse_kernel<4>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
-    else if (b->D <= 1536)   // a fused visual | audio map (512 + 1024 columns, BASELINE config 5)
-        hipLaunchKernelGGL(fuse_kernel<6>, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, b->sum_feat,
-                           b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+    // batched launches run over the owners K2 compacted; single frames and the generic kernel: wave per sample
+    const bool compact = b->D <= 1536 && P >= kAggregateSamples;
+    const unsigned wb = compact ? (unsigned)((P + 255) / 256) * (kFuseWaves / 4) : (unsigned)((P + 3) / 4);
+#define AVL_FUSE_LAUNCH(CH)                                                                                                              \
+    do {                                                                                                                                 \
+        if (compact)                                                                                                                     \
+            hipLaunchKernelGGL((fuse_kernel<CH, true>), dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,  \
+                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, b->owners);                 \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
+                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, OwnerList{});               \
+    } while (0)
+    if (b->D <= 256) AVL_FUSE_LAUNCH(1);
+    else if (b->D <= 512) AVL_FUSE_LAUNCH(2);
+    else if (b->D == 768) AVL_FUSE_LAUNCH(3);      // CLIP ViT-L: three full chunks (the full-width path: unconditional row accesses)
+    else if (b->D <= 1024) AVL_FUSE_LAUNCH(4);
+    else if (b->D <= 1536) AVL_FUSE_LAUNCH(6);     // a fused visual | audio map (512 + 1024 columns, BASELINE config 5)
     else
         hipLaunchKernelGGL(fuse_generic_kernel, dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,
                            b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+#undef AVL_FUSE_LAUNCH
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }
@@ -1524,7 +1589,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     rc = flush_pending(b, st);
     if (rc != AVL_OK) return rc;
     hipLaunchKernelGGL(voxelize_link_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb,
-                       b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key);
+                       b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, b->owners);
     if (b->log.slot) b->log_used += P;
     return launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st);
 }
