@@ -44,6 +44,7 @@ _SIGS = {
     "avl_memcpy_d2d": (C.c_int, [_vp, _vp, _sz, _vp]),
     "avl_gather_rows": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "avl_scatter_rows": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "avl_rows_div_f32": (C.c_int, [_i64, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "avl_argsort_bits_work_bytes": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_sz)]),
     "avl_argsort_bits": (C.c_int, [_i64, _vp, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "avl_hbm_read_probe": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _vp]),

@@ -1933,6 +1933,41 @@ int avl_rows_add_f64_async(int64_t n, int cols, const int64_t* d_rows, int64_t r
     return AVL_OK;
 }
 
+// out[rows[i], :] = (float)(acc[i, :] / w[rows[i]]): the shared rows of a rank's block from their float64 sums -- finalize_kernel's
+// division -- without the (k, D) float64 and float32 temporaries of the tensor expression.  Wave per row.
+__global__ __launch_bounds__(256) void rows_div_f32_kernel(int64_t k, int D, const double* __restrict__ acc, const int64_t* __restrict__ rows,
+                                                           const double* __restrict__ w4, float* __restrict__ out, int64_t n_out,
+                                                           int* __restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < k; i += nwaves) {
+        const int64_t r = rows[i];
+        if (r < 0 || r >= n_out) {
+            if (lane == 0 && err_flag) atomicOr(err_flag, 1);
+            continue;
+        }
+        const double w = w4[r * 4];
+        const double* a = acc + i * D;
+        float* o = out + r * D;
+        for (int c = lane; c < D; c += 64) o[c] = (float)(a[c] / w);
+    }
+}
+
+int avl_rows_div_f32(int64_t k, int D, const double* d_acc, const int64_t* d_rows, const double* d_w4, float* d_out, int64_t n_out,
+                     int32_t* d_err_flag, void* stream) {
+    AVL_REQUIRE(k >= 0 && D > 0 && n_out >= 0, "avl_rows_div_f32: bad shape");
+    if (k == 0) return AVL_OK;
+    AVL_REQUIRE(d_acc && d_rows && d_w4 && d_out, "avl_rows_div_f32: null pointer");
+    int64_t blocks = (k + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(rows_div_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), k, D, d_acc, d_rows, d_w4, d_out, n_out,
+                       reinterpret_cast<int*>(d_err_flag));
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
 int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream) {
     AVL_REQUIRE(n >= 0, "avl_replay_state_apply: bad n");
     if (n == 0) return AVL_OK;

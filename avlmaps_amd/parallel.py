@@ -1185,7 +1185,10 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
             out["grid_feat"].index_copy_(0, done_rows, done_feat)
         tr3('copy done rows')
         if part_rows.numel():
-            out["grid_feat"].index_copy_(0, part_rows, (part_acc / w4[part_rows, :1]).float())
+            # (one kernel, no (k, D) float64 / float32 temporaries: the tensor expression's allocations were the erratic part of a
+            # rank's fold when eight processes share one device)
+            _lib.check(lib.avl_rows_div_f32(int(part_rows.shape[0]), D, part_acc.data_ptr(), part_rows.contiguous().data_ptr(), w4.data_ptr(),
+                                            out["grid_feat"].data_ptr(), n_own, err_flag.data_ptr(), st), "avl_rows_div_f32")
         tr3('divide shared rows')
         _lib.check(lib.avl_finalize_side(n_own, ex.r0, acc.gs, acc.vh, own_cell.data_ptr(), w4.data_ptr(), out["grid_pos"].data_ptr(),
                                          out["weight"].data_ptr(), out["grid_rgb"].data_ptr(), None, st), "avl_finalize_side")

@@ -423,6 +423,11 @@ AVL_API int avl_finalize_merged(int64_t n, int64_t row0, int D, int gs, int vh, 
  * vlmap_builder.py:286-311), or ~0 if the map is smaller.  avl_replay_state_apply writes weight / grid_rgb from the final state. */
 AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                                      void* stream);
+/* Shared rows of a rank's block of the merged map: row d_rows[i] of d_out (n_out x D float32) = (float)(d_acc[i, :] / d_w4[d_rows[i], 0]),
+ * i < k -- the division of finalize (vlmap_builder.py:172-174's running mean in closed form) applied to the float64 sums several
+ * ranks contributed to (avlmaps_amd/parallel.py).  An index outside [0, n_out) is skipped and sets bit 0 of *d_err_flag (nullable). */
+AVL_API int avl_rows_div_f32(int64_t k, int D, const double* d_acc, const int64_t* d_rows, const double* d_w4, float* d_out, int64_t n_out,
+                             int32_t* d_err_flag, void* stream);
 AVL_API int avl_replay_state_apply(int64_t n, const void* d_state, float* d_weight, uint8_t* d_grid_rgb, void* stream);
 /* Mixed payload of the row-sharded merge (round 4).  A voxel only ONE rank touched is finished where its accumulators live:
  * d_out[i, :D] = (float)((a1^2 first_feat[s] + sum_feat[s]) / sum alpha), s = d_slots[i] -- the float64 expression of the
