@@ -22,6 +22,7 @@ SOURCES = {
     "avl_heat.hip": [],
     "avl_map2d.hip": [],
     "avl_lseg.hip": [],
+    "avl_merge.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-munsafe-fp-atomics"]

@@ -554,6 +554,24 @@ def _argsort_bits(t, bits: int):
     return perm
 
 
+def _merge_hip(t):
+    """the fused kernels of the plan's local steps (csrc/avl_merge.hip) for device tensors; AVLMAPS_MERGE_KERNELS=0 keeps the tensor
+    code, which is also the CPU twin (gloo tests) and what the GPU tests compare the kernels with"""
+    if not t.is_cuda or os.environ.get("AVLMAPS_MERGE_KERNELS", "1") == "0":
+        return None
+    from . import _lib
+    return _lib.load()
+
+
+def _merge_work(lib, n, dev):
+    import ctypes as C
+    import torch
+    from . import _lib
+    nb = C.c_size_t()
+    _lib.check(lib.avl_merge_work_bytes(int(n), C.byref(nb)), "avl_merge_work_bytes")
+    return torch.empty(int(nb.value), dtype=torch.uint8, device=dev), int(nb.value)
+
+
 def _group_counts(sorted_ids, k: int, masks=()):
     """Histogram of a SORTED vector of group ids in [0, k) -- and, per boolean mask, how many of each group's elements have it
     set -- from the groups' boundaries (one searchsorted, a running sum per mask).  torch.bincount reads the largest value back
@@ -654,20 +672,40 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     plan = ShardPlan()
     plan.rank, plan.ws, plan.coll, plan.n = rank, ws, coll, n
     tr = _Trace('plan', dev)
-    cell64 = cell.to(i64)
-    tr('to i64')
-    dest = _dir_owner(cell64, ws)
-    tr('hash')
-    ordd = _argsort_bits(dest, max(1, (ws - 1).bit_length()))     # local slots grouped by directory rank (stable)
-    tr('argsort')
-    dest_o = dest[ordd]
-    sc, = _group_counts(dest_o, ws)
-    tr('bincount')
-    kmin = key.min().reshape(1) if n else torch.full((1,), I64_MAX, dtype=i64, device=dev)
-    kmax = key.max().reshape(1) if n else torch.full((1,), -1, dtype=i64, device=dev)
-    tr('minmax')
-    hv = torch.tensor([n] + [int(a) for a in aux], dtype=i64).to(dev)          # one small upload
-    head = torch.cat([sc, hv[:1], kmin, kmax, hv[1:]])
+    hip = _merge_hip(cell) if (ws <= 64 and cell.dtype == torch.int32) else None
+    st = None
+    if hip is not None:
+        from . import _lib
+        from .device import torch_stream_ptr
+        st = torch_stream_ptr()
+        cell = cell.contiguous()
+        key = key.contiguous()
+        # one entry point: directory rank of every voxel, the slots grouped by it (stable), their cells in that order, the counts
+        # and the key range (avl_merge_partition)
+        ordd = torch.empty(n, dtype=i64, device=dev)
+        cell_sorted = torch.empty(n, dtype=torch.int32, device=dev)
+        head0 = torch.empty(ws + 3, dtype=i64, device=dev)
+        work, wb = _merge_work(hip, n, dev)
+        _lib.check(hip.avl_merge_partition(n, cell.data_ptr(), key.data_ptr(), ws, ordd.data_ptr(), cell_sorted.data_ptr(), head0.data_ptr(),
+                                           work.data_ptr(), wb, st), "avl_merge_partition")
+        head = torch.cat([head0, torch.tensor([int(a) for a in aux], dtype=i64).to(dev)]) if len(aux) else head0
+        dest_o = None
+    else:
+        cell64 = cell.to(i64)
+        tr('to i64')
+        dest = _dir_owner(cell64, ws)
+        tr('hash')
+        ordd = _argsort_bits(dest, max(1, (ws - 1).bit_length()))     # local slots grouped by directory rank (stable)
+        tr('argsort')
+        dest_o = dest[ordd]
+        sc, = _group_counts(dest_o, ws)
+        tr('bincount')
+        kmin = key.min().reshape(1) if n else torch.full((1,), I64_MAX, dtype=i64, device=dev)
+        kmax = key.max().reshape(1) if n else torch.full((1,), -1, dtype=i64, device=dev)
+        tr('minmax')
+        hv = torch.tensor([n] + [int(a) for a in aux], dtype=i64).to(dev)          # one small upload
+        head = torch.cat([sc, hv[:1], kmin, kmax, hv[1:]])
+        cell_sorted = None
     tr('hash+sort+head')
     allh_d = torch.stack(gather(head))
     allh = allh_d.cpu()
@@ -685,46 +723,81 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     sc_l = allh[rank, :ws].tolist()
     rc_l = allh[:, rank].tolist()
     # 1. directory: (cell, source rank) order -> neighbouring contributors of every entry
-    recv = a2a(cell[ordd].contiguous(), sc_l, rc_l)
+    recv = a2a(cell_sorted if cell_sorted is not None else cell[ordd].contiguous(), sc_l, rc_l)
     R = int(recv.shape[0])
     plan.dir_entries = R
     tr('a2a cells')
-    # source rank of every arrival (arrivals are grouped by source): a search in the running sum of the counts, which are on the
-    # device already (repeat_interleave with a host-side count list cost 0.9 ms of a 4 ms plan at 2.25 M entries)
-    src = torch.bucketize(torch.arange(R, dtype=i64, device=dev), torch.cumsum(allh_d[:, rank], 0), right=True)
-    perm = torch.argsort(recv, stable=True)                      # arrival order is by source rank: stable = (cell, rank) order
-    cs, ss = recv[perm], src[perm]
-    first = torch.ones(R, dtype=torch.bool, device=dev)
-    lastm = torch.ones(R, dtype=torch.bool, device=dev)
-    if R > 1:
-        first[1:] = cs[1:] != cs[:-1]
-        lastm[:-1] = first[1:]
-    neg = torch.full((R,), -1, dtype=i64, device=dev)
-    prev_r = torch.empty(R, dtype=i64, device=dev)
-    next_r = torch.empty(R, dtype=i64, device=dev)
-    prev_r[perm] = torch.where(first, neg, torch.roll(ss, 1))
-    next_r[perm] = torch.where(lastm, neg, torch.roll(ss, -1))
-    tr('directory sort')
-    back = a2a(((prev_r + 1) | ((next_r + 1) << 16)).to(torch.int32), rc_l, sc_l).to(i64)
-    tr('a2a reply')
-    prev = torch.empty(n, dtype=i64, device=dev)
-    nxt = torch.empty(n, dtype=i64, device=dev)
-    prev[ordd] = (back & 0xFFFF) - 1
-    nxt[ordd] = (back >> 16) - 1
-    # 2. new voxels in key order; row bases
-    is_new = prev < 0
-    # The size of EVERY data-dependent list below -- my new voxels, the directory's distinct cells, the four lists of the two
-    # directory round trips -- rides on one tiny all_gather, so that no boolean mask is ever counted on the host (_mask_idx).
-    # The per-rank list sizes come from the group boundaries of the (sorted) rank vectors (_group_counts), not from histograms.
-    m3 = (is_new & (nxt >= 0))[ordd]                             # my new voxels that others share, in sending order
-    m4 = (~is_new)[ordd]                                         # my voxels whose row somebody else assigns
-    m3r = (prev_r < 0) & (next_r >= 0)
-    m4r = prev_r >= 0
-    _, n3, n4 = _group_counts(dest_o, ws, (m3, m4))              # my entries are grouped by directory rank,
-    _, n3r, n4r = _group_counts(src, ws, (m3r, m4r))             # the directory's arrivals by source rank
-    ranks = torch.arange(ws, dtype=i64, device=dev)
-    cnt = torch.cat([is_new.sum().reshape(1), first.sum().reshape(1), n3, n3r, n4r, n4,
-                     (prev[:, None] == ranks).sum(0), (nxt[:, None] == ranks).sum(0)]).to(i64)   # ... and the replay's hop sizes
+    if hip is not None:
+        # directory side in one entry point (avl_merge_dir_scan): (cell, source rank) order, the neighbours of every entry, the
+        # packed reply, the masks and counts of the two later round trips
+        recv = recv.contiguous()
+        perm = torch.empty(R, dtype=i64, device=dev)
+        first = torch.empty(R, dtype=torch.uint8, device=dev)
+        prev_r = torch.empty(R, dtype=i64, device=dev)
+        next_r = torch.empty(R, dtype=i64, device=dev)
+        reply = torch.empty(R, dtype=torch.int32, device=dev)
+        m3r = torch.empty(R, dtype=torch.uint8, device=dev)
+        m4r = torch.empty(R, dtype=torch.uint8, device=dev)
+        cnt_dir = torch.empty(2 * ws + 1, dtype=i64, device=dev)
+        work, wb = _merge_work(hip, R, dev)
+        _lib.check(hip.avl_merge_dir_scan(R, recv.data_ptr(), allh_d[:, rank].contiguous().data_ptr(), ws, 31, perm.data_ptr(), first.data_ptr(),
+                                          prev_r.data_ptr(), next_r.data_ptr(), reply.data_ptr(), m3r.data_ptr(), m4r.data_ptr(),
+                                          cnt_dir.data_ptr(), work.data_ptr(), wb, st), "avl_merge_dir_scan")
+        first, m3r, m4r = first.view(torch.bool), m3r.view(torch.bool), m4r.view(torch.bool)
+        tr('directory sort')
+        back = a2a(reply, rc_l, sc_l).contiguous()
+        tr('a2a reply')
+        # ... and home again (avl_merge_classify): prev / next / is_new per slot, the masks in sending order, every count
+        prev = torch.empty(n, dtype=i64, device=dev)
+        nxt = torch.empty(n, dtype=i64, device=dev)
+        is_new = torch.empty(n, dtype=torch.uint8, device=dev)
+        m3 = torch.empty(n, dtype=torch.uint8, device=dev)
+        m4 = torch.empty(n, dtype=torch.uint8, device=dev)
+        cnt_me = torch.empty(1 + 4 * ws, dtype=i64, device=dev)
+        _lib.check(hip.avl_merge_classify(n, back.data_ptr(), ordd.data_ptr(), cell_sorted.data_ptr(), ws, prev.data_ptr(), nxt.data_ptr(),
+                                          is_new.data_ptr(), m3.data_ptr(), m4.data_ptr(), cnt_me.data_ptr(), st), "avl_merge_classify")
+        is_new, m3, m4 = is_new.view(torch.bool), m3.view(torch.bool), m4.view(torch.bool)
+        cnt = torch.cat([cnt_me[0:1], cnt_dir[2 * ws:], cnt_me[1:1 + ws], cnt_dir[:ws], cnt_dir[ws:2 * ws], cnt_me[1 + ws:1 + 2 * ws],
+                         cnt_me[1 + 2 * ws:1 + 3 * ws], cnt_me[1 + 3 * ws:]])
+    else:
+        cnt = None
+    if cnt is None:
+        # source rank of every arrival (arrivals are grouped by source): a search in the running sum of the counts, which are on the
+        # device already (repeat_interleave with a host-side count list cost 0.9 ms of a 4 ms plan at 2.25 M entries)
+        src = torch.bucketize(torch.arange(R, dtype=i64, device=dev), torch.cumsum(allh_d[:, rank], 0), right=True)
+        perm = torch.argsort(recv, stable=True)                      # arrival order is by source rank: stable = (cell, rank) order
+        cs, ss = recv[perm], src[perm]
+        first = torch.ones(R, dtype=torch.bool, device=dev)
+        lastm = torch.ones(R, dtype=torch.bool, device=dev)
+        if R > 1:
+            first[1:] = cs[1:] != cs[:-1]
+            lastm[:-1] = first[1:]
+        neg = torch.full((R,), -1, dtype=i64, device=dev)
+        prev_r = torch.empty(R, dtype=i64, device=dev)
+        next_r = torch.empty(R, dtype=i64, device=dev)
+        prev_r[perm] = torch.where(first, neg, torch.roll(ss, 1))
+        next_r[perm] = torch.where(lastm, neg, torch.roll(ss, -1))
+        tr('directory sort')
+        back = a2a(((prev_r + 1) | ((next_r + 1) << 16)).to(torch.int32), rc_l, sc_l).to(i64)
+        tr('a2a reply')
+        prev = torch.empty(n, dtype=i64, device=dev)
+        nxt = torch.empty(n, dtype=i64, device=dev)
+        prev[ordd] = (back & 0xFFFF) - 1
+        nxt[ordd] = (back >> 16) - 1
+        # 2. new voxels in key order; row bases
+        is_new = prev < 0
+        # The size of EVERY data-dependent list below -- my new voxels, the directory's distinct cells, the four lists of the two
+        # directory round trips -- rides on one tiny all_gather, so that no boolean mask is ever counted on the host (_mask_idx).
+        # The per-rank list sizes come from the group boundaries of the (sorted) rank vectors (_group_counts), not from histograms.
+        m3 = (is_new & (nxt >= 0))[ordd]                             # my new voxels that others share, in sending order
+        m4 = (~is_new)[ordd]                                         # my voxels whose row somebody else assigns
+        m3r = (prev_r < 0) & (next_r >= 0)
+        m4r = prev_r >= 0
+        _, n3, n4 = _group_counts(dest_o, ws, (m3, m4))              # my entries are grouped by directory rank,
+        _, n3r, n4r = _group_counts(src, ws, (m3r, m4r))             # the directory's arrivals by source rank
+        ranks = torch.arange(ws, dtype=i64, device=dev)
+        cnt = torch.cat([is_new.sum().reshape(1), first.sum().reshape(1), n3, n3r, n4r, n4,
+                         (prev[:, None] == ranks).sum(0), (nxt[:, None] == ranks).sum(0)]).to(i64)   # ... and the replay's hop sizes
     tr('new voxels + counts')
     allc = torch.stack(gather(cnt)).cpu()
     tr('gather counts')

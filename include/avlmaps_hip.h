@@ -423,6 +423,33 @@ AVL_API int avl_finalize_merged(int64_t n, int64_t row0, int D, int gs, int vh, 
  * vlmap_builder.py:286-311), or ~0 if the map is smaller.  avl_replay_state_apply writes weight / grid_rgb from the final state. */
 AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                                      void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * The local steps of the multi-GPU merge plan (avlmaps_amd/parallel.py, plan_merge_directory): which final row -- the reference's
+ * voxel id, vlmap_builder.py:163-170 -- every voxel of every rank gets.  torch.distributed carries the collectives between them;
+ * each entry point replaces the 20-40 small tensor operations a rank ran between two collectives by a radix sort over the bits
+ * the keys have and one or two kernels (no host synchronisation inside).  At most 64 ranks.  d_work: caller-owned scratch of
+ * avl_merge_work_bytes(max(n, R)) bytes.
+ *   avl_merge_partition  local voxels -> directory ranks: d_ordd[n] = the slots grouped by directory rank (stable), d_cell_sorted[n] =
+ *                        their cells in that order (what the first all_to_all sends), d_head[ws + 3] = [voxels per directory
+ *                        rank | n | smallest first-touch key | largest]
+ *   avl_merge_dir_scan   directory side, the R cells that arrived (grouped by source rank; d_rc[ws] = how many from each): d_perm[R] =
+ *                        their (cell, source rank) order, d_first[R] = "first entry of its cell" in that order, and in ARRIVAL order
+ *                        d_prev_r / d_next_r[R] = the neighbouring contributors of the entry's cell (-1: none), d_reply[R] = both
+ *                        packed for the way back ((prev + 1) | (next + 1) << 16), d_m3r / d_m4r[R] = the masks of the two later
+ *                        round trips; d_cnt[2 ws + 1] = [m3r per source | m4r per source | distinct cells]
+ *   avl_merge_classify   back home, d_back[n] = the replies in sending order: d_prev / d_next[n] per slot, d_is_new[n] per slot,
+ *                        d_m3 / d_m4[n] in sending order, d_cnt[1 + 4 ws] = [new voxels | m3 per directory rank | m4 per directory
+ *                        rank | voxels per prev rank | voxels per next rank]
+ * ------------------------------------------------------------------------------------------------ */
+AVL_API int avl_merge_work_bytes(int64_t n, size_t* h_bytes);
+AVL_API int avl_merge_partition(int64_t n, const int32_t* d_cell, const int64_t* d_key, int ws, int64_t* d_ordd, int32_t* d_cell_sorted,
+                                int64_t* d_head, void* d_work, size_t work_bytes, void* stream);
+AVL_API int avl_merge_dir_scan(int64_t R, const int32_t* d_recv, const int64_t* d_rc, int ws, int cell_bits, int64_t* d_perm, uint8_t* d_first,
+                               int64_t* d_prev_r, int64_t* d_next_r, int32_t* d_reply, uint8_t* d_m3r, uint8_t* d_m4r, int64_t* d_cnt,
+                               void* d_work, size_t work_bytes, void* stream);
+AVL_API int avl_merge_classify(int64_t n, const int32_t* d_back, const int64_t* d_ordd, const int32_t* d_cell_sorted, int ws, int64_t* d_prev,
+                               int64_t* d_next, uint8_t* d_is_new, uint8_t* d_m3, uint8_t* d_m4, int64_t* d_cnt, void* stream);
+
 /* Shared rows of a rank's block of the merged map: row d_rows[i] of d_out (n_out x D float32) = (float)(d_acc[i, :] / d_w4[d_rows[i], 0]),
  * i < k -- the division of finalize (vlmap_builder.py:172-174's running mean in closed form) applied to the float64 sums several
  * ranks contributed to (avlmaps_amd/parallel.py).  An index outside [0, n_out) is skipped and sets bit 0 of *d_err_flag (nullable). */

@@ -179,3 +179,24 @@ def test_argsort_bits_is_torchs_stable_argsort(env):
     assert a.M == b.M == n and torch.equal(a.row_of_slot, b.row_of_slot) and torch.equal(a.prev, b.prev) and torch.equal(a.next, b.next)
     assert torch.equal(torch.sort(a.row_of_slot).values, torch.arange(n, device="cuda"))
     assert torch.equal(a.row_of_slot[torch.argsort(key)], torch.arange(n, device="cuda"))       # one rank: rows in key order
+
+
+def test_merge_plan_kernels_equal_the_tensor_code(env, monkeypatch):
+    """csrc/avl_merge.hip (avl_merge_partition / _dir_scan / _classify) against the tensor code of plan_merge_directory on the same
+    device tensors: every output of the plan identical -- one rank here; the N-rank builds of test_api_gpu run the kernels with
+    real neighbours and compare the merged map with the single-rank one"""
+    import torch
+    from avlmaps_amd import parallel
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n in (0, 1, 777, 200_003):
+        cell = torch.randperm(max(4 * n, 8), generator=g)[:n].to(torch.int32).cuda()
+        key = ((torch.randint(0, 50, (n,), generator=g) << 32) | torch.randperm(max(n, 1), generator=g)[:n]).cuda()
+        monkeypatch.setenv("AVLMAPS_MERGE_KERNELS", "1")
+        a = parallel.plan_merge_directory(cell, key, local=True, grow_row=n // 2, aux=(1, 0))
+        monkeypatch.setenv("AVLMAPS_MERGE_KERNELS", "0")
+        b = parallel.plan_merge_directory(cell, key, local=True, grow_row=n // 2, aux=(1, 0))
+        assert a.M == b.M == n and a.grow_key == b.grow_key and a.dir_entries == b.dir_entries and a.counts == b.counts
+        assert list(a.n_prev) == list(b.n_prev) and list(a.n_next) == list(b.n_next)
+        for f in ("row_of_slot", "is_new", "prev", "next"):
+            assert torch.equal(getattr(a, f), getattr(b, f)), (n, f)
+        assert np.array_equal(a.aux_all, b.aux_all)
