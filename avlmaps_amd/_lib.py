@@ -46,6 +46,10 @@ _SIGS = {
     "avl_scatter_rows": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "avl_rows_div_f32": (C.c_int, [_i64, C.c_int, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "avl_merge_work_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
+    "avl_merge_rows_work_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
+    "avl_merge_rows_new": (C.c_int, [_i64, _i64, _vp, _vp, C.c_int, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "avl_merge_dir_rows": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
+    "avl_merge_rows_other": (C.c_int, [_i64, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _vp]),
     "avl_merge_partition": (C.c_int, [_i64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_merge_dir_scan": (C.c_int, [_i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_merge_classify": (C.c_int, [_i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -11,6 +11,8 @@
 #include <cstdint>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "avl_common.h"
 
@@ -179,7 +181,73 @@ __global__ __launch_bounds__(256) void merge_classify_kernel(long long n, const 
     if (threadIdx.x == 0 && hnew) atomicAdd(&cnt[0], (unsigned long long)hnew);
 }
 
+// ---- second half of the plan: rows of the new voxels, and the two lists through which shared voxels learn theirs
+
+struct FlagToCount {
+    __device__ long long operator()(uint8_t v) const { return v ? 1 : 0; }
+};
+
+// row = -1 everywhere; the new voxels (is_new) compacted in slot order with their first-touch keys
+__global__ void merge_new_compact_kernel(long long n, const uint8_t* __restrict__ is_new, const long long* __restrict__ off,
+                                         const long long* __restrict__ key, long long* __restrict__ row, unsigned long long* __restrict__ ukeys,
+                                         long long* __restrict__ uidx) {
+    for (long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (long long)gridDim.x * blockDim.x) {
+        row[s] = -1;
+        if (is_new[s]) {
+            const long long j = off[s];
+            ukeys[j] = (unsigned long long)key[s];
+            uidx[j] = s;
+        }
+    }
+}
+
+__global__ void merge_new_rows_kernel(long long c, const long long* __restrict__ idx_new, long long base, long long* __restrict__ row) {
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < c; j += (long long)gridDim.x * blockDim.x) row[idx_new[j]] = base + j;
+}
+
+// out[off[i]] = src[via ? via[i] : i] for every flagged i (a compaction that keeps the order)
+__global__ void merge_compact_rows_kernel(long long n, const uint8_t* __restrict__ flag, const long long* __restrict__ off,
+                                          const long long* __restrict__ via, const long long* __restrict__ src, long long* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (flag[i]) out[off[i]] = src[via ? via[i] : i];
+}
+
+// dst[via[i]] = src[off[i]] for every flagged i (the reverse: a list in flag order placed back)
+__global__ void merge_place_rows_kernel(long long n, const uint8_t* __restrict__ flag, const long long* __restrict__ off,
+                                        const long long* __restrict__ via, const long long* __restrict__ src, long long* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (flag[i]) dst[via[i]] = src[off[i]];
+}
+
+__global__ void merge_head_pos_kernel(long long R, const uint8_t* __restrict__ first, long long* __restrict__ v) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < R; p += (long long)gridDim.x * blockDim.x) v[p] = first[p] ? p : 0;
+}
+
+// every directory entry gets the row its cell's FIRST contributor reported (-1 if that one has not: it is not a sender of list 3)
+__global__ void merge_propagate_kernel(long long R, const long long* __restrict__ perm, const long long* __restrict__ head_pos,
+                                       const uint8_t* __restrict__ m3r, const long long* __restrict__ off3r, const long long* __restrict__ recv3,
+                                       long long* __restrict__ row_r) {
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < R; p += (long long)gridDim.x * blockDim.x) {
+        const long long ah = perm[head_pos[p]];
+        row_r[perm[p]] = m3r[ah] ? recv3[off3r[ah]] : -1;
+    }
+}
+
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+
+static hipError_t scan_flags(void* tmp, size_t& tmp_bytes, const uint8_t* flags, long long* out, long long n, hipStream_t st) {
+    auto it = rocprim::make_transform_iterator(flags, FlagToCount{});
+    return rocprim::exclusive_scan(tmp, tmp_bytes, it, out, 0ll, (size_t)n, rocprim::plus<long long>(), st);
+}
+
+static hipError_t scan_max(void* tmp, size_t& tmp_bytes, const long long* in, long long* out, long long n, hipStream_t st) {
+    return rocprim::inclusive_scan(tmp, tmp_bytes, in, out, (size_t)n, rocprim::maximum<long long>(), st);
+}
+
+static hipError_t sort_u64_i64(void* tmp, size_t& tmp_bytes, const unsigned long long* k, unsigned long long* ko, const long long* v, long long* vo,
+                               long long n, int bits, hipStream_t st) {
+    return rocprim::radix_sort_pairs(tmp, tmp_bytes, k, ko, v, vo, (size_t)n, 0, bits, st);
+}
 
 static hipError_t sort_u32_i64(void* tmp, size_t& tmp_bytes, const uint32_t* k, uint32_t* ko, const long long* v, long long* vo, long long n,
                                int bits, hipStream_t st) {
@@ -287,6 +355,118 @@ int avl_merge_classify(int64_t n, const int32_t* d_back, const int64_t* d_ordd, 
     hipLaunchKernelGGL(merge_classify_kernel, dim3(grid_for(n)), dim3(256), 0, st, (long long)n, d_back, reinterpret_cast<const long long*>(d_ordd),
                        d_cell_sorted, ws, reinterpret_cast<long long*>(d_prev), reinterpret_cast<long long*>(d_next), d_is_new, d_m3, d_m4,
                        reinterpret_cast<unsigned long long*>(d_cnt));
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_merge_rows_work_bytes(int64_t n, size_t* h_bytes) {
+    AVL_REQUIRE(h_bytes && n >= 0 && n < (1ll << 31), "avl_merge_rows_work_bytes: bad arguments");
+    const long long m = n ? n : 1;
+    size_t t_scan = 0, t_max = 0, t_sort = 0;
+    AVL_HIP_CHECK(scan_flags(nullptr, t_scan, nullptr, nullptr, m, nullptr));
+    AVL_HIP_CHECK(scan_max(nullptr, t_max, nullptr, nullptr, m, nullptr));
+    AVL_HIP_CHECK(sort_u64_i64(nullptr, t_sort, nullptr, nullptr, nullptr, nullptr, m, 63, nullptr));
+    // [offsets | keys | sorted keys | indices | a second offset / row vector | rocPRIM's storage]
+    *h_bytes = 5 * al256((size_t)m * 8) + al256(std::max(std::max(t_scan, t_max), t_sort)) + 512;
+    return AVL_OK;
+}
+
+struct RowsWork {
+    long long *off, *idx, *aux;
+    unsigned long long *keys, *keys_out;
+    void* tmp;
+    size_t tmp_bytes;
+};
+
+static int carve_rows_work(int64_t n, void* d_work, size_t work_bytes, RowsWork& w, const char* who) {
+    size_t need = 0;
+    int rc = avl_merge_rows_work_bytes(n, &need);
+    if (rc != AVL_OK) return rc;
+    AVL_REQUIRE(d_work && work_bytes >= need, "%s: work buffer of %zu bytes, %zu needed (avl_merge_rows_work_bytes)", who, work_bytes, need);
+    const size_t b = al256((size_t)(n ? n : 1) * 8);
+    char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(d_work) + 255) / 256 * 256);
+    w.off = reinterpret_cast<long long*>(p); p += b;
+    w.keys = reinterpret_cast<unsigned long long*>(p); p += b;
+    w.keys_out = reinterpret_cast<unsigned long long*>(p); p += b;
+    w.idx = reinterpret_cast<long long*>(p); p += b;
+    w.aux = reinterpret_cast<long long*>(p); p += b;
+    w.tmp = p;
+    w.tmp_bytes = need - 512 - 5 * b;
+    return AVL_OK;
+}
+
+int avl_merge_rows_new(int64_t n, int64_t c, const uint8_t* d_is_new, const int64_t* d_key, int key_bits, int64_t base, const int64_t* d_ordd,
+                       const uint8_t* d_m3, int64_t n3, int64_t* d_row, int64_t* d_idx_new, int64_t* d_send3, void* d_work, size_t work_bytes,
+                       void* stream) {
+    AVL_REQUIRE(n >= 0 && c >= 0 && c <= n && n3 >= 0 && n3 <= n && key_bits >= 1 && key_bits <= 63, "avl_merge_rows_new: bad arguments");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_is_new && d_key && d_ordd && d_m3 && d_row && (c == 0 || d_idx_new) && (n3 == 0 || d_send3), "avl_merge_rows_new: null pointer");
+    hipStream_t st = as_stream(stream);
+    RowsWork w;
+    int rc = carve_rows_work(n, d_work, work_bytes, w, "avl_merge_rows_new");
+    if (rc != AVL_OK) return rc;
+    size_t tb = w.tmp_bytes;
+    AVL_HIP_CHECK(scan_flags(w.tmp, tb, d_is_new, w.off, n, st));
+    hipLaunchKernelGGL(merge_new_compact_kernel, dim3(grid_for(n)), dim3(256), 0, st, (long long)n, d_is_new, w.off,
+                       reinterpret_cast<const long long*>(d_key), reinterpret_cast<long long*>(d_row), w.keys, w.idx);
+    if (c > 0) {
+        // the rank's new voxels in first-touch-key order = their order among the final rows
+        tb = w.tmp_bytes;
+        AVL_HIP_CHECK(sort_u64_i64(w.tmp, tb, w.keys, w.keys_out, w.idx, reinterpret_cast<long long*>(d_idx_new), c, key_bits, st));
+        hipLaunchKernelGGL(merge_new_rows_kernel, dim3(grid_for(c)), dim3(256), 0, st, (long long)c, reinterpret_cast<const long long*>(d_idx_new),
+                           (long long)base, reinterpret_cast<long long*>(d_row));
+    }
+    if (n3 > 0) {
+        tb = w.tmp_bytes;
+        AVL_HIP_CHECK(scan_flags(w.tmp, tb, d_m3, w.off, n, st));
+        hipLaunchKernelGGL(merge_compact_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, (long long)n, d_m3, w.off,
+                           reinterpret_cast<const long long*>(d_ordd), reinterpret_cast<const long long*>(d_row), reinterpret_cast<long long*>(d_send3));
+    }
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_merge_dir_rows(int64_t R, const int64_t* d_recv3, const uint8_t* d_m3r, const uint8_t* d_first, const int64_t* d_perm,
+                       const uint8_t* d_m4r, int64_t n4, int64_t* d_send4, void* d_work, size_t work_bytes, void* stream) {
+    AVL_REQUIRE(R >= 0 && n4 >= 0 && n4 <= R, "avl_merge_dir_rows: bad arguments");
+    if (R == 0 || n4 == 0) return AVL_OK;
+    AVL_REQUIRE(d_m3r && d_first && d_perm && d_m4r && d_send4, "avl_merge_dir_rows: null pointer");
+    hipStream_t st = as_stream(stream);
+    RowsWork w;
+    int rc = carve_rows_work(R, d_work, work_bytes, w, "avl_merge_dir_rows");
+    if (rc != AVL_OK) return rc;
+    long long* off3r = w.off;
+    long long* head_pos = w.idx;
+    long long* row_r = w.aux;
+    long long* off4r = reinterpret_cast<long long*>(w.keys);
+    size_t tb = w.tmp_bytes;
+    AVL_HIP_CHECK(scan_flags(w.tmp, tb, d_m3r, off3r, R, st));
+    hipLaunchKernelGGL(merge_head_pos_kernel, dim3(grid_for(R)), dim3(256), 0, st, (long long)R, d_first, reinterpret_cast<long long*>(w.keys_out));
+    tb = w.tmp_bytes;
+    AVL_HIP_CHECK(scan_max(w.tmp, tb, reinterpret_cast<const long long*>(w.keys_out), head_pos, R, st));
+    hipLaunchKernelGGL(merge_propagate_kernel, dim3(grid_for(R)), dim3(256), 0, st, (long long)R, reinterpret_cast<const long long*>(d_perm), head_pos,
+                       d_m3r, off3r, reinterpret_cast<const long long*>(d_recv3), row_r);
+    tb = w.tmp_bytes;
+    AVL_HIP_CHECK(scan_flags(w.tmp, tb, d_m4r, off4r, R, st));
+    hipLaunchKernelGGL(merge_compact_rows_kernel, dim3(grid_for(R)), dim3(256), 0, st, (long long)R, d_m4r, off4r, (const long long*)nullptr, row_r,
+                       reinterpret_cast<long long*>(d_send4));
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_merge_rows_other(int64_t n, const uint8_t* d_m4, const int64_t* d_ordd, const int64_t* d_recv4, int64_t n4, int64_t* d_row, void* d_work,
+                         size_t work_bytes, void* stream) {
+    AVL_REQUIRE(n >= 0 && n4 >= 0 && n4 <= n, "avl_merge_rows_other: bad arguments");
+    if (n == 0 || n4 == 0) return AVL_OK;
+    AVL_REQUIRE(d_m4 && d_ordd && d_recv4 && d_row, "avl_merge_rows_other: null pointer");
+    hipStream_t st = as_stream(stream);
+    RowsWork w;
+    int rc = carve_rows_work(n, d_work, work_bytes, w, "avl_merge_rows_other");
+    if (rc != AVL_OK) return rc;
+    size_t tb = w.tmp_bytes;
+    AVL_HIP_CHECK(scan_flags(w.tmp, tb, d_m4, w.off, n, st));
+    hipLaunchKernelGGL(merge_place_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, (long long)n, d_m4, w.off, reinterpret_cast<const long long*>(d_ordd),
+                       reinterpret_cast<const long long*>(d_recv4), reinterpret_cast<long long*>(d_row));
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }

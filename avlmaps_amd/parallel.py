@@ -563,12 +563,12 @@ def _merge_hip(t):
     return _lib.load()
 
 
-def _merge_work(lib, n, dev):
+def _merge_work(lib, n, dev, rows=False):
     import ctypes as C
     import torch
     from . import _lib
     nb = C.c_size_t()
-    _lib.check(lib.avl_merge_work_bytes(int(n), C.byref(nb)), "avl_merge_work_bytes")
+    _lib.check((lib.avl_merge_rows_work_bytes if rows else lib.avl_merge_work_bytes)(int(n), C.byref(nb)), "avl_merge_work_bytes")
     return torch.empty(int(nb.value), dtype=torch.uint8, device=dev), int(nb.value)
 
 
@@ -809,23 +809,46 @@ def plan_merge_directory(cell: "torch.Tensor", first_key: "torch.Tensor", group=
     n_first = int(allc[rank, 1])
     s3, r3, s4, r4, plan.n_prev, plan.n_next = (allc[rank, 2 + k * ws:2 + (k + 1) * ws].tolist() for k in range(6))
     c = int(counts[rank])
-    idx_new = _mask_idx(is_new, c)
-    idx_new = idx_new[torch.argsort(key[idx_new])]
-    row = torch.full((n,), -1, dtype=i64, device=dev)
-    row[idx_new] = bases[rank] + torch.arange(c, dtype=i64, device=dev)
-    # 3. rows of shared voxels: first contributor -> directory -> the other contributors
-    recv3 = a2a(row[ordd[_mask_idx(m3, sum(s3))]].contiguous(), s3, r3)
-    tr('a2a first rows')
-    rowfirst_r = torch.full((R,), -1, dtype=i64, device=dev)
-    rowfirst_r[_mask_idx(m3r, sum(r3))] = recv3                  # both sides keep the order of the first all_to_all
-    seg = torch.cumsum(first.to(i64), 0) - 1
-    row_s = rowfirst_r[perm[_mask_idx(first, n_first)]][seg] if R else rowfirst_r
-    row_r = torch.empty(R, dtype=i64, device=dev)
-    row_r[perm] = row_s
-    tr('propagate')
-    recv4 = a2a(row_r[_mask_idx(m4r, sum(s4))].contiguous(), s4, r4)
-    row[ordd[_mask_idx(m4, sum(r4))]] = recv4
-    tr('a2a other rows')
+    if hip is not None:
+        # the second half in three entry points: my new voxels in key order and their rows + the rows I report (avl_merge_rows_new);
+        # the directory hands every entry its cell's first row (avl_merge_dir_rows); the rows I learn (avl_merge_rows_other)
+        u8 = lambda t: t.view(torch.uint8)
+        kbits = max(1, int(allh[:, ws + 2].max()).bit_length()) if n else 1
+        row = torch.empty(n, dtype=i64, device=dev)
+        idx_new = torch.empty(c, dtype=i64, device=dev)
+        send3 = torch.empty(int(sum(s3)), dtype=i64, device=dev)
+        work, wb = _merge_work(hip, max(n, R), dev, rows=True)
+        _lib.check(hip.avl_merge_rows_new(n, c, u8(is_new).data_ptr(), key.data_ptr(), min(kbits, 63), int(bases[rank]), ordd.data_ptr(),
+                                          u8(m3).data_ptr(), int(sum(s3)), row.data_ptr(), idx_new.data_ptr(), send3.data_ptr(),
+                                          work.data_ptr(), wb, st), "avl_merge_rows_new")
+        recv3 = a2a(send3, s3, r3).contiguous()
+        tr('a2a first rows')
+        send4 = torch.empty(int(sum(s4)), dtype=i64, device=dev)
+        _lib.check(hip.avl_merge_dir_rows(R, recv3.data_ptr(), u8(m3r).data_ptr(), u8(first).data_ptr(), perm.data_ptr(), u8(m4r).data_ptr(),
+                                          int(sum(s4)), send4.data_ptr(), work.data_ptr(), wb, st), "avl_merge_dir_rows")
+        tr('propagate')
+        recv4 = a2a(send4, s4, r4).contiguous()
+        _lib.check(hip.avl_merge_rows_other(n, u8(m4).data_ptr(), ordd.data_ptr(), recv4.data_ptr(), int(sum(r4)), row.data_ptr(),
+                                            work.data_ptr(), wb, st), "avl_merge_rows_other")
+        tr('a2a other rows')
+    else:
+        idx_new = _mask_idx(is_new, c)
+        idx_new = idx_new[torch.argsort(key[idx_new])]
+        row = torch.full((n,), -1, dtype=i64, device=dev)
+        row[idx_new] = bases[rank] + torch.arange(c, dtype=i64, device=dev)
+        # 3. rows of shared voxels: first contributor -> directory -> the other contributors
+        recv3 = a2a(row[ordd[_mask_idx(m3, sum(s3))]].contiguous(), s3, r3)
+        tr('a2a first rows')
+        rowfirst_r = torch.full((R,), -1, dtype=i64, device=dev)
+        rowfirst_r[_mask_idx(m3r, sum(r3))] = recv3                  # both sides keep the order of the first all_to_all
+        seg = torch.cumsum(first.to(i64), 0) - 1
+        row_s = rowfirst_r[perm[_mask_idx(first, n_first)]][seg] if R else rowfirst_r
+        row_r = torch.empty(R, dtype=i64, device=dev)
+        row_r[perm] = row_s
+        tr('propagate')
+        recv4 = a2a(row_r[_mask_idx(m4r, sum(s4))].contiguous(), s4, r4)
+        row[ordd[_mask_idx(m4, sum(r4))]] = recv4
+        tr('a2a other rows')
     plan.row_of_slot, plan.is_new, plan.prev, plan.next = row, is_new, prev, nxt
     # the key after which the reference's arrays have their post-growth dtypes (vlmap_builder.py:286-311)
     plan.grow_key = U64_ALL_ONES

@@ -440,8 +440,24 @@ AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d
  *   avl_merge_classify   back home, d_back[n] = the replies in sending order: d_prev / d_next[n] per slot, d_is_new[n] per slot,
  *                        d_m3 / d_m4[n] in sending order, d_cnt[1 + 4 ws] = [new voxels | m3 per directory rank | m4 per directory
  *                        rank | voxels per prev rank | voxels per next rank]
+ *   avl_merge_rows_new   after the count all_gather (c = this rank's new voxels, base = its first final row): d_idx_new[c] = the new
+ *                        voxels' slots in first-touch-key order (radix sort over key_bits), d_row[n] = base + position for them and
+ *                        -1 for the others, d_send3[n3] = the rows of the new voxels other ranks share, in sending order (d_m3)
+ *   avl_merge_dir_rows   directory side: d_recv3 = the rows that arrived for the d_m3r entries (arrival order); every entry of a cell
+ *                        inherits the row of the cell's first contributor; d_send4[n4] = those rows for the d_m4r entries
+ *   avl_merge_rows_other home: d_recv4[n4] = the rows of this rank's voxels whose first touch another rank holds (d_m4, sending
+ *                        order) -> d_row
+ *                        (scratch of these three: avl_merge_rows_work_bytes(max(n, R)))
  * ------------------------------------------------------------------------------------------------ */
 AVL_API int avl_merge_work_bytes(int64_t n, size_t* h_bytes);
+AVL_API int avl_merge_rows_work_bytes(int64_t n, size_t* h_bytes);
+AVL_API int avl_merge_rows_new(int64_t n, int64_t c, const uint8_t* d_is_new, const int64_t* d_key, int key_bits, int64_t base,
+                               const int64_t* d_ordd, const uint8_t* d_m3, int64_t n3, int64_t* d_row, int64_t* d_idx_new, int64_t* d_send3,
+                               void* d_work, size_t work_bytes, void* stream);
+AVL_API int avl_merge_dir_rows(int64_t R, const int64_t* d_recv3, const uint8_t* d_m3r, const uint8_t* d_first, const int64_t* d_perm,
+                               const uint8_t* d_m4r, int64_t n4, int64_t* d_send4, void* d_work, size_t work_bytes, void* stream);
+AVL_API int avl_merge_rows_other(int64_t n, const uint8_t* d_m4, const int64_t* d_ordd, const int64_t* d_recv4, int64_t n4, int64_t* d_row,
+                                 void* d_work, size_t work_bytes, void* stream);
 AVL_API int avl_merge_partition(int64_t n, const int32_t* d_cell, const int64_t* d_key, int ws, int64_t* d_ordd, int32_t* d_cell_sorted,
                                 int64_t* d_head, void* d_work, size_t work_bytes, void* stream);
 AVL_API int avl_merge_dir_scan(int64_t R, const int32_t* d_recv, const int64_t* d_rc, int ws, int cell_bits, int64_t* d_perm, uint8_t* d_first,
