@@ -53,6 +53,8 @@ _SIGS = {
     "avl_merge_partition": (C.c_int, [_i64, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_merge_dir_scan": (C.c_int, [_i64, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_merge_classify": (C.c_int, [_i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_merge_side_pack": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_merge_side_unpack": (C.c_int, [_i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "avl_argsort_bits_work_bytes": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_sz)]),
     "avl_argsort_bits": (C.c_int, [_i64, _vp, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "avl_hbm_read_probe": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _vp]),
@@ -106,6 +108,7 @@ _SIGS = {
     "avl_builder_scatter_merge": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "avl_finalize_merged": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),
+    "avl_builder_drop_replay_cache": (C.c_int, [_vp, _vp]),
     "avl_replay_state_apply": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_rows_add_f64": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "avl_rows_add_f64_async": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),

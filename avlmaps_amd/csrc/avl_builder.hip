@@ -933,6 +933,34 @@ __device__ __forceinline__ void replay_step(double& w, double (&c)[3], bool& sta
     }
 }
 
+// The updates [i0, i1) of one voxel, in order.  The state is a serial chain, the loads are not: kReplayAhead entries' index ->
+// {alpha, rgb, key} gathers are requested together (unconditionally: positions past the end re-read the last entry), so a long
+// segment pays one memory round trip per kReplayAhead entries instead of two per entry.
+#ifndef AVL_REPLAY_AHEAD
+#define AVL_REPLAY_AHEAD 4
+#endif
+constexpr int kReplayAhead = AVL_REPLAY_AHEAD;
+__device__ __forceinline__ void replay_walk(double& w, double (&c)[3], bool& started, long long i0, long long i1, const int32_t* __restrict__ order,
+                                            const ReplayLog& log, unsigned long long gkey) {
+    for (long long i = i0; i < i1; i += kReplayAhead) {
+        int32_t e[kReplayAhead];
+#pragma unroll
+        for (int k = 0; k < kReplayAhead; ++k) e[k] = order[i + k < i1 ? i + k : i1 - 1];
+        double a[kReplayAhead];
+        uint32_t v[kReplayAhead];
+        unsigned long long ky[kReplayAhead];
+#pragma unroll
+        for (int k = 0; k < kReplayAhead; ++k) {
+            a[k] = log.alpha[e[k]];
+            v[k] = log.rgb[e[k]];
+            ky[k] = log.key[e[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < kReplayAhead; ++k)
+            if (i + k < i1) replay_step(w, c, started, a[k], v[k], ky[k] > gkey);
+    }
+}
+
 // Thread per output row: replay the voxel's updates in the reference's order (the log is in key order, `order` is its stable
 // sort by slot).
 __global__ __launch_bounds__(256) void replay_rgb_kernel(int64_t n, long long gs2, const int32_t* __restrict__ perm,
@@ -945,10 +973,7 @@ __global__ __launch_bounds__(256) void replay_rgb_kernel(int64_t n, long long gs
         const int32_t sl = perm[r];
         double w = 0.0, c[3] = {0.0, 0.0, 0.0};
         bool started = false;
-        for (long long i = seg_start[sl]; i < seg_end[sl]; ++i) {
-            const int32_t e = order[i];
-            replay_step(w, c, started, log.alpha[e], log.rgb[e], log.key[e] > gkey);
-        }
+        replay_walk(w, c, started, seg_start[sl], seg_end[sl], order, log, gkey);
         if (started) {
             if (weight) weight[r] = (float)w;
             if (grid_rgb)
@@ -977,10 +1002,7 @@ __global__ __launch_bounds__(256) void replay_chain_kernel(int64_t n, unsigned l
         ReplayState& st = state[si];
         double w = st.w, c[3] = {(double)st.c[0], (double)st.c[1], (double)st.c[2]};
         bool started = st.started != 0;
-        for (long long i = seg_start[sl]; i < seg_end[sl]; ++i) {
-            const int32_t e = order[i];
-            replay_step(w, c, started, log.alpha[e], log.rgb[e], log.key[e] > gkey);
-        }
+        replay_walk(w, c, started, seg_start[sl], seg_end[sl], order, log, gkey);
         st.w = w;
         for (int k = 0; k < 3; ++k) st.c[k] = (float)c[k];
         st.started = started ? 1u : 0u;
@@ -1230,44 +1252,102 @@ static int grow_builder(avl_builder* b, int64_t want, hipStream_t st) {
     return AVL_OK;
 }
 
-// the key-ordered replay log, stably sorted by slot: order[i] = log position, [seg_start[s], seg_end[s]) = the run of slot s
-// predicate of the log compaction: the sample updated a voxel
-struct LogActive {
-    const uint32_t* slot;
-    __device__ bool operator()(int32_t i) const { return slot[i] != 0xFFFFFFFFu; }
-};
+// Compaction of the replay log to the entries that updated a voxel (slot != 0xFFFFFFFF), order kept: kLogParts contiguous parts,
+// one workgroup each -- count, one-workgroup scan of the counts, then every part writes its survivors' log position and slot behind
+// its offset (ballot ranks inside a wave, LDS across the four waves).  rocprim::select with a predicate over a counting iterator
+// took 0.92 ms for 78 M entries (0.43 GB of traffic); these three kernels read the slots twice and write 2 x 4 B per survivor.
+constexpr int kLogParts = 2048;
 
-__global__ void gather_u32_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, long long n, uint32_t* __restrict__ dst) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+__global__ __launch_bounds__(256) void log_count_kernel(const uint32_t* __restrict__ slot, long long L, long long chunk, int* __restrict__ counts) {
+    __shared__ int wsum[4];
+    const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < L ? lo + chunk : L;
+    int c = 0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) c += slot[i] != 0xFFFFFFFFu;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// the key-ordered replay log, stably sorted by slot: order[i] = log position, [seg_start[s], seg_end[s]) = the run of slot s.
+__global__ __launch_bounds__(1024) void log_offsets_kernel(const int* __restrict__ counts, long long* __restrict__ offsets, long long* __restrict__ total) {
+    __shared__ long long part[1024];
+    static_assert(kLogParts == 2048, "two parts per thread");
+    const int t = threadIdx.x;
+    const long long a = counts[2 * t], b = counts[2 * t + 1];
+    part[t] = a + b;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const long long before = part[t] - (a + b);
+    offsets[2 * t] = before;
+    offsets[2 * t + 1] = before + a;
+    if (t == 1023) *total = part[t];
+}
+
+__global__ __launch_bounds__(256) void log_compact_kernel(const uint32_t* __restrict__ slot, long long L, long long chunk,
+                                                          const long long* __restrict__ offsets, int32_t* __restrict__ active,
+                                                          uint32_t* __restrict__ active_slot) {
+    __shared__ int wsum[4];
+    const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < L ? lo + chunk : L;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long base = offsets[blockIdx.x];
+    for (long long i0 = lo; i0 < hi; i0 += 256) {                 // (chunk is a multiple of 256: a uniform trip count per workgroup)
+        const long long i = i0 + threadIdx.x;
+        const uint32_t sl = i < hi ? slot[i] : 0xFFFFFFFFu;
+        const bool keep = sl != 0xFFFFFFFFu;
+        const unsigned long long m = __ballot(keep);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 4; ++w) {
+            before += w < wave ? wsum[w] : 0;
+            all += wsum[w];
+        }
+        if (keep) {
+            active[base + before + rank] = (int32_t)i;
+            active_slot[base + before + rank] = sl;
+        }
+        base += all;
+        __syncthreads();
+    }
+}
+
+// The replay log sorted by voxel: `order` = the positions of the entries that updated a voxel, stably sorted by slot (the log is
+// in key order, so every voxel's run is in the reference's update order), [seg_start[s], seg_end[s]) = the run of slot s.
 // Only ~35 % of the sampled pixels update a voxel (depth mask, feature-image bounds): the log is first compacted to those
-// entries (rocprim::select keeps their order), and the radix sort only looks at the bits a slot index can have -- a third of
-// the entries and three of the four passes: 6.5 -> ~2 ms of a 12 ms finalisation at 2.25 M voxels / 78 M log entries.
+// entries, and the radix sort only looks at the bits a slot index can have -- a third of the entries and three of the four
+// passes (sorting all 78 M entries of a 10 000-frame log instead: 0.58 ms per pass against 0.22).
 struct LogSegments {
     uint32_t *active_slot = nullptr, *sorted_slot = nullptr;
     int32_t *active = nullptr, *order = nullptr;
     long long *seg_start = nullptr, *seg_end = nullptr, *d_count = nullptr;
-    void *tmp = nullptr, *tmp_sel = nullptr;
+    void* tmp = nullptr;
     char *block1 = nullptr, *block2 = nullptr;   // TWO pool allocations hold all of the above (a hipMallocAsync / hipFreeAsync pair costs
                                                  // ~90 us of host time: nine of them were most of a small rank's replay)
     static size_t al(size_t bytes) { return (bytes + 255) / 256 * 256; }
     int build(avl_builder* b, int64_t n, hipStream_t st) {
         const long long L = b->log_used;
-        size_t sel_bytes = 0, tmp_bytes = 0;
-        const LogActive pred{b->log.slot};
-        rocprim::counting_iterator<int32_t> first(0);
-        AVL_HIP_CHECK(rocprim::select(nullptr, sel_bytes, first, (int32_t*)nullptr, (long long*)nullptr, (size_t)L, pred, st));
-        const size_t b_active = al((size_t)L * sizeof(int32_t)), b_seg = al((size_t)n * sizeof(long long)), b_sel = al(sel_bytes ? sel_bytes : 16);
-        AVL_HIP_CHECK(hipMallocAsync((void**)&block1, b_active + 256 + 2 * b_seg + b_sel, st));
+        const long long chunk = ((L + kLogParts - 1) / kLogParts + 255) / 256 * 256;
+        size_t tmp_bytes = 0;
+        const size_t b_active = al((size_t)L * sizeof(int32_t)), b_seg = al((size_t)n * sizeof(long long));
+        const size_t b_counts = al(kLogParts * sizeof(int)), b_off = al(kLogParts * sizeof(long long));
+        AVL_HIP_CHECK(hipMallocAsync((void**)&block1, 2 * b_active + 256 + 2 * b_seg + b_counts + b_off, st));
         active = reinterpret_cast<int32_t*>(block1);
-        d_count = reinterpret_cast<long long*>(block1 + b_active);
-        seg_start = reinterpret_cast<long long*>(block1 + b_active + 256);
-        seg_end = reinterpret_cast<long long*>(block1 + b_active + 256 + b_seg);
-        tmp_sel = block1 + b_active + 256 + 2 * b_seg;
+        active_slot = reinterpret_cast<uint32_t*>(block1 + b_active);
+        d_count = reinterpret_cast<long long*>(block1 + 2 * b_active);
+        seg_start = reinterpret_cast<long long*>(block1 + 2 * b_active + 256);
+        seg_end = reinterpret_cast<long long*>(block1 + 2 * b_active + 256 + b_seg);
+        int* counts = reinterpret_cast<int*>(block1 + 2 * b_active + 256 + 2 * b_seg);
+        long long* offsets = reinterpret_cast<long long*>(block1 + 2 * b_active + 256 + 2 * b_seg + b_counts);
         AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, 2 * b_seg, st));
-        AVL_HIP_CHECK(rocprim::select(tmp_sel, sel_bytes, first, active, d_count, (size_t)L, pred, st));
+        hipLaunchKernelGGL(log_count_kernel, dim3(kLogParts), dim3(256), 0, st, b->log.slot, L, chunk, counts);
+        hipLaunchKernelGGL(log_offsets_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, d_count);
+        hipLaunchKernelGGL(log_compact_kernel, dim3(kLogParts), dim3(256), 0, st, b->log.slot, L, chunk, offsets, active, active_slot);
         long long La = 0;
         AVL_HIP_CHECK(hipMemcpyAsync(&La, d_count, sizeof(La), hipMemcpyDeviceToHost, st));
         AVL_HIP_CHECK(hipStreamSynchronize(st));
@@ -1278,14 +1358,11 @@ struct LogSegments {
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                                                     (size_t)La, 0, bits, st));
         const size_t b_ls = al(Ls * sizeof(uint32_t));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&block2, 3 * b_ls + al(tmp_bytes ? tmp_bytes : 16), st));
-        active_slot = reinterpret_cast<uint32_t*>(block2);
-        sorted_slot = reinterpret_cast<uint32_t*>(block2 + b_ls);
-        order = reinterpret_cast<int32_t*>(block2 + 2 * b_ls);
-        tmp = block2 + 3 * b_ls;
+        AVL_HIP_CHECK(hipMallocAsync((void**)&block2, 2 * b_ls + al(tmp_bytes ? tmp_bytes : 16), st));
+        sorted_slot = reinterpret_cast<uint32_t*>(block2);
+        order = reinterpret_cast<int32_t*>(block2 + b_ls);
+        tmp = block2 + 2 * b_ls;
         if (La > 0) {
-            hipLaunchKernelGGL(gather_u32_kernel, dim3((unsigned)std::min<long long>((La + 255) / 256, 8192)), dim3(256), 0, st, b->log.slot,
-                               active, La, active_slot);
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, active_slot, sorted_slot, active, order, (size_t)La, 0, bits, st));
             hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((La + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
                                La, (long long)n, seg_start, seg_end);
@@ -1844,6 +1921,12 @@ int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32
     return AVL_OK;
 }
 
+int avl_builder_drop_replay_cache(avl_builder* b, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_drop_replay_cache: null handle");
+    drop_log_segments(b, as_stream(stream));
+    return AVL_OK;
+}
+
 int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                              void* stream) {
     AVL_REQUIRE(b, "avl_builder_replay_chain: null handle");
@@ -1898,6 +1981,36 @@ __global__ __launch_bounds__(256) void rows_add_f64_kernel(int64_t n, int cols, 
     }
 }
 
+// the same for rows of a few columns (the four [alpha, alpha rgb] sums of a side record): a lane per element, not a wave per row
+__global__ __launch_bounds__(256) void rows_add_f64_narrow_kernel(int64_t n, int cols, const int64_t* __restrict__ rows, int64_t row0, int64_t nrows,
+                                                                  const double* __restrict__ src, int64_t ld_src, double* __restrict__ dst,
+                                                                  int64_t ld_dst, int* __restrict__ err_flag) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n * cols; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / cols;
+        const int c = (int)(t - i * cols);
+        const int64_t r = rows[i] - row0;
+        if (r < 0 || r >= nrows) {
+            if (c == 0 && err_flag) atomicOr(err_flag, 1);
+            continue;
+        }
+        dst[r * ld_dst + c] += src[i * ld_src + c];
+    }
+}
+
+static void launch_rows_add(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src, int64_t ld_src,
+                            double* d_dst, int64_t ld_dst, int* flag, hipStream_t st) {
+    const int64_t maxb = (int64_t)num_cus() * 16;
+    if (cols <= 16) {
+        const int64_t blocks = std::min<int64_t>((n * cols + 255) / 256, maxb);
+        hipLaunchKernelGGL(rows_add_f64_narrow_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, cols, d_rows, row0, nrows, d_src, ld_src, d_dst,
+                           ld_dst, flag);
+    } else {
+        const int64_t blocks = std::min<int64_t>((n + 3) / 4, maxb);
+        hipLaunchKernelGGL(rows_add_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, cols, d_rows, row0, nrows, d_src, ld_src, d_dst, ld_dst,
+                           flag);
+    }
+}
+
 int avl_rows_add_f64(int64_t n, int cols, const int64_t* d_rows, int64_t row0, int64_t nrows, const double* d_src, int64_t ld_src,
                      double* d_dst, int64_t ld_dst, void* stream) {
     AVL_REQUIRE(n >= 0 && cols > 0 && nrows >= 0 && ld_src >= cols && ld_dst >= cols, "avl_rows_add_f64: bad shape");
@@ -1907,11 +2020,7 @@ int avl_rows_add_f64(int64_t n, int cols, const int64_t* d_rows, int64_t row0, i
     int* flag = static_cast<int*>(avl::scratch(64));
     if (!flag) return AVL_ERR_HIP;
     AVL_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int), st));
-    int64_t blocks = (n + 3) / 4;
-    const int64_t maxb = (int64_t)num_cus() * 16;
-    if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(rows_add_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n, cols, d_rows, row0, nrows, d_src, ld_src, d_dst,
-                       ld_dst, flag);
+    launch_rows_add(n, cols, d_rows, row0, nrows, d_src, ld_src, d_dst, ld_dst, flag, st);
     int h = 0;
     AVL_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     AVL_HIP_CHECK(hipStreamSynchronize(st));
@@ -1924,11 +2033,7 @@ int avl_rows_add_f64_async(int64_t n, int cols, const int64_t* d_rows, int64_t r
     AVL_REQUIRE(n >= 0 && cols > 0 && nrows >= 0 && ld_src >= cols && ld_dst >= cols, "avl_rows_add_f64_async: bad shape");
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(d_rows && d_src && d_dst && d_err_flag, "avl_rows_add_f64_async: null pointer");
-    int64_t blocks = (n + 3) / 4;
-    const int64_t maxb = (int64_t)num_cus() * 16;
-    if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(rows_add_f64_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), n, cols, d_rows, row0, nrows, d_src, ld_src,
-                       d_dst, ld_dst, reinterpret_cast<int*>(d_err_flag));
+    launch_rows_add(n, cols, d_rows, row0, nrows, d_src, ld_src, d_dst, ld_dst, reinterpret_cast<int*>(d_err_flag), as_stream(stream));
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }

@@ -233,6 +233,58 @@ __global__ void merge_propagate_kernel(long long R, const long long* __restrict_
     }
 }
 
+// MixedExchange's side record of every local voxel, in final-row order: 64 B = [row | cell << 32 | single << 63, sum_w4 (4 x f64),
+// replay state (3 x i64), zeros unless next[voxel] < 0] -- four lanes per record, 16 B each (coalesced stores; the gathers by `order` are 32 / 24 B rows)
+__global__ void merge_side_pack_kernel(long long n, const long long* __restrict__ order, const long long* __restrict__ rows_sorted,
+                                       const uint8_t* __restrict__ single_sorted, const int32_t* __restrict__ cell,
+                                       const long long* __restrict__ w4, const long long* __restrict__ state, const long long* __restrict__ next,
+                                       long long* __restrict__ side) {
+    using i64x2 = __attribute__((ext_vector_type(2))) long long;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < 4 * n; t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t >> 2, o = order[i];
+        const int p = (int)(t & 3);
+        const bool st = state && (!next || next[o] < 0);      // only a voxel's LAST contributor (no higher rank holds it) sends its state
+        long long a, b;
+        if (p == 0) {
+            a = rows_sorted[i] | ((long long)cell[o] << 32) | (single_sorted[i] ? (long long)(1ull << 63) : 0ll);
+            b = w4[4 * o];
+        } else if (p == 1) {
+            a = w4[4 * o + 1];
+            b = w4[4 * o + 2];
+        } else if (p == 2) {
+            a = w4[4 * o + 3];
+            b = st ? state[3 * o] : 0ll;
+        } else {
+            a = st ? state[3 * o + 1] : 0ll;
+            b = st ? state[3 * o + 2] : 0ll;
+        }
+        *reinterpret_cast<i64x2*>(side + 2 * t) = i64x2{a, b};
+    }
+}
+
+// owner side: the records that arrived -> row (relative to the block, clamped), the block's cells, the final replay states (only a
+// voxel's LAST contributor sends one: `started` in the high half of the third word).  A row outside the block sets bit 0 of *err.
+__global__ void merge_side_unpack_kernel(long long R, const long long* __restrict__ side, long long r0, long long n_own, long long* __restrict__ rows,
+                                         int32_t* __restrict__ own_cell, long long* __restrict__ state, int* __restrict__ err) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (long long)gridDim.x * blockDim.x) {
+        const long long word = side[8 * i];
+        long long row = (word & 0xFFFFFFFFll) - r0;
+        if (row < 0 || row >= n_own) {
+            if (err) atomicOr(err, 1);
+            rows[i] = row < 0 ? 0 : (n_own > 0 ? n_own - 1 : 0);
+            continue;
+        }
+        rows[i] = row;
+        own_cell[row] = (int32_t)((word >> 32) & 0x7FFFFFFFll);
+        const long long s2 = side[8 * i + 7];
+        if (((unsigned long long)s2 >> 32) != 0) {
+            state[3 * row] = side[8 * i + 5];
+            state[3 * row + 1] = side[8 * i + 6];
+            state[3 * row + 2] = s2;
+        }
+    }
+}
+
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 
 static hipError_t scan_flags(void* tmp, size_t& tmp_bytes, const uint8_t* flags, long long* out, long long n, hipStream_t st) {
@@ -467,6 +519,31 @@ int avl_merge_rows_other(int64_t n, const uint8_t* d_m4, const int64_t* d_ordd, 
     AVL_HIP_CHECK(scan_flags(w.tmp, tb, d_m4, w.off, n, st));
     hipLaunchKernelGGL(merge_place_rows_kernel, dim3(grid_for(n)), dim3(256), 0, st, (long long)n, d_m4, w.off, reinterpret_cast<const long long*>(d_ordd),
                        reinterpret_cast<const long long*>(d_recv4), reinterpret_cast<long long*>(d_row));
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_merge_side_pack(int64_t n, const int64_t* d_order, const int64_t* d_rows_sorted, const uint8_t* d_single_sorted, const int32_t* d_cell,
+                        const double* d_w4, const int64_t* d_state, const int64_t* d_next, int64_t* d_side, void* stream) {
+    AVL_REQUIRE(n >= 0 && n < (1ll << 40), "avl_merge_side_pack: bad arguments");
+    if (n == 0) return AVL_OK;
+    AVL_REQUIRE(d_order && d_rows_sorted && d_single_sorted && d_cell && d_w4 && d_side, "avl_merge_side_pack: null pointer");
+    hipLaunchKernelGGL(merge_side_pack_kernel, dim3(grid_for(4 * n)), dim3(256), 0, as_stream(stream), (long long)n,
+                       reinterpret_cast<const long long*>(d_order), reinterpret_cast<const long long*>(d_rows_sorted), d_single_sorted, d_cell,
+                       reinterpret_cast<const long long*>(d_w4), reinterpret_cast<const long long*>(d_state), reinterpret_cast<const long long*>(d_next),
+                       reinterpret_cast<long long*>(d_side));
+    AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, int64_t n_own, int64_t* d_rows, int32_t* d_own_cell, int64_t* d_state,
+                          int* d_err_flag, void* stream) {
+    AVL_REQUIRE(R >= 0 && r0 >= 0 && n_own >= 0, "avl_merge_side_unpack: bad arguments");
+    if (R == 0) return AVL_OK;
+    AVL_REQUIRE(d_side && d_rows && d_own_cell && d_state, "avl_merge_side_unpack: null pointer");
+    hipLaunchKernelGGL(merge_side_unpack_kernel, dim3(grid_for(R)), dim3(256), 0, as_stream(stream), (long long)R,
+                       reinterpret_cast<const long long*>(d_side), (long long)r0, (long long)n_own, reinterpret_cast<long long*>(d_rows), d_own_cell,
+                       reinterpret_cast<long long*>(d_state), d_err_flag);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }

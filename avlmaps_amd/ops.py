@@ -358,6 +358,12 @@ class VoxelAccumulator:
     def has_replay_log(self):
         return self._has_log
 
+    def drop_replay_cache(self):
+        """forget the log sorted by voxel that avl_builder_replay_chain keeps until the next frame (bench.py: a second merge of the
+        same map should pay for the sort again)"""
+        from .device import torch_stream_ptr
+        _lib.check(_lib.load().avl_builder_drop_replay_cache(self._h, torch_stream_ptr()), "avl_builder_drop_replay_cache")
+
     def close(self):
         if getattr(self, "_h", None):
             try:

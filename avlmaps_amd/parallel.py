@@ -986,7 +986,7 @@ class MixedExchange:
         self.recv_all, self.recv_done, self.recv_part = (recv[:, k].tolist() for k in range(3))
 
 
-def _fold_mixed(plan, ex, D, side, done, part, rows_add, tr=None):
+def _fold_mixed(plan, ex, D, side, done, part, rows_add, tr=None, unpack=None):
     """owner side of the mixed exchange, shared by the device path and its torch twin: returns (own_cell, w4 (n_own, 4) f64,
     state (n_own, 3) i64, done_rows, done_feat, part_rows (k,), part_acc (k, D) f64, bad_rows (1,) int32 = some received row
     index lay outside the block) -- rows relative to this rank's block"""
@@ -996,15 +996,25 @@ def _fold_mixed(plan, ex, D, side, done, part, rows_add, tr=None):
     tr = tr or (lambda label: None)
     n_own = ex.r1 - ex.r0
     word = side[:, 0]
-    rows = (word & 0xFFFFFFFF) - ex.r0
-    # a row outside this rank's block would be a plan / exchange bug: never index with it (a device-side assert would take the
-    # process down before anybody could report it) -- clamp, and let the caller raise on EVERY rank (bad_rows)
-    bad_rows = ((rows < 0) | (rows >= n_own)).any().reshape(1).to(torch.int32) if rows.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
-    rows = rows.clamp(0, max(n_own - 1, 0))
-    own_cell = torch.zeros(max(n_own, 1), dtype=torch.int32, device=dev)
-    own_cell[rows] = ((word >> 32) & 0x7FFFFFFF).to(torch.int32)
-    own_cell = own_cell[:n_own]
-    tr('rows + cells')
+    if unpack is not None:                          # device path: one kernel (avl_merge_side_unpack; bad rows go to its error flag)
+        rows, own_cell, state = unpack(side)
+        bad_rows = torch.zeros(1, dtype=torch.int32, device=dev)
+    else:
+        rows = (word & 0xFFFFFFFF) - ex.r0
+        # a row outside this rank's block would be a plan / exchange bug: never index with it (a device-side assert would take the
+        # process down before anybody could report it) -- clamp, and let the caller raise on EVERY rank (bad_rows)
+        bad_rows = ((rows < 0) | (rows >= n_own)).any().reshape(1).to(torch.int32) if rows.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+        rows = rows.clamp(0, max(n_own - 1, 0))
+        own_cell = torch.zeros(max(n_own, 1), dtype=torch.int32, device=dev)
+        own_cell[rows] = ((word >> 32) & 0x7FFFFFFF).to(torch.int32)
+        own_cell = own_cell[:n_own]
+        st = side[:, 5:8]
+        fin = (st[:, 2] >> 32) != 0                 # `started` of the 24-byte state: only a voxel's LAST contributor sends it
+        # (no boolean-mask indexing here: every mask would be counted on the host.  States that are not final land in one spare row)
+        state = torch.zeros((max(n_own, 1) + 1, 3), dtype=i64, device=dev)
+        state[torch.where(fin, rows, torch.full_like(rows, max(n_own, 1)))] = st
+        state = state[:max(n_own, 1)]
+    tr('rows + cells + states')
     w4 = torch.zeros((max(n_own, 1), 4), dtype=torch.float64, device=dev)
     o = 0
     for c in ex.recv_all:                           # peer by peer, in rank order: a reproducible float64 sum
@@ -1012,17 +1022,11 @@ def _fold_mixed(plan, ex, D, side, done, part, rows_add, tr=None):
             rows_add(rows[o:o + c], side[o:o + c, 1:5].view(torch.float64), w4)
         o += c
     tr('w4 adds')
-    st = side[:, 5:8]
-    fin = (st[:, 2] >> 32) != 0                     # `started` of the 24-byte state: only a voxel's LAST contributor sends it
-    # (no boolean-mask indexing here: every mask would be counted on the host.  States that are not final land in one spare row)
-    state = torch.zeros((max(n_own, 1) + 1, 3), dtype=i64, device=dev)
-    state[torch.where(fin, rows, torch.full_like(rows, max(n_own, 1)))] = st
-    state = state[:max(n_own, 1)]
     # rows of the two feature lists: the side list of a peer is in final-row order, and so are its done / part sublists
     single_flag = (word >> 63) != 0                 # bit 63 of the word: the voxel travelled as a finished row
     done_rows = rows[_mask_idx(single_flag, sum(ex.recv_done))]
     part_rows_all = rows[_mask_idx(~single_flag, sum(ex.recv_part))]
-    tr('state + lists')
+    tr('lists')
     part_rows, inv = (torch.unique(part_rows_all, return_inverse=True) if part_rows_all.numel() else
                       (part_rows_all, part_rows_all))
     tr('unique')
@@ -1139,6 +1143,10 @@ def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: 
             import sys
             prof.__exit__(None, None, None)
             print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40), file=sys.stderr, flush=True)
+            try:
+                print(prof.key_averages().table(sort_by="self_device_time_total", row_limit=60, max_name_column_width=110), file=sys.stderr, flush=True)
+            except Exception:       # (older torch: the key is self_cuda_time_total)
+                print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=110), file=sys.stderr, flush=True)
 
 
 def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_to, status, glock):
@@ -1222,18 +1230,16 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
             idx = torch.where(sel, ar, minus).contiguous()
             _lib.check(lib.avl_builder_replay_chain(acc._h, n, idx.data_ptr(), plan.grow_key, stt.data_ptr(), st), "avl_builder_replay_chain")
         state = chain_replay(plan, cell, replay_fn, tr2 := _Trace('replay', dev, coll))
-        state = torch.where((plan.next < 0)[:, None], state, torch.zeros_like(state))
-        tr2('final mask')
-        tr2.done(plan.rank)
+        tr2.done(plan.rank)               # (only a voxel's last contributor sends its state: avl_merge_side_pack looks at plan.next)
     chain_bytes = (coll.bytes_out - chain_bytes0) if coll is not None else 0
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     c3 = coll.comm_s if coll is not None else 0.0
     lw3 = glock.wait_s
     side = torch.empty((n, 8), dtype=i64, device=dev)
-    side[:, 0] = ex.rows_sorted | (cell[ex.order].to(i64) << 32) | (single.to(i64) << 63)
-    side[:, 1:5] = w4_loc[:n][ex.order].view(i64)
-    side[:, 5:8] = state[ex.order]
+    _lib.check(lib.avl_merge_side_pack(n, ex.order.contiguous().data_ptr(), ex.rows_sorted.data_ptr(), single.contiguous().view(torch.uint8).data_ptr(),
+                                       cell.data_ptr(), w4_loc.data_ptr(), state.contiguous().data_ptr() if have_log else None,
+                                       plan.next.contiguous().data_ptr(), side.data_ptr(), st), "avl_merge_side_pack")
     if coll is not None:
         side = coll.all_to_all(side, ex.send_all, ex.recv_all)
         done = coll.all_to_all(done[:n_done], ex.send_done, ex.recv_done)
@@ -1250,12 +1256,21 @@ def _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_
     err_flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def rows_add(rows, src, dst):
-        src = src.contiguous()
+        if src.stride(1) != 1:
+            src = src.contiguous()                  # (a column window of wider rows goes as it is: ld = its row stride)
         rows = rows.contiguous()
         _lib.check(lib.avl_rows_add_f64_async(int(rows.shape[0]), int(src.shape[1]), rows.data_ptr(), 0, int(dst.shape[0]), src.data_ptr(),
-                                              int(src.shape[1]), dst.data_ptr(), int(dst.shape[1]), err_flag.data_ptr(), st), "avl_rows_add_f64_async")
+                                              int(src.stride(0)), dst.data_ptr(), int(dst.shape[1]), err_flag.data_ptr(), st), "avl_rows_add_f64_async")
     tr3 = _Trace('fold', dev, coll)
-    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc, bad_rows = _fold_mixed(plan, ex, D, side, done, part, rows_add, tr3)
+    def unpack(side):
+        R = int(side.shape[0])
+        rows = torch.empty((R,), dtype=i64, device=dev)
+        own_cell = torch.zeros(max(n_own, 1), dtype=torch.int32, device=dev)
+        own_state = torch.zeros((max(n_own, 1), 3), dtype=i64, device=dev)
+        _lib.check(lib.avl_merge_side_unpack(R, side.data_ptr(), ex.r0, n_own, rows.data_ptr(), own_cell.data_ptr(), own_state.data_ptr(),
+                                             err_flag.data_ptr(), st), "avl_merge_side_unpack")
+        return rows, own_cell[:n_own], own_state
+    own_cell, w4, own_state, done_rows, done_feat, part_rows, part_acc, bad_rows = _fold_mixed(plan, ex, D, side, done, part, rows_add, tr3, unpack)
     # every rank learns whether ANY rank saw a bad row and raises with it: a rank raising alone would leave the others in
     # gather_row_shards' collectives
     err_flag = torch.maximum(err_flag, bad_rows.to(err_flag.device))

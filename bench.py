@@ -777,7 +777,9 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         torch.cuda.empty_cache()
         single_gpu_merge = {}
         merge_ranks(parallel, acc, mode, exact_rgb)            # untimed: torch's sort kernels, RCCL's communicator (forced collectives),
-        merge_ranks(parallel, acc, mode, exact_rgb, timings=single_gpu_merge)      # and the allocator's first multi-GB blocks
+        if exact_rgb:                                          # and the allocator's first multi-GB blocks
+            acc.drop_replay_cache()                            # (the timed merge sorts the replay log itself, as a merge that runs once does)
+        merge_ranks(parallel, acc, mode, exact_rgb, timings=single_gpu_merge)
         t_fin = time.perf_counter()
         acc.finalize(as_torch=True)
         torch.cuda.synchronize()

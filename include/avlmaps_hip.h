@@ -423,6 +423,9 @@ AVL_API int avl_finalize_merged(int64_t n, int64_t row0, int D, int gs, int vh, 
  * vlmap_builder.py:286-311), or ~0 if the map is smaller.  avl_replay_state_apply writes weight / grid_rgb from the final state. */
 AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                                      void* stream);
+/* The log sorted by voxel is kept between avl_builder_replay_chain calls until the next frame is fused (a merge calls it twice);
+ * this drops it, so that a caller timing a merge twice on the same map pays for the sort both times (bench.py). */
+AVL_API int avl_builder_drop_replay_cache(avl_builder* b, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * The local steps of the multi-GPU merge plan (avlmaps_amd/parallel.py, plan_merge_directory): which final row -- the reference's
  * voxel id, vlmap_builder.py:163-170 -- every voxel of every rank gets.  torch.distributed carries the collectives between them;
@@ -465,6 +468,22 @@ AVL_API int avl_merge_dir_scan(int64_t R, const int32_t* d_recv, const int64_t* 
                                void* d_work, size_t work_bytes, void* stream);
 AVL_API int avl_merge_classify(int64_t n, const int32_t* d_back, const int64_t* d_ordd, const int32_t* d_cell_sorted, int ws, int64_t* d_prev,
                                int64_t* d_next, uint8_t* d_is_new, uint8_t* d_m3, uint8_t* d_m4, int64_t* d_cnt, void* stream);
+
+/* The 64-byte side record every local voxel sends to the owner of its final row (avlmaps_amd/parallel.py: MixedExchange):
+ * [row | cell << 32 | single << 63, sum_w4 (4 x f64), replay state (3 x i64)].
+ *   avl_merge_side_pack    sender: record i (final-row order) from voxel d_order[i]: d_rows_sorted[i], d_single_sorted[i] (by position),
+ *                          d_cell / d_w4 (n x 4) / d_state (n x 3, nullable = zeros; sent only where d_next[voxel] < 0,
+ *                          d_next nullable = everywhere) (by voxel) -> d_side (n x 8 int64)
+ *   avl_merge_side_unpack  owner: R records that arrived -> d_rows[i] = row - r0 (clamped into the block), d_own_cell[row] = cell,
+ *                          d_state[row] = the state of the voxel's LAST contributor (`started` != 0); d_own_cell (n_own) and
+ *                          d_state (n_own x 3) are zeroed by the caller.  A row outside [r0, r0 + n_own) is skipped and sets
+ *                          bit 0 of *d_err_flag (nullable).
+ * The reference has no such step (one process, one map: vlmap_builder.py:136-178); it is part of the N-rank merge of north_star. */
+AVL_API int avl_merge_side_pack(int64_t n, const int64_t* d_order, const int64_t* d_rows_sorted, const uint8_t* d_single_sorted,
+                                const int32_t* d_cell, const double* d_w4, const int64_t* d_state, const int64_t* d_next, int64_t* d_side,
+                                void* stream);
+AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, int64_t n_own, int64_t* d_rows, int32_t* d_own_cell,
+                                  int64_t* d_state, int* d_err_flag, void* stream);
 
 /* Shared rows of a rank's block of the merged map: row d_rows[i] of d_out (n_out x D float32) = (float)(d_acc[i, :] / d_w4[d_rows[i], 0]),
  * i < k -- the division of finalize (vlmap_builder.py:172-174's running mean in closed form) applied to the float64 sums several

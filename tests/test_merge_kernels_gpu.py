@@ -200,3 +200,61 @@ def test_merge_plan_kernels_equal_the_tensor_code(env, monkeypatch):
         for f in ("row_of_slot", "is_new", "prev", "next"):
             assert torch.equal(getattr(a, f), getattr(b, f)), (n, f)
         assert np.array_equal(a.aux_all, b.aux_all)
+
+
+def test_side_records_pack_and_unpack_equal_the_tensor_code(env):
+    """avl_merge_side_pack / avl_merge_side_unpack against the tensor expressions of merge_raw_sharded / _fold_mixed (the CPU twin
+    of the device merge): the 64-byte records, and what an owner reads out of them; plus the narrow rows_add on a column window"""
+    import torch
+    _lib, lib, ops, DeviceArray = env
+    i64 = torch.int64
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for n in (1, 5, 1000, 70_001):
+        order = torch.randperm(n, generator=g).cuda()
+        rows_sorted = (torch.sort(torch.randperm(3 * n, generator=g)[:n]).values + 40).cuda()
+        single = (torch.rand(n, generator=g) < 0.6).cuda()
+        cell = torch.randint(0, 2**31 - 1, (n,), generator=g, dtype=torch.int32).cuda()
+        w4 = torch.randn((n, 4), generator=g, dtype=torch.float64).cuda()
+        state = torch.randint(-2**62, 2**62, (n, 3), generator=g, dtype=i64).cuda()
+        state[:, 2] |= 1 << 32                                      # started
+        nxt = torch.where(torch.rand(n, generator=g) < 0.5, -1, 3).to(i64).cuda()
+        for have_state, have_next in ((True, True), (True, False), (False, True)):
+            side = torch.full((n, 8), -7, dtype=i64, device="cuda")
+            _lib.check(lib.avl_merge_side_pack(n, order.data_ptr(), rows_sorted.data_ptr(), single.view(torch.uint8).data_ptr(), cell.data_ptr(),
+                                               w4.data_ptr(), state.data_ptr() if have_state else None, nxt.data_ptr() if have_next else None,
+                                               side.data_ptr(), None), "side_pack")
+            st = state if have_state else torch.zeros_like(state)
+            if have_next:
+                st = torch.where((nxt < 0)[:, None], st, torch.zeros_like(st))
+            want = torch.empty((n, 8), dtype=i64, device="cuda")
+            want[:, 0] = rows_sorted | (cell[order].to(i64) << 32) | (single.to(i64) << 63)
+            want[:, 1:5] = w4[order].view(i64)
+            want[:, 5:8] = st[order]
+            assert torch.equal(side, want), (n, have_state, have_next)
+        # owner side: a block [r0, r0 + n_own) that holds every row but the last two records' (those must raise the flag)
+        r0, n_own = 40, int(rows_sorted[max(n - 3, 0)].item()) - 40 + 1 if n > 2 else 3 * n + 1
+        rows = torch.full((n,), -5, dtype=i64, device="cuda")
+        own_cell = torch.zeros(n_own, dtype=torch.int32, device="cuda")
+        own_state = torch.zeros((n_own, 3), dtype=i64, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(lib.avl_merge_side_unpack(n, side.data_ptr(), r0, n_own, rows.data_ptr(), own_cell.data_ptr(), own_state.data_ptr(),
+                                             flag.data_ptr(), None), "side_unpack")
+        word = side[:, 0]
+        rel = (word & 0xFFFFFFFF) - r0
+        ok = (rel >= 0) & (rel < n_own)
+        assert int(flag.item()) == int((~ok).any().item())
+        assert torch.equal(rows, rel.clamp(0, n_own - 1))
+        want_cell = torch.zeros_like(own_cell)
+        want_cell[rel[ok]] = ((word[ok] >> 32) & 0x7FFFFFFF).to(torch.int32)
+        want_state = torch.zeros_like(own_state)
+        fin = ok & ((side[:, 7] >> 32) != 0)
+        want_state[rel[fin]] = side[fin][:, 5:8]
+        assert torch.equal(own_cell, want_cell) and torch.equal(own_state, want_state)
+        # the four sums of the records, added straight out of the (n, 8) buffer (ld = 8)
+        dst = torch.zeros((n_own, 4), dtype=torch.float64, device="cuda")
+        k = int(ok.sum().item())
+        src = side[:, 1:5].view(torch.float64)
+        _lib.check(lib.avl_rows_add_f64_async(k, 4, rows.data_ptr(), 0, n_own, src.data_ptr(), 8, dst.data_ptr(), 4, flag.data_ptr(), None), "rows_add")
+        want = torch.zeros_like(dst)
+        want[rel[:k]] = src[:k]
+        assert torch.equal(dst, want)
