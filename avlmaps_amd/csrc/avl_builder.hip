@@ -657,8 +657,21 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
     }
 }
 
+#ifndef AVL_K3_WPE
+#define AVL_K3_WPE 0
+#endif
+#if AVL_K3_WPE
+#define AVL_K3_OCC(CH) __attribute__((amdgpu_waves_per_eu((CH) <= 2 ? AVL_K3_WPE : 1)))
+#else
+#define AVL_K3_OCC(CH)
+#endif
+
+#ifndef AVL_K3_THREADS
+#define AVL_K3_THREADS 256      // wave-per-sample K3 launches (single frames): threads per workgroup
+#endif
+
 template <int CH, bool COMPACT>
-__global__ __launch_bounds__(256) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
+__global__ __launch_bounds__(COMPACT ? 256 : AVL_K3_THREADS) AVL_K3_OCC(CH) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                                    double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
@@ -679,7 +692,7 @@ struct FusePrev {
 };
 
 template <int CH>
-__global__ __launch_bounds__(256) void pipe_kernel(FrameParams fp, int pb, const float* depth, const int32_t* __restrict__ sample_idx,
+__global__ __launch_bounds__(AVL_K3_THREADS) AVL_K3_OCC(CH) void pipe_kernel(FrameParams fp, int pb, const float* depth, const int32_t* __restrict__ sample_idx,
                                                    const uint8_t* rgb, int32_t* __restrict__ cell_slot, int32_t* __restrict__ slot_cell,
                                                    Recs recs, int32_t* __restrict__ head, unsigned long long* __restrict__ counters,
                                                    int* __restrict__ err_flags, ReplayLog log, long long log_base,
@@ -1391,14 +1404,15 @@ static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, cons
                        int32_t* head, const float* d_feat, hipStream_t st) {
     // batched launches run over the owners K2 compacted; single frames and the generic kernel: wave per sample
     const bool compact = b->D <= 1536 && P >= kAggregateSamples;
-    const unsigned wb = compact ? (unsigned)((P + 255) / 256) * (kFuseWaves / 4) : (unsigned)((P + 3) / 4);
+    constexpr int kWaves = AVL_K3_THREADS / 64;
+    const unsigned wb = compact ? (unsigned)((P + 255) / 256) * (kFuseWaves / 4) : (unsigned)((P + kWaves - 1) / kWaves);
 #define AVL_FUSE_LAUNCH(CH)                                                                                                              \
     do {                                                                                                                                 \
         if (compact)                                                                                                                     \
             hipLaunchKernelGGL((fuse_kernel<CH, true>), dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,  \
                                b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, b->owners);                 \
         else                                                                                                                             \
-            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
+            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb), dim3(AVL_K3_THREADS), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
                                b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, OwnerList{});               \
     } while (0)
     if (b->D <= 256) AVL_FUSE_LAUNCH(1);
@@ -1425,8 +1439,9 @@ static int flush_pending(avl_builder* b, hipStream_t st) {
 template <int CH>
 static void launch_pipe(avl_builder* b, const FrameParams& fp, unsigned pb, const void* d_depth, const int32_t* d_sample_idx,
                         const uint8_t* d_rgb, unsigned long long frame_key, const FusePrev& prev, hipStream_t st) {
-    const unsigned wb = prev.P ? (unsigned)((prev.P + 3) / 4) : 0u;
-    hipLaunchKernelGGL(pipe_kernel<CH>, dim3(pb + wb), dim3(256), 0, st, fp, (int)pb, reinterpret_cast<const float*>(d_depth), d_sample_idx,
+    constexpr int kWaves = AVL_K3_THREADS / 64;
+    const unsigned wb = prev.P ? (unsigned)((prev.P + kWaves - 1) / kWaves) : 0u;
+    hipLaunchKernelGGL(pipe_kernel<CH>, dim3(pb + wb), dim3(AVL_K3_THREADS), 0, st, fp, (int)pb, reinterpret_cast<const float*>(d_depth), d_sample_idx,
                        d_rgb, b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, prev,
                        b->D, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
 }
@@ -1649,6 +1664,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     if (b->deferred && B == 0 && b->D <= 1536) {
         // ONE launch: K1 + K2 of this frame next to K3 of the previous one; this frame's K3 rides in the next launch (or a flush)
         const FusePrev prev{b->pend.P, b->pend.frame_key, b->recs_alt, b->head_alt, b->pend.feat};
+        const unsigned pb = (unsigned)((P + AVL_K3_THREADS - 1) / AVL_K3_THREADS);      // (its K1 + K2 workgroups have the kernel's size)
         if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
         else if (b->D == 768) launch_pipe<3>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
