@@ -118,10 +118,11 @@ constexpr int kAggregateSamples = 32768;   // launches at least this large alloc
 constexpr unsigned long long kNoKey = ~0ull;
 constexpr int kMaxPendingSpins = 1 << 18;   // link step of a deferred-fuse launch: polls of a cell that is being created
 
-__device__ __forceinline__ long long py_int(double v) {
-    // Python int(): truncate toward zero.  Saturate far-out values (they are out of range anyway).
-    if (!(v > -4.0e18 && v < 4.0e18)) return v > 0 ? (long long)4e18 : (long long)-4e18;
-    return (long long)v;  // C conversion truncates
+__device__ __forceinline__ int py_int(double v) {
+    // Python int(): truncate toward zero.  Far-out values saturate at +-2e9 and NaN goes to -2e9 (all of them fail the range
+    // tests that follow: grid, image and feature-image bounds are far below that), which lets the conversion be ONE instruction
+    // (v_cvt_i32_f64) instead of the ~15 of a float64 -> int64 conversion -- five of those sat on every sample's chain in K1.
+    return (int)fmin(fmax(v, -2.0e9), 2.0e9);
 }
 
 __device__ __forceinline__ double gemv3(const double* a, double x0, double x1, double x2) {
@@ -156,91 +157,102 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     int32_t cell = -1, fpix = 0;
     uint32_t rgbv = 0;
 
-    const BatchEntry* be = (fp.batch && valid) ? fp.batch + s / fp.P_frame : nullptr;
-    const double* T = be ? be->t : fp.t;
+    // (kernel-uniform null test: a single-frame launch reads its pose from the kernel arguments, i.e. scalar registers -- selecting
+    // per lane between be->t and fp.t made twelve vector loads behind twelve branches, issued only after the depth had arrived:
+    // one more memory round trip on every sample's chain)
+    const BatchEntry* be = fp.batch ? fp.batch + (valid ? s / fp.P_frame : 0) : nullptr;
+    double T[12];
     if (be) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = be->t[k];
         depth = be->depth;
         rgb = be->rgb;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = fp.t[k];
     }
     const int pix = !valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]);
-    bool ok = pix >= 0 && pix < fp.H * fp.W;
+    const bool ok0 = pix >= 0 && pix < fp.H * fp.W;
     AVL_STAMP(pt1);
-    double pl0 = 0, pl1 = 0, pl2 = 0;
-    if (ok) {
-        // depth2pc: p_2d = (u + 0.5, v + 0.5, 1); pc = Kinv @ p_2d (dgemm: FMA chain over k); pc *= z
-        const double x = (double)(pix % fp.W) + 0.5, y = (double)(pix / fp.W) + 0.5;
-        const double z = fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(depth)[pix] / fp.depth_div : (double)depth[pix];
-        pl0 = fma(fp.kinv[2], 1.0, fma(fp.kinv[1], y, fp.kinv[0] * x)) * z;
-        pl1 = fma(fp.kinv[5], 1.0, fma(fp.kinv[4], y, fp.kinv[3] * x)) * z;
-        pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
-        ok = (pl2 > fp.min_depth) && (pl2 < fp.max_depth);  // strict on both sides, NaN fails
-    }
+    // From here to the CAS the code is STRAIGHT-LINE (flags and selects, no branch around a load): the sample's chain is depth ->
+    // cell -> cell_slot, and the cell's slot is requested as soon as the cell is known; the two pinhole projections (four of the
+    // seven fp64 divides), the colour gather and the weight's exp() are computed while that load is in flight.  They used to sit
+    // in `if (ok)` blocks in FRONT of it: ~1.4-1.7 us of dependent fp64 arithmetic on every sample's chain (one wave per SIMD in
+    // these workgroups: nothing hides it).  A sample that dropped out keeps computing on harmless values and reads element 0.
+    // The arithmetic of a surviving sample is unchanged, operation for operation.
+    // depth2pc: p_2d = (u + 0.5, v + 0.5, 1); pc = Kinv @ p_2d (dgemm: FMA chain over k); pc *= z
+    const int pixc = ok0 ? pix : 0;
+    const float* dsrc = ok0 ? depth : reinterpret_cast<const float*>(cell_slot);   // (batched launches carry no frame-level pointers)
+    const double x = (double)(pixc % fp.W) + 0.5, y = (double)(pixc / fp.W) + 0.5;
+    const double z = fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(dsrc)[pixc] / fp.depth_div : (double)dsrc[pixc];
+    const double pl0 = fma(fp.kinv[2], 1.0, fma(fp.kinv[1], y, fp.kinv[0] * x)) * z;
+    const double pl1 = fma(fp.kinv[5], 1.0, fma(fp.kinv[4], y, fp.kinv[3] * x)) * z;
+    const double pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
+    const bool ok1 = ok0 && (pl2 > fp.min_depth) && (pl2 < fp.max_depth);  // strict on both sides, NaN fails
     AVL_STAMP(pt2);
-    long long row = 0, col = 0, h = 0;
-    size_t rgb_off = 0;
-    if (ok) {
-        // transform_pc: pose @ [pc; 1]  (dgemm FMA chain k = 0..3)
-        const double g0 = fma(T[3], 1.0, fma(T[2], pl2, fma(T[1], pl1, T[0] * pl0)));
-        const double g1 = fma(T[7], 1.0, fma(T[6], pl2, fma(T[5], pl1, T[4] * pl0)));
-        const double g2 = fma(T[11], 1.0, fma(T[10], pl2, fma(T[9], pl1, T[8] * pl0)));
-        if (fp.mode == 0) {
-            // base_pos2grid_id_3d: int(gs/2 - int(x/cs)) with a true fp64 divide
-            row = py_int(fp.half_gs - (double)py_int(g0 / fp.cs));
-            col = py_int(fp.half_gs - (double)py_int(g1 / fp.cs));
-            h = py_int(g2 / fp.cs);
-        } else {
-            // row, height, col = np.round((p - pcd_min) / cs).astype(int)   (vlmap_builder_multi_floor.py:146; half-to-even)
-            row = py_int(rint((g0 - fp.pcd_min[0]) / fp.cs));
-            h = py_int(rint((g1 - fp.pcd_min[1]) / fp.cs));
-            col = py_int(rint((g2 - fp.pcd_min[2]) / fp.cs));
-        }
-        ok = !(col >= fp.n1 || row >= fp.n0 || h >= fp.n2 || col < 0 || row < 0 || h < 0);
-        // global mode: the reference only tests the upper row/col bounds and otherwise wraps or raises; a point outside
-        // the pass-1 bounding box is dropped here and reported
-        if (!ok && fp.mode == 1) atomicOr(err_flags, 8);
+    // transform_pc: pose @ [pc; 1]  (dgemm FMA chain k = 0..3)
+    const double g0 = fma(T[3], 1.0, fma(T[2], pl2, fma(T[1], pl1, T[0] * pl0)));
+    const double g1 = fma(T[7], 1.0, fma(T[6], pl2, fma(T[5], pl1, T[4] * pl0)));
+    const double g2 = fma(T[11], 1.0, fma(T[10], pl2, fma(T[9], pl1, T[8] * pl0)));
+    int row, col, h;          // (32-bit from here on: saturated values fail the range tests, in-range ones are small)
+    if (fp.mode == 0) {       // (kernel-uniform)
+        // base_pos2grid_id_3d: int(gs/2 - int(x/cs)) with a true fp64 divide
+        row = py_int(fp.half_gs - (double)py_int(g0 / fp.cs));
+        col = py_int(fp.half_gs - (double)py_int(g1 / fp.cs));
+        h = py_int(g2 / fp.cs);
+    } else {
+        // row, height, col = np.round((p - pcd_min) / cs).astype(int)   (vlmap_builder_multi_floor.py:146; half-to-even)
+        row = py_int(rint((g0 - fp.pcd_min[0]) / fp.cs));
+        h = py_int(rint((g1 - fp.pcd_min[1]) / fp.cs));
+        col = py_int(rint((g2 - fp.pcd_min[2]) / fp.cs));
     }
+    const bool in_grid = !(col >= fp.n1 || row >= fp.n0 || h >= fp.n2 || col < 0 || row < 0 || h < 0);
+    const bool ok2 = ok1 && in_grid;
+    // global mode: the reference only tests the upper row/col bounds and otherwise wraps or raises; a point outside
+    // the pass-1 bounding box is dropped here and reported
+    const bool err_box = ok1 && !in_grid && fp.mode == 1;
+    const int32_t cell_try = ok2 ? (int32_t)(((unsigned)row * (unsigned)fp.n1 + (unsigned)col) * (unsigned)fp.n2 + (unsigned)h) : 0;
+    // cell states only move forward (empty -> pending -> slot), so a slot read here is final even if the line is old
+    const int32_t seen = cell_slot[cell_try];
+    __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the request below the arithmetic that follows)
+    // project_point(calib, p_local) -> rgb[py, px] with numpy's negative-index wrap
+    double q0 = gemv3(fp.k + 0, pl0, pl1, pl2), q1 = gemv3(fp.k + 3, pl0, pl1, pl2), q2 = gemv3(fp.k + 6, pl0, pl1, pl2);
+    int px = py_int(q0 / q2 - 0.5), py = py_int(q1 / q2 - 0.5);
+    px += px < 0 ? fp.W : 0;
+    py += py < 0 ? fp.H : 0;
+    const bool in_img = !(px < 0 || px >= fp.W || py < 0 || py >= fp.H);
+    const bool err_img = ok2 && !in_img;    // the reference raises IndexError here; we drop the point and flag it
+    const bool ok3 = ok2 && in_img;
+    const size_t rgb_off = ok3 ? ((size_t)py * fp.W + px) * 3 : 0;
+    // the colour gather (a sample that dropped out reads element 0 of cell_slot: batched launches carry no frame-level rgb pointer)
+    // (global address space stated: a FLAT load -- batched launches read the pointer from memory -- may return out of order with the
+    // cell_slot load, so the wait before the CAS would have to be for both)
+    using gbyte_ptr = const __attribute__((address_space(1))) uint8_t*;
+    const gbyte_ptr c = (gbyte_ptr)(ok3 ? rgb + rgb_off : reinterpret_cast<const uint8_t*>(cell_slot));
+    const uint8_t c0 = c[0], c1 = c[1], c2 = c[2];
+    __builtin_amdgcn_sched_barrier(0);
+    // project_point(get_sim_cam_mat(Hf, Wf), p_local) -> feature pixel, bounds-checked (vlmap_builder.py:161)
+    q0 = gemv3(fp.kf + 0, pl0, pl1, pl2);
+    q1 = gemv3(fp.kf + 3, pl0, pl1, pl2);
+    q2 = gemv3(fp.kf + 6, pl0, pl1, pl2);
+    px = py_int(q0 / q2 - 0.5);
+    py = py_int(q1 / q2 - 0.5);
+    const bool ok = ok3 && !(px < 0 || py < 0 || px >= fp.Wf || py >= fp.Hf);
+    if (ok2) fpix = (int32_t)((unsigned)py * (unsigned)fp.Wf + (unsigned)px);
+    const double radial = (pl0 * pl0 + pl1 * pl1) + pl2 * pl2;  // np.sum(np.square(p_local))
+    const double alpha_try = exp(-radial / fp.two_sigma_sq);
     if (ok) {
-        // project_point(calib, p_local) -> rgb[py, px] with numpy's negative-index wrap
-        double q0 = gemv3(fp.k + 0, pl0, pl1, pl2), q1 = gemv3(fp.k + 3, pl0, pl1, pl2), q2 = gemv3(fp.k + 6, pl0, pl1, pl2);
-        long long px = py_int(q0 / q2 - 0.5), py = py_int(q1 / q2 - 0.5);
-        if (px < 0) px += fp.W;
-        if (py < 0) py += fp.H;
-        if (px < 0 || px >= fp.W || py < 0 || py >= fp.H) {
-            atomicOr(err_flags, 2);  // the reference raises IndexError here; we drop the point and flag it
-            ok = false;
-        } else {
-            rgb_off = ((size_t)py * fp.W + px) * 3;
-        }
-        // project_point(get_sim_cam_mat(Hf, Wf), p_local) -> feature pixel, bounds-checked (vlmap_builder.py:161)
-        q0 = gemv3(fp.kf + 0, pl0, pl1, pl2);
-        q1 = gemv3(fp.kf + 3, pl0, pl1, pl2);
-        q2 = gemv3(fp.kf + 6, pl0, pl1, pl2);
-        px = py_int(q0 / q2 - 0.5);
-        py = py_int(q1 / q2 - 0.5);
-        if (px < 0 || py < 0 || px >= fp.Wf || py >= fp.Hf) ok = false;
-        fpix = (int32_t)(py * fp.Wf + px);
-    }
-    if (ok) {
-        const double radial = (pl0 * pl0 + pl1 * pl1) + pl2 * pl2;  // np.sum(np.square(p_local))
-        alpha = exp(-radial / fp.two_sigma_sq);
-        cell = (int32_t)((row * fp.n1 + col) * fp.n2 + h);
+        alpha = alpha_try;
+        cell = cell_try;
     }
     // create the voxel if the cell is empty: the CAS winner takes the next slot.  One counter atomic per wave:
     // winners are ranked with a ballot (a single hot word only sustains ~90 atomics/us).
-    // cell states only move forward (empty -> pending -> slot), so a slot read here is final even if the line is old
     int32_t known = -1;
     bool creator = false;
-    // The colour gather and the cell's slot are requested TOGETHER, in straight-line code (a sample that dropped out reads
-    // element 0 of both): inside the `ok` branches the three colour bytes had to arrive before the cell_slot load was issued --
-    // one round trip of this kernel's dependent chain for a value that is only stored at the end.
     AVL_STAMP(pt3);
-    const uint8_t* c = ok ? rgb + rgb_off : reinterpret_cast<const uint8_t*>(cell_slot);   // (batched launches carry no frame-level rgb pointer)
-    const uint8_t c0 = c[0], c1 = c[1], c2 = c[2];
-    const int32_t seen = cell_slot[ok ? cell : 0];
     if (ok) {
         if (seen == kEmpty) creator = atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
         else if (seen >= 0) known = seen;
-        rgbv = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
     }
     AVL_STAMP(pt4);
     const unsigned long long cmask = __ballot(creator);
@@ -274,11 +286,15 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
             known = (int32_t)slot;
         }
     }
+    // (the colour bytes are first looked at HERE: the CAS above only waits for the cell's slot, the gather is still in flight then)
+    if (ok) rgbv = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
     if (valid) {
         recs.alpha[s] = alpha;
         recs.fpix[s] = fpix;
         recs.rgb[s] = rgbv;
     }
+    if (err_box) atomicOr(err_flags, 8);
+    if (err_img) atomicOr(err_flags, 2);
 #ifdef AVL_PROBE_CHAIN
     {
         AVL_STAMP(pt5);
