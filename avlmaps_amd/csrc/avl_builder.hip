@@ -118,6 +118,39 @@ constexpr int kAggregateSamples = 32768;   // launches at least this large alloc
 constexpr unsigned long long kNoKey = ~0ull;
 constexpr int kMaxPendingSpins = 1 << 18;   // link step of a deferred-fuse launch: polls of a cell that is being created
 
+// The kernel-argument block of these kernels is 450-1 040 bytes (FrameParams alone: three 3 x 3 matrices and the pose), the
+// compiler fetches it piecemeal, each piece where it is first needed and behind the branch that needs it, and every piece is a
+// scalar-cache miss that goes to memory: several dependent misses at the head of every work item's chain.  Touch every line of the
+// block at once, first thing in the kernels that read most of it (LINES x 64 bytes, LINES in {4, 8, 12, 16} and not beyond the segment): one miss time for all of them.
+template <int LINES>
+__device__ __forceinline__ void warm_kernel_arguments() {
+#ifndef AVL_NO_KERNARG_WARMUP
+    static_assert(LINES == 4 || LINES == 8 || LINES == 12 || LINES == 16, "four lines per step");
+    const auto p = __builtin_amdgcn_kernarg_segment_ptr();     // (an address_space(4) pointer: two scalar registers)
+    int t0, t1, t2, t3;
+    if constexpr (LINES == 4)
+        asm volatile("s_load_dword %0, %4, 0x0\n s_load_dword %1, %4, 0x40\n s_load_dword %2, %4, 0x80\n s_load_dword %3, %4, 0xc0\n"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
+    if constexpr (LINES == 8)
+        asm volatile("s_load_dword %0, %4, 0x0\n s_load_dword %1, %4, 0x40\n s_load_dword %2, %4, 0x80\n s_load_dword %3, %4, 0xc0\n"
+                     "s_load_dword %0, %4, 0x100\n s_load_dword %1, %4, 0x140\n s_load_dword %2, %4, 0x180\n s_load_dword %3, %4, 0x1c0\n"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
+    if constexpr (LINES == 12)
+        asm volatile("s_load_dword %0, %4, 0x0\n s_load_dword %1, %4, 0x40\n s_load_dword %2, %4, 0x80\n s_load_dword %3, %4, 0xc0\n"
+                     "s_load_dword %0, %4, 0x100\n s_load_dword %1, %4, 0x140\n s_load_dword %2, %4, 0x180\n s_load_dword %3, %4, 0x1c0\n"
+                     "s_load_dword %0, %4, 0x200\n s_load_dword %1, %4, 0x240\n s_load_dword %2, %4, 0x280\n s_load_dword %3, %4, 0x2c0\n"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
+    if constexpr (LINES == 16)
+        asm volatile("s_load_dword %0, %4, 0x0\n s_load_dword %1, %4, 0x40\n s_load_dword %2, %4, 0x80\n s_load_dword %3, %4, 0xc0\n"
+                     "s_load_dword %0, %4, 0x100\n s_load_dword %1, %4, 0x140\n s_load_dword %2, %4, 0x180\n s_load_dword %3, %4, 0x1c0\n"
+                     "s_load_dword %0, %4, 0x200\n s_load_dword %1, %4, 0x240\n s_load_dword %2, %4, 0x280\n s_load_dword %3, %4, 0x2c0\n"
+                     "s_load_dword %0, %4, 0x300\n s_load_dword %1, %4, 0x340\n s_load_dword %2, %4, 0x380\n s_load_dword %3, %4, 0x3c0\n"
+                     "s_waitcnt lgkmcnt(0)" : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3) : "s"(p));
+    (void)t0; (void)t1; (void)t2; (void)t3;
+    __builtin_amdgcn_sched_barrier(0);     // (nothing of the kernel is scheduled in front of the touches)
+#endif
+}
+
 __device__ __forceinline__ int py_int(double v) {
     // Python int(): truncate toward zero.  Far-out values saturate at +-2e9 and NaN goes to -2e9 (all of them fail the range
     // tests that follow: grid, image and feature-image bounds are far below that), which lets the conversion be ONE instruction
@@ -258,7 +291,10 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     const unsigned long long cmask = __ballot(creator);
     const int lane = threadIdx.x & 63;
     unsigned long long base = 0;
-    if (fp.P >= kAggregateSamples) {   // kernel-uniform: batched launches take the two barriers, single frames do not
+#ifndef AVL_K1_AGG_MIN
+#define AVL_K1_AGG_MIN kAggregateSamples
+#endif
+    if (fp.P >= AVL_K1_AGG_MIN) {   // kernel-uniform: batched launches take the two barriers, single frames do not
         unsigned woff = 0;
         if (cmask) {
             const int leader = __ffsll((long long)cmask) - 1;
@@ -404,6 +440,7 @@ __global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, cons
                                                             int32_t* __restrict__ slot_cell, Recs recs, int32_t* __restrict__ head,
                                                             unsigned long long* __restrict__ counters, int* __restrict__ err_flags,
                                                             ReplayLog log, long long log_base, unsigned long long frame_key, OwnerList ol) {
+    warm_kernel_arguments<12>();       // (944 bytes with the hidden arguments)
     const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
     link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags, ol);
 }
@@ -717,6 +754,8 @@ __global__ __launch_bounds__(AVL_K3_THREADS) AVL_K3_OCC(CH) void pipe_kernel(Fra
                                                    double* __restrict__ first_alpha, unsigned long long* __restrict__ slot_key,
                                                    uint8_t* __restrict__ dirty) {
     if ((int)blockIdx.x < pb) {
+        warm_kernel_arguments<12>();   // (K1 + K2 read FrameParams and a dozen pointers; a K3 wave needs two lines, and touching more
+                                       // costs it: fuse_kernel 10.4-10.7 -> 10.9-11.1 us, 64 frames per launch 230 -> 255 us)
         const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
         link_body<false>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
     } else {
