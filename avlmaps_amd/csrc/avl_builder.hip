@@ -111,6 +111,9 @@ struct OwnerList {
     uint32_t* o_rgb;
     int32_t* ocnt;
 };
+#ifndef AVL_K3_THREADS
+#define AVL_K3_THREADS 256      // wave-per-sample K3 launches (single frames): threads per workgroup
+#endif
 constexpr int kFuseWaves = 128;   // K3 waves per K2 workgroup of 256 samples (more owners than that: a wave takes several)
 
 constexpr int kEmpty = -1, kPending = -2;
@@ -173,6 +176,9 @@ struct SampleRec {
 
 // K1 body: block `blk` of a launch over fp.P samples.  Slots are published with agent-scope atomic stores so that a
 // K2 running in the SAME kernel (other workgroups, other XCDs) can wait for them.
+// (THREADS = the workgroup size, a compile-time constant: blockDim.x is a hidden kernel argument on a cache line of its own,
+// i.e. one more scalar miss at the head of every chain)
+template <int THREADS>
 __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams& fp, const float* depth,
                                                       const int32_t* __restrict__ sample_idx, const uint8_t* rgb,
                                                       int32_t* __restrict__ cell_slot, int32_t* __restrict__ slot_cell, const Recs& recs,
@@ -183,7 +189,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     __shared__ unsigned long long blk_base;
     if (threadIdx.x == 0) blk_new = 0;
     __syncthreads();
-    const int s = blk * blockDim.x + threadIdx.x;   // global sample index: frame-major within a batch
+    const int s = blk * THREADS + threadIdx.x;   // global sample index: frame-major within a batch
     const bool valid = s < fp.P;
     AVL_STAMP(pt0);
     double alpha = 0.0;
@@ -354,7 +360,7 @@ struct ReplayLog {
 // K2 body.  Runs right behind K1 in the same kernel: the sample comes in registers, and a cell another workgroup is still
 // creating (kPending) is waited for.  That cannot deadlock: a creator publishes its slot without waiting for anybody but
 // its own workgroup's barrier (batched launches), which every wave of the workgroup reaches before it spins.
-template <bool MAY_COMPACT = true>
+template <bool MAY_COMPACT = true, int THREADS = 256>
 __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restrict__ cell_slot, int32_t* __restrict__ head,
                                           const Recs& recs, unsigned long long* __restrict__ counters, const ReplayLog& log,
                                           long long log_base, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
@@ -365,7 +371,7 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
     __shared__ unsigned sh_own[4];
     if (threadIdx.x < 2) blk_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int s = blk * blockDim.x + threadIdx.x;
+    const int s = blk * THREADS + threadIdx.x;
     const bool valid = s < P;
     int32_t slot = -1, next = -1;
     uint8_t owner = 0;
@@ -441,8 +447,8 @@ __global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, cons
                                                             unsigned long long* __restrict__ counters, int* __restrict__ err_flags,
                                                             ReplayLog log, long long log_base, unsigned long long frame_key, OwnerList ol) {
     warm_kernel_arguments<12>();       // (944 bytes with the hidden arguments)
-    const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
-    link_body(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags, ol);
+    const SampleRec r = bp_voxelize_body<256>(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+    link_body<true, 256>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags, ol);
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
@@ -678,7 +684,7 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
     if constexpr (!COMPACT) {
         // a single frame (and every launch below kAggregateSamples samples): wave per SAMPLE, the owner flag fetched with the record (72 % of the waves leave here).  The compacted
         // form below measured slower at this size -- pipe_kernel 11.2 -> 12.0 us, fuse_kernel 10.35 -> 10.7 (profiles/r05_ab_builder_k3.txt s27)
-        const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * blockDim.x + threadIdx.x) >> 6));
+        const int s0 = __builtin_amdgcn_readfirstlane((int)((blk * AVL_K3_THREADS + threadIdx.x) >> 6));   // (not blockDim.x: see bp_voxelize_body)
         if (s0 >= P) return;
         const uint8_t own = recs.owner[s0];
         const int32_t slot = recs.slot[s0];
@@ -719,10 +725,6 @@ __device__ __forceinline__ void fuse_body(int blk, int P, int D, unsigned long l
 #define AVL_K3_OCC(CH)
 #endif
 
-#ifndef AVL_K3_THREADS
-#define AVL_K3_THREADS 256      // wave-per-sample K3 launches (single frames): threads per workgroup
-#endif
-
 template <int CH, bool COMPACT>
 __global__ __launch_bounds__(COMPACT ? 256 : AVL_K3_THREADS) AVL_K3_OCC(CH) void fuse_kernel(int P, int D, unsigned long long frame_key, const BatchEntry* __restrict__ batch,
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
@@ -756,8 +758,8 @@ __global__ __launch_bounds__(AVL_K3_THREADS) AVL_K3_OCC(CH) void pipe_kernel(Fra
     if ((int)blockIdx.x < pb) {
         warm_kernel_arguments<12>();   // (K1 + K2 read FrameParams and a dozen pointers; a K3 wave needs two lines, and touching more
                                        // costs it: fuse_kernel 10.4-10.7 -> 10.9-11.1 us, 64 frames per launch 230 -> 255 us)
-        const SampleRec r = bp_voxelize_body(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
-        link_body<false>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
+        const SampleRec r = bp_voxelize_body<AVL_K3_THREADS>(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+        link_body<false, AVL_K3_THREADS>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
     } else {
         fuse_body<CH>((int)blockIdx.x - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
                       first_feat, first_alpha, slot_key, dirty);
