@@ -546,7 +546,11 @@ __device__ __forceinline__ void fuse_group_impl(int s0, int32_t slot, double alp
         if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
     };
     const float* feat0 = row_of(s0, fpix0);
+#ifdef AVL_ABL_K3_SINGLE      // timing ablation only (WRONG maps): every group treated as a single-sample group -- what the long groups cost
+    if (true) {
+#else
     if (h0 == s0) {
+#endif
         float v[CH][4];
         load_row(v, feat0);
         add(s0, alpha0, rgb0, v);   // one sample for this voxel in this launch: 70 % of the groups of a single frame
