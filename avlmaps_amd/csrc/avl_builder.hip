@@ -88,7 +88,28 @@ struct FrameParams {
     int mode;            // 0 = mobile-base map (vlmap_builder.py), 1 = global multi-floor map (vlmap_builder_multi_floor.py)
     int depth_u16;
     long long capacity;
+    const int2* pre;     // {pixel, depth bits} of every sample, gathered by the previous launch (PreGather); nullptr: gather here
 };
+
+// The frame loop in C (avl_builder_integrate_frames) knows frame i + 1 while it launches frame i: a few extra workgroups at the END
+// of frame i's last launch read frame i + 1's sample indices and the depths under them into one array, so that K1 of frame i + 1
+// starts its chain with ONE coalesced load instead of two dependent ones (sample index -> depth: ~0.8 us per chain).  The inputs of
+// a frame depend on nothing the builder computes, so this crosses no dependency.  float32 depth images, single-frame launches.
+struct PreGather {
+    const int32_t* samples;   // nullptr: nothing to gather
+    const float* depth;
+    int2* out;
+    int P, HW;
+};
+
+__device__ __forceinline__ void pre_gather_body(int blk, int threads, const PreGather& g) {
+    const int s = blk * threads + threadIdx.x;
+    if (s >= g.P) return;
+    const int pix = g.samples[s];
+    const bool ok = pix >= 0 && pix < g.HW;
+    const float z = g.depth[ok ? pix : 0];
+    g.out[s] = int2{pix, __float_as_int(z)};
+}
 
 // per-frame sample records (structure of arrays, sized for the largest P seen)
 struct Recs {
@@ -210,7 +231,8 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
 #pragma unroll
         for (int k = 0; k < 12; ++k) T[k] = fp.t[k];
     }
-    const int pix = !valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]);
+    const int2 pre = (fp.pre && valid) ? fp.pre[s] : int2{-1, 0};      // (kernel-uniform test; never set in batched launches)
+    const int pix = fp.pre ? pre.x : (!valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]));
     const bool ok0 = pix >= 0 && pix < fp.H * fp.W;
     AVL_STAMP(pt1);
     // From here to the CAS the code is STRAIGHT-LINE (flags and selects, no branch around a load): the sample's chain is depth ->
@@ -223,7 +245,8 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     const int pixc = ok0 ? pix : 0;
     const float* dsrc = ok0 ? depth : reinterpret_cast<const float*>(cell_slot);   // (batched launches carry no frame-level pointers)
     const double x = (double)(pixc % fp.W) + 0.5, y = (double)(pixc / fp.W) + 0.5;
-    const double z = fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(dsrc)[pixc] / fp.depth_div : (double)dsrc[pixc];
+    const double z = fp.pre ? (double)__int_as_float(pre.y)
+                            : (fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(dsrc)[pixc] / fp.depth_div : (double)dsrc[pixc]);
     const double pl0 = fma(fp.kinv[2], 1.0, fma(fp.kinv[1], y, fp.kinv[0] * x)) * z;
     const double pl1 = fma(fp.kinv[5], 1.0, fma(fp.kinv[4], y, fp.kinv[3] * x)) * z;
     const double pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
@@ -734,8 +757,15 @@ __global__ __launch_bounds__(COMPACT ? 256 : AVL_K3_THREADS) AVL_K3_OCC(CH) void
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                                    double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty, OwnerList ol) {
-    fuse_body<CH, COMPACT>(blockIdx.x, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty, ol);
+                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty, OwnerList ol, PreGather next,
+                                                   int gb) {
+    // (gb workgroups in FRONT of K3's gather the next frame's samples and depths, see PreGather: dispatched first, done after two
+    // round trips; behind K3's they started last and made the launch longer)
+    if (!COMPACT && (int)blockIdx.x < gb) {
+        pre_gather_body((int)blockIdx.x, AVL_K3_THREADS, next);
+        return;
+    }
+    fuse_body<CH, COMPACT>((int)blockIdx.x - (COMPACT ? 0 : gb), P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty, ol);
 }
 
 // Deferred-fuse launch (avl_builder_set_deferred_fuse): ONE kernel per frame.  Workgroups [0, pb) run K1 + K2 of the NEW frame
@@ -758,14 +788,19 @@ __global__ __launch_bounds__(AVL_K3_THREADS) AVL_K3_OCC(CH) void pipe_kernel(Fra
                                                    unsigned long long frame_key, FusePrev prev, int D, double* __restrict__ sum_feat,
                                                    double* __restrict__ sum_w4, float* __restrict__ first_feat,
                                                    double* __restrict__ first_alpha, unsigned long long* __restrict__ slot_key,
-                                                   uint8_t* __restrict__ dirty) {
-    if ((int)blockIdx.x < pb) {
+                                                   uint8_t* __restrict__ dirty, PreGather next, int gb) {
+    if ((int)blockIdx.x < gb) {                   // (in front of K1 + K2's and K3's workgroups: see PreGather)
+        pre_gather_body((int)blockIdx.x, AVL_K3_THREADS, next);
+        return;
+    }
+    const int blk = (int)blockIdx.x - gb;
+    if (blk < pb) {
         warm_kernel_arguments<12>();   // (K1 + K2 read FrameParams and a dozen pointers; a K3 wave needs two lines, and touching more
                                        // costs it: fuse_kernel 10.4-10.7 -> 10.9-11.1 us, 64 frames per launch 230 -> 255 us)
-        const SampleRec r = bp_voxelize_body<AVL_K3_THREADS>(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
-        link_body<false, AVL_K3_THREADS>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
+        const SampleRec r = bp_voxelize_body<AVL_K3_THREADS>(blk, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+        link_body<false, AVL_K3_THREADS>(blk, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
     } else {
-        fuse_body<CH>((int)blockIdx.x - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
+        fuse_body<CH>(blk - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
                       first_feat, first_alpha, slot_key, dirty);
     }
 }
@@ -1216,6 +1251,15 @@ struct avl_builder {
     LogSegments* ls_cache = nullptr;
     long long ls_log_used = -1;
     int64_t ls_n = -1;
+    // next-frame gather of the C frame loop (PreGather): two buffers of recs_cap entries, the one K1 reads and the one being written
+    int2* pre_buf[2] = {nullptr, nullptr};
+    struct PreHeld {           // what pre_buf[buf] holds: the samples / depths of the frame with exactly these inputs
+        const int32_t* samples = nullptr;
+        const void* depth = nullptr;
+        int P = 0, HW = 0, buf = 0;
+        bool valid = false;
+    } pre_held;
+    PreGather pre_next{};      // set by avl_builder_integrate_frames for the launch being issued: the frame after it
 };
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
@@ -1257,7 +1301,8 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     const size_t cap = ((size_t)P + P / 4 + 1024 + 255) / 256 * 256;
     const size_t one = (cap * (8 + 4 * 4 + 1) + 255) / 256 * 256;
     const size_t own = (cap * (8 + 4 * 4) + (cap / 256 + 1) * 4 + 255) / 256 * 256;
-    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one + own));
+    const size_t pre = (cap * sizeof(int2) + 255) / 256 * 256;
+    AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one + own + 2 * pre));
     auto carve = [&](Recs& r, char* p) {
         r.alpha = reinterpret_cast<double*>(p); p += cap * 8;
         r.slot = reinterpret_cast<int32_t*>(p); p += cap * 4;
@@ -1278,6 +1323,9 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
         o.o_rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
         o.ocnt = reinterpret_cast<int32_t*>(p);
     }
+    b->pre_buf[0] = reinterpret_cast<int2*>(b->recs_mem + 2 * one + own);
+    b->pre_buf[1] = reinterpret_cast<int2*>(b->recs_mem + 2 * one + own + pre);
+    b->pre_held.valid = false;
     b->recs_cap = (int)cap;
     return AVL_OK;
 }
@@ -1462,19 +1510,21 @@ static void drop_log_segments(avl_builder* b, hipStream_t st) {
 
 // K3 over one launch's records (CH = 256-float register chunks of a feature row)
 static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, const BatchEntry* batch, int P_frame, const Recs& recs,
-                       int32_t* head, const float* d_feat, hipStream_t st) {
+                       int32_t* head, const float* d_feat, hipStream_t st, const PreGather& next = PreGather{}) {
     // batched launches run over the owners K2 compacted; single frames and the generic kernel: wave per sample
     const bool compact = b->D <= 1536 && P >= kAggregateSamples;
     constexpr int kWaves = AVL_K3_THREADS / 64;
     const unsigned wb = compact ? (unsigned)((P + 255) / 256) * (kFuseWaves / 4) : (unsigned)((P + kWaves - 1) / kWaves);
+    const unsigned gb = (!compact && next.samples && b->D <= 1536) ? (unsigned)((next.P + AVL_K3_THREADS - 1) / AVL_K3_THREADS) : 0u;
 #define AVL_FUSE_LAUNCH(CH)                                                                                                              \
     do {                                                                                                                                 \
         if (compact)                                                                                                                     \
             hipLaunchKernelGGL((fuse_kernel<CH, true>), dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,  \
-                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, b->owners);                 \
+                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, b->owners, PreGather{},     \
+                               0);                                                                                                       \
         else                                                                                                                             \
-            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb), dim3(AVL_K3_THREADS), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
-                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, OwnerList{});               \
+            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb + gb), dim3(AVL_K3_THREADS), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
+                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, OwnerList{}, next, (int)gb); \
     } while (0)
     if (b->D <= 256) AVL_FUSE_LAUNCH(1);
     else if (b->D <= 512) AVL_FUSE_LAUNCH(2);
@@ -1499,12 +1549,13 @@ static int flush_pending(avl_builder* b, hipStream_t st) {
 
 template <int CH>
 static void launch_pipe(avl_builder* b, const FrameParams& fp, unsigned pb, const void* d_depth, const int32_t* d_sample_idx,
-                        const uint8_t* d_rgb, unsigned long long frame_key, const FusePrev& prev, hipStream_t st) {
+                        const uint8_t* d_rgb, unsigned long long frame_key, const FusePrev& prev, hipStream_t st, const PreGather& next) {
     constexpr int kWaves = AVL_K3_THREADS / 64;
     const unsigned wb = prev.P ? (unsigned)((prev.P + kWaves - 1) / kWaves) : 0u;
-    hipLaunchKernelGGL(pipe_kernel<CH>, dim3(pb + wb), dim3(AVL_K3_THREADS), 0, st, fp, (int)pb, reinterpret_cast<const float*>(d_depth), d_sample_idx,
+    const unsigned gb = next.samples ? (unsigned)((next.P + AVL_K3_THREADS - 1) / AVL_K3_THREADS) : 0u;
+    hipLaunchKernelGGL(pipe_kernel<CH>, dim3(pb + wb + gb), dim3(AVL_K3_THREADS), 0, st, fp, (int)pb, reinterpret_cast<const float*>(d_depth), d_sample_idx,
                        d_rgb, b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, prev,
-                       b->D, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty);
+                       b->D, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, next, (int)gb);
 }
 
 extern "C" {
@@ -1714,6 +1765,21 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     fp.depth_u16 = depth_u16;
     fp.depth_div = depth_div;
     fp.capacity = b->capacity;
+    // next-frame gather (PreGather): use what the previous launch gathered for exactly these inputs; let this launch gather for the
+    // frame the C loop will issue next (single float32 frames below the batched-launch size, the register-resident K3 kernels)
+    fp.pre = nullptr;
+    PreGather next{};
+    const bool pre_ok = B == 0 && !depth_u16 && !h_pcd_min && b->D <= 1536 && P < kAggregateSamples;
+    if (pre_ok) {
+        const auto& h = b->pre_held;
+        if (h.valid && h.samples == d_sample_idx && h.depth == d_depth && h.P == P && h.HW == H * W) fp.pre = b->pre_buf[h.buf];
+        if (b->pre_next.samples && b->pre_next.P == P) {
+            next = b->pre_next;
+            next.out = b->pre_buf[fp.pre ? 1 - h.buf : 0];
+        }
+    }
+    const int next_buf = next.out == b->pre_buf[1] ? 1 : 0;
+    b->pre_held.valid = false;
     const unsigned long long frame_key = b->key_bias | ((unsigned long long)frame_idx << 32);
 
     if (b->ls_cache) drop_log_segments(b, st);   // the sorted log of the last merge is stale from here on
@@ -1726,11 +1792,11 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         // ONE launch: K1 + K2 of this frame next to K3 of the previous one; this frame's K3 rides in the next launch (or a flush)
         const FusePrev prev{b->pend.P, b->pend.frame_key, b->recs_alt, b->head_alt, b->pend.feat};
         const unsigned pb = (unsigned)((P + AVL_K3_THREADS - 1) / AVL_K3_THREADS);      // (its K1 + K2 workgroups have the kernel's size)
-        if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
-        else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
-        else if (b->D == 768) launch_pipe<3>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
-        else if (b->D <= 1024) launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
-        else launch_pipe<6>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st);
+        if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
+        else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
+        else if (b->D == 768) launch_pipe<3>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
+        else if (b->D <= 1024) launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
+        else launch_pipe<6>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
         if (b->log.slot) b->log_used += P;
         b->pend.P = P;
         b->pend.frame_key = frame_key;
@@ -1738,6 +1804,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         std::swap(b->recs, b->recs_alt);
         std::swap(b->head, b->head_alt);
         AVL_HIP_CHECK(hipGetLastError());
+        if (next.samples) b->pre_held = {next.samples, next.depth, next.P, next.HW, next_buf, true};
         return AVL_OK;
     }
     rc = flush_pending(b, st);
@@ -1745,7 +1812,9 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     hipLaunchKernelGGL(voxelize_link_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb,
                        b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, b->owners);
     if (b->log.slot) b->log_used += P;
-    return launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st);
+    rc = launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st, next);
+    if (rc == AVL_OK && next.samples) b->pre_held = {next.samples, next.depth, next.P, next.HW, next_buf, true};
+    return rc;
 }
 
 int avl_builder_set_deferred_fuse(avl_builder* b, int on, void* stream) {
@@ -1808,9 +1877,15 @@ int avl_builder_integrate_frames(avl_builder* b, int n_frames, const float* cons
                                  double min_depth, double max_depth, double sigma_sq, void* stream) {
     AVL_REQUIRE(n_frames > 0, "avl_builder_integrate_frames: n_frames must be positive");
     AVL_REQUIRE(h_depth_ptrs && h_sample_ptrs && h_feat_ptrs && h_rgb_ptrs && h_pc_transforms, "avl_builder_integrate_frames: null pointer table");
+    AVL_REQUIRE(b, "avl_builder_integrate_frames: null handle");
     for (int i = 0; i < n_frames; ++i) {
+        // the frame after this one, for the gather workgroups of this frame's launch (PreGather); the last frame of a call has none:
+        // what a later call brings is not known to be resident yet
+        b->pre_next = (i + 1 < n_frames && h_sample_ptrs[i + 1] && h_depth_ptrs[i + 1])
+                          ? PreGather{h_sample_ptrs[i + 1], h_depth_ptrs[i + 1], nullptr, P, H * W} : PreGather{};
         const int rc = integrate_impl(b, h_depth_ptrs[i], 0, 1.0, H, W, h_calib, h_calib_inv, h_pc_transforms + 16 * i, h_sample_ptrs[i], P,
                                       h_feat_ptrs[i], Hf, Wf, h_rgb_ptrs[i], frame_idx0 + i, min_depth, max_depth, sigma_sq, nullptr, stream);
+        b->pre_next = PreGather{};
         if (rc != AVL_OK) return rc;
     }
     return AVL_OK;

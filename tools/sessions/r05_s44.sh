@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 5: the C frame loop lets frame i's last launch gather frame i + 1's samples and depths (PreGather); prev = the tree before
+R=$GRAFT_REPO_ROOT
+cd $R
+timeout -s KILL 900 python -m pytest tests/test_builder_gpu.py tests/test_geometry_gpu.py tests/test_api_gpu.py -q -m gpu -x 2>&1 | tail -2
+cd /tmp; export TMPDIR=/tmp
+for rep in 1 2; do
+for lib in avlmaps_amd/lib/libavlmaps_hip.so variants/libavlmaps_hip_prev.so; do
+for f in "" "--deferred-fuse"; do
+ rm -rf /tmp/prof
+ AVLMAPS_HIP_LIB=$R/$lib timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python $R/bench.py --workload build --steps 4000 --no-cpu $f > /tmp/o.txt 2>&1
+ python - "$lib" "$f" <<PY
+import csv,glob,sys,json
+f=glob.glob('/tmp/prof/**/*kernel_stats.csv', recursive=True)
+out=[]
+for r in csv.DictReader(open(f[0])):
+    n=r['Name']
+    for k in ('pipe_kernel','fuse_kernel','voxelize_link_kernel'):
+        if k in n: out.append(f"{k}:{float(r['AverageNs'])/1e3:.2f}us x{r['Calls']}")
+print(sys.argv[1].split('/')[-1], sys.argv[2], ' '.join(out))
+PY
+done; done; done
+for rep in 1 2; do for lib in avlmaps_amd/lib/libavlmaps_hip.so variants/libavlmaps_hip_prev.so; do for f in "" "--deferred-fuse"; do
+AVLMAPS_HIP_LIB=$R/$lib timeout 300 python $R/bench.py --workload build --steps 10000 --no-cpu $f 2>/dev/null | grep '^{"metric"' | python -c "
+import sys,json
+j=json.loads(sys.stdin.read()); print('$lib [$f]', round(j['value']), 'fps', round(1e6/j['value'],2), 'us/frame')"
+done; done; done
