@@ -59,8 +59,12 @@ constexpr int kProbeK12Row0 = 16384;
 #define AVL_STAMP(var)                                                                                             \
     unsigned long long var;                                                                                        \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#define AVL_STAMP_DECL(var) unsigned long long var = 0
+#define AVL_RESTAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
 #else
 #define AVL_STAMP(var)
+#define AVL_STAMP_DECL(var)
+#define AVL_RESTAMP(var)
 #endif
 
 // one frame of a batch (avl_builder_integrate_batch): what differs between the frames of one launch
@@ -88,28 +92,31 @@ struct FrameParams {
     int mode;            // 0 = mobile-base map (vlmap_builder.py), 1 = global multi-floor map (vlmap_builder_multi_floor.py)
     int depth_u16;
     long long capacity;
-    const int2* pre;     // {pixel, depth bits} of every sample, gathered by the previous launch (PreGather); nullptr: gather here
+    const struct PreRec* pre;   // the stateless half of K1 for THIS frame, computed by the previous launch (PreGather); nullptr: compute here
 };
 
-// The frame loop in C (avl_builder_integrate_frames) knows frame i + 1 while it launches frame i: a few extra workgroups at the END
-// of frame i's last launch read frame i + 1's sample indices and the depths under them into one array, so that K1 of frame i + 1
-// starts its chain with ONE coalesced load instead of two dependent ones (sample index -> depth: ~0.8 us per chain).  The inputs of
-// a frame depend on nothing the builder computes, so this crosses no dependency.  float32 depth images, single-frame launches.
+// The frame loop in C (avl_builder_integrate_frames) knows frame i + 1 while it launches frame i, and the first half of K1 --
+// sample index -> depth -> back-projection, pose, cell, the two pinhole projections, the colour gather, the weight -- depends on
+// nothing the builder holds: only from the cell's slot onwards does a sample touch the map.  A few workgroups in FRONT of frame
+// i's launch run that half for frame i + 1 (bp_voxelize_body<.., 2>) and leave 24 bytes per sample; K1 of frame i + 1
+// (bp_voxelize_body<.., 1>) then starts its chain with one coalesced load and goes straight to the slot: four of the chain's
+// hops (sample index, depth, geometry, colour) move out of the dependent path into the shadow of the previous frame.
+// Single float32-depth frames of one avl_builder_integrate_frames call; the same arithmetic, operation for operation.
+struct PreRec {
+    double alpha;     // 0 if the sample dropped out
+    int32_t cell;     // -1 if the sample dropped out
+    int32_t fpix;
+    uint32_t rgbv;
+    uint32_t flags;   // bit 0: outside the pass-1 bounding box (global mode), bit 1: projected outside the RGB image
+};
+static_assert(sizeof(PreRec) == 24, "PreRec");
+
 struct PreGather {
-    const int32_t* samples;   // nullptr: nothing to gather
+    PreRec* out;              // nullptr: nothing to prepare
     const float* depth;
-    int2* out;
-    int P, HW;
+    const int32_t* samples;
+    const uint8_t* rgb;
 };
-
-__device__ __forceinline__ void pre_gather_body(int blk, int threads, const PreGather& g) {
-    const int s = blk * threads + threadIdx.x;
-    if (s >= g.P) return;
-    const int pix = g.samples[s];
-    const bool ok = pix >= 0 && pix < g.HW;
-    const float z = g.depth[ok ? pix : 0];
-    g.out[s] = int2{pix, __float_as_int(z)};
-}
 
 // per-frame sample records (structure of arrays, sized for the largest P seen)
 struct Recs {
@@ -199,23 +206,49 @@ struct SampleRec {
 // K2 running in the SAME kernel (other workgroups, other XCDs) can wait for them.
 // (THREADS = the workgroup size, a compile-time constant: blockDim.x is a hidden kernel argument on a cache line of its own,
 // i.e. one more scalar miss at the head of every chain)
-template <int THREADS>
+// MODE 0: all of K1.  MODE 2: its stateless half only, for the NEXT frame, result to pre_out (PreGather).  MODE 1: the stateful half,
+// starting from what a MODE-2 workgroup of the previous launch left in fp.pre.
+template <int THREADS, int MODE = 0>
 __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams& fp, const float* depth,
                                                       const int32_t* __restrict__ sample_idx, const uint8_t* rgb,
                                                       int32_t* __restrict__ cell_slot, int32_t* __restrict__ slot_cell, const Recs& recs,
-                                                      unsigned long long* __restrict__ counters, int* __restrict__ err_flags) {
+                                                      unsigned long long* __restrict__ counters, int* __restrict__ err_flags,
+                                                      PreRec* __restrict__ pre_out = nullptr) {
     // slots are allocated per workgroup: creators are counted in LDS and ONE device atomic per 256 samples reserves the
     // block's range (a single hot device word only sustains ~90 atomics/us)
     __shared__ unsigned blk_new;
     __shared__ unsigned long long blk_base;
-    if (threadIdx.x == 0) blk_new = 0;
-    __syncthreads();
+    if constexpr (MODE != 2) {
+        if (threadIdx.x == 0) blk_new = 0;
+        __syncthreads();
+    }
     const int s = blk * THREADS + threadIdx.x;   // global sample index: frame-major within a batch
     const bool valid = s < fp.P;
     AVL_STAMP(pt0);
+    AVL_STAMP_DECL(pt1);
+    AVL_STAMP_DECL(pt2);
+    AVL_STAMP_DECL(pt3);
     double alpha = 0.0;
     int32_t cell = -1, fpix = 0;
     uint32_t rgbv = 0;
+    int32_t seen = kEmpty;
+    bool ok = false, err_box = false, err_img = false;
+    uint8_t c0 = 0, c1 = 0, c2 = 0;
+    if constexpr (MODE == 1) {
+        // 24 bytes per sample from the previous launch, then straight to the cell's slot
+        const PreRec r = valid ? fp.pre[s] : PreRec{0.0, -1, 0, 0u, 0u};
+        alpha = r.alpha;
+        cell = r.cell;
+        fpix = r.fpix;
+        rgbv = r.rgbv;
+        ok = cell >= 0;
+        err_box = (r.flags & 1u) != 0;
+        err_img = (r.flags & 2u) != 0;
+        AVL_RESTAMP(pt1);
+        seen = cell_slot[ok ? cell : 0];
+        AVL_RESTAMP(pt2);
+        AVL_RESTAMP(pt3);
+    } else {
 
     // (kernel-uniform null test: a single-frame launch reads its pose from the kernel arguments, i.e. scalar registers -- selecting
     // per lane between be->t and fp.t made twelve vector loads behind twelve branches, issued only after the depth had arrived:
@@ -231,10 +264,9 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
 #pragma unroll
         for (int k = 0; k < 12; ++k) T[k] = fp.t[k];
     }
-    const int2 pre = (fp.pre && valid) ? fp.pre[s] : int2{-1, 0};      // (kernel-uniform test; never set in batched launches)
-    const int pix = fp.pre ? pre.x : (!valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]));
+    const int pix = !valid ? -1 : (be ? be->samples[s % fp.P_frame] : sample_idx[s]);
     const bool ok0 = pix >= 0 && pix < fp.H * fp.W;
-    AVL_STAMP(pt1);
+    AVL_RESTAMP(pt1);
     // From here to the CAS the code is STRAIGHT-LINE (flags and selects, no branch around a load): the sample's chain is depth ->
     // cell -> cell_slot, and the cell's slot is requested as soon as the cell is known; the two pinhole projections (four of the
     // seven fp64 divides), the colour gather and the weight's exp() are computed while that load is in flight.  They used to sit
@@ -245,13 +277,12 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     const int pixc = ok0 ? pix : 0;
     const float* dsrc = ok0 ? depth : reinterpret_cast<const float*>(cell_slot);   // (batched launches carry no frame-level pointers)
     const double x = (double)(pixc % fp.W) + 0.5, y = (double)(pixc / fp.W) + 0.5;
-    const double z = fp.pre ? (double)__int_as_float(pre.y)
-                            : (fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(dsrc)[pixc] / fp.depth_div : (double)dsrc[pixc]);
+    const double z = fp.depth_u16 ? (double)reinterpret_cast<const uint16_t*>(dsrc)[pixc] / fp.depth_div : (double)dsrc[pixc];
     const double pl0 = fma(fp.kinv[2], 1.0, fma(fp.kinv[1], y, fp.kinv[0] * x)) * z;
     const double pl1 = fma(fp.kinv[5], 1.0, fma(fp.kinv[4], y, fp.kinv[3] * x)) * z;
     const double pl2 = fma(fp.kinv[8], 1.0, fma(fp.kinv[7], y, fp.kinv[6] * x)) * z;
     const bool ok1 = ok0 && (pl2 > fp.min_depth) && (pl2 < fp.max_depth);  // strict on both sides, NaN fails
-    AVL_STAMP(pt2);
+    AVL_RESTAMP(pt2);
     // transform_pc: pose @ [pc; 1]  (dgemm FMA chain k = 0..3)
     const double g0 = fma(T[3], 1.0, fma(T[2], pl2, fma(T[1], pl1, T[0] * pl0)));
     const double g1 = fma(T[7], 1.0, fma(T[6], pl2, fma(T[5], pl1, T[4] * pl0)));
@@ -272,10 +303,10 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     const bool ok2 = ok1 && in_grid;
     // global mode: the reference only tests the upper row/col bounds and otherwise wraps or raises; a point outside
     // the pass-1 bounding box is dropped here and reported
-    const bool err_box = ok1 && !in_grid && fp.mode == 1;
+    err_box = ok1 && !in_grid && fp.mode == 1;
     const int32_t cell_try = ok2 ? (int32_t)(((unsigned)row * (unsigned)fp.n1 + (unsigned)col) * (unsigned)fp.n2 + (unsigned)h) : 0;
     // cell states only move forward (empty -> pending -> slot), so a slot read here is final even if the line is old
-    const int32_t seen = cell_slot[cell_try];
+    if constexpr (MODE == 0) seen = cell_slot[cell_try];
     __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the request below the arithmetic that follows)
     // project_point(calib, p_local) -> rgb[py, px] with numpy's negative-index wrap
     double q0 = gemv3(fp.k + 0, pl0, pl1, pl2), q1 = gemv3(fp.k + 3, pl0, pl1, pl2), q2 = gemv3(fp.k + 6, pl0, pl1, pl2);
@@ -283,7 +314,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     px += px < 0 ? fp.W : 0;
     py += py < 0 ? fp.H : 0;
     const bool in_img = !(px < 0 || px >= fp.W || py < 0 || py >= fp.H);
-    const bool err_img = ok2 && !in_img;    // the reference raises IndexError here; we drop the point and flag it
+    err_img = ok2 && !in_img;    // the reference raises IndexError here; we drop the point and flag it
     const bool ok3 = ok2 && in_img;
     const size_t rgb_off = ok3 ? ((size_t)py * fp.W + px) * 3 : 0;
     // the colour gather (a sample that dropped out reads element 0 of cell_slot: batched launches carry no frame-level rgb pointer)
@@ -291,7 +322,9 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     // cell_slot load, so the wait before the CAS would have to be for both)
     using gbyte_ptr = const __attribute__((address_space(1))) uint8_t*;
     const gbyte_ptr c = (gbyte_ptr)(ok3 ? rgb + rgb_off : reinterpret_cast<const uint8_t*>(cell_slot));
-    const uint8_t c0 = c[0], c1 = c[1], c2 = c[2];
+    c0 = c[0];
+    c1 = c[1];
+    c2 = c[2];
     __builtin_amdgcn_sched_barrier(0);
     // project_point(get_sim_cam_mat(Hf, Wf), p_local) -> feature pixel, bounds-checked (vlmap_builder.py:161)
     q0 = gemv3(fp.kf + 0, pl0, pl1, pl2);
@@ -299,7 +332,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
     q2 = gemv3(fp.kf + 6, pl0, pl1, pl2);
     px = py_int(q0 / q2 - 0.5);
     py = py_int(q1 / q2 - 0.5);
-    const bool ok = ok3 && !(px < 0 || py < 0 || px >= fp.Wf || py >= fp.Hf);
+    ok = ok3 && !(px < 0 || py < 0 || px >= fp.Wf || py >= fp.Hf);
     if (ok2) fpix = (int32_t)((unsigned)py * (unsigned)fp.Wf + (unsigned)px);
     const double radial = (pl0 * pl0 + pl1 * pl1) + pl2 * pl2;  // np.sum(np.square(p_local))
     const double alpha_try = exp(-radial / fp.two_sigma_sq);
@@ -307,11 +340,18 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         alpha = alpha_try;
         cell = cell_try;
     }
+    AVL_RESTAMP(pt3);
+    }   // (MODE != 1)
+    if constexpr (MODE == 2) {
+        if (valid)
+            pre_out[s] = PreRec{alpha, cell, fpix, ok ? ((uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16)) : 0u,
+                                (err_box ? 1u : 0u) | (err_img ? 2u : 0u)};
+        return SampleRec{};
+    }
     // create the voxel if the cell is empty: the CAS winner takes the next slot.  One counter atomic per wave:
     // winners are ranked with a ballot (a single hot word only sustains ~90 atomics/us).
     int32_t known = -1;
     bool creator = false;
-    AVL_STAMP(pt3);
     if (ok) {
         if (seen == kEmpty) creator = atomicCAS(&cell_slot[cell], kEmpty, kPending) == kEmpty;
         else if (seen >= 0) known = seen;
@@ -352,7 +392,7 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
         }
     }
     // (the colour bytes are first looked at HERE: the CAS above only waits for the cell's slot, the gather is still in flight then)
-    if (ok) rgbv = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
+    if (MODE == 0 && ok) rgbv = (uint32_t)c0 | ((uint32_t)c1 << 8) | ((uint32_t)c2 << 16);
     if (valid) {
         recs.alpha[s] = alpha;
         recs.fpix[s] = fpix;
@@ -472,6 +512,26 @@ __global__ __launch_bounds__(256) void voxelize_link_kernel(FrameParams fp, cons
     warm_kernel_arguments<12>();       // (944 bytes with the hidden arguments)
     const SampleRec r = bp_voxelize_body<256>(blockIdx.x, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
     link_body<true, 256>(blockIdx.x, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, fp.batch, fp.P_frame, r, err_flags, ol);
+}
+
+// The same for one frame of the C frame loop (avl_builder_integrate_frames): gb workgroups in FRONT run the stateless half of K1 for
+// the NEXT frame (fpn / next, see PreGather), and this frame's K1 starts from what the previous launch prepared when fp.pre is set.
+__global__ __launch_bounds__(256) void voxelize_link_next_kernel(FrameParams fp, const float* depth, const int32_t* __restrict__ sample_idx,
+                                                                 const uint8_t* rgb, int32_t* __restrict__ cell_slot,
+                                                                 int32_t* __restrict__ slot_cell, Recs recs, int32_t* __restrict__ head,
+                                                                 unsigned long long* __restrict__ counters, int* __restrict__ err_flags,
+                                                                 ReplayLog log, long long log_base, unsigned long long frame_key,
+                                                                 FrameParams fpn, PreGather next, int gb) {
+    if ((int)blockIdx.x < gb) {
+        bp_voxelize_body<256, 2>((int)blockIdx.x, fpn, next.depth, next.samples, next.rgb, cell_slot, slot_cell, recs, counters, err_flags, next.out);
+        return;
+    }
+    const int blk = (int)blockIdx.x - gb;
+    warm_kernel_arguments<12>();
+    SampleRec r;
+    if (fp.pre) r = bp_voxelize_body<256, 1>(blk, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+    else r = bp_voxelize_body<256, 0>(blk, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+    link_body<false, 256>(blk, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
 }
 
 // wave per sampled point; only owners work.  CH = number of 256-float chunks kept in registers (D <= 256*CH).
@@ -757,15 +817,8 @@ __global__ __launch_bounds__(COMPACT ? 256 : AVL_K3_THREADS) AVL_K3_OCC(CH) void
                                                    int P_frame, Recs recs, int32_t* __restrict__ head, const float* __restrict__ feat,
                                                    double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                    float* __restrict__ first_feat, double* __restrict__ first_alpha,
-                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty, OwnerList ol, PreGather next,
-                                                   int gb) {
-    // (gb workgroups in FRONT of K3's gather the next frame's samples and depths, see PreGather: dispatched first, done after two
-    // round trips; behind K3's they started last and made the launch longer)
-    if (!COMPACT && (int)blockIdx.x < gb) {
-        pre_gather_body((int)blockIdx.x, AVL_K3_THREADS, next);
-        return;
-    }
-    fuse_body<CH, COMPACT>((int)blockIdx.x - (COMPACT ? 0 : gb), P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty, ol);
+                                                   unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty, OwnerList ol) {
+    fuse_body<CH, COMPACT>(blockIdx.x, P, D, frame_key, batch, P_frame, recs, head, feat, sum_feat, sum_w4, first_feat, first_alpha, slot_key, dirty, ol);
 }
 
 // Deferred-fuse launch (avl_builder_set_deferred_fuse): ONE kernel per frame.  Workgroups [0, pb) run K1 + K2 of the NEW frame
@@ -788,16 +841,19 @@ __global__ __launch_bounds__(AVL_K3_THREADS) AVL_K3_OCC(CH) void pipe_kernel(Fra
                                                    unsigned long long frame_key, FusePrev prev, int D, double* __restrict__ sum_feat,
                                                    double* __restrict__ sum_w4, float* __restrict__ first_feat,
                                                    double* __restrict__ first_alpha, unsigned long long* __restrict__ slot_key,
-                                                   uint8_t* __restrict__ dirty, PreGather next, int gb) {
-    if ((int)blockIdx.x < gb) {                   // (in front of K1 + K2's and K3's workgroups: see PreGather)
-        pre_gather_body((int)blockIdx.x, AVL_K3_THREADS, next);
+                                                   uint8_t* __restrict__ dirty, FrameParams fpn, PreGather next, int gb) {
+    if ((int)blockIdx.x < gb) {                   // (in front of K1 + K2's and K3's workgroups: the stateless half of the NEXT frame's K1)
+        bp_voxelize_body<AVL_K3_THREADS, 2>((int)blockIdx.x, fpn, next.depth, next.samples, next.rgb, cell_slot, slot_cell, recs, counters, err_flags,
+                                            next.out);
         return;
     }
     const int blk = (int)blockIdx.x - gb;
     if (blk < pb) {
         warm_kernel_arguments<12>();   // (K1 + K2 read FrameParams and a dozen pointers; a K3 wave needs two lines, and touching more
                                        // costs it: fuse_kernel 10.4-10.7 -> 10.9-11.1 us, 64 frames per launch 230 -> 255 us)
-        const SampleRec r = bp_voxelize_body<AVL_K3_THREADS>(blk, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+        SampleRec r;
+        if (fp.pre) r = bp_voxelize_body<AVL_K3_THREADS, 1>(blk, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
+        else r = bp_voxelize_body<AVL_K3_THREADS, 0>(blk, fp, depth, sample_idx, rgb, cell_slot, slot_cell, recs, counters, err_flags);
         link_body<false, AVL_K3_THREADS>(blk, fp.P, cell_slot, head, recs, counters, log, log_base, frame_key, nullptr, fp.P_frame, r, err_flags);
     } else {
         fuse_body<CH>(blk - pb, prev.P, D, prev.frame_key, nullptr, prev.P, prev.recs, prev.head, prev.feat, sum_feat, sum_w4,
@@ -1251,16 +1307,29 @@ struct avl_builder {
     LogSegments* ls_cache = nullptr;
     long long ls_log_used = -1;
     int64_t ls_n = -1;
-    // next-frame gather of the C frame loop (PreGather): two buffers of recs_cap entries, the one K1 reads and the one being written
-    int2* pre_buf[2] = {nullptr, nullptr};
-    struct PreHeld {           // what pre_buf[buf] holds: the samples / depths of the frame with exactly these inputs
+    // next frame's stateless half of K1 in the C frame loop (PreGather): two buffers of recs_cap records, the one K1 reads and the one
+    // being written
+    PreRec* pre_buf[2] = {nullptr, nullptr};
+    struct PreHeld {           // what pre_buf[buf] holds: the frame with exactly these inputs and parameters
+        FrameParams fp{};
         const int32_t* samples = nullptr;
         const void* depth = nullptr;
-        int P = 0, HW = 0, buf = 0;
+        const uint8_t* rgb = nullptr;
+        int buf = 0;
         bool valid = false;
     } pre_held;
-    PreGather pre_next{};      // set by avl_builder_integrate_frames for the launch being issued: the frame after it
+    struct PreNext {           // set by avl_builder_integrate_frames for the launch being issued: the frame after it
+        const int32_t* samples = nullptr;
+        const float* depth = nullptr;
+        const uint8_t* rgb = nullptr;
+        const double* h_pc_transform = nullptr;
+    } pre_next;
 };
+
+// the parameters the stateless half of K1 reads (everything of FrameParams up to the grid shape, the mode; not pre / capacity / batch)
+static bool same_geometry(const FrameParams& a, const FrameParams& b) {
+    return std::memcmp(&a, &b, offsetof(FrameParams, batch)) == 0 && a.P_frame == b.P_frame && a.mode == b.mode && a.depth_u16 == b.depth_u16;
+}
 
 static int builder_check_flags(avl_builder* b, hipStream_t st) {
     int flags = 0;
@@ -1301,7 +1370,7 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
     const size_t cap = ((size_t)P + P / 4 + 1024 + 255) / 256 * 256;
     const size_t one = (cap * (8 + 4 * 4 + 1) + 255) / 256 * 256;
     const size_t own = (cap * (8 + 4 * 4) + (cap / 256 + 1) * 4 + 255) / 256 * 256;
-    const size_t pre = (cap * sizeof(int2) + 255) / 256 * 256;
+    const size_t pre = (cap * sizeof(PreRec) + 255) / 256 * 256;
     AVL_HIP_CHECK(hipMalloc((void**)&b->recs_mem, 2 * one + own + 2 * pre));
     auto carve = [&](Recs& r, char* p) {
         r.alpha = reinterpret_cast<double*>(p); p += cap * 8;
@@ -1323,8 +1392,8 @@ static int ensure_recs(avl_builder* b, int P, hipStream_t st) {
         o.o_rgb = reinterpret_cast<uint32_t*>(p); p += cap * 4;
         o.ocnt = reinterpret_cast<int32_t*>(p);
     }
-    b->pre_buf[0] = reinterpret_cast<int2*>(b->recs_mem + 2 * one + own);
-    b->pre_buf[1] = reinterpret_cast<int2*>(b->recs_mem + 2 * one + own + pre);
+    b->pre_buf[0] = reinterpret_cast<PreRec*>(b->recs_mem + 2 * one + own);
+    b->pre_buf[1] = reinterpret_cast<PreRec*>(b->recs_mem + 2 * one + own + pre);
     b->pre_held.valid = false;
     b->recs_cap = (int)cap;
     return AVL_OK;
@@ -1510,21 +1579,19 @@ static void drop_log_segments(avl_builder* b, hipStream_t st) {
 
 // K3 over one launch's records (CH = 256-float register chunks of a feature row)
 static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, const BatchEntry* batch, int P_frame, const Recs& recs,
-                       int32_t* head, const float* d_feat, hipStream_t st, const PreGather& next = PreGather{}) {
+                       int32_t* head, const float* d_feat, hipStream_t st) {
     // batched launches run over the owners K2 compacted; single frames and the generic kernel: wave per sample
     const bool compact = b->D <= 1536 && P >= kAggregateSamples;
     constexpr int kWaves = AVL_K3_THREADS / 64;
     const unsigned wb = compact ? (unsigned)((P + 255) / 256) * (kFuseWaves / 4) : (unsigned)((P + kWaves - 1) / kWaves);
-    const unsigned gb = (!compact && next.samples && b->D <= 1536) ? (unsigned)((next.P + AVL_K3_THREADS - 1) / AVL_K3_THREADS) : 0u;
 #define AVL_FUSE_LAUNCH(CH)                                                                                                              \
     do {                                                                                                                                 \
         if (compact)                                                                                                                     \
             hipLaunchKernelGGL((fuse_kernel<CH, true>), dim3(wb), dim3(256), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat,  \
-                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, b->owners, PreGather{},     \
-                               0);                                                                                                       \
+                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, b->owners);                 \
         else                                                                                                                             \
-            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb + gb), dim3(AVL_K3_THREADS), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
-                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, OwnerList{}, next, (int)gb); \
+            hipLaunchKernelGGL((fuse_kernel<CH, false>), dim3(wb), dim3(AVL_K3_THREADS), 0, st, P, b->D, frame_key, batch, P_frame, recs, head, d_feat, \
+                               b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, OwnerList{});               \
     } while (0)
     if (b->D <= 256) AVL_FUSE_LAUNCH(1);
     else if (b->D <= 512) AVL_FUSE_LAUNCH(2);
@@ -1549,13 +1616,14 @@ static int flush_pending(avl_builder* b, hipStream_t st) {
 
 template <int CH>
 static void launch_pipe(avl_builder* b, const FrameParams& fp, unsigned pb, const void* d_depth, const int32_t* d_sample_idx,
-                        const uint8_t* d_rgb, unsigned long long frame_key, const FusePrev& prev, hipStream_t st, const PreGather& next) {
+                        const uint8_t* d_rgb, unsigned long long frame_key, const FusePrev& prev, hipStream_t st, const FrameParams& fpn,
+                        const PreGather& next) {
     constexpr int kWaves = AVL_K3_THREADS / 64;
     const unsigned wb = prev.P ? (unsigned)((prev.P + kWaves - 1) / kWaves) : 0u;
-    const unsigned gb = next.samples ? (unsigned)((next.P + AVL_K3_THREADS - 1) / AVL_K3_THREADS) : 0u;
+    const unsigned gb = next.out ? (unsigned)((fpn.P + AVL_K3_THREADS - 1) / AVL_K3_THREADS) : 0u;
     hipLaunchKernelGGL(pipe_kernel<CH>, dim3(pb + wb + gb), dim3(AVL_K3_THREADS), 0, st, fp, (int)pb, reinterpret_cast<const float*>(d_depth), d_sample_idx,
                        d_rgb, b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, prev,
-                       b->D, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, next, (int)gb);
+                       b->D, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, b->slot_key, b->dirty, fpn, next, (int)gb);
 }
 
 extern "C" {
@@ -1765,21 +1833,33 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     fp.depth_u16 = depth_u16;
     fp.depth_div = depth_div;
     fp.capacity = b->capacity;
-    // next-frame gather (PreGather): use what the previous launch gathered for exactly these inputs; let this launch gather for the
-    // frame the C loop will issue next (single float32 frames below the batched-launch size, the register-resident K3 kernels)
+    // PreGather: start from what the previous launch prepared for exactly this frame; let this launch prepare the frame the C loop
+    // issues next (single float32 frames below the batched-launch size, the register-resident K3 kernels)
     fp.pre = nullptr;
+    FrameParams fpn{};
     PreGather next{};
-    const bool pre_ok = B == 0 && !depth_u16 && !h_pcd_min && b->D <= 1536 && P < kAggregateSamples;
+    const bool pre_ok = B == 0 && !depth_u16 && b->D <= 1536 && P < kAggregateSamples;
     if (pre_ok) {
         const auto& h = b->pre_held;
-        if (h.valid && h.samples == d_sample_idx && h.depth == d_depth && h.P == P && h.HW == H * W) fp.pre = b->pre_buf[h.buf];
-        if (b->pre_next.samples && b->pre_next.P == P) {
-            next = b->pre_next;
-            next.out = b->pre_buf[fp.pre ? 1 - h.buf : 0];
+        if (h.valid && h.samples == d_sample_idx && h.depth == d_depth && h.rgb == d_rgb && same_geometry(h.fp, fp)) fp.pre = b->pre_buf[h.buf];
+        if (b->pre_next.samples) {
+            fpn = fp;
+            fpn.pre = nullptr;
+            for (int i = 0; i < 16; ++i) fpn.t[i] = b->pre_next.h_pc_transform[i];
+            next = PreGather{b->pre_buf[fp.pre ? 1 - h.buf : 0], b->pre_next.depth, b->pre_next.samples, b->pre_next.rgb};
         }
     }
     const int next_buf = next.out == b->pre_buf[1] ? 1 : 0;
     b->pre_held.valid = false;
+    auto hold_next = [&]() {
+        if (!next.out) return;
+        b->pre_held.fp = fpn;
+        b->pre_held.samples = next.samples;
+        b->pre_held.depth = next.depth;
+        b->pre_held.rgb = next.rgb;
+        b->pre_held.buf = next_buf;
+        b->pre_held.valid = true;
+    };
     const unsigned long long frame_key = b->key_bias | ((unsigned long long)frame_idx << 32);
 
     if (b->ls_cache) drop_log_segments(b, st);   // the sorted log of the last merge is stale from here on
@@ -1792,11 +1872,11 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         // ONE launch: K1 + K2 of this frame next to K3 of the previous one; this frame's K3 rides in the next launch (or a flush)
         const FusePrev prev{b->pend.P, b->pend.frame_key, b->recs_alt, b->head_alt, b->pend.feat};
         const unsigned pb = (unsigned)((P + AVL_K3_THREADS - 1) / AVL_K3_THREADS);      // (its K1 + K2 workgroups have the kernel's size)
-        if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
-        else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
-        else if (b->D == 768) launch_pipe<3>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
-        else if (b->D <= 1024) launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
-        else launch_pipe<6>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, next);
+        if (b->D <= 256) launch_pipe<1>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, fpn, next);
+        else if (b->D <= 512) launch_pipe<2>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, fpn, next);
+        else if (b->D == 768) launch_pipe<3>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, fpn, next);
+        else if (b->D <= 1024) launch_pipe<4>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, fpn, next);
+        else launch_pipe<6>(b, fp, pb, d_depth, d_sample_idx, d_rgb, frame_key, prev, st, fpn, next);
         if (b->log.slot) b->log_used += P;
         b->pend.P = P;
         b->pend.frame_key = frame_key;
@@ -1804,16 +1884,23 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         std::swap(b->recs, b->recs_alt);
         std::swap(b->head, b->head_alt);
         AVL_HIP_CHECK(hipGetLastError());
-        if (next.samples) b->pre_held = {next.samples, next.depth, next.P, next.HW, next_buf, true};
+        hold_next();
         return AVL_OK;
     }
     rc = flush_pending(b, st);
     if (rc != AVL_OK) return rc;
-    hipLaunchKernelGGL(voxelize_link_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb,
-                       b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, b->owners);
+    if (fp.pre || next.out) {     // a frame of the C loop: K1 from the prepared records and / or the next frame's stateless half in front
+        const unsigned gb = next.out ? pb : 0u;
+        hipLaunchKernelGGL(voxelize_link_next_kernel, dim3(gb + pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx,
+                           d_rgb, b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, fpn,
+                           next, (int)gb);
+    } else {
+        hipLaunchKernelGGL(voxelize_link_kernel, dim3(pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx, d_rgb,
+                           b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, b->owners);
+    }
     if (b->log.slot) b->log_used += P;
-    rc = launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st, next);
-    if (rc == AVL_OK && next.samples) b->pre_held = {next.samples, next.depth, next.P, next.HW, next_buf, true};
+    rc = launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st);
+    if (rc == AVL_OK) hold_next();
     return rc;
 }
 
@@ -1881,11 +1968,12 @@ int avl_builder_integrate_frames(avl_builder* b, int n_frames, const float* cons
     for (int i = 0; i < n_frames; ++i) {
         // the frame after this one, for the gather workgroups of this frame's launch (PreGather); the last frame of a call has none:
         // what a later call brings is not known to be resident yet
-        b->pre_next = (i + 1 < n_frames && h_sample_ptrs[i + 1] && h_depth_ptrs[i + 1])
-                          ? PreGather{h_sample_ptrs[i + 1], h_depth_ptrs[i + 1], nullptr, P, H * W} : PreGather{};
+        b->pre_next = {};
+        if (i + 1 < n_frames && h_sample_ptrs[i + 1] && h_depth_ptrs[i + 1] && h_rgb_ptrs[i + 1])
+            b->pre_next = {h_sample_ptrs[i + 1], h_depth_ptrs[i + 1], h_rgb_ptrs[i + 1], h_pc_transforms + 16 * (i + 1)};
         const int rc = integrate_impl(b, h_depth_ptrs[i], 0, 1.0, H, W, h_calib, h_calib_inv, h_pc_transforms + 16 * i, h_sample_ptrs[i], P,
                                       h_feat_ptrs[i], Hf, Wf, h_rgb_ptrs[i], frame_idx0 + i, min_depth, max_depth, sigma_sq, nullptr, stream);
-        b->pre_next = PreGather{};
+        b->pre_next = {};
         if (rc != AVL_OK) return rc;
     }
     return AVL_OK;
