@@ -306,6 +306,10 @@ AVL_API int avl_builder_integrate_batch(avl_builder* b, int B, const float* cons
  * batch: no two frames share a launch or a list -- issued from C.  A call through a language binding costs more host time than the
  * frame's kernels take (12.4 us per ctypes call against 11.9 us of pipe_kernel, tools/probe_frame_loop.py).  Arguments as for
  * avl_builder_integrate_batch; with deferred fuse the LAST frame's features are still to be fused when the call returns.
+ * Every frame of the call must be resident when it is made (as for a batch): while frame i is launched, a few workgroups of the
+ * same launch already read frame i + 1's sample indices, depth and colour image and run the half of its back-projection that
+ * does not depend on the map (geometry, projections, colour gather, weight), so that frame i + 1's dependent chain starts at the
+ * voxel-hash lookup.  Same arithmetic, same maps; the frames of one launch still share nothing.
  */
 AVL_API int avl_builder_integrate_frames(avl_builder* b, int n_frames, const float* const* h_depth_ptrs, int H, int W,
                                         const double* h_calib, const double* h_calib_inv, const double* h_pc_transforms,

@@ -826,3 +826,50 @@ def test_config3_sequence_5000_frames(ops):
     for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
         assert torch.equal(dev[k], out[k]), k
     assert float((dev["grid_feat"] - out["grid_feat"]).abs().max()) <= 1e-5 and tim["merged_voxels"] == n and tim["exact_rgb"]
+
+
+def test_frame_loop_in_c_with_a_ring_of_input_buffers(ops):
+    """avl_builder_integrate_frames prepares frame i + 1's map-independent half of K1 inside frame i's launch and recognises the
+    prepared frame by its inputs AND its parameters: a ring of three device buffers walked with eight different poses (the same
+    pointers come back with another pose), repeated frames, calls of one frame and a call after a parameter change must all give
+    the map of eight single calls, bit for bit, deferred or not"""
+    import torch
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(21)
+    H, W, Hf, Wf, D, nfr, ring = 96, 128, 47, 63, 32, 8, 3
+    gs, cam_h, cs = 80, 1.5, 0.25
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(9)
+    d_dev = [torch.from_numpy(np.ascontiguousarray(depths[i], dtype=np.float32)).cuda() for i in range(ring)]
+    r_dev = [torch.from_numpy(np.ascontiguousarray(rgbs[i])).cuda() for i in range(ring)]
+    f_dev = [torch.from_numpy(np.ascontiguousarray(np.transpose(feats[i], (1, 2, 0)), dtype=np.float32)).cuda() for i in range(ring)]
+    s_dev = [torch.from_numpy(O.sample_indices(rs, H * W, 3).astype(np.int32)).cuda() for _ in range(ring)]
+    vh = int(cam_h / cs)
+
+    def build(chunks, deferred, sigma_change_at=None):
+        acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=1 << 15, deferred_fuse=deferred)
+        acc.enable_replay_log(nfr * H * W)
+        i = 0
+        for k in chunks:
+            idx = [j % ring for j in range(i, i + k)]
+            sig = 0.6 if sigma_change_at is None or i < sigma_change_at else 0.9
+            if k == 1:
+                acc.integrate_frame(d_dev[idx[0]], calib, Ts[i], s_dev[idx[0]], f_dev[idx[0]], r_dev[idx[0]], frame_idx=i, sigma_sq=sig)
+            else:
+                bp = acc.make_batch_plan([d_dev[j] for j in idx], [s_dev[j] for j in idx], [f_dev[j] for j in idx], [r_dev[j] for j in idx])
+                acc.integrate_frames(bp, calib, Ts[i:i + k], frame_idx0=i, sigma_sq=sig)
+            i += k
+        assert i == nfr
+        return acc.finalize()
+
+    want = build([1] * nfr, False)
+    assert want["grid_pos"].shape[0] > 500
+    for deferred in (False, True):
+        for chunks in ([nfr], [3, 5], [1, 2, 1, 4], [4, 1, 3]):
+            _same_map(build(chunks, deferred), want)
+    want2 = build([1] * nfr, False, sigma_change_at=5)          # the weights change from frame 5 on: a call boundary, nothing prepared across it
+    _same_map(build([5, 3], True, sigma_change_at=5), want2)
+    _same_map(build([5, 3], False, sigma_change_at=5), want2)

@@ -15,7 +15,7 @@ f=glob.glob('/tmp/prof/**/*kernel_stats.csv', recursive=True)
 out=[]
 for r in csv.DictReader(open(f[0])):
     n=r['Name']
-    for k in ('pipe_kernel','fuse_kernel','voxelize_link_kernel'):
+    for k in ('pipe_kernel','fuse_kernel','voxelize_link_kernel','voxelize_link_next_kernel'):
         if k in n: out.append(f"{k}:{float(r['AverageNs'])/1e3:.2f}us x{r['Calls']}")
 print(sys.argv[1].split('/')[-1], sys.argv[2], ' '.join(out))
 PY
