@@ -1,7 +1,7 @@
 """GPU box: where a frame-by-frame builder launch spends its time.  Needs the instrumented library
 (python tools/build_variant.py probe --src avl_builder.hip -DAVL_PROBE_CHAIN; AVLMAPS_HIP_LIB=variants/libavlmaps_hip_probe.so):
 every work item of ONE launch stamps s_memrealtime (100 MHz) after each hop of its dependent-load chain.
-usage: probe_chain.py [frames_before=1500]"""
+usage: probe_chain.py [frames_before=1500] [seq]   (seq: the probed launch is the third frame of an avl_builder_integrate_frames call)"""
 import ctypes as C
 import os
 import sys
@@ -16,8 +16,9 @@ from avlmaps_amd import _lib, ops  # noqa: E402
 H, W, Hf, Wf, D, rate = 720, 1080, 347, 520, 512, 100
 nbuf = 4
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+seq = len(sys.argv) > 2 and sys.argv[2] == "seq"
 depths, rgbs, feats = bench.make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=99)
-Ts = bench.pc_transforms(bench.trajectory(n + 8))
+Ts = bench.pc_transforms(bench.trajectory(n + 16))
 calib = np.array([540, 0, 540, 0, 540, 360, 0, 0, 1.0])
 rs = np.random.RandomState(5)
 samples = []
@@ -52,7 +53,12 @@ for deferred in (False, True):
         assert setp(buf.data_ptr()) == 0
         i = n + rep
         b = i % nbuf
-        acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
+        if seq:     # the C frame loop: three frames in one call, the stamps that remain are the LAST launch's (K1 from prepared records)
+            idx = [(i + k) % nbuf for k in range(3)]
+            plan = acc.make_batch_plan([depths[j] for j in idx], [samples[j] for j in idx], [feats[j] for j in idx], [rgbs[j] for j in idx])
+            acc.integrate_frames(plan, calib, Ts[i:i + 3], frame_idx0=i)
+        else:
+            acc.integrate_frame(depths[b], calib, Ts[i], samples[b], feats[b], rgbs[b], frame_idx=i)
         torch.cuda.synchronize()
         assert setp(None) == 0
         t = buf.cpu().numpy().astype(np.uint64).reshape(-1, 8)
