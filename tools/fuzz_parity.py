@@ -1,6 +1,6 @@
 """GPU box: randomised parity sweep (time-boxed).  fuzz_parity.py [seconds] [seed] [max cases per kind]
   sim:     random N / D / Q / row strides / precision modes / column windows / prepared maps against float64 NumPy
-  builder: random frame shapes / grids / widths / sample rates, frame-by-frame vs deferred vs batched vs the sequential oracle
+  builder: random frame shapes / grids / widths / sample rates, frame-by-frame vs deferred vs batched vs the C frame loop (plain / deferred, random pieces) vs the sequential oracle
   aux:     heat decay, argmax / top-k, pool_3d_label_to_2d, rgb top-down, obstacle map on random maps against the oracle (bit exact)
 Prints one line per failure with the configuration that reproduces it; exit status 1 if anything failed."""
 import os
@@ -114,8 +114,8 @@ def builder_case(i):
     vh = int(cam_h / cs)
     fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
     outs = {}
-    for mode in ("frames", "deferred", "batch"):
-        acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=int(rng.choice([4, 64, 5000])), deferred_fuse=mode == "deferred")
+    for mode in ("frames", "deferred", "batch", "loop", "loop-deferred"):
+        acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=int(rng.choice([4, 64, 5000])), deferred_fuse=mode.endswith("deferred"))
         acc.enable_replay_log(sum(len(s) for s in samples))
         if mode == "batch":
             k = 0
@@ -123,6 +123,18 @@ def builder_case(i):
                 b = int(rng.integers(1, nfr - k + 1))
                 sl = slice(k, k + b)
                 acc.integrate_batch(list(depths[sl]), calib, Ts[sl], samples[sl], fs[sl], list(rgbs[sl]), frame_idx0=k)
+                k += b
+        elif mode.startswith("loop"):       # the frame loop in C, in random pieces (a frame's launch prepares the next frame's K1)
+            k = 0
+            while k < nfr:
+                b = int(rng.integers(1, nfr - k + 1))
+                sl = slice(k, k + b)
+                if all(len(samples[j]) == len(samples[k]) for j in range(k, k + b)) and len(samples[k]) > 0:
+                    plan = acc.make_batch_plan(list(depths[sl]), samples[sl], fs[sl], list(rgbs[sl]))
+                    acc.integrate_frames(plan, calib, Ts[sl], frame_idx0=k)
+                else:
+                    for j in range(k, k + b):
+                        acc.integrate_frame(depths[j], calib, Ts[j], samples[j], fs[j], rgbs[j], frame_idx=j)
                 k += b
         else:
             for k in range(nfr):
@@ -164,6 +176,15 @@ def builder_case(i):
         fa, fb = outs["frames"]["grid_feat"], outs["deferred"]["grid_feat"]      # equal up to the summation order inside a list
         if not (np.mean(fa == fb) > 0.999 and np.allclose(fa, fb, rtol=1e-6, atol=1e-6 * max(1.0, float(np.abs(fa).max())))):
             fails.append((dict(cfg, mode="deferred-vs-frames"), "grid_feat differs beyond fp64 summation order"))
+    for m in ("loop", "loop-deferred"):         # the C frame loop issues the same launches as single calls: everything bit for bit
+        if m in outs and "frames" in outs and len(ref["grid_pos"]):
+            for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight", "grid_feat"):
+                if k == "grid_feat" and D > 1536:       # (the generic-width kernel adds a list in ARRIVAL order: equal to rounding only)
+                    fa, fb = outs[m][k], outs["frames"][k]
+                    if not np.allclose(fa, fb, rtol=1e-6, atol=1e-6 * max(1.0, float(np.abs(fa).max()))):
+                        fails.append((dict(cfg, mode=m + "-vs-frames"), "grid_feat differs beyond fp64 summation order"))
+                elif not np.array_equal(outs[m][k], outs["frames"][k]):
+                    fails.append((dict(cfg, mode=m + "-vs-frames"), f"{k} not identical"))
 
 
 def aux_case(i):
