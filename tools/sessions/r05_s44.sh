@@ -6,7 +6,7 @@ timeout -s KILL 900 python -m pytest tests/test_builder_gpu.py tests/test_geomet
 cd /tmp; export TMPDIR=/tmp
 for rep in 1 2; do
 for lib in avlmaps_amd/lib/libavlmaps_hip.so variants/libavlmaps_hip_prev.so; do
-for f in "" "--deferred-fuse"; do
+for f in "" "--deferred-fuse" "--python-frame-loop"; do
  rm -rf /tmp/prof
  AVLMAPS_HIP_LIB=$R/$lib timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o p -- python $R/bench.py --workload build --steps 4000 --no-cpu $f > /tmp/o.txt 2>&1
  python - "$lib" "$f" <<PY
@@ -20,7 +20,7 @@ for r in csv.DictReader(open(f[0])):
 print(sys.argv[1].split('/')[-1], sys.argv[2], ' '.join(out))
 PY
 done; done; done
-for rep in 1 2; do for lib in avlmaps_amd/lib/libavlmaps_hip.so variants/libavlmaps_hip_prev.so; do for f in "" "--deferred-fuse"; do
+for rep in 1 2; do for lib in avlmaps_amd/lib/libavlmaps_hip.so variants/libavlmaps_hip_prev.so; do for f in "" "--deferred-fuse" "--python-frame-loop"; do
 AVLMAPS_HIP_LIB=$R/$lib timeout 300 python $R/bench.py --workload build --steps 10000 --no-cpu $f 2>/dev/null | grep '^{"metric"' | python -c "
 import sys,json
 j=json.loads(sys.stdin.read()); print('$lib [$f]', round(j['value']), 'fps', round(1e6/j['value'],2), 'us/frame')"
