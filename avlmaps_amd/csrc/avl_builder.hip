@@ -36,6 +36,11 @@
 //                   (36 us/frame, 47 MB of write traffic for 11 MB of algorithmic RMW).  The owner also finds the
 //                   voxel's first-touch sample (smallest position) when the voxel is new.
 // Deferred fuse (avl_builder_set_deferred_fuse): pipe_kernel = voxelize_link of frame i + fuse of frame i - 1 in one launch.
+// The frame loop in C (avl_builder_integrate_frames) additionally runs the map-independent half of K1 for frame i + 1 -- everything
+// in front of the cell_slot lookup -- in workgroups of its own at the front of frame i's launch (struct PreGather,
+// voxelize_link_next_kernel / pipe_kernel), so that a frame's dependent chain starts at the voxel-hash lookup.
+// K1 and K3 are written as STRAIGHT-LINE code around their loads (flags and selects, full-width rows): a load inside a branch makes
+// the compiler wait for everything outstanding where the branches merge, and these kernels live on having several loads in flight.
 // Slots are handed out in arrival order, so finalisation sorts the first-touch keys (rocPRIM radix sort) to emit
 // rows in the reference's voxel-id order; the sort is a once-per-save cost.
 #include <algorithm>
