@@ -1583,10 +1583,12 @@ static void drop_log_segments(avl_builder* b, hipStream_t st) {
 }
 
 // K3 over one launch's records (CH = 256-float register chunks of a feature row)
+// `owners_compacted`: the K2 that produced `recs` was voxelize_link_kernel with b->owners (it compacts iff P >= kAggregateSamples);
+// pipe_kernel's and voxelize_link_next_kernel's K2 never write the OwnerList, so their K3 is always wave-per-sample
 static int launch_fuse(avl_builder* b, int P, unsigned long long frame_key, const BatchEntry* batch, int P_frame, const Recs& recs,
-                       int32_t* head, const float* d_feat, hipStream_t st) {
+                       int32_t* head, const float* d_feat, hipStream_t st, bool owners_compacted) {
     // batched launches run over the owners K2 compacted; single frames and the generic kernel: wave per sample
-    const bool compact = b->D <= 1536 && P >= kAggregateSamples;
+    const bool compact = owners_compacted && b->D <= 1536 && P >= kAggregateSamples;
     constexpr int kWaves = AVL_K3_THREADS / 64;
     const unsigned wb = compact ? (unsigned)((P + 255) / 256) * (kFuseWaves / 4) : (unsigned)((P + kWaves - 1) / kWaves);
 #define AVL_FUSE_LAUNCH(CH)                                                                                                              \
@@ -1616,7 +1618,7 @@ static int flush_pending(avl_builder* b, hipStream_t st) {
     if (b->pend.P == 0) return AVL_OK;
     const int P = b->pend.P;
     b->pend.P = 0;
-    return launch_fuse(b, P, b->pend.frame_key, nullptr, P, b->recs_alt, b->head_alt, b->pend.feat, st);
+    return launch_fuse(b, P, b->pend.frame_key, nullptr, P, b->recs_alt, b->head_alt, b->pend.feat, st, /*owners_compacted=*/false);
 }
 
 template <int CH>
@@ -1650,6 +1652,7 @@ int avl_builder_reset(avl_builder* b, void* stream) {
     AVL_HIP_CHECK(hipMemsetAsync(b->head, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->head_alt, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     b->pend = avl_builder::Pending{};   // a pending frame is dropped with the rest of the map
+    b->pre_held.valid = false;
     AVL_HIP_CHECK(hipMemsetAsync(b->dirty, 0, (size_t)b->capacity, st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_cell, 0xFF, (size_t)b->capacity * sizeof(int32_t), st));
     AVL_HIP_CHECK(hipMemsetAsync(b->slot_key, 0xFF, (size_t)b->capacity * sizeof(unsigned long long), st));
@@ -1768,6 +1771,10 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
                           const void* const* h_depth_ptrs = nullptr, const int32_t* const* h_sample_ptrs = nullptr,
                           const float* const* h_feat_ptrs = nullptr, const uint8_t* const* h_rgb_ptrs = nullptr) {
     AVL_REQUIRE(b, "avl_builder_integrate_frame: null handle");
+    // the records a previous launch prepared are good for THIS call only: whatever path leaves this function (errors included),
+    // a later call must not find them (the ring slot they were read from may hold another frame by then)
+    const auto held = b->pre_held;
+    b->pre_held.valid = false;
     AVL_REQUIRE(H > 0 && W > 0 && Hf > 0 && Wf > 0 && P >= 0, "avl_builder_integrate_frame: bad shape");
     AVL_REQUIRE(P < (1 << 30), "avl_builder_integrate_frame: at most 2^30 samples per frame");
     AVL_REQUIRE(B >= 0 && (int64_t)(B > 0 ? B : 1) * P < (1ll << 30), "avl_builder_integrate_batch: at most 2^30 samples per launch");
@@ -1845,7 +1852,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     PreGather next{};
     const bool pre_ok = B == 0 && !depth_u16 && b->D <= 1536 && P < kAggregateSamples;
     if (pre_ok) {
-        const auto& h = b->pre_held;
+        const auto& h = held;
         if (h.valid && h.samples == d_sample_idx && h.depth == d_depth && h.rgb == d_rgb && same_geometry(h.fp, fp)) fp.pre = b->pre_buf[h.buf];
         if (b->pre_next.samples) {
             fpn = fp;
@@ -1855,7 +1862,6 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
         }
     }
     const int next_buf = next.out == b->pre_buf[1] ? 1 : 0;
-    b->pre_held.valid = false;
     auto hold_next = [&]() {
         if (!next.out) return;
         b->pre_held.fp = fpn;
@@ -1894,7 +1900,8 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
     }
     rc = flush_pending(b, st);
     if (rc != AVL_OK) return rc;
-    if (fp.pre || next.out) {     // a frame of the C loop: K1 from the prepared records and / or the next frame's stateless half in front
+    const bool k2_compacts = !(fp.pre || next.out);
+    if (!k2_compacts) {     // a frame of the C loop: K1 from the prepared records and / or the next frame's stateless half in front
         const unsigned gb = next.out ? pb : 0u;
         hipLaunchKernelGGL(voxelize_link_next_kernel, dim3(gb + pb), dim3(256), 0, st, fp, reinterpret_cast<const float*>(d_depth), d_sample_idx,
                            d_rgb, b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, fpn,
@@ -1904,7 +1911,7 @@ static int integrate_impl(avl_builder* b, const void* d_depth, int depth_u16, do
                            b->cell_slot, b->slot_cell, b->recs, b->head, b->counters, b->err_flags, b->log, b->log_used, frame_key, b->owners);
     }
     if (b->log.slot) b->log_used += P;
-    rc = launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st);
+    rc = launch_fuse(b, P, frame_key, fp.batch, P_frame, b->recs, b->head, d_feat, st, k2_compacts);
     if (rc == AVL_OK) hold_next();
     return rc;
 }

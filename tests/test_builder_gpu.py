@@ -20,15 +20,21 @@ def ops():
 
 
 def run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats_chw, samples, capacity=None, frame_offset=0,
-                    replay=False, deferred=False):
+                    replay=False, deferred=False, c_loop=False):
+    """c_loop: every frame through ONE avl_builder_integrate_frames call (the frame loop in C: K1's PreGather instantiations --
+    frame i + 1's stateless half inside frame i's launch, K1 resumed from the 24-byte records) instead of one call per frame"""
     D = feats_chw.shape[1]
     vh = int(cam_h / cs)
     acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=capacity, deferred_fuse=deferred)
     if replay:
         acc.enable_replay_log(sum(len(s) for s in samples))
+    fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats_chw]
+    if c_loop:
+        plan = acc.make_batch_plan(list(depths), list(samples), fs, list(rgbs))
+        acc.integrate_frames(plan, calib, np.asarray(Ts)[:len(depths)], frame_idx0=frame_offset)
+        return acc
     for i in range(len(depths)):
-        feat_hwc = np.ascontiguousarray(np.transpose(feats_chw[i], (1, 2, 0)))
-        acc.integrate_frame(depths[i], calib, Ts[i], samples[i], feat_hwc, rgbs[i], frame_idx=frame_offset + i)
+        acc.integrate_frame(depths[i], calib, Ts[i], samples[i], fs[i], rgbs[i], frame_idx=frame_offset + i)
     return acc
 
 
@@ -62,13 +68,17 @@ def compare_maps(out, ref, feat_scale, rgb_lsb=RGB_LSB):
     assert d.mean() < 1.5, d.mean()
 
 
+@pytest.mark.parametrize("path", ["frame_calls", "c_frame_loop", "c_frame_loop_deferred", "deferred"])
 @pytest.mark.parametrize("name", ["g2a_builder_small.npz", "g2b_builder_growth.npz"])
-def test_builder_matches_reference_golden(ops, golden, name):
+def test_builder_matches_reference_golden(ops, golden, name, path):
+    """the reference's own build (golden arrays) against every way the library issues a frame: one call per frame (K1 + K2, K3),
+    the frame loop in C (PreGather instantiations of K1), both also with the one-launch deferred fuse (pipe_kernel)"""
     from oracle import avl_oracle as O
     g = golden(name)
     Ts = O.pc_transforms(g["poses_rt"], g["base_transform"], g["base2cam_tf"])
+    how = dict(deferred=path.endswith("deferred"), c_loop=path.startswith("c_frame_loop"))
     acc = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"],
-                          g["rgbs"], g["feats"], g["samples"], capacity=2000)
+                          g["rgbs"], g["feats"], g["samples"], capacity=2000, **how)
     assert acc.num_voxels() == int(g["max_id"])
     out = acc.finalize()
     occ = -np.ones(tuple(g["occ_shape"]), dtype=np.int32)
@@ -82,7 +92,7 @@ def test_builder_matches_reference_golden(ops, golden, name):
     # with the replay log, weight and grid_rgb follow the reference's sequential dtype semantics EXACTLY
     # (float32 running weight, truncating uint8 colour store, float64/float32 after the capacity doubling)
     acc2 = run_gpu_builder(ops, int(g["gs"]), float(g["cs"]), float(g["camera_height"]), g["calib"], Ts, g["depths"],
-                           g["rgbs"], g["feats"], g["samples"], capacity=2000, replay=True)
+                           g["rgbs"], g["feats"], g["samples"], capacity=2000, replay=True, **how)
     out2 = acc2.finalize()
     assert np.array_equal(out2["grid_pos"], g["grid_pos"])
     assert np.array_equal(out2["grid_rgb"], np.floor(g["grid_rgb"]).astype(np.uint8))
@@ -698,6 +708,60 @@ def test_deferred_fuse_heavy_collisions_and_mixed_calls(ops):
     for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
         assert np.array_equal(out[k], want[k]), k
     np.testing.assert_allclose(out["grid_feat"], want["grid_feat"], rtol=1e-6, atol=1e-6)
+
+
+def test_deferred_frames_at_the_batched_launch_size(ops):
+    """a deferred single frame with >= 32 768 samples (kAggregateSamples: the size from which a NON-deferred K2 compacts the owners
+    for K3): pipe_kernel's K2 never writes that owner list, so the K3 such a frame is owed -- inside the next launch or from a
+    flush / finalize / switch-off -- must be the wave-per-sample kernel.  Same map as frame-by-frame, with flushes at every
+    position a pending frame can be caught in."""
+    from oracle import avl_oracle as O
+    rng = np.random.default_rng(31)
+    H, W, Hf, Wf, D, nfr = 200, 200, 47, 47, 32, 5
+    gs, cam_h, cs = 120, 1.6, 0.15
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(5)
+    samples = [O.sample_indices(rs, H * W, 1) for _ in range(nfr)]                    # every pixel: 40 000 samples per frame
+    assert len(samples[0]) >= 32768
+    fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
+    vh = int(cam_h / cs)
+
+    def build(plan, deferred):
+        acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=1 << 16, deferred_fuse=deferred)
+        acc.enable_replay_log(nfr * H * W)
+        i = 0
+        for step in plan:
+            if step == "flush":
+                acc.flush()
+            elif step == "count":
+                acc.num_voxels()
+            elif step == "off":
+                acc.set_deferred_fuse(False)
+            elif step == "on":
+                acc.set_deferred_fuse(True)
+            elif step == 1:
+                acc.integrate_frame(depths[i], calib, Ts[i], samples[i], fs[i], rgbs[i], frame_idx=i)
+                i += 1
+            else:
+                sl = slice(i, i + step[1])
+                bp = acc.make_batch_plan(list(depths[sl]), samples[sl], fs[sl], list(rgbs[sl]))
+                acc.integrate_frames(bp, calib, Ts[sl], frame_idx0=i)
+                i += step[1]
+        assert i == nfr
+        return acc
+
+    ref = build([1] * nfr, False)
+    n, pts = ref.num_voxels(), ref.num_points()
+    assert n > 1000 and pts > 3 * n
+    want = ref.finalize()
+    for plan in ([1] * nfr, [1, "flush", 1, 1, "count", 1, 1, "flush"], [1, 1, "off", 1, "on", 1, 1], [("seq", nfr)],
+                 [("seq", 2), "flush", 1, ("seq", 2)]):
+        acc = build(plan, True)
+        assert acc.num_voxels() == n and acc.num_points() == pts, plan
+        _same_map(acc.finalize(), want)
 
 
 def test_full_size_build_properties(ops):

@@ -56,10 +56,13 @@ def expected_voxels(g):
     return ids, inside, first_touch_unique(ids[inside])
 
 
-@pytest.mark.parametrize("mode", ["frame_by_frame", "deferred", "batched"])
+@pytest.mark.parametrize("mode", ["frame_by_frame", "deferred", "batched", "c_frame_loop", "c_frame_loop_deferred"])
 def test_g1_voxel_ids_through_the_kernel(ops, golden, mode):
     """every golden point of base_pos2grid_id_3d, one single-sample frame each: grid_pos == the reference's ids of the in-range
-    points in first-touch order, out-of-range points (vlmap_builder.py:283-284) create nothing"""
+    points in first-touch order, out-of-range points (vlmap_builder.py:283-284) create nothing.  The modes are the
+    instantiations of K1 (bp_voxelize_body): <0> inside voxelize_link_kernel / pipe_kernel (frame_by_frame / deferred / batched),
+    and the PreGather pair of the frame loop in C -- <2>, the stateless half run one frame ahead, + <1>, the resume from the
+    24-byte record (c_frame_loop*: avl_builder_integrate_frames over chunks of single-sample frames, per-frame T)"""
     from avlmaps_amd.device import DeviceArray
     g = golden("g1_geometry.npz")
     assert int(g["vox_gs"]) == GS and float(g["vox_cs"]) == CS
@@ -75,8 +78,15 @@ def test_g1_voxel_ids_through_the_kernel(ops, golden, mode):
     rgb = DeviceArray.from_numpy(np.array([[[7, 8, 9]]], np.uint8))
     feat = DeviceArray.from_numpy(np.ones((1, 1, D), np.float32))
     idx = DeviceArray.from_numpy(np.zeros(1, np.int32))
-    acc = ops.VoxelAccumulator(GS, CS, VH, D, capacity=4096, deferred_fuse=(mode == "deferred"))
-    if mode == "batched":
+    acc = ops.VoxelAccumulator(GS, CS, VH, D, capacity=4096, deferred_fuse=mode.endswith("deferred"))
+    if mode.startswith("c_frame_loop"):
+        B = 61                                   # chunk boundaries: the first frame of a call has nothing prepared for it
+        for lo in range(0, len(pts), B):
+            chunk = pts[lo:lo + B]
+            n = len(chunk)
+            plan = acc.make_batch_plan([depth] * n, [idx] * n, [feat] * n, [rgb] * n)
+            acc.integrate_frames(plan, UNIT_K, np.stack([inject_transform(p) for p in chunk]), frame_idx0=lo, calib_inv=UNIT_KINV)
+    elif mode == "batched":
         B = 64
         for lo in range(0, len(pts), B):
             chunk = pts[lo:lo + B]
