@@ -23,6 +23,7 @@ SOURCES = {
     "avl_map2d.hip": [],
     "avl_lseg.hip": [],
     "avl_merge.hip": [],
+    "avl_merge2.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-munsafe-fp-atomics"]

@@ -192,6 +192,25 @@ class _Coll:
         self._toc(t, t0, t.numel() * t.element_size() * (self.ws - 1))
         return res
 
+    def all_gather_into(self, out, chunk):
+        """every rank's equal-sized `chunk` into the flat `out` (ws x chunk), in place: `chunk` is this rank's slice of `out`"""
+        t0 = self._tic(out)
+        if self.stage or not out.is_cuda:
+            h = self._h(chunk).contiguous()
+            parts = [h.new_empty(h.shape) for _ in range(self.ws)]
+            with self._net():
+                self.dist.all_gather(parts, h, group=self.group)
+            n = chunk.numel()
+            for r, part in enumerate(parts):
+                if r != self.rank:
+                    out[r * n:(r + 1) * n].copy_(part)
+            del parts, h
+        else:
+            with self._net():
+                self.dist.all_gather_into_tensor(out, chunk, group=self.group)
+        self._toc(out, t0, chunk.numel() * chunk.element_size() * (self.ws - 1))
+        return out
+
     def all_reduce(self, t, op):
         t0 = self._tic(t)
         h = self._h(t)
@@ -1136,6 +1155,17 @@ def merge_accumulator_sharded(acc, group=None, exact_rgb: bool = True, timings: 
         prof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA])
         prof.__enter__()
     try:
+        which = os.environ.get("AVLMAPS_MERGE_PLAN", "gather")
+        if which == "gather":
+            # the product path: two all_gathers, ONE payload all_to_all, every local stretch one HIP entry point (avlmaps_amd/merge2.py)
+            from . import merge2
+            out = merge2.merge_accumulator_v2(acc, group, exact_rgb, timings, gather_to, status, glock)
+            if out is not None:
+                return out
+            out = _merge_accumulator_sharded_general(acc, group, exact_rgb, timings, gather_to)      # keys not ordered by rank
+            r0, r1 = out["rows"]
+            out["cell"] = out["cell"][r0:r1]
+            return out
         return _merge_accumulator_sharded_directory(acc, group, exact_rgb, timings, gather_to, status, glock)
     finally:
         glock.release()

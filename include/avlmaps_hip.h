@@ -489,6 +489,52 @@ AVL_API int avl_merge_side_pack(int64_t n, const int64_t* d_order, const int64_t
 AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, int64_t n_own, int64_t* d_rows, int32_t* d_own_cell,
                                   int64_t* d_state, int* d_err_flag, void* stream);
 
+/* The N-rank merge of the map build, second form ("gather plan"; avlmaps_amd/merge2.py carries the collectives, csrc/avl_merge2.hip
+ * holds the kernels).  The reference has no such step (one process, one map: vlmap_builder.py:102-183 is the loop being sharded); a
+ * voxel's final row is the reference's voxel id = its position in first-touch order (vlmap_builder.py:163-170).
+ *   avl_merge2_plan   EVERY rank, after the all_gather of the ranks' (first-touch key, cell) lists: d_gathered holds ws chunks of
+ *                     nmax + (nmax + 1) / 2 int64 words each -- [keys (nmax x i64) | cells (nmax x i32)], h_n_all[p] entries valid in
+ *                     chunk p; keys must be ordered by rank (contiguous frame shards) and lie below 2^key_bits, cells below
+ *                     2^cell_bits.  Work buffer: avl_merge2_work_bytes(sum n, n of this rank, ws).  Results (byte offsets into
+ *                     d_work returned in h_off[11]): 0 row (n x i32, final row of own voxel s), 1 prev, 2 next (n x i32: the
+ *                     neighbouring contributors of the voxel in rank order, -1 = none), 3 order (n x i32: own voxels in final-row
+ *                     order), 4 sidx (n x i32: single-rank voxels before position i of that order), 5 selA, 6 selB (n x i64:
+ *                     avl_builder_replay_chain selections: s where prev < 0 / prev >= 0, else -1), 7 idx_prev, 8 idx_next
+ *                     (n x i32: own voxels grouped by prev / next rank, final-row order inside a group, voxels without one last;
+ *                     only with want_replay_lists), 9 rowcell (M x i32: cell of every final row), 10 the device copy of h_res.
+ *                     h_res[2 + 3 ws^2] (host; the call synchronises once to deliver it): M, the first-touch key of row grow_row
+ *                     (-1 if M <= grow_row), then three ws x ws tables [sender p][receiver q]: voxels of p whose row q owns, the
+ *                     single-rank ones among them, voxels of q whose previous contributor is p.
+ *   avl_builder_m2_pack   sender: own voxels in final-row order -> the send buffer of the ONE payload all_to_all (int64 words).
+ *                     Destination q gets own voxels [h_start[q], h_start[q + 1]) (h_dstart[q] single-rank voxels precede them):
+ *                     64-byte side records at word h_side_off[q] ([row - q * per | list index << 32 | single << 63 | direct << 62,
+ *                     sum_w4 (4 x f64), 3 zero words]), finished float32 rows of single-rank voxels at h_done_off[q] (row stride
+ *                     (D + 1) / 2 words), float64 partial rows of shared voxels at h_part_off[q].  d_own_feat (nullable): this rank's
+ *                     block of grid_feat -- single-rank voxels whose row it owns are written there directly (`direct`).
+ *   avl_merge2_side_state  after the replay: words 5..7 of every side record = the replay state (d_state n x 3 i64, nullable) where
+ *                     this rank is the voxel's last contributor (d_next < 0), zeros elsewhere.
+ *   avl_merge2_state_gather / _scatter   the 24-byte replay states of the listed voxels <-> a contiguous hop buffer.
+ *   avl_merge2_fold   owner: the block [r0, r0 + n_own) from what the peers sent (h_side / h_done / h_part: per peer the device
+ *                     addresses of its three lists, h_count[p] records; the rank's own lists stay in its send buffer): contributors
+ *                     summed in rank order, grid_feat / grid_pos / weight / grid_rgb / cell of the block written.  Bits of
+ *                     *d_err_flag: 2 = a row nobody sent, 4 = a single-rank record next to other contributors. */
+AVL_API int avl_merge2_header(int64_t n, const int64_t* d_key, int64_t flags, int64_t* d_hdr, void* stream);   /* d_hdr[4] = n, min key, max key, flags */
+AVL_API int avl_merge2_work_bytes(int64_t n_entries, int64_t n_own, int ws, size_t* h_bytes);
+AVL_API int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, int cell_bits, int key_bits,
+                            int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off, int64_t* h_res,
+                            void* stream);
+AVL_API int avl_builder_m2_pack(avl_builder* b, int64_t n, int ws, int rank, int64_t per, const int64_t* h_start, const int64_t* h_dstart,
+                                const int64_t* h_side_off, const int64_t* h_done_off, const int64_t* h_part_off, const int32_t* d_order,
+                                const int32_t* d_row, const int32_t* d_prev, const int32_t* d_next, const int32_t* d_sidx, int64_t* d_send,
+                                float* d_own_feat, void* stream);
+AVL_API int avl_merge2_side_state(int64_t n, int ws, const int64_t* h_start, const int64_t* h_side_off, const int32_t* d_order,
+                                  const int32_t* d_next, const int64_t* d_state, int64_t* d_send, void* stream);
+AVL_API int avl_merge2_state_gather(int64_t k, const int32_t* d_idx, const int64_t* d_state, int64_t* d_out, void* stream);
+AVL_API int avl_merge2_state_scatter(int64_t k, const int32_t* d_idx, const int64_t* d_in, int64_t* d_state, void* stream);
+AVL_API int avl_merge2_fold(int64_t n_own, int64_t r0, int ws, int D, int gs, int vh, const void* const* h_side, const void* const* h_done,
+                            const void* const* h_part, const int64_t* h_count, const int32_t* d_rowcell, int have_log, float* d_grid_feat,
+                            int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_cell, int32_t* d_err_flag, void* stream);
+
 /* Shared rows of a rank's block of the merged map: row d_rows[i] of d_out (n_out x D float32) = (float)(d_acc[i, :] / d_w4[d_rows[i], 0]),
  * i < k -- the division of finalize (vlmap_builder.py:172-174's running mean in closed form) applied to the float64 sums several
  * ranks contributed to (avlmaps_amd/parallel.py).  An index outside [0, n_out) is skipped and sets bit 0 of *d_err_flag (nullable). */

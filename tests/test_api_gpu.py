@@ -657,7 +657,7 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
             t = json.loads((many / f"merge_timings_rank{r}.json").read_text())
             assert t["mode"].startswith("row-sharded") and t["world_size"] == nproc and t["backend"] == "gloo"
             assert tuple(t["shard_rows"]) == parallel.shard_rows(M, r, nproc) and t["shard_feat_shape"] == [t["own_rows"], D]
-            assert t["plan"].startswith("directory")             # contiguous frame shards: nothing O(M) on any rank
+            assert t["plan"].startswith("gather plan")           # contiguous frame shards: two all_gathers, one payload all_to_all (merge2.py)
             assert t["rows_sent"] <= t["local_voxels"] and t["payload_bytes_fp64_form"] == t["rows_sent"] * ((D + 4) * 8 + 8)
             # mixed payload: 64 B of side record per row + a float32 row (voxels of this rank alone) or a float64 row (shared)
             assert t["rows_sent"] * (64 + D * 4) <= t["payload_bytes_sent"] <= t["rows_sent"] * (64 + D * 8)

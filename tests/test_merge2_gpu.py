@@ -1,0 +1,218 @@
+"""The gather-plan merge on the GPU: the product choreography (avlmaps_amd/merge2.merge_sharded_v2) with the HIP kernels
+(csrc/avl_merge2.hip, avl_builder_m2_pack) for several ranks of ONE process -- every rank a thread with its own VoxelAccumulator,
+the collectives an in-process stand-in that moves the same bytes -- against (a) the single-process map of all frames and (b) the
+NumPy twin of the kernels on the exported accumulators, bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from avlmaps_amd import _lib, ops
+    _lib.load()
+    _lib.require_gpu()
+    return ops
+
+
+class _NoLock:
+    wait_s, held = 0.0, False
+
+
+class ThreadWorld:
+    def __init__(self, ws):
+        self.ws, self.barrier, self.slots = ws, threading.Barrier(ws), [None] * ws
+
+
+class ThreadColl:
+    """parallel._Coll's interface over threads of one process (device or CPU tensors)"""
+
+    class _Dist:
+        class ReduceOp:
+            MAX = "max"
+
+        @staticmethod
+        def get_backend(group):
+            return "threads"
+
+    def __init__(self, world, rank):
+        self.w, self.rank, self.ws = world, rank, world.ws
+        self.comm_s, self.bytes_out, self.calls, self.gpu_lock, self.dist, self.group = 0.0, 0, 0, _NoLock(), self._Dist, None
+
+    def _sync(self, t):
+        if getattr(t, "is_cuda", False):
+            import torch
+            torch.cuda.synchronize()
+
+    def _round(self, mine, take):
+        self._sync(mine[0] if isinstance(mine, tuple) else mine)
+        self.w.slots[self.rank] = mine
+        self.w.barrier.wait()
+        res = take(self.w.slots)
+        self._sync(res[0] if isinstance(res, list) else res)
+        self.w.barrier.wait()
+        self.calls += 1
+        return res
+
+    def all_gather(self, t):
+        return self._round(t, lambda s: [x.clone() for x in s])
+
+    def all_gather_into(self, out, chunk):
+        n = chunk.numel()
+
+        def take(s):
+            for r, c in enumerate(s):
+                if r != self.rank:
+                    out[r * n:(r + 1) * n].copy_(c)
+            return out
+        return self._round(chunk, take)
+
+    def all_to_all(self, inp, in_splits, out_splits):
+        import torch
+
+        def take(s):
+            parts = []
+            for p, (t, ins) in enumerate(s):
+                o = sum(ins[:self.rank])
+                assert ins[self.rank] == out_splits[p], (p, self.rank, ins, out_splits)
+                parts.append(t[o:o + ins[self.rank]])
+            return torch.cat(parts) if parts else inp[:0]
+        self.bytes_out += 8 * (sum(in_splits) - in_splits[self.rank])
+        return self._round((inp, list(in_splits)), take)
+
+    def all_reduce(self, t, op):
+        import torch
+        return self._round(t, lambda s: torch.stack([x for x in s]).max(0).values)
+
+
+def run_ranks(ws, fn):
+    world = ThreadWorld(ws)
+    out, errs = [None] * ws, []
+
+    def body(r):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            out[r] = fn(r, ThreadColl(world, r))
+        except BaseException as e:      # noqa: BLE001 -- a failing rank must not leave the others in a barrier
+            errs.append(e)
+            world.barrier.abort()
+    th = [threading.Thread(target=body, args=(r,)) for r in range(ws)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+    return out
+
+
+def build_shards(ops, ws, D=64, nfr=24, seed=7, rate=5, cs=0.1, gs=400, replay=True):
+    from oracle import avl_oracle as O
+    from test_builder_gpu import synth_scene
+    rng = np.random.default_rng(seed)
+    H, W, Hf, Wf = 120, 160, 58, 77
+    cam_h = 1.5
+    calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
+    depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
+    b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
+    Ts = O.pc_transforms(poses, bt, b2c)
+    rs = np.random.RandomState(3)
+    samples = [O.sample_indices(rs, H * W, rate) for _ in range(nfr)]
+    fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
+    vh = int(cam_h / cs)
+    from avlmaps_amd import parallel
+
+    def build(lo, hi):
+        acc = ops.VoxelAccumulator(gs, cs, vh, D, capacity=1 << 16)
+        if replay:
+            acc.enable_replay_log(max(1, (hi - lo) * len(samples[0])))
+        for i in range(lo, hi):
+            acc.integrate_frame(depths[i], calib, Ts[i], samples[i], fs[i], rgbs[i], frame_idx=i)
+        return acc
+    whole = build(0, nfr)
+    shards = [build(*parallel.shard_frames(nfr, r, ws)) for r in range(ws)]
+    return whole, shards, gs, vh
+
+
+@pytest.mark.parametrize("ws,D", [(1, 64), (2, 64), (3, 30), (8, 64), (8, 5)])
+def test_gather_plan_merge_on_device_equals_the_single_process_map_and_the_twin(ops, ws, D):
+    import torch
+    from avlmaps_amd import merge2
+    whole, shards, gs, vh = build_shards(ops, ws, D=D)
+    want = whole.finalize()
+    M = len(want["grid_pos"])
+    ncell = gs * gs * vh
+    grow_row = M // 2                                    # (a growth inside the map: the replay switches dtypes at that voxel's key)
+
+    def device_rank(r, coll):
+        acc = shards[r]
+        n = acc.num_voxels()
+        K = merge2.HipKernels(acc, n)
+        out, L, info = merge2.merge_sharded_v2(K, coll if ws > 1 else None, D, merge2._bit_length(ncell - 1), grow_row, gs, vh, True,
+                                               timings={}, sync=torch.cuda.synchronize)
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in out.items()}, L, info
+
+    def twin_rank(r, coll):
+        raw = shards[r].export_raw()
+        raw["first_key"] = raw["first_key"].astype(np.int64)
+        K = merge2.HostKernels(raw)
+        out, L, info = merge2.merge_sharded_v2(K, coll if ws > 1 else None, D, merge2._bit_length(ncell - 1), grow_row, gs, vh, False)
+        return out, L, info
+
+    dev = run_ranks(ws, device_rank)
+    twin = run_ranks(ws, twin_rank)
+    from avlmaps_amd import parallel
+    pos = np.concatenate([d[0]["grid_pos"] for d in dev])
+    feat = np.concatenate([d[0]["grid_feat"] for d in dev])
+    assert np.array_equal(pos, want["grid_pos"])                                   # the reference's voxel ids, bit-exact, in id order
+    cells = np.concatenate([d[0]["cell"] for d in dev])
+    occ = parallel.occupied_ids_from_cells(torch.from_numpy(cells), gs, gs, vh).numpy()
+    assert np.array_equal(occ, want["occupied_ids"])
+    shared = 0
+    for r in range(ws):
+        (o, L, info), (t, Lt, _) = dev[r], twin[r]
+        assert (L.r0, L.r1) == parallel.shard_rows(M, r, ws) == (Lt.r0, Lt.r1) and L.M == M == Lt.M
+        assert np.array_equal(L.A, Lt.A) and np.array_equal(L.Dn, Lt.Dn) and np.array_equal(L.H, Lt.H) and L.grow_key == Lt.grow_key
+        assert np.array_equal(o["grid_feat"], t["grid_feat"])                      # kernels == their NumPy twin, bit for bit
+        assert np.array_equal(o["grid_pos"], t["grid_pos"]) and np.array_equal(o["cell"], t["cell"])
+        shared += int(L.A[r].sum() - L.Dn[r].sum())
+        assert info["have_log"]
+    if ws > 1:
+        assert shared > 50, shared                                                 # the point of the test: voxels several ranks touched
+    # against the single-process build: a voxel of one rank is bit-identical, a shared one differs by the float64 summation order
+    np.testing.assert_allclose(feat, want["grid_feat"], rtol=1e-6, atol=1e-6)
+    assert np.mean(feat == want["grid_feat"]) > 0.99
+    # exact sequential weight / colour through the replay hops (growth key = first-touch key of voxel M // 2 on both sides)
+    w = np.concatenate([d[0]["weight"] for d in dev])
+    rgb = np.concatenate([d[0]["grid_rgb"] for d in dev])
+    one = run_ranks(1, lambda r, coll: merge2.merge_sharded_v2(merge2.HipKernels(whole, whole.num_voxels()), None, D, merge2._bit_length(ncell - 1),
+                                                               grow_row, gs, vh, True))[0][0]
+    assert np.array_equal(w, one["weight"].cpu().numpy()) and np.array_equal(rgb, one["grid_rgb"].cpu().numpy())
+    assert np.array_equal(one["grid_feat"].cpu().numpy(), want["grid_feat"])       # one rank: the plain finalisation, bit for bit
+
+
+def test_gather_plan_merge_through_the_product_entry_point(ops):
+    """parallel.merge_accumulator_sharded (one process): the gather plan is the default, its block is the whole map and equals
+    VoxelAccumulator.finalize bit for bit, replay included; AVLMAPS_MERGE_PLAN=directory still gives the same map"""
+    import os
+    import torch
+    from avlmaps_amd import parallel
+    whole, _, gs, vh = build_shards(ops, 1, D=64)
+    want = whole.finalize()
+    tim = {}
+    out = parallel.merge_accumulator_sharded(whole, timings=tim, gather_to=0)
+    assert "gather plan" in tim["plan"] and tim["merged_voxels"] == len(want["grid_pos"]) and tim["exact_rgb"]
+    for k in ("grid_feat", "grid_pos", "weight", "grid_rgb"):
+        assert np.array_equal(out[k].cpu().numpy(), want[k]), k
+        assert np.array_equal(out["full"][k].cpu().numpy(), want[k]), k
+    assert np.array_equal(out["full"]["occupied_ids"].cpu().numpy(), want["occupied_ids"])
+    os.environ["AVLMAPS_MERGE_PLAN"] = "directory"
+    try:
+        old = parallel.merge_accumulator_sharded(whole, timings={})
+    finally:
+        del os.environ["AVLMAPS_MERGE_PLAN"]
+    for k in ("grid_feat", "grid_pos", "weight", "grid_rgb"):
+        assert torch.equal(old[k], out[k]), k
