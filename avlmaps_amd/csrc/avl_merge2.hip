@@ -398,7 +398,7 @@ int avl_merge2_work_bytes(int64_t E, int64_t n, int ws, size_t* h_bytes) {
 int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, int cell_bits, int key_bits,
                     int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off, int64_t* h_res, void* stream) {
     AVL_REQUIRE(ws >= 1 && ws <= kM2MaxRanks && rank >= 0 && rank < ws && h_n_all && h_off && h_res, "avl_merge2_plan: bad arguments");
-    AVL_REQUIRE(cell_bits >= 1 && cell_bits <= 31 && key_bits >= 1 && key_bits <= 62, "avl_merge2_plan: cell_bits in [1, 31], key_bits in [1, 62]");
+    AVL_REQUIRE(cell_bits >= 1 && cell_bits <= 31 && key_bits >= 1 && key_bits <= 63, "avl_merge2_plan: cell_bits in [1, 31], key_bits in [1, 63]");
     M2Offsets o;
     long long E = 0;
     for (int p = 0; p < ws; ++p) {

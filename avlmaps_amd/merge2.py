@@ -136,8 +136,8 @@ class HostKernels:
         rs = erank[se]
         prev = np.where(head, -1, np.roll(rs, 1)) if E else rs
         nxt = np.where(tail, -1, np.roll(rs, -1)) if E else rs
-        sentinel = 1 << key_bits
-        k2 = np.where(head, ekey[se], sentinel)
+        sentinel = np.uint64(1 << key_bits)
+        k2 = np.where(head, ekey[se].astype(np.uint64), sentinel)
         v2s = np.argsort(k2, kind="stable")
         M = int(head.sum())
         rowofhead = np.zeros(E, np.int64)
@@ -424,7 +424,7 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
     K.fill_chunk(chunk, nmax)
     if coll is not None:
         coll.all_gather_into(gathered, chunk)
-    key_bits = min(62, _bit_length(max(last, 1)))
+    key_bits = min(63, _bit_length(max(last, 1)))     # (a resumed build's new keys carry bit 62: avl_builder_import_map)
     res = K.plan(gathered, n_all, nmax, rank, ws, cell_bits, key_bits, grow_row, have_log and ws > 1)
     L = Layout(res, rank, ws, D)
     del gathered, chunk

@@ -494,7 +494,7 @@ AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, 
  * voxel's final row is the reference's voxel id = its position in first-touch order (vlmap_builder.py:163-170).
  *   avl_merge2_plan   EVERY rank, after the all_gather of the ranks' (first-touch key, cell) lists: d_gathered holds ws chunks of
  *                     nmax + (nmax + 1) / 2 int64 words each -- [keys (nmax x i64) | cells (nmax x i32)], h_n_all[p] entries valid in
- *                     chunk p; keys must be ordered by rank (contiguous frame shards) and lie below 2^key_bits, cells below
+ *                     chunk p; keys must be ordered by rank (contiguous frame shards) and lie below 2^key_bits (key_bits <= 63), cells below
  *                     2^cell_bits.  Work buffer: avl_merge2_work_bytes(sum n, n of this rank, ws).  Results (byte offsets into
  *                     d_work returned in h_off[11]): 0 row (n x i32, final row of own voxel s), 1 prev, 2 next (n x i32: the
  *                     neighbouring contributors of the voxel in rank order, -1 = none), 3 order (n x i32: own voxels in final-row
