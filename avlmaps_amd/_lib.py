@@ -55,14 +55,16 @@ _SIGS = {
     "avl_merge_classify": (C.c_int, [_i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge_side_pack": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge_side_unpack": (C.c_int, [_i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
-    "avl_merge2_header": (C.c_int, [_i64, _vp, _i64, _vp, _vp]),
+    "avl_merge2_prepare_work_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
+    "avl_merge2_prepare": (C.c_int, [_i64, _vp, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_merge2_work_bytes": (C.c_int, [_i64, _i64, C.c_int, C.POINTER(_sz)]),
-    "avl_merge2_plan": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, C.c_int, C.c_int, _i64, C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "avl_merge2_plan": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _sz, _vp, _vp, _vp]),
     "avl_builder_m2_pack": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge2_side_state": (C.c_int, [_i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge2_state_gather": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_merge2_state_scatter": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
-    "avl_merge2_fold": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_merge2_fold": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "avl_merge2_fold_work_bytes": (C.c_int, [_i64, C.c_int, C.POINTER(_sz)]),
     "avl_argsort_bits_work_bytes": (C.c_int, [_i64, C.c_int, C.c_int, C.POINTER(_sz)]),
     "avl_argsort_bits": (C.c_int, [_i64, _vp, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "avl_hbm_read_probe": (C.c_int, [_vp, _i64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _vp]),

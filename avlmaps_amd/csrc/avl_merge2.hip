@@ -38,38 +38,23 @@ struct M2Offsets {
     long long off[kM2MaxRanks + 1];   // entry index of rank p's first voxel; off[ws] = E
 };
 
-// header of a rank: [voxel count, smallest first-touch key, largest, flags] -- one block; the keys of a rank are 12 B x 300 k voxels
-__global__ __launch_bounds__(1024) void m2_header_kernel(long long n, const long long* __restrict__ key, long long flags, long long* __restrict__ hdr) {
-    __shared__ long long smin[16], smax[16];
-    long long kmin = 0x7FFFFFFFFFFFFFFFll, kmax = -1;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const long long k = key[i];
-        kmin = k < kmin ? k : kmin;
-        kmax = k > kmax ? k : kmax;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const long long a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
-        kmin = a < kmin ? a : kmin;
-        kmax = b > kmax ? b : kmax;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        smin[threadIdx.x >> 6] = kmin;
-        smax[threadIdx.x >> 6] = kmax;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) {
-            kmin = smin[w] < kmin ? smin[w] : kmin;
-            kmax = smax[w] > kmax ? smax[w] : kmax;
-        }
+// a rank's (first-touch key, cell) list sorted by key goes out: iota for the sort's values, then the cells in that order + the header
+__global__ void m2_iota_kernel(long long n, int32_t* __restrict__ v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) v[i] = (int32_t)i;
+}
+
+__global__ void m2_presorted_kernel(long long n, const int32_t* __restrict__ cell, const int32_t* __restrict__ perm, const long long* __restrict__ key_sorted,
+                                    long long flags, int32_t* __restrict__ cell_sorted, long long* __restrict__ hdr) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) cell_sorted[i] = cell[perm[i]];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr[0] = n;
-        hdr[1] = kmin;
-        hdr[2] = kmax;
+        hdr[1] = n ? key_sorted[0] : 0x7FFFFFFFFFFFFFFFll;
+        hdr[2] = n ? key_sorted[n - 1] : -1;
         hdr[3] = flags;
     }
 }
 
-// entry e = (rank p, slot s): its cell (sort key), its index (sort value), its rank
+// entry e = (rank p, position j in p's key-sorted list): its cell (sort key), its index (sort value), its rank
 __global__ __launch_bounds__(256) void m2_compact_kernel(long long E, int ws, M2Offsets o, long long stride, long long nmax,
                                                          const long long* __restrict__ g, uint32_t* __restrict__ ecell,
                                                          uint32_t* __restrict__ eidx, uint8_t* __restrict__ erank) {
@@ -85,55 +70,47 @@ __global__ __launch_bounds__(256) void m2_compact_kernel(long long E, int ws, M2
 }
 
 // sorted position i (by cell, contributors of a cell in rank order): head position of its cell's run, neighbouring contributors,
-// and the key the rows are sorted by: the first contributor's first-touch key, every other entry a sentinel above all keys
-__global__ __launch_bounds__(256) void m2_segments_kernel(long long E, M2Offsets o, long long stride, const long long* __restrict__ g,
-                                                          const uint32_t* __restrict__ scell, const uint32_t* __restrict__ se,
-                                                          const uint8_t* __restrict__ erank, unsigned long long sentinel,
-                                                          uint32_t* __restrict__ hp, uint16_t* __restrict__ pn,
-                                                          unsigned long long* __restrict__ k2, uint32_t* __restrict__ v2,
-                                                          unsigned long long* __restrict__ res) {
+// and the flag "first contributor of its cell" back in entry order.  The ranks' lists are sorted by key and the keys ordered by rank,
+// so ENTRY order is key order: a first contributor's row is the number of first contributors before it (one scan, no second sort).
+__global__ __launch_bounds__(256) void m2_segments_kernel(long long E, const uint32_t* __restrict__ scell, const uint32_t* __restrict__ se,
+                                                          const uint8_t* __restrict__ erank, uint32_t* __restrict__ hp, uint16_t* __restrict__ pn,
+                                                          uint8_t* __restrict__ headflag, unsigned long long* __restrict__ res) {
+    __shared__ unsigned sh_heads[4];
     unsigned heads = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (long long)gridDim.x * blockDim.x) {
         const uint32_t c = scell[i];
         const bool head = i == 0 || scell[i - 1] != c;
         const bool tail = i + 1 == E || scell[i + 1] != c;
         long long h = i;
-        while (h > 0 && scell[h - 1] == c) --h;                         // a cell has at most ws contributors
+        if (!head) {
+            --h;
+            while (h > 0 && scell[h - 1] == c) --h;                     // a cell has at most ws contributors
+        }
         hp[i] = (uint32_t)h;
         const int prev = head ? -1 : (int)erank[se[i - 1]];
         const int next = tail ? -1 : (int)erank[se[i + 1]];
         pn[i] = (uint16_t)((prev + 1) | ((next + 1) << 8));
-        const uint32_t e = se[i];
-        const int p = erank[e];
-        k2[i] = head ? (unsigned long long)g[p * stride + (e - o.off[p])] : sentinel;
-        v2[i] = (uint32_t)i;
+        headflag[se[i]] = head ? 1 : 0;
         heads += head ? 1u : 0u;
     }
     for (int off = 32; off > 0; off >>= 1) heads += __shfl_xor(heads, off, 64);
-    if ((threadIdx.x & 63) == 0 && heads) atomicAdd(&res[0], (unsigned long long)heads);      // res[0] = M
-}
-
-// row j of the merged map: the j-th smallest first-touch key
-__global__ void m2_rows_kernel(long long E, const unsigned long long* __restrict__ k2s, const uint32_t* __restrict__ v2s,
-                               unsigned long long sentinel, const uint32_t* __restrict__ scell, long long grow_row,
-                               uint32_t* __restrict__ rowofhead, int32_t* __restrict__ rowcell, unsigned long long* __restrict__ res) {
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < E; j += (long long)gridDim.x * blockDim.x) {
-        const unsigned long long k = k2s[j];
-        if (k >= sentinel) continue;
-        const uint32_t i = v2s[j];
-        rowofhead[i] = (uint32_t)j;
-        rowcell[j] = (int32_t)scell[i];
-        if (j == grow_row) res[1] = k;
+    if ((threadIdx.x & 63) == 0) sh_heads[threadIdx.x >> 6] = heads;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = sh_heads[0] + sh_heads[1] + sh_heads[2] + sh_heads[3];
+        if (t) atomicAdd(&res[0], (unsigned long long)t);                 // res[0] = M
     }
 }
 
-// every entry: its final row and destination; the ws x ws tables [sender][owner] of list sizes; this rank's own voxels by slot
-__global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, int rank, M2Offsets o, const uint32_t* __restrict__ se,
+// every entry: its final row and destination; the ws x ws tables [sender][owner] of list sizes; the cell of every row; this rank's
+// own voxels by slot (perm: position in the rank's key-sorted list -> slot)
+__global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, int rank, M2Offsets o, long long stride, const long long* __restrict__ g,
+                                                         const uint32_t* __restrict__ scell, const uint32_t* __restrict__ se,
                                                          const uint8_t* __restrict__ erank, const uint32_t* __restrict__ hp,
-                                                         const uint16_t* __restrict__ pn, const uint32_t* __restrict__ rowofhead,
-                                                         unsigned long long* __restrict__ res, int32_t* __restrict__ row_s,
-                                                         int32_t* __restrict__ prev_s, int32_t* __restrict__ next_s,
-                                                         uint32_t* __restrict__ krow, uint32_t* __restrict__ vslot) {
+                                                         const uint16_t* __restrict__ pn, const int32_t* __restrict__ rowscan,
+                                                         const int32_t* __restrict__ perm, long long grow_row, unsigned long long* __restrict__ res,
+                                                         int32_t* __restrict__ rowcell, int32_t* __restrict__ row_s, int32_t* __restrict__ prev_s,
+                                                         int32_t* __restrict__ next_s, uint32_t* __restrict__ krow, uint32_t* __restrict__ vslot) {
     extern __shared__ unsigned m2_hist[];                 // [all | done | hop] x ws x ws
     const int W2 = ws * ws;
     for (int t = threadIdx.x; t < 3 * W2; t += blockDim.x) m2_hist[t] = 0;
@@ -143,7 +120,12 @@ __global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, in
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < E; i += (long long)gridDim.x * blockDim.x) {
         const uint32_t e = se[i];
         const int p = erank[e];
-        const long long row = rowofhead[hp[i]];
+        const uint32_t h = hp[i];
+        const long long row = rowscan[se[h]];
+        if (h == (uint32_t)i) {
+            rowcell[row] = (int32_t)scell[i];
+            if (row == grow_row) res[1] = (unsigned long long)g[p * stride + (e - o.off[p])];
+        }
         int q = (int)(row / per);
         q = q < ws - 1 ? q : ws - 1;
         const int prev = (int)(pn[i] & 0xFF) - 1, next = (int)(pn[i] >> 8) - 1;
@@ -151,12 +133,13 @@ __global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, in
         if (prev < 0 && next < 0) atomicAdd(&m2_hist[W2 + p * ws + q], 1u);
         if (prev >= 0) atomicAdd(&m2_hist[2 * W2 + prev * ws + p], 1u);
         if (p == rank) {
-            const long long s = e - o.off[p];
+            const long long j = e - o.off[p];
+            const int32_t s = perm[j];
             row_s[s] = (int32_t)row;
             prev_s[s] = prev;
             next_s[s] = next;
-            krow[s] = (uint32_t)row;
-            vslot[s] = (uint32_t)s;
+            krow[j] = (uint32_t)row;
+            vslot[j] = (uint32_t)s;
         }
     }
     __syncthreads();
@@ -233,97 +216,119 @@ struct ReplayState24 {
     uint32_t started;
 };
 
-// Owner side.  Wave per row r of the block: lane p looks r up in peer p's side list (sorted by row); the contributors are summed
-// in rank order -- [sum alpha, sum alpha rgb] and, for a voxel several ranks touched, the float64 feature partials -- and the row
-// is finished with finalize_kernel's expressions (avl_builder.hip).  A voxel with one contributor arrives as a finished float32
-// row (or is in place already: kM2Direct).
-__global__ __launch_bounds__(256) void m2_fold_kernel(long long n_own, long long r0, int ws, int D, long long ldf, long long ldp, int gs, int vh,
-                                                      M2Peers pe, const int32_t* __restrict__ rowcell, int have_log,
-                                                      float* __restrict__ grid_feat, int32_t* __restrict__ grid_pos,
-                                                      float* __restrict__ weight, uint8_t* __restrict__ grid_rgb,
-                                                      int32_t* __restrict__ cell_out, int* __restrict__ err) {
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
-    for (long long r = wave0; r < n_own; r += nwaves) {
-        long long found = -1;
-        if (lane < ws) {
-            const long long* sd = pe.side[lane];
-            long long lo = 0, hi = pe.count[lane];
-            while (lo < hi) {
-                const long long mid = (lo + hi) >> 1;
-                const long long v = sd[8 * mid] & 0xFFFFFFFFll;
-                if (v < r) lo = mid + 1;
-                else hi = mid;
-            }
-            if (lo < pe.count[lane] && (sd[8 * lo] & 0xFFFFFFFFll) == r) found = lo;
-        }
-        unsigned long long mask = __ballot(found >= 0);
-        if (mask == 0) {
-            if (lane == 0 && err) atomicOr(err, 2);          // a row of the block nobody sent: a plan / exchange bug
+// Owner side, step 1: record i of peer p belongs to row (word & 0xFFFFFFFF) of the block: table[row * ws + p] = i (the table starts at -1).
+// A row outside the block sets bit 1 of *err.
+__global__ void m2_fold_index_kernel(long long R, int ws, M2Peers pe, long long n_own, int32_t* __restrict__ table, int* __restrict__ err) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < R; t += (long long)gridDim.x * blockDim.x) {
+        int p = 0;
+        long long i = t;
+        while (p + 1 < ws && i >= pe.count[p]) { i -= pe.count[p]; ++p; }
+        const long long row = pe.side[p][8 * i] & 0xFFFFFFFFll;
+        if (row >= n_own) {
+            if (err) atomicOr(err, 1);
             continue;
         }
-        const int ncontrib = __popcll(mask);
+        table[row * ws + p] = (int32_t)i;
+    }
+}
+
+// Owner side, step 2.  Thread per row r of the block: the contributors' [sum alpha, sum alpha rgb] summed in rank order, the replay
+// state of the last one, position / weight / colour written (finalize_kernel's lane-0 part); need[r] = the row's features still
+// have to be produced (anything but a single-rank voxel that is in place already).
+__global__ __launch_bounds__(256) void m2_fold_scalar_kernel(long long n_own, long long r0, int ws, int gs, int vh, M2Peers pe,
+                                                             const int32_t* __restrict__ table, const int32_t* __restrict__ rowcell, int have_log,
+                                                             int32_t* __restrict__ grid_pos, float* __restrict__ weight,
+                                                             uint8_t* __restrict__ grid_rgb, int32_t* __restrict__ cell_out,
+                                                             double* __restrict__ wsum, uint8_t* __restrict__ need, int* __restrict__ err) {
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n_own; r += (long long)gridDim.x * blockDim.x) {
         double w4[4] = {0.0, 0.0, 0.0, 0.0};
         ReplayState24 st{0.0, {0.f, 0.f, 0.f}, 0u};
         unsigned long long word0 = 0;
-        int p0 = -1;
-        for (unsigned long long m = mask; m; m &= m - 1) {
-            const int p = __ffsll((long long)m) - 1;
-            const long long idx = __shfl(found, p, 64);
-            const long long* rec = pe.side[p] + 8 * idx;
-            if (p0 < 0) { p0 = p; word0 = (unsigned long long)rec[0]; }
+        int ncontrib = 0;
+        for (int p = 0; p < ws; ++p) {
+            const int32_t idx = table[r * ws + p];
+            if (idx < 0) continue;
+            const long long* rec = pe.side[p] + 8ll * idx;
+            if (ncontrib++ == 0) word0 = (unsigned long long)rec[0];
             for (int k = 0; k < 4; ++k) w4[k] += __longlong_as_double(rec[1 + k]);
             const unsigned long long s2 = (unsigned long long)rec[7];
             if ((s2 >> 32) != 0) {
-                st.w = __longlong_as_double(rec[5]);
                 const unsigned long long s1 = (unsigned long long)rec[6];
+                st.w = __longlong_as_double(rec[5]);
                 st.c[0] = __uint_as_float((unsigned)(s1 & 0xFFFFFFFFull));
                 st.c[1] = __uint_as_float((unsigned)(s1 >> 32));
                 st.c[2] = __uint_as_float((unsigned)(s2 & 0xFFFFFFFFull));
                 st.started = (uint32_t)(s2 >> 32);
             }
         }
+        if (ncontrib == 0) {
+            if (err) atomicOr(err, 2);                       // a row of the block nobody sent: a plan / exchange bug
+            need[r] = 0;
+            continue;
+        }
+        const bool single = (word0 & kM2Single) != 0;
+        if (single && ncontrib > 1 && err) atomicOr(err, 4);
+        need[r] = (single && ncontrib == 1 && (word0 & kM2Direct)) ? 0 : 1;
         const double w = w4[0];
-        float* o = grid_feat + r * D;
-        if (ncontrib == 1 && (word0 & kM2Single)) {
-            if (!(word0 & kM2Direct)) {
+        wsum[r] = w;
+        const int32_t cl = rowcell[r0 + r];
+        if (cell_out) cell_out[r] = cl;
+        grid_pos[r * 3 + 0] = cl / (gs * vh);
+        grid_pos[r * 3 + 1] = (cl / vh) % gs;
+        grid_pos[r * 3 + 2] = cl % vh;
+        float wt = (float)w;
+        uint8_t c3[3];
+        for (int k = 0; k < 3; ++k) {
+            double m = w4[1 + k] / w + 1e-9;          // as finalize_kernel
+            m = fmin(fmax(m, 0.0), 255.0);
+            c3[k] = (uint8_t)m;
+        }
+        if (have_log && st.started) {               // replay_apply_kernel
+            wt = (float)st.w;
+            for (int k = 0; k < 3; ++k) c3[k] = (uint8_t)fminf(fmaxf(st.c[k], 0.f), 255.f);
+        }
+        weight[r] = wt;
+        for (int k = 0; k < 3; ++k) grid_rgb[r * 3 + k] = c3[k];
+    }
+}
+
+// Owner side, step 3.  Wave per group of 16 rows, the rows that still need their features one after the other: a single-rank voxel's
+// finished float32 row is copied, a voxel several ranks touched gets (sum over the contributors, in rank order, of their float64
+// partial rows) / sum alpha -- finalize_kernel's expression (avl_builder.hip).
+__global__ __launch_bounds__(256) void m2_fold_feat_kernel(long long n_own, int ws, int D, long long ldf, long long ldp, M2Peers pe,
+                                                           const int32_t* __restrict__ table, const double* __restrict__ wsum,
+                                                           const uint8_t* __restrict__ need, float* __restrict__ grid_feat) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long ngroups = (n_own + 15) / 16;
+    for (long long gq = wave0; gq < ngroups; gq += nwaves) {
+        const long long rl = gq * 16 + lane;
+        unsigned long long todo = __ballot(lane < 16 && rl < n_own && need[rl] != 0);
+        for (; todo; todo &= todo - 1) {
+            const long long r = gq * 16 + (__ffsll((long long)todo) - 1);
+            const int32_t found = lane < ws ? table[r * ws + lane] : -1;
+            const unsigned long long mask = __ballot(found >= 0);
+            const unsigned long long wd = found >= 0 ? (unsigned long long)pe.side[lane][8ll * found] : 0ull;
+            const int p0 = __ffsll((long long)mask) - 1;
+            const unsigned long long word0 = (unsigned long long)__shfl((long long)wd, p0, 64);
+            float* o = grid_feat + r * D;
+            if (__popcll(mask) == 1 && (word0 & kM2Single)) {
                 const float* src = pe.done[p0] + (long long)((word0 >> 32) & 0x3FFFFFFFull) * ldf;
                 for (int c = lane; c < D; c += 64) o[c] = src[c];
+                continue;
             }
-        } else {
-            if (lane == 0 && err && (word0 & kM2Single)) atomicOr(err, 4);
+            const double w = wsum[r];
             for (int c0 = 0; c0 < D; c0 += 64) {          // (whole-wave trips: the shuffles below need every lane)
                 const int c = c0 + lane;
                 double acc = 0.0;
                 for (unsigned long long m = mask; m; m &= m - 1) {
                     const int p = __ffsll((long long)m) - 1;
-                    const long long idx = __shfl(found, p, 64);
-                    const unsigned long long wd = (unsigned long long)pe.side[p][8 * idx];
-                    if (c < D) acc += pe.part[p][(long long)((wd >> 32) & 0x3FFFFFFFull) * ldp + c];
+                    const unsigned long long wp = (unsigned long long)__shfl((long long)wd, p, 64);
+                    if (c < D) acc += pe.part[p][(long long)((wp >> 32) & 0x3FFFFFFFull) * ldp + c];
                 }
                 if (c < D) o[c] = (float)(acc / w);
             }
-        }
-        if (lane == 0) {
-            const int32_t cl = rowcell[r0 + r];
-            if (cell_out) cell_out[r] = cl;
-            grid_pos[r * 3 + 0] = cl / (gs * vh);
-            grid_pos[r * 3 + 1] = (cl / vh) % gs;
-            grid_pos[r * 3 + 2] = cl % vh;
-            float wt = (float)w;
-            uint8_t c3[3];
-            for (int k = 0; k < 3; ++k) {
-                double m = w4[1 + k] / w + 1e-9;          // as finalize_kernel
-                m = fmin(fmax(m, 0.0), 255.0);
-                c3[k] = (uint8_t)m;
-            }
-            if (have_log && st.started) {               // replay_apply_kernel
-                wt = (float)st.w;
-                for (int k = 0; k < 3; ++k) c3[k] = (uint8_t)fminf(fmaxf(st.c[k], 0.f), 255.f);
-            }
-            weight[r] = wt;
-            for (int k = 0; k < 3; ++k) grid_rgb[r * 3 + k] = c3[k];
         }
     }
 }
@@ -339,21 +344,20 @@ static int bit_length(unsigned long long v) {
 // layout of the work buffer of avl_merge2_plan (byte offsets from the 256-aligned base)
 struct M2Layout {
     size_t row, prev, next, order, sidx, selA, selB, idx_prev, idx_next, rowcell, res;   // results (see avl_merge2_plan)
-    size_t ecell, eidx, erank, scell, se, hp, pn, k2, v2, k2s, v2s, rowofhead, krow, vslot, krow_s, single, kp, kn, kps, tmp, total;
+    size_t ecell, eidx, erank, scell, se, hp, pn, headflag, rowscan, krow, vslot, krow_s, single, kp, kn, kps, tmp, total;
     size_t tmp_bytes;
 };
 
 static int m2_layout(long long E, long long n, int ws, M2Layout& L) {
     const size_t e = (size_t)(E > 0 ? E : 1), m = (size_t)(n > 0 ? n : 1);
-    size_t t_cell = 0, t_key = 0, t_row = 0, t_small = 0, t_scan = 0;
+    size_t t_cell = 0, t_row = 0, t_small = 0, t_scan = 0, t_scan_e = 0;
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_cell, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, e, 0, 32, nullptr));
-    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_key, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr,
-                                            (uint32_t*)nullptr, e, 0, 64, nullptr));
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_row, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, 32, nullptr));
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_small, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 8, nullptr));
     {
         auto it = rocprim::make_transform_iterator((const uint8_t*)nullptr, FlagToI32{});
         AVL_HIP_CHECK(rocprim::exclusive_scan(nullptr, t_scan, it, (int32_t*)nullptr, 0, m, rocprim::plus<int32_t>(), nullptr));
+        AVL_HIP_CHECK(rocprim::exclusive_scan(nullptr, t_scan_e, it, (int32_t*)nullptr, 0, e, rocprim::plus<int32_t>(), nullptr));
     }
     size_t p = 0;
     auto take = [&](size_t bytes) { const size_t at = p; p += m2_al(bytes); return at; };
@@ -362,10 +366,10 @@ static int m2_layout(long long E, long long n, int ws, M2Layout& L) {
     L.rowcell = take(e * 4);
     L.res = take((size_t)(2 + 3 * ws * ws) * 8);
     L.ecell = take(e * 4); L.eidx = take(e * 4); L.erank = take(e); L.scell = take(e * 4); L.se = take(e * 4); L.hp = take(e * 4);
-    L.pn = take(e * 2); L.k2 = take(e * 8); L.v2 = take(e * 4); L.k2s = take(e * 8); L.v2s = take(e * 4); L.rowofhead = take(e * 4);
+    L.pn = take(e * 2); L.headflag = take(e); L.rowscan = take(e * 4);
     L.krow = take(m * 4); L.vslot = take(m * 4); L.krow_s = take(m * 4); L.single = take(m); L.kp = take(m * 4); L.kn = take(m * 4);
     L.kps = take(m * 4);
-    L.tmp_bytes = std::max(std::max(t_cell, t_key), std::max(std::max(t_row, t_small), t_scan));
+    L.tmp_bytes = std::max(std::max(t_cell, t_scan_e), std::max(std::max(t_row, t_small), t_scan));
     L.tmp = take(L.tmp_bytes ? L.tmp_bytes : 16);
     L.total = p + 256;
     return AVL_OK;
@@ -377,11 +381,44 @@ using namespace avl;
 
 extern "C" {
 
-int avl_merge2_header(int64_t n, const int64_t* d_key, int64_t flags, int64_t* d_hdr, void* stream) {
-    AVL_REQUIRE(n >= 0 && d_hdr && (n == 0 || d_key), "avl_merge2_header: bad arguments");
-    hipLaunchKernelGGL(m2_header_kernel, dim3(1), dim3(1024), 0, as_stream(stream), (long long)n, reinterpret_cast<const long long*>(d_key),
-                       (long long)flags, reinterpret_cast<long long*>(d_hdr));
+int avl_merge2_prepare_work_bytes(int64_t n, size_t* h_bytes) {
+    AVL_REQUIRE(h_bytes && n >= 0 && n < (1ll << 31), "avl_merge2_prepare_work_bytes: bad arguments");
+    size_t t = 0;
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 64,
+                                            nullptr));
+    *h_bytes = m2_al(m * 4) + m2_al(t ? t : 16) + 256;
+    return AVL_OK;
+}
+
+int avl_merge2_prepare(int64_t n, const int64_t* d_key, const int32_t* d_cell, int key_bits, int64_t flags, int64_t* d_key_sorted,
+                       int32_t* d_cell_sorted, int32_t* d_perm, int64_t* d_hdr, void* d_work, size_t work_bytes, void* stream) {
+    AVL_REQUIRE(n >= 0 && n < (1ll << 31) && d_hdr && key_bits >= 1 && key_bits <= 63, "avl_merge2_prepare: bad arguments");
+    hipStream_t st = as_stream(stream);
+    if (n > 0) {
+        AVL_REQUIRE(d_key && d_cell && d_key_sorted && d_cell_sorted && d_perm, "avl_merge2_prepare: null pointer");
+        size_t need = 0;
+        int rc = avl_merge2_prepare_work_bytes(n, &need);
+        if (rc != AVL_OK) return rc;
+        AVL_REQUIRE(d_work && work_bytes >= need, "avl_merge2_prepare: work buffer of %zu bytes, %zu needed", work_bytes, need);
+        char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(d_work) + 255) / 256 * 256);
+        int32_t* iota = reinterpret_cast<int32_t*>(base);
+        void* tmp = base + m2_al((size_t)n * 4);
+        size_t tb = need - 256 - m2_al((size_t)n * 4);
+        hipLaunchKernelGGL(m2_iota_kernel, dim3(m2_grid(n)), dim3(256), 0, st, (long long)n, iota);
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, reinterpret_cast<const unsigned long long*>(d_key), reinterpret_cast<unsigned long long*>(d_key_sorted),
+                                                iota, d_perm, (size_t)n, 0, key_bits, st));
+    }
+    hipLaunchKernelGGL(m2_presorted_kernel, dim3(n > 0 ? m2_grid(n) : 1), dim3(256), 0, st, (long long)n, d_cell, d_perm,
+                       reinterpret_cast<const long long*>(d_key_sorted), (long long)flags, d_cell_sorted, reinterpret_cast<long long*>(d_hdr));
     AVL_HIP_CHECK(hipGetLastError());
+    return AVL_OK;
+}
+
+int avl_merge2_fold_work_bytes(int64_t n_own, int ws, size_t* h_bytes) {
+    AVL_REQUIRE(h_bytes && n_own >= 0 && ws >= 1 && ws <= kM2MaxRanks, "avl_merge2_fold_work_bytes: bad arguments");
+    const size_t m = (size_t)(n_own > 0 ? n_own : 1);
+    *h_bytes = m2_al(m * ws * sizeof(int32_t)) + m2_al(m * 8) + m2_al(m) + 256;
     return AVL_OK;
 }
 
@@ -395,10 +432,10 @@ int avl_merge2_work_bytes(int64_t E, int64_t n, int ws, size_t* h_bytes) {
     return AVL_OK;
 }
 
-int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, int cell_bits, int key_bits,
+int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, const int32_t* d_perm, int cell_bits,
                     int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off, int64_t* h_res, void* stream) {
     AVL_REQUIRE(ws >= 1 && ws <= kM2MaxRanks && rank >= 0 && rank < ws && h_n_all && h_off && h_res, "avl_merge2_plan: bad arguments");
-    AVL_REQUIRE(cell_bits >= 1 && cell_bits <= 31 && key_bits >= 1 && key_bits <= 63, "avl_merge2_plan: cell_bits in [1, 31], key_bits in [1, 63]");
+    AVL_REQUIRE(cell_bits >= 1 && cell_bits <= 31, "avl_merge2_plan: cell_bits in [1, 31]");
     M2Offsets o;
     long long E = 0;
     for (int p = 0; p < ws; ++p) {
@@ -423,26 +460,26 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
     const int nres = 2 + 3 * ws * ws;
     unsigned long long* res = reinterpret_cast<unsigned long long*>(base + L.res);
     AVL_HIP_CHECK(hipMemsetAsync(res, 0, (size_t)nres * 8, st));
-    const unsigned long long sentinel = 1ull << key_bits;
     if (E > 0) {
-        AVL_REQUIRE(d_gathered, "avl_merge2_plan: null gathered lists");
+        AVL_REQUIRE(d_gathered && (n == 0 || d_perm), "avl_merge2_plan: null lists");
         auto U32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
         auto I32 = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
-        auto U64 = [&](size_t off) { return reinterpret_cast<unsigned long long*>(base + off); };
         const long long* g = reinterpret_cast<const long long*>(d_gathered);
         uint8_t* erank = reinterpret_cast<uint8_t*>(base + L.erank);
+        uint8_t* headflag = reinterpret_cast<uint8_t*>(base + L.headflag);
         hipLaunchKernelGGL(m2_compact_kernel, dim3(m2_grid(E)), dim3(256), 0, st, E, ws, o, stride, (long long)nmax, g, U32(L.ecell), U32(L.eidx), erank);
         size_t tb = L.tmp_bytes;
         AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.ecell), U32(L.scell), U32(L.eidx), U32(L.se), (size_t)E, 0, cell_bits, st));
-        hipLaunchKernelGGL(m2_segments_kernel, dim3(m2_grid(E)), dim3(256), 0, st, E, o, stride, g, U32(L.scell), U32(L.se), erank, sentinel, U32(L.hp),
-                           reinterpret_cast<uint16_t*>(base + L.pn), U64(L.k2), U32(L.v2), res);
-        tb = L.tmp_bytes;
-        AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U64(L.k2), U64(L.k2s), U32(L.v2), U32(L.v2s), (size_t)E, 0, key_bits + 1, st));
-        hipLaunchKernelGGL(m2_rows_kernel, dim3(m2_grid(E)), dim3(256), 0, st, E, U64(L.k2s), U32(L.v2s), sentinel, U32(L.scell), (long long)grow_row,
-                           U32(L.rowofhead), I32(L.rowcell), res);
-        hipLaunchKernelGGL(m2_entries_kernel, dim3(std::min(m2_grid(E), 512u)), dim3(256), (size_t)(3 * ws * ws) * sizeof(unsigned), st, E, ws, rank, o,
-                           U32(L.se), erank, U32(L.hp), reinterpret_cast<const uint16_t*>(base + L.pn), U32(L.rowofhead), res, I32(L.row), I32(L.prev),
-                           I32(L.next), U32(L.krow), U32(L.vslot));
+        hipLaunchKernelGGL(m2_segments_kernel, dim3(m2_grid(E)), dim3(256), 0, st, E, U32(L.scell), U32(L.se), erank, U32(L.hp),
+                           reinterpret_cast<uint16_t*>(base + L.pn), headflag, res);
+        {
+            tb = L.tmp_bytes;
+            auto it = rocprim::make_transform_iterator(reinterpret_cast<const uint8_t*>(headflag), FlagToI32{});
+            AVL_HIP_CHECK(rocprim::exclusive_scan(base + L.tmp, tb, it, I32(L.rowscan), 0, (size_t)E, rocprim::plus<int32_t>(), st));
+        }
+        hipLaunchKernelGGL(m2_entries_kernel, dim3(std::min(m2_grid(E), 1024u)), dim3(256), (size_t)(3 * ws * ws) * sizeof(unsigned), st, E, ws, rank, o,
+                           stride, g, U32(L.scell), U32(L.se), erank, U32(L.hp), reinterpret_cast<const uint16_t*>(base + L.pn), I32(L.rowscan), d_perm,
+                           (long long)grow_row, res, I32(L.rowcell), I32(L.row), I32(L.prev), I32(L.next), U32(L.krow), U32(L.vslot));
         if (n > 0) {
             tb = L.tmp_bytes;
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.krow), U32(L.krow_s), U32(L.vslot), U32(L.order), (size_t)n, 0,
@@ -506,24 +543,43 @@ int avl_merge2_side_state(int64_t n, int ws, const int64_t* h_start, const int64
 
 int avl_merge2_fold(int64_t n_own, int64_t r0, int ws, int D, int gs, int vh, const void* const* h_side, const void* const* h_done,
                     const void* const* h_part, const int64_t* h_count, const int32_t* d_rowcell, int have_log, float* d_grid_feat,
-                    int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_cell, int32_t* d_err_flag, void* stream) {
+                    int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_cell, void* d_work, size_t work_bytes, int32_t* d_err_flag,
+                    void* stream) {
     AVL_REQUIRE(n_own >= 0 && r0 >= 0 && ws >= 1 && ws <= kM2MaxRanks && D > 0 && gs > 0 && vh > 0, "avl_merge2_fold: bad shape");
     if (n_own == 0) return AVL_OK;
-    AVL_REQUIRE(h_side && h_done && h_part && h_count && d_rowcell && d_grid_feat && d_grid_pos && d_weight && d_grid_rgb, "avl_merge2_fold: null pointer");
+    AVL_REQUIRE(h_side && h_done && h_part && h_count && d_rowcell && d_grid_feat && d_grid_pos && d_weight && d_grid_rgb && d_work,
+                "avl_merge2_fold: null pointer");
+    size_t need_bytes = 0;
+    (void)avl_merge2_fold_work_bytes(n_own, ws, &need_bytes);
+    AVL_REQUIRE(work_bytes >= need_bytes && (reinterpret_cast<uintptr_t>(d_work) & 255) == 0, "avl_merge2_fold: %zu bytes of 256-aligned work needed (avl_merge2_fold_work_bytes)",
+                need_bytes);
+    int32_t* d_table = reinterpret_cast<int32_t*>(d_work);
     M2Peers pe{};
+    long long R = 0;
     for (int p = 0; p < ws; ++p) {
         pe.side[p] = reinterpret_cast<const long long*>(h_side[p]);
         pe.done[p] = reinterpret_cast<const float*>(h_done[p]);
         pe.part[p] = reinterpret_cast<const double*>(h_part[p]);
         pe.count[p] = h_count[p];
+        R += h_count[p];
         AVL_REQUIRE(h_count[p] == 0 || h_side[p], "avl_merge2_fold: peer %d has records but no buffer", p);
     }
+    hipStream_t st = as_stream(stream);
+    AVL_HIP_CHECK(hipMemsetAsync(d_table, 0xFF, (size_t)n_own * ws * sizeof(int32_t), st));
+    if (R > 0)
+        hipLaunchKernelGGL(m2_fold_index_kernel, dim3(m2_grid(R)), dim3(256), 0, st, R, ws, pe, (long long)n_own, d_table, reinterpret_cast<int*>(d_err_flag));
     const long long ldf = (D + 1) / 2 * 2;      // float32 rows are padded to whole 8-byte words
-    int64_t blocks = (n_own + 3) / 4;
-    const int64_t maxb = (int64_t)num_cus() * 16;
+    // scratch behind the table: sum alpha (f64) and the "features still to do" flag of every row
+    char* sb = reinterpret_cast<char*>(d_table) + m2_al((size_t)n_own * ws * sizeof(int32_t));
+    double* wsum = reinterpret_cast<double*>(sb);
+    uint8_t* need = reinterpret_cast<uint8_t*>(sb + m2_al((size_t)n_own * 8));
+    hipLaunchKernelGGL(m2_fold_scalar_kernel, dim3(m2_grid(n_own)), dim3(256), 0, st, (long long)n_own, (long long)r0, ws, gs, vh, pe, d_table, d_rowcell,
+                       have_log, d_grid_pos, d_weight, d_grid_rgb, d_cell, wsum, need, reinterpret_cast<int*>(d_err_flag));
+    int64_t blocks = ((n_own + 15) / 16 + 3) / 4;
+    const int64_t maxb = (int64_t)num_cus() * 32;
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(m2_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), (long long)n_own, (long long)r0, ws, D, ldf, (long long)D,
-                       gs, vh, pe, d_rowcell, have_log, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_cell, reinterpret_cast<int*>(d_err_flag));
+    hipLaunchKernelGGL(m2_fold_feat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n_own, ws, D, ldf, (long long)D, pe, d_table, wsum, need,
+                       d_grid_feat);
     AVL_HIP_CHECK(hipGetLastError());
     return AVL_OK;
 }

@@ -57,6 +57,15 @@ class VLMapBuilder:
                                                    # -> stays frame-at-once; one that returns fresh storage (any torch model
                                                    # does: the caching allocator cannot reuse memory that is still referenced) ->
                                                    # deferral is switched on from the third frame.  True / False force it.
+        self.frame_loop_frames = 4                 # frame-by-frame runs: whenever further frames are already staged (prefetch threads
+                                                   # ahead of the fusing thread) up to this many consecutive frames go to the library
+                                                   # in ONE call (avl_builder_integrate_frames: the frame loop in C -- still one launch
+                                                   # (pair) per frame, the same map bit for bit, but frame i + 1's map-independent half
+                                                   # of K1 runs inside frame i's launch and the per-call Python cost is paid once).
+                                                   # Needs device-resident features whose storage the extractor does not recycle while
+                                                   # they wait (found out like deferred_fuse "auto" does); 1 = one call per frame
+        self.frame_loop_max_extract_s = 1e-3       # ... and only while the extractor call returns within this time
+        self.frame_loop_eager = False              # True: hold frames until frame_loop_frames are together even if the next one is not staged yet
         self.prefetch_frames = 4                   # frames decoded ahead by host threads (0 = load inline like upstream)
         self.stage_frames = True                   # with prefetch_frames > 0: depth / rgb / sample lists travel through page-locked
                                                    # buffers on a copy stream (device.FrameStager) instead of three pageable,
@@ -241,6 +250,7 @@ class VLMapBuilder:
             waits for.  staged is None otherwise (the arrays are copied synchronously by the fusing thread, as before).
         Pillow, np.load, the shuffle (host C) and large NumPy copies release the GIL."""
         n = int(self.prefetch_frames or 0)
+        self._frames_ready = lambda: 0                                    # how many further frames could be taken without waiting
         self._resolve_pixel_sampling()
         if self.pixel_sampling not in ("reference", "uniform"):
             raise ValueError(f"pixel_sampling must be 'reference' or 'uniform', not {self.pixel_sampling!r}")
@@ -262,6 +272,7 @@ class VLMapBuilder:
         st_ = self.pipeline_stats = dict(sampler_busy_s=0.0, stager_busy_s=0.0, fuse_thread_wait_s=0.0, frames=0)
         sampled = queue.Queue(maxsize=n)                  # sampler -> stager (or straight to the consumer)
         out = queue.Queue(maxsize=n) if stage else sampled
+        self._frames_ready = out.qsize
         stop = threading.Event()
         stager = None
         if stage:
@@ -269,7 +280,7 @@ class VLMapBuilder:
             from ..device import FrameStager
             dev = _lib.current_device()
             # slots: frames queued for the consumer + the one being staged + the one being fused + a batch held back for one launch
-            stager = self._stager = FrameStager(n + max(1, int(self.batch_frames or 1)) + 3, device=dev)
+            stager = self._stager = FrameStager(n + max(1, int(self.batch_frames or 1), int(self.frame_loop_frames or 1)) + 3, device=dev)
 
         def put(q, item) -> bool:
             """blocking put that gives up once the consumer has gone (never blocks forever on a full queue)"""
@@ -463,12 +474,36 @@ class VLMapBuilder:
         stage = bool(self.stage_frames and (self.prefetch_frames or 0) > 0)
         self._stager = None
         self.pipeline_stats = {}
-        self.build_times = dict(checkpoints_on_fusing_thread_s=0.0, checkpoints=0)
+        self.build_times = dict(checkpoints_on_fusing_thread_s=0.0, checkpoints=0, frames_in_c_loop_calls=0, c_loop_calls=0)
         t_loop = time.perf_counter()
+        import collections
+        group = []                  # frames waiting for one avl_builder_integrate_frames call
+        group_shape = None
+        recent = collections.deque(maxlen=2 * max(1, int(self.frame_loop_frames or 1)) + 2)     # storage ranges of the last frames' features
+        ring_k = 1 << 30            # smallest distance at which the extractor was seen to recycle feature storage
+
+        def issue_group():
+            if not group:
+                return
+            kw = dict(calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth, sigma_sq=self.sigma_sq)
+            if len(group) == 1:
+                fi, d_, s_, f_, r_, _st = group[0]
+                acc.integrate_frame(d_, calib_mat, transforms[fi], s_, f_, r_, frame_idx=fi, **kw)
+            else:
+                plan = acc.make_batch_plan([g[1] for g in group], [g[2] for g in group], [g[3] for g in group], [g[4] for g in group])
+                acc.integrate_frames(plan, calib_mat, np.stack([transforms[g[0]] for g in group]), frame_idx0=group[0][0], **kw)
+                self.build_times["frames_in_c_loop_calls"] += len(group)
+                self.build_times["c_loop_calls"] += 1
+            for g in group:
+                if g[5] is not None:
+                    self._stager.release(g[5])        # depth / rgb / samples are read by these launches only (features: deferred)
+            group.clear()
         for frame_i, rgb, depth, samples, staged in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip, stage=stage):
             if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
                 continue        # the pixel shuffle of the skipped frame was still drawn, so later frames sample as upstream
+            t_ext = time.perf_counter()
             feat = self._features_hwc(rgb)
+            t_ext = time.perf_counter() - t_ext
             if acc is None:
                 D = int(feat.shape[2])
                 self.clip_feat_dim = D
@@ -498,32 +533,52 @@ class VLMapBuilder:
                 if len(pending) >= self.batch_frames:
                     self._flush(acc, pending, calib_mat, calib_inv, transforms)
             else:
-                if self.deferred_fuse_active and pending_storage is not None and _storage_key(feat) == pending_storage:
-                    # the extractor wrote this frame into the storage in which the PREVIOUS frame's features still wait to be
-                    # fused (probation saw fresh storage for the first two frames; the extractor started recycling later).  That
-                    # frame's features are gone -- fail loudly instead of fusing the wrong bytes
+                rng_ = _storage_range(feat)
+                # how long ago did the extractor last hand out memory overlapping this frame's features?  (compared by address RANGE:
+                # per-frame views of one batched output are different memory, a recycled ring buffer is the same)
+                dist_ = next((k + 1 for k, (r, _ref) in enumerate(recent) if _ranges_overlap(r, rng_)), None)
+                waiting = len(group) + (1 if (self.deferred_fuse_active and pending_storage is not None) else 0)
+                if dist_ is not None and dist_ <= waiting:
+                    # the extractor wrote this frame into storage in which an EARLIER frame's features still wait to be fused
+                    # (probation saw fresh storage; the extractor started recycling later).  Those features are gone -- fail loudly
+                    # instead of fusing the wrong bytes
                     raise RuntimeError(f"frame {frame_i}: the feature extractor reused the storage of the previous frame's features "
-                                       "before they were fused (deferred fuse); build with deferred_fuse=False for this extractor")
-                acc.integrate_frame(depth, calib_mat, transforms[frame_i], samples, feat, rgb, frame_idx=frame_i,
-                                    calib_inv=calib_inv, min_depth=self.min_depth, max_depth=self.max_depth,
-                                    sigma_sq=self.sigma_sq)
-                if staged is not None:
-                    self._stager.release(staged)          # depth / rgb / samples are read by this launch only (features: deferred)
+                                       "before they were fused (deferred fuse / frame_loop_frames); build with deferred_fuse=False and "
+                                       "frame_loop_frames=1 for this extractor")
+                if dist_ is not None and recent[dist_ - 1][1] is not None:
+                    ring_k = min(ring_k, dist_)          # that tensor is still referenced here: the allocator did not hand its memory out
+                                                         # again, the extractor itself recycles its output buffers at this distance
+                # frames are held back only while the extractor is not what the loop waits for (a model that takes milliseconds per
+                # frame gains nothing from sharing a call); the last frames' tensors are then kept referenced, so that an address
+                # seen again within the window is the extractor recycling a buffer, not the allocator reusing freed memory
+                fast = t_ext < self.frame_loop_max_extract_s and int(self.frame_loop_frames or 1) > 1
+                recent.appendleft((rng_, feat if fast else None))
+                # frames held back for ONE avl_builder_integrate_frames call: only features that are device tensors in storage the
+                # extractor has not been seen to recycle within twice that distance, consecutive frame indices, equal shapes
+                limit = 1
+                if rng_ is not None and probation is None and fast:
+                    limit = max(1, min(int(self.frame_loop_frames), min(len(recent), ring_k) // 2))
+                shp = (tuple(depth.shape), tuple(feat.shape), tuple(np.shape(samples) if isinstance(samples, np.ndarray) else samples.shape))
+                if group and (frame_i != group[-1][0] + 1 or shp != group_shape):
+                    issue_group()
+                group_shape = shp
+                group.append((frame_i, depth, samples, feat, rgb, staged))
+                if len(group) >= limit or (self._frames_ready() <= 0 and not self.frame_loop_eager):
+                    issue_group()
                 if probation is not None:
                     # deferred fuse on probation: does the extractor hand out fresh storage while the previous tensor is alive?
-                    # Compared by STORAGE, not by data pointer: two views at different offsets of one persistent buffer are
-                    # the same memory being refilled
                     probation.append(feat)
                     if len(probation) == 2:
-                        keys = [_storage_key(f) for f in probation]
-                        fresh = keys[0] is None or keys[0] != keys[1]     # NumPy features are staged by us: always fresh
+                        rr = [_storage_range(f) for f in probation]
+                        fresh = rr[0] is None or not _ranges_overlap(rr[0], rr[1])     # NumPy features are staged by us: always fresh
                         if fresh:
                             acc.set_deferred_fuse(True)
                         self.deferred_fuse_active = bool(fresh)
                         probation = None
-                pending_storage = _storage_key(feat)
+                pending_storage = rng_
             mapped_iter_set.add(frame_i)
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
+                issue_group()
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 t_ck = time.perf_counter()
                 if not (self.skip_busy_checkpoints and getattr(self, "_save_thread", None) is not None and self._save_thread.is_alive()):
@@ -534,9 +589,11 @@ class VLMapBuilder:
             elif ws > 1 and self.save_every and (frame_i - lo) % self.save_every == self.save_every - 1 and rounds_done < rounds_total:
                 # upstream saves every 100 frames (vlmap_builder.py:181-183); with several ranks a checkpoint is a merge, i.e. a
                 # collective: every rank joins round j after its (j + 1) * save_every-th frame (or at the end of its shard)
+                issue_group()
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=False)
                 rounds_done += 1
+        issue_group()
         if acc is None:
             if ws == 1:
                 raise RuntimeError("no frames to map")
@@ -847,6 +904,22 @@ class VLMapBuilder:
 import threading as _threading
 
 _SCRATCH = _threading.local()
+
+
+def _storage_range(feat):
+    """(device, first byte, one past the last byte) of the memory a feature tensor occupies, None for anything the builder stages
+    itself (NumPy arrays are copied into fresh device buffers)"""
+    if not hasattr(feat, "untyped_storage"):
+        return None
+    try:
+        a = int(feat.data_ptr())
+        return (str(feat.device), a, a + int(feat.numel()) * int(feat.element_size()))
+    except Exception:
+        return None
+
+
+def _ranges_overlap(a, b) -> bool:
+    return a is not None and b is not None and a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
 
 
 def _storage_key(feat):

@@ -100,6 +100,7 @@ class HostKernels:
         a = lambda x: np.ascontiguousarray(x.numpy() if hasattr(x, "numpy") else x)
         self.raw = {k: a(v) for k, v in raw.items()}
         self.n = int(self.raw["cell"].shape[0])
+        self.perm = np.argsort(self.raw["first_key"], kind="stable").astype(np.int32)      # avl_merge2_prepare: the list goes out in key order
         self.D = int(self.raw["sum_feat"].shape[1])
         self.replay_fn = replay_fn
         self.device = "cpu"
@@ -115,10 +116,10 @@ class HostKernels:
 
     def fill_chunk(self, chunk, nmax):
         c = chunk.numpy()
-        c[:self.n] = self.raw["first_key"]
-        c[nmax:].view(np.int32)[:self.n] = self.raw["cell"]
+        c[:self.n] = self.raw["first_key"][self.perm]
+        c[nmax:].view(np.int32)[:self.n] = self.raw["cell"][self.perm]
 
-    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, key_bits, grow_row, want_lists):
+    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, grow_row, want_lists):
         g = gathered.numpy()
         stride = nmax + (nmax + 1) // 2
         off = np.concatenate([[0], np.cumsum(n_all)]).astype(np.int64)
@@ -136,26 +137,29 @@ class HostKernels:
         rs = erank[se]
         prev = np.where(head, -1, np.roll(rs, 1)) if E else rs
         nxt = np.where(tail, -1, np.roll(rs, -1)) if E else rs
-        sentinel = np.uint64(1 << key_bits)
-        k2 = np.where(head, ekey[se].astype(np.uint64), sentinel)
-        v2s = np.argsort(k2, kind="stable")
+        # the ranks' lists are in key order and the keys ordered by rank: ENTRY order is key order, a first contributor's row is the
+        # number of first contributors before it
+        headflag = np.zeros(E, np.int64)
+        headflag[se] = head
+        rowscan = np.cumsum(headflag) - headflag
         M = int(head.sum())
-        rowofhead = np.zeros(E, np.int64)
-        rowofhead[v2s[:M]] = np.arange(M)
-        self.rowcell = scell[v2s[:M]].astype(np.int32)
-        row = rowofhead[hp] if E else rowofhead
+        row = rowscan[se[hp]] if E else rowscan
+        self.rowcell = np.zeros(M, np.int32)
+        self.rowcell[row[head]] = scell[head]
+        keyrow = np.zeros(M, np.int64)
+        keyrow[row[head]] = ekey[se][head]
         per = max(1, (M + ws - 1) // ws)
         q = np.minimum(row // per, ws - 1)
         res = np.zeros(2 + 3 * ws * ws, np.int64)
         res[0] = M
-        res[1] = int(k2[v2s[grow_row]]) if 0 <= grow_row < M else -1
+        res[1] = int(keyrow[grow_row]) if 0 <= grow_row < M else -1
         W2 = ws * ws
         np.add.at(res, 2 + rs * ws + q, 1)
         single_e = (prev < 0) & (nxt < 0)
         np.add.at(res, 2 + W2 + (rs * ws + q)[single_e], 1)
         np.add.at(res, 2 + 2 * W2 + (prev * ws + rs)[prev >= 0], 1)
         mine = rs == rank
-        s = se[mine] - off[rank]
+        s = self.perm[se[mine] - off[rank]]
         n = self.n
         self.row, self.prev, self.next = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
         self.row[s], self.prev[s], self.next[s] = row[mine], prev[mine], nxt[mine]
@@ -294,15 +298,25 @@ class HipKernels:
         self.torch = torch
 
     def header(self, flags):
-        """also exports the keys once (the header needs their range); fill_chunk copies from there"""
+        """the rank's (key, cell) list sorted by key (avl_merge2_prepare) + its header; fill_chunk copies from there"""
+        import ctypes as C
         t = self.torch
-        self._key = t.empty(max(self.n, 1), dtype=t.int64, device=self.device)
-        self._cell = t.empty(max(self.n, 1), dtype=t.int32, device=self.device)
+        m = max(self.n, 1)
+        key = t.empty(m, dtype=t.int64, device=self.device)
+        cell = t.empty(m, dtype=t.int32, device=self.device)
+        self._key = t.empty(m, dtype=t.int64, device=self.device)
+        self._cell = t.empty(m, dtype=t.int32, device=self.device)
+        self.perm = t.empty(m, dtype=t.int32, device=self.device)
         if self.n:
-            self.check(self.lib.avl_builder_export_raw(self.acc._h, self.n, self._cell.data_ptr(), self._key.data_ptr(), None, None, None, None, self.st),
+            self.check(self.lib.avl_builder_export_raw(self.acc._h, self.n, cell.data_ptr(), key.data_ptr(), None, None, None, None, self.st),
                        "avl_builder_export_raw")
+        nb = C.c_size_t()
+        self.check(self.lib.avl_merge2_prepare_work_bytes(self.n, C.byref(nb)), "avl_merge2_prepare_work_bytes")
+        work = t.empty(int(nb.value), dtype=t.uint8, device=self.device)
         hdr = t.empty(4, dtype=t.int64, device=self.device)
-        self.check(self.lib.avl_merge2_header(self.n, self._key.data_ptr(), int(flags), hdr.data_ptr(), self.st), "avl_merge2_header")
+        self.check(self.lib.avl_merge2_prepare(self.n, key.data_ptr(), cell.data_ptr(), int(self.acc.key_bits()), int(flags), self._key.data_ptr(),
+                                               self._cell.data_ptr(), self.perm.data_ptr(), hdr.data_ptr(), work.data_ptr(), int(nb.value), self.st),
+                   "avl_merge2_prepare")
         return hdr
 
     def new_words(self, words):
@@ -314,7 +328,7 @@ class HipKernels:
             chunk[nmax:].view(self.torch.int32)[:self.n].copy_(self._cell[:self.n])
         del self._key, self._cell
 
-    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, key_bits, grow_row, want_lists):
+    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, grow_row, want_lists):
         import ctypes as C
         t = self.torch
         E = int(sum(n_all))
@@ -325,7 +339,7 @@ class HipKernels:
         h_off = (C.c_int64 * 11)()
         nres = 2 + 3 * ws * ws
         h_res = (C.c_int64 * nres)()
-        self.check(self.lib.avl_merge2_plan(ws, rank, h_n, int(nmax), gathered.data_ptr(), int(cell_bits), int(key_bits), int(grow_row),
+        self.check(self.lib.avl_merge2_plan(ws, rank, h_n, int(nmax), gathered.data_ptr(), self.perm.data_ptr(), int(cell_bits), int(grow_row),
                                             1 if want_lists else 0, self.work.data_ptr(), int(nb.value), h_off, h_res, self.st), "avl_merge2_plan")
         base = self.work.data_ptr()
         names = ("row", "prev", "next", "order", "sidx", "selA", "selB", "idx_prev", "idx_next", "rowcell", "res")
@@ -374,6 +388,9 @@ class HipKernels:
                    grid_rgb=t.empty((n_own, 3), dtype=t.uint8, device=self.device),
                    cell=t.empty((n_own,), dtype=t.int32, device=self.device))
         self.err = t.zeros(1, dtype=t.int32, device=self.device)
+        nb = C.c_size_t()
+        self.check(self.lib.avl_merge2_fold_work_bytes(n_own, L.ws, C.byref(nb)), "avl_merge2_fold_work_bytes")
+        table = t.empty(int(nb.value), dtype=t.uint8, device=self.device)          # (torch's blocks are 512-byte aligned)
         ptr = dict(send=send.data_ptr(), recv=recv.data_ptr() if recv is not None else 0)
         side, done, part, cnt = [], [], [], []
         for p in range(L.ws):
@@ -385,7 +402,8 @@ class HipKernels:
         vps = lambda a: (C.c_void_p * len(a))(*a)
         self.check(self.lib.avl_merge2_fold(n_own, L.r0, L.ws, D, gs, vh, vps(side), vps(done), vps(part), self._i64s(cnt), self.p["rowcell"],
                                             1 if have_log else 0, out["grid_feat"].data_ptr(), out["grid_pos"].data_ptr(), out["weight"].data_ptr(),
-                                            out["grid_rgb"].data_ptr(), out["cell"].data_ptr(), self.err.data_ptr(), self.st), "avl_merge2_fold")
+                                            out["grid_rgb"].data_ptr(), out["cell"].data_ptr(), table.data_ptr(), int(nb.value), self.err.data_ptr(), self.st),
+                   "avl_merge2_fold")
         return out
 
 
@@ -398,6 +416,7 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
     rank, ws = (coll.rank, coll.ws) if coll is not None else (0, 1)
     sync = sync or (lambda: None)
     marks = []
+    trace = timings is not None and os.environ.get("AVLMAPS_MERGE_TRACE") == "1"
 
     def mark(label):
         if timings is not None:
@@ -422,10 +441,13 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
     gathered = K.new_words(ws * stride)
     chunk = gathered[rank * stride:(rank + 1) * stride]
     K.fill_chunk(chunk, nmax)
+    if trace:
+        mark("plan: header + lists out")
     if coll is not None:
         coll.all_gather_into(gathered, chunk)
-    key_bits = min(63, _bit_length(max(last, 1)))     # (a resumed build's new keys carry bit 62: avl_builder_import_map)
-    res = K.plan(gathered, n_all, nmax, rank, ws, cell_bits, key_bits, grow_row, have_log and ws > 1)
+    res = K.plan(gathered, n_all, nmax, rank, ws, cell_bits, grow_row, have_log and ws > 1)
+    if trace:
+        mark("plan: kernels + read-back")
     L = Layout(res, rank, ws, D)
     del gathered, chunk
     mark("plan")
@@ -467,14 +489,23 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
         recv = coll.all_to_all(send[:L.remote_words], L.in_splits(), L.out_splits())
     mark("exchange")
     out = K.fold(send, recv, L, gs, vh, have_log, own_feat)
+    if trace:
+        mark("fold: kernels")
     err = getattr(K, "err", None)
     if err is not None:
         if coll is not None:
             err = coll.all_reduce(err, coll.dist.ReduceOp.MAX)      # every rank raises together (nobody is left inside a later collective)
         if int(err.item()):
             raise RuntimeError(f"multi-rank merge: the fold found an inconsistent exchange (flags {int(err.item())})")
+    if trace:
+        mark("fold: flags")
     del send, recv
     mark("fold")
+    if trace:
+        import sys
+        steps = [(b[0], 1e3 * ((b[1] - a[1]) - (b[2] - a[2]) - (b[3] - a[3]))) for a, b in zip(marks[:-1], marks[1:])]
+        print(f"[merge2 trace] rank {rank}: " + " | ".join(f"{k} {v:.2f}" for k, v in steps) + " (own ms)", file=sys.stderr, flush=True)
+        marks[:] = [m for m in marks if ":" not in m[0]]
     info = dict(marks=marks, n_all=n_all, have_log=have_log, chain_bytes=chain_bytes, n_own=n_own)
     return out, L, info
 

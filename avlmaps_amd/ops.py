@@ -287,6 +287,7 @@ class VoxelAccumulator:
                    "avl_builder_create_grid")
         self._h = h
         self._has_log = False
+        self._max_frame, self._imported = 0, False          # bounds of the first-touch keys (key_bits)
         if max_capacity is None:
             max_capacity = min(ncell, (1 << 31) - 1)
         if max_capacity and max_capacity > cap0:
@@ -332,6 +333,11 @@ class VoxelAccumulator:
         if c is None or c[0] != key:
             c = self._kinv_cache = (key, np.ascontiguousarray(np.linalg.inv(K)))
         return K, c[1]
+
+    def key_bits(self) -> int:
+        """first-touch keys of this map lie below 2^key_bits: frame index << 32 | sample index, bit 62 once a map was imported
+        (avl_builder_import_map: new voxels order after every imported one) -- the bits the merge's key sort has to look at"""
+        return 63 if self._imported else 32 + max(1, int(self._max_frame).bit_length())
 
     def set_deferred_fuse(self, on, stream=None):
         _lib.check(_lib.load().avl_builder_set_deferred_fuse(self._h, int(bool(on)), stream), "avl_builder_set_deferred_fuse")
@@ -379,6 +385,7 @@ class VoxelAccumulator:
 
     def reset(self, stream=None):
         _lib.check(_lib.load().avl_builder_reset(self._h, stream), "avl_builder_reset")
+        self._max_frame, self._imported = 0, False
 
     def enable_replay_log(self, max_samples):
         """log every sampled pixel so that finalize() replays the reference's sequential weight / grid_rgb exactly"""
@@ -403,6 +410,7 @@ class VoxelAccumulator:
                                              sp, int(np.prod(sshape)), fp_, fshape[0], fshape[1], rp, int(frame_idx),
                                              float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_frame")
+        self._max_frame = max(self._max_frame, int(frame_idx))
         self._retain((k1, k2, k3, k4), stream)   # inputs must outlive the asynchronous launches
         return self
 
@@ -429,6 +437,7 @@ class VoxelAccumulator:
                                               plan.samples, plan.P, plan.feat, plan.Hf, plan.Wf, plan.rgb, int(frame_idx0),
                                               float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_frames")
+        self._max_frame = max(self._max_frame, int(frame_idx0) + B)
         self._retain(plan.keep, stream)
         return self
 
@@ -466,6 +475,7 @@ class VoxelAccumulator:
                                              plan.samples, plan.P, plan.feat, plan.Hf, plan.Wf, plan.rgb, int(frame_idx0),
                                              float(min_depth), float(max_depth), float(sigma_sq), stream)
         _lib.check(rc, "avl_builder_integrate_batch")
+        self._max_frame = max(self._max_frame, int(frame_idx0) + B)
         self._retain(plan.keep, stream)
         return self
 
@@ -491,6 +501,7 @@ class VoxelAccumulator:
                                                     fshape[1], rp, int(frame_idx), float(min_depth), float(max_depth),
                                                     float(sigma_sq), pm.ctypes.data, stream)
         _lib.check(rc, "avl_builder_integrate_frame_global")
+        self._max_frame = max(self._max_frame, int(frame_idx))
         self._retain((k1, k2, k3, k4), stream)
         return self
 
@@ -506,12 +517,14 @@ class VoxelAccumulator:
             rgb8 = np.clip(np.asarray(grid_rgb), 0, 255).astype(np.uint8) if isinstance(grid_rgb, np.ndarray) else grid_rgb
             rp, _, k4 = as_device(rgb8, np.uint8, stream)
         _lib.check(lib.avl_builder_import_map(self._h, fshape[0], fp_, pp, wp, rp, stream), "avl_builder_import_map")
+        self._imported = True
         return self
 
     def mark_resumed(self, stream=None):
         """this (empty) accumulator continues a map another rank imported: same first-touch key space as that rank, so that in the
         merge the voxels of new frames order after every imported one (avl_builder_import_map with n = 0)"""
         _lib.check(_lib.load().avl_builder_import_map(self._h, 0, None, None, None, None, stream), "avl_builder_import_map")
+        self._imported = True
         return self
 
     def num_voxels(self, stream=None):

@@ -641,6 +641,9 @@ def make_vit_standin(torch):
     return step
 
 
+_MERGED_ONCE = []          # non-empty once this process has run a merge (the first one is the cold one)
+
+
 def merge_ranks(parallel, acc, mode, exact_rgb, timings=None):
     """the multi-GPU merge of the build: row-sharded all_to_all of every rank's own voxel rows (default; the finished map stays
     row-sharded over the ranks' HBM, where the index kernels want it) or ONE dense sum-reduce to rank 0 (--merge-mode reduce)"""
@@ -726,11 +729,18 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     # the warm-up covers the tail of the path too: the first merge of a process pays for torch's sort / unique kernels, RCCL's
     # lazily created point-to-point communicators and the allocator's first large blocks (tens to hundreds of ms, once)
     mode = merge_mode or getattr(args, "merge_mode", "sharded")
-    if ws > 1 or os.environ.get("AVLMAPS_FORCE_COLLECTIVES") == "1":
-        # torch's large-size sort / unique code objects (lazy, per process) and the allocator's first exchange-sized blocks
-        parallel.warm_up_merge(1 << 20, D=D, n_exchange=cap)
+    first_merge_s = None
     if ws > 1:
-        merge_ranks(parallel, acc, mode, exact_rgb)                      # every rank, also one without warm-up frames
+        # one untimed merge of the warm-up frames (every rank, also one without warm-up frames): RCCL's communicator, the first
+        # launches of the merge's code objects.  If it is the FIRST merge of this process its wall time is reported
+        # (merge_first_call_s); no other warm-up exists -- the gather-plan merge has nothing lazy to load (merge2.py), and the timed
+        # merge below allocates its 10k-frame-sized buffers inside the timed region, as a production build does
+        t_first = time.perf_counter()
+        merge_ranks(parallel, acc, mode, exact_rgb)
+        torch.cuda.synchronize()
+        if not _MERGED_ONCE:
+            first_merge_s = time.perf_counter() - t_first
+        _MERGED_ONCE.append(1)
     elif warmup:
         acc.finalize(as_torch=True)
     if warmup or ws > 1:
@@ -776,10 +786,26 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         del fin
         torch.cuda.empty_cache()
         single_gpu_merge = {}
-        merge_ranks(parallel, acc, mode, exact_rgb)            # untimed: torch's sort kernels, RCCL's communicator (forced collectives),
-        if exact_rgb:                                          # and the allocator's first multi-GB blocks
+        # the FIRST merge of the process, timed as it is (no warm-up of any kind before it: code objects, allocator blocks of the
+        # map's size, the replay log's sort): what a build that merges ONCE pays -- then the same merge again, warm
+        cold = {}
+        if exact_rgb:
+            acc.drop_replay_cache()
+        torch.cuda.synchronize()
+        t_cold = time.perf_counter()
+        merge_ranks(parallel, acc, mode, exact_rgb, timings=cold)
+        torch.cuda.synchronize()
+        t_cold = time.perf_counter() - t_cold
+        was_first = not _MERGED_ONCE
+        _MERGED_ONCE.append(1)
+        if exact_rgb:
             acc.drop_replay_cache()                            # (the timed merge sorts the replay log itself, as a merge that runs once does)
         merge_ranks(parallel, acc, mode, exact_rgb, timings=single_gpu_merge)
+        single_gpu_merge["merge_cold_s" if was_first else "merge_after_empty_cache_s"] = t_cold
+        single_gpu_merge["merge_cold_compute_s"] = cold.get("compute_s")
+        single_gpu_merge["merge_cold_note"] = ("wall time of the FIRST merge of this process (no warm-up merge, no warm_up_merge; the accumulators' map of "
+                                               f"{nvox} voxels; its {nvox * D * 4 / 1e9:.1f} GB block of finished rows is allocated inside)" if was_first else
+                                               "an earlier build of this process had merged already: the allocator's blocks were released (empty_cache), the code was warm")
         t_fin = time.perf_counter()
         acc.finalize(as_torch=True)
         torch.cuda.synchronize()
@@ -804,7 +830,7 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
                                "stand-in for LSeg's cost" if feature_standin else "no feature extraction"),
                ms_per_frame_fuse=fuse_ms / nfr, sampled_px_per_frame=P, active_points_per_frame=pts_per_frame,
                voxel_groups_per_frame=groups, new_voxels_per_frame=newv, voxels_local=nvox, voxels_merged=n_final,
-               merge_breakdown=tim or None, single_gpu_merge_path=single_gpu_merge,
+               merge_breakdown=tim or None, single_gpu_merge_path=single_gpu_merge, merge_first_call_s=first_merge_s,
                algorithmic_bytes_per_frame=alg_frame, fuse_achieved_gbs=alg_frame * nloc / (fuse_ms * 1e-3) / 1e9 if fuse_ms > 0 else None)
     acc.close()
     del acc
@@ -1029,6 +1055,64 @@ def pretty_kernel(name):
     return name.split("(")[0].replace("avl::", "").replace("void ", "")
 
 
+def rehearsal_per_rank_merge():
+    """per-rank compute of the merge in the committed eight-rank rehearsal (8 processes taking turns on ONE MI355X, gloo; the only
+    8-rank evidence a 1-GPU box can give): profiles/r06_merge_rehearsal_8ranks.json, written by tools/summarize_merge.py --json"""
+    f = Path(__file__).resolve().parent / "profiles" / "r06_merge_rehearsal_8ranks.json"
+    if not f.exists():
+        return None
+    try:
+        return json.loads(f.read_text())
+    except Exception:
+        return None
+
+
+def make_summary(out):
+    """The secondary numbers of this run in <= 1.5 kB at the END of the JSON line: ms / us and fraction of the 8 TB/s
+    HBM peak of the bytes each kernel reads; build rates per frame; the merge path warm and cold; the product pipeline."""
+    r3 = lambda v: None if v is None else round(float(v), 4)
+    ex = out.get("extra", {}) or {}
+    sm = {}
+    c5 = ex.get("fused_multimodal_config5") or {}
+    if "ms" in c5:
+        cc = c5.get("compact_resident_copy") or {}
+        sm["config5"] = dict(raw_ms=r3(c5["ms"]), raw_frac=r3(c5.get("frac_of_hbm_peak")), compact_ms=r3(cc.get("ms")), compact_frac=r3(cc.get("frac_of_hbm_peak")))
+    cp = ex.get("compact_prepared_map_variant") or {}
+    if "ms" in cp:
+        sm["compact_config2"] = dict(ms=r3(cp["ms"]), frac=r3(cp["gbs"] / HBM_PEAK_GBS))
+    q65 = ex.get("q65_64_categories_plus_other") or {}
+    if "ms" in q65:
+        sm["q65"] = dict(ms=r3(q65["ms"]), frac=r3(q65.get("frac_of_hbm_peak")))
+    builds = {}
+    for key, name in (("map_build_strong", "two_launch"), ("map_build_strong_deferred_fuse", "one_launch"), ("map_build_strong_batched64", "b64")):
+        b = ex.get(key) or {}
+        if b.get("ms_per_frame_fuse") is not None:
+            builds[name] = dict(us_per_frame=r3(1e3 * b["ms_per_frame_fuse"]), frac=r3((b.get("fuse_achieved_gbs") or 0) / HBM_PEAK_GBS),
+                                frames_per_s=round(b["frames_per_s"]))
+    if builds:
+        sm["build"] = builds
+    b1 = ex.get("map_build_strong_deferred_fuse") or ex.get("map_build_strong") or {}
+    mp = (ex.get("map_build_strong") or {}).get("single_gpu_merge_path") or b1.get("single_gpu_merge_path") or {}
+    mpd = (ex.get("map_build_strong_deferred_fuse") or {}).get("single_gpu_merge_path") or {}
+    if mp:
+        sm["merge_path"] = dict(compute_total_ms=r3(1e3 * min(x for x in (mp.get("compute_total_s"), mpd.get("compute_total_s")) if x is not None)),
+                                merge_cold_ms=r3(1e3 * mp["merge_cold_s"]) if mp.get("merge_cold_s") is not None else None,
+                                plain_finalize_ms=r3(1e3 * mp.get("plain_finalize_s", 0)), voxels=mp.get("merged_voxels"))
+    reh = rehearsal_per_rank_merge()
+    if reh and b1.get("seconds"):
+        t1, fuse1 = b1["seconds"], b1["fuse_seconds_max_rank"]
+        m8 = max(reh["per_rank_compute_ms"]) * 1e-3
+        sm["projected_speedup_8gpu"] = dict(value=r3(t1 / (fuse1 / 8 + m8)), t1_ms=r3(1e3 * t1), fuse1_ms=r3(1e3 * fuse1), per_rank_merge_ms=r3(1e3 * m8),
+                                            note="PROJECTION, not a measurement: T1 / (T1_fuse / 8 + slowest rank's merge compute in the committed 8-rank "
+                                                 "rehearsal on one GPU); the collectives' time on xGMI is NOT in it (no 8-GPU node)")
+    pp = ex.get("vlmapbuilder_pipeline") or {}
+    if pp and "error" not in pp:
+        sm["pipeline_frames_per_s"] = {k.split("_")[0]: dict(total=round(v["frames_per_s"]), frame_loop=round(v["frame_loop_frames_per_s"]),
+                                                               final_save_s=r3(v["final_save_s"]))
+                                       for k, v in pp.items() if isinstance(v, dict) and "frames_per_s" in v}
+    return sm
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1180,6 +1264,10 @@ def main():
         except Exception as e:
             out["roofline"]["traffic_in_run_error"] = repr(e)
     if rank == 0:
+        try:
+            out["summary"] = make_summary(out)          # LAST key of the line: the driver keeps the tail of a long line
+        except Exception as e:
+            out["summary"] = dict(error=repr(e))
         print(json.dumps(out, default=_json_default))
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

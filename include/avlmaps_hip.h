@@ -492,10 +492,14 @@ AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, 
 /* The N-rank merge of the map build, second form ("gather plan"; avlmaps_amd/merge2.py carries the collectives, csrc/avl_merge2.hip
  * holds the kernels).  The reference has no such step (one process, one map: vlmap_builder.py:102-183 is the loop being sharded); a
  * voxel's final row is the reference's voxel id = its position in first-touch order (vlmap_builder.py:163-170).
- *   avl_merge2_plan   EVERY rank, after the all_gather of the ranks' (first-touch key, cell) lists: d_gathered holds ws chunks of
- *                     nmax + (nmax + 1) / 2 int64 words each -- [keys (nmax x i64) | cells (nmax x i32)], h_n_all[p] entries valid in
- *                     chunk p; keys must be ordered by rank (contiguous frame shards) and lie below 2^key_bits (key_bits <= 63), cells below
- *                     2^cell_bits.  Work buffer: avl_merge2_work_bytes(sum n, n of this rank, ws).  Results (byte offsets into
+ *   avl_merge2_prepare  a rank's own list, sorted by first-touch key (keys below 2^key_bits): d_key_sorted, d_cell_sorted, d_perm (n x i32:
+ *                     position in that order -> voxel slot), d_hdr[4] = n, smallest key, largest key, flags (the header every rank
+ *                     all_gathers first).
+ *   avl_merge2_plan   EVERY rank, after the all_gather of the ranks' key-sorted (first-touch key, cell) lists: d_gathered holds ws chunks
+ *                     of nmax + (nmax + 1) / 2 int64 words each -- [keys (nmax x i64) | cells (nmax x i32)], h_n_all[p] entries valid in
+ *                     chunk p; keys must be ordered by rank (contiguous frame shards), so that the concatenation is in key order and a
+ *                     voxel's row is the number of first contributors before it; cells below 2^cell_bits; d_perm: this rank's own
+ *                     avl_merge2_prepare permutation.  Work buffer: avl_merge2_work_bytes(sum n, n of this rank, ws).  Results (byte offsets into
  *                     d_work returned in h_off[11]): 0 row (n x i32, final row of own voxel s), 1 prev, 2 next (n x i32: the
  *                     neighbouring contributors of the voxel in rank order, -1 = none), 3 order (n x i32: own voxels in final-row
  *                     order), 4 sidx (n x i32: single-rank voxels before position i of that order), 5 selA, 6 selB (n x i64:
@@ -516,13 +520,16 @@ AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, 
  *   avl_merge2_state_gather / _scatter   the 24-byte replay states of the listed voxels <-> a contiguous hop buffer.
  *   avl_merge2_fold   owner: the block [r0, r0 + n_own) from what the peers sent (h_side / h_done / h_part: per peer the device
  *                     addresses of its three lists, h_count[p] records; the rank's own lists stay in its send buffer): contributors
- *                     summed in rank order, grid_feat / grid_pos / weight / grid_rgb / cell of the block written.  Bits of
- *                     *d_err_flag: 2 = a row nobody sent, 4 = a single-rank record next to other contributors. */
-AVL_API int avl_merge2_header(int64_t n, const int64_t* d_key, int64_t flags, int64_t* d_hdr, void* stream);   /* d_hdr[4] = n, min key, max key, flags */
+ *                     summed in rank order, grid_feat / grid_pos / weight / grid_rgb / cell of the block written.  d_work: 256-aligned scratch of
+ *                     avl_merge2_fold_work_bytes (which record of peer p belongs to row r, sum alpha and a to-do flag per row).  Bits of *d_err_flag: 1 = a record outside the
+ *                     block, 2 = a row nobody sent, 4 = a single-rank record next to other contributors. */
+AVL_API int avl_merge2_prepare_work_bytes(int64_t n, size_t* h_bytes);
+AVL_API int avl_merge2_prepare(int64_t n, const int64_t* d_key, const int32_t* d_cell, int key_bits, int64_t flags, int64_t* d_key_sorted,
+                               int32_t* d_cell_sorted, int32_t* d_perm, int64_t* d_hdr, void* d_work, size_t work_bytes, void* stream);
 AVL_API int avl_merge2_work_bytes(int64_t n_entries, int64_t n_own, int ws, size_t* h_bytes);
-AVL_API int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, int cell_bits, int key_bits,
-                            int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off, int64_t* h_res,
-                            void* stream);
+AVL_API int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, const int32_t* d_perm,
+                            int cell_bits, int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off,
+                            int64_t* h_res, void* stream);
 AVL_API int avl_builder_m2_pack(avl_builder* b, int64_t n, int ws, int rank, int64_t per, const int64_t* h_start, const int64_t* h_dstart,
                                 const int64_t* h_side_off, const int64_t* h_done_off, const int64_t* h_part_off, const int32_t* d_order,
                                 const int32_t* d_row, const int32_t* d_prev, const int32_t* d_next, const int32_t* d_sidx, int64_t* d_send,
@@ -533,7 +540,9 @@ AVL_API int avl_merge2_state_gather(int64_t k, const int32_t* d_idx, const int64
 AVL_API int avl_merge2_state_scatter(int64_t k, const int32_t* d_idx, const int64_t* d_in, int64_t* d_state, void* stream);
 AVL_API int avl_merge2_fold(int64_t n_own, int64_t r0, int ws, int D, int gs, int vh, const void* const* h_side, const void* const* h_done,
                             const void* const* h_part, const int64_t* h_count, const int32_t* d_rowcell, int have_log, float* d_grid_feat,
-                            int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_cell, int32_t* d_err_flag, void* stream);
+                            int32_t* d_grid_pos, float* d_weight, uint8_t* d_grid_rgb, int32_t* d_cell, void* d_work, size_t work_bytes,
+                            int32_t* d_err_flag, void* stream);
+AVL_API int avl_merge2_fold_work_bytes(int64_t n_own, int ws, size_t* h_bytes);
 
 /* Shared rows of a rank's block of the merged map: row d_rows[i] of d_out (n_out x D float32) = (float)(d_acc[i, :] / d_w4[d_rows[i], 0]),
  * i < k -- the division of finalize (vlmap_builder.py:172-174's running mean in closed form) applied to the float64 sums several

@@ -3,7 +3,10 @@
 import json
 import sys
 
-for path in sys.argv[1:]:
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+# --json=<file>: the per-rank record bench.py's projected_speedup_8gpu reads (profiles/r06_merge_rehearsal_8ranks.json)
+json_out = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--json=")), None)
+for path in args:
     d = json.loads([l for l in open(path) if l.startswith("{")][-1])
     e = d["extra"] if "voxels_merged" in d.get("extra", {}) else d["extra"]["map_build_strong"]
     mb = e["merge_breakdown"]
@@ -14,3 +17,13 @@ for path in sys.argv[1:]:
     print("   per rank: compute ms", [r(p["compute_total_s"]) for p in mb["per_rank"]], "local voxels", [p["local_voxels"] for p in mb["per_rank"]],
           "single-rank voxels", [p.get("single_rank_voxels") for p in mb["per_rank"]], "null launch us", [round(p.get("null_launch_us") or 0, 1) for p in mb["per_rank"]])
     print("   payload MB sent", [round(p["payload_bytes_sent"] / 1e6) for p in mb["per_rank"]], "fp64 form", [round((p.get("payload_bytes_fp64_form") or 0) / 1e6) for p in mb["per_rank"]])
+    if json_out:
+        rec = dict(what="merge of a 10 000-frame build sharded over 8 ranks that take turns on ONE MI355X (gloo, AVLMAPS_SHARED_GPU_LOCK): per-rank "
+                        "compute = wall time of the merge minus time inside collectives and waiting for the shared GPU",
+                   source=path, world_size=mb.get("world_size"), merged_voxels=mb.get("merged_voxels"), plan=mb.get("plan"),
+                   trajectory=e.get("trajectory"), per_rank_compute_ms=[r(p["compute_total_s"]) for p in mb["per_rank"]],
+                   per_rank_compute_phases_ms=[{k: r(v) for k, v in p["compute_s"].items()} for p in mb["per_rank"]],
+                   per_rank_local_voxels=[p["local_voxels"] for p in mb["per_rank"]],
+                   per_rank_payload_MB=[round(p["payload_bytes_sent"] / 1e6) for p in mb["per_rank"]],
+                   merge_first_call_s=e.get("merge_first_call_s"))
+        open(json_out, "w").write(json.dumps(rec, indent=1))
