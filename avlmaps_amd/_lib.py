@@ -55,6 +55,7 @@ _SIGS = {
     "avl_merge_classify": (C.c_int, [_i64, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge_side_pack": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge_side_unpack": (C.c_int, [_i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "avl_merge2_load": (C.c_int, []),
     "avl_merge2_prepare_work_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "avl_merge2_prepare": (C.c_int, [_i64, _vp, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "avl_merge2_work_bytes": (C.c_int, [_i64, _i64, C.c_int, C.POINTER(_sz)]),

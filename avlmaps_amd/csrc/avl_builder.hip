@@ -1359,6 +1359,9 @@ struct avl_builder {
     unsigned long long key_bias = 0;  // set after import_map so that imported voxels order before new ones
     ReplayLog log{};
     long long log_cap = 0, log_used = 0;
+    char* rs_mem = nullptr;     // scratch of the log's slot-sorted form (LogSegments), allocated WITH the log: the first finalisation /
+    size_t rs_bytes = 0;        // merge of a build does not grow a pool by a GB inside its timed path (22 ms at 78 M samples)
+    size_t rs_tmp_bytes = 0;
     BatchEntry* d_table = nullptr;
     int table_cap = 0;
     int64_t vox_bound = 0;       // host-side upper bound on the voxel counter (every fused sample may create one voxel)
@@ -1588,14 +1591,24 @@ struct LogSegments {
         size_t tmp_bytes = 0;
         const size_t b_active = al((size_t)L * sizeof(int32_t)), b_seg = al((size_t)n * sizeof(long long));
         const size_t b_counts = al(kLogParts * sizeof(int)), b_off = al(kLogParts * sizeof(long long));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&block1, 2 * b_active + 256 + 2 * b_seg + b_counts + b_off, st));
-        active = reinterpret_cast<int32_t*>(block1);
-        active_slot = reinterpret_cast<uint32_t*>(block1 + b_active);
-        d_count = reinterpret_cast<long long*>(block1 + 2 * b_active);
-        seg_start = reinterpret_cast<long long*>(block1 + 2 * b_active + 256);
-        seg_end = reinterpret_cast<long long*>(block1 + 2 * b_active + 256 + b_seg);
-        int* counts = reinterpret_cast<int*>(block1 + 2 * b_active + 256 + 2 * b_seg);
-        long long* offsets = reinterpret_cast<long long*>(block1 + 2 * b_active + 256 + 2 * b_seg + b_counts);
+        // the two L-sized arrays (and, below, the two La-sized ones + the sort's storage) come from the scratch allocated with the log
+        // when it is there and large enough; the small per-voxel arrays always from the pool
+        const bool own = b->rs_mem && b->rs_bytes >= 4 * b_active + b->rs_tmp_bytes + 256;
+        AVL_HIP_CHECK(hipMallocAsync((void**)&block1, (own ? 0 : 2 * b_active) + 256 + 2 * b_seg + b_counts + b_off, st));
+        char* p1 = block1;
+        if (own) {
+            active = reinterpret_cast<int32_t*>(b->rs_mem);
+            active_slot = reinterpret_cast<uint32_t*>(b->rs_mem + b_active);
+        } else {
+            active = reinterpret_cast<int32_t*>(p1);
+            active_slot = reinterpret_cast<uint32_t*>(p1 + b_active);
+            p1 += 2 * b_active;
+        }
+        d_count = reinterpret_cast<long long*>(p1);
+        seg_start = reinterpret_cast<long long*>(p1 + 256);
+        seg_end = reinterpret_cast<long long*>(p1 + 256 + b_seg);
+        int* counts = reinterpret_cast<int*>(p1 + 256 + 2 * b_seg);
+        long long* offsets = reinterpret_cast<long long*>(p1 + 256 + 2 * b_seg + b_counts);
         AVL_HIP_CHECK(hipMemsetAsync(seg_start, 0, 2 * b_seg, st));
         hipLaunchKernelGGL(log_count_kernel, dim3(kLogParts), dim3(256), 0, st, b->log.slot, L, chunk, counts);
         hipLaunchKernelGGL(log_offsets_kernel, dim3(1), dim3(1024), 0, st, counts, offsets, d_count);
@@ -1610,10 +1623,17 @@ struct LogSegments {
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                                                     (size_t)La, 0, bits, st));
         const size_t b_ls = al(Ls * sizeof(uint32_t));
-        AVL_HIP_CHECK(hipMallocAsync((void**)&block2, 2 * b_ls + al(tmp_bytes ? tmp_bytes : 16), st));
-        sorted_slot = reinterpret_cast<uint32_t*>(block2);
-        order = reinterpret_cast<int32_t*>(block2 + b_ls);
-        tmp = block2 + 2 * b_ls;
+        if (own && tmp_bytes <= b->rs_tmp_bytes) {
+            char* p2 = b->rs_mem + 2 * b_active;
+            sorted_slot = reinterpret_cast<uint32_t*>(p2);
+            order = reinterpret_cast<int32_t*>(p2 + b_ls);
+            tmp = p2 + 2 * b_active;                   // (behind the four L-sized words: La <= L)
+        } else {
+            AVL_HIP_CHECK(hipMallocAsync((void**)&block2, 2 * b_ls + al(tmp_bytes ? tmp_bytes : 16), st));
+            sorted_slot = reinterpret_cast<uint32_t*>(block2);
+            order = reinterpret_cast<int32_t*>(block2 + b_ls);
+            tmp = block2 + 2 * b_ls;
+        }
         if (La > 0) {
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tmp_bytes, active_slot, sorted_slot, active, order, (size_t)La, 0, bits, st));
             hipLaunchKernelGGL(log_segments_kernel, dim3((unsigned)std::min<long long>((La + 255) / 256, 8192)), dim3(256), 0, st, sorted_slot,
@@ -1623,8 +1643,8 @@ struct LogSegments {
         return AVL_OK;
     }
     void release(hipStream_t st) {
-        (void)hipFreeAsync(block2, st);
-        (void)hipFreeAsync(block1, st);
+        if (block2) (void)hipFreeAsync(block2, st);
+        if (block1) (void)hipFreeAsync(block1, st);
         block1 = block2 = nullptr;
     }
 };
@@ -1730,6 +1750,7 @@ int avl_builder_destroy(avl_builder* b) {
     (void)hipFree(b->dirty);
     (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
     (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+    (void)hipFree(b->rs_mem);
     (void)hipFree(b->d_table);
     delete b;
     return AVL_OK;
@@ -1739,6 +1760,7 @@ int avl_builder_create_grid(avl_builder** h_out, int n0, int gs, int vh, double 
     AVL_REQUIRE(h_out, "avl_builder_create: null output");
     *h_out = nullptr;
     avl::keep_mempool_once();
+    avl_merge2_load();      // (the merge's kernels live in another code object: loaded with the builder, not inside the first merge)
     AVL_REQUIRE(n0 > 0 && gs > 0 && vh > 0 && D > 0 && cs > 0 && capacity > 0, "avl_builder_create: bad parameters");
     const double ncell_d = (double)n0 * gs * vh;
     AVL_REQUIRE(ncell_d < 2.0e9, "avl_builder_create: gs*gs*vh = %.0f cells exceeds the int32 cell index", ncell_d);
@@ -1797,6 +1819,26 @@ int avl_builder_enable_replay_log(avl_builder* b, int64_t max_samples) {
         return AVL_ERR_HIP;
     }
     b->log_cap = max_samples;
+    // the log's slot-sorted form (LogSegments: two words per sample + two per ACTIVE sample + the radix sort's storage) lives next to
+    // the log itself: allocated here, not inside the first finalisation / merge
+    (void)hipFree(b->rs_mem);
+    b->rs_mem = nullptr;
+    b->rs_bytes = b->rs_tmp_bytes = 0;
+    {
+        size_t tb = 0;
+        if (rocprim::radix_sort_pairs(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)max_samples, 0, 32,
+                                      nullptr) == hipSuccess) {
+            const size_t w = ((size_t)max_samples * 4 + 255) / 256 * 256;
+            const size_t total = 4 * w + (tb + 255) / 256 * 256 + 256;
+            if (hipMalloc((void**)&b->rs_mem, total) == hipSuccess) {
+                b->rs_bytes = total;
+                b->rs_tmp_bytes = (tb + 255) / 256 * 256;
+            } else {
+                b->rs_mem = nullptr;      // (not fatal: LogSegments falls back to the stream-ordered pool)
+            }
+        }
+        (void)hipGetLastError();
+    }
     return AVL_OK;
 }
 

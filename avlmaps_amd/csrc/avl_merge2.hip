@@ -5,20 +5,24 @@
 // What is merged: the ranks' voxel maps of the reference's builder loop (avlmaps/map/vlmap_builder.py:102-183), frames sharded
 // contiguously over the ranks.  A voxel's final row is the reference's voxel id = its position in first-touch order
 // (vlmap_builder.py:163-170).  Protocol (avlmaps_amd/merge2.py carries the collectives through torch.distributed):
+//   0. avl_merge2_prepare: the rank's own (first-touch key, cell) list sorted by key (n entries); the header comes out of it
 //   1. all_gather of a 4-word header per rank (voxel count, key range, flags)
-//   2. all_gather of every rank's (first-touch key, cell) list, 12 B per voxel           -> avl_merge2_plan on EVERY rank:
-//        the union of the cells (radix sort by cell; stable, so a cell's contributors stay in rank order), the first
-//        contributor of every cell, the reference's row of every cell (radix sort of the first contributors' keys), and for the
-//        rank's OWN voxels: final row, neighbouring contributors (prev / next rank), the send order, the replay lists; the
-//        ws x ws tables of list sizes every later exchange needs are read back ONCE (the only host synchronisation)
+//   2. all_gather of every rank's key-sorted (first-touch key, cell) list, 12 B per voxel    -> avl_merge2_plan on EVERY rank:
+//        the union of the cells (ONE radix sort of all sum(n) entries by cell; stable, so a cell's contributors stay in rank
+//        order), the first contributor of every cell; the keys are ordered by rank and every list is in key order, so ENTRY
+//        order is key order and the reference's row of a cell is the number of first contributors before its own (a scan, no
+//        second sort); for the rank's OWN voxels: final row, neighbouring contributors (prev / next rank), the send order, the
+//        replay lists; the ws x ws tables of list sizes every later exchange needs are read back ONCE (the only host
+//        synchronisation)
 //   3. the sequential weight / colour replay hops rank -> next rank for voxels several ranks touched (24 B of state each)
 //   4. ONE all_to_all of the payload: per destination [side records 64 B | finished float32 rows | float64 partial rows]
-//   5. avl_merge2_fold: wave per row of the rank's block -- contributors found by binary search in the peers' (row-sorted) side
-//      lists, summed in rank order (reproducible float64 sums), divided, written; position / weight / colour from the side sums
-//      or the replay state.
+//   5. avl_merge2_fold: a scatter builds the table "which record of peer p belongs to row r" (the side lists carry their rows);
+//      thread per row: the contributors' sums in rank order (reproducible float64), position / weight / colour from them or the
+//      replay state; wave per row that still needs features: copy of the finished float32 row, or (sum of the float64 partials in
+//      rank order) / sum alpha.
 // The first plan (avl_merge.hip + parallel.plan_merge_directory: directory ranks, five small round trips, nothing O(sum n) per
-// rank) stays as the fall-back; here every rank sorts all sum(n) entries (2.3 M entries at 8 ranks x 290 k voxels: two radix
-// sorts, ~0.3 ms) and the round trips are gone.
+// rank) stays selectable (AVLMAPS_MERGE_PLAN=directory); here every rank sorts all sum(n) entries by cell (2.3 M entries at 8 ranks
+// x 290 k voxels: ~0.15 ms) and the round trips are gone: 3.7-4.1 ms of compute per rank against 7.9-12.3 (profiles/r06_*).
 #include <algorithm>
 #include <cstdint>
 
@@ -380,6 +384,17 @@ static int m2_layout(long long E, long long n, int ws, M2Layout& L) {
 using namespace avl;
 
 extern "C" {
+
+// HIP loads a code object when one of its kernels is first used (15 ms for this file's: the radix sort and scan instantiations): asking
+// for a kernel's attributes does it, once per process
+int avl_merge2_load(void) {
+    static bool done = false;
+    if (done) return AVL_OK;
+    hipFuncAttributes attr;
+    AVL_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(m2_compact_kernel)));
+    done = true;
+    return AVL_OK;
+}
 
 int avl_merge2_prepare_work_bytes(int64_t n, size_t* h_bytes) {
     AVL_REQUIRE(h_bytes && n >= 0 && n < (1ll << 31), "avl_merge2_prepare_work_bytes: bad arguments");

@@ -78,18 +78,18 @@ class VLMapBuilder:
                                                    # mapped_iter_list (upstream restores the list but re-fuses every frame)
         self.incremental_checkpoints = True        # periodic saves write only the rows that changed + the new rows
                                                    # (utils.mapping_utils.MapFileWriter); False = full rewrite like upstream
-        self.pixel_sampling = "auto"               # "auto" (default): "reference" in a single process, "uniform" with several ranks
-                                                   # (the reference's sampling is ONE serial random stream: the last of 8 ranks of a
-                                                   # 40 k-frame build would fast-forward ~10 s before its first frame; a line on
-                                                   # stdout says so, ask for "reference" explicitly to prove N ranks == 1 rank).
-                                                   # "reference": np.random.shuffle(arange(H*W))[::rate] on the global RNG, the pixels a
-                                                   # seeded upstream run samples (its draws are serial by nature: 0.3-0.5 ms per
-                                                   # 720x1080 frame through avl_mt19937_skip_shuffles, see sampler_workers; NumPy's
-                                                   # shuffle takes 6.6 ms); "uniform": the same distribution -- an
-                                                   # ordered uniform sample without replacement -- from a per-frame generator
-                                                   # seeded by ONE draw of the global RNG and the frame index (0.25 ms; not the
-                                                   # reference's pixels, but reproducible under np.random.seed and independent
-                                                   # of how the frames are sharded over ranks)
+        self.pixel_sampling = "reference"          # "reference" (default, also with several ranks): np.random.shuffle(arange(H*W))[::rate] on the
+                                                   # global RNG -- the pixels a seeded upstream / single-process run samples, so that N ranks
+                                                   # == 1 rank out of the box.  Its draws are serial by nature (0.3-0.5 ms per
+                                                   # 720x1080 frame through avl_mt19937_skip_shuffles, see sampler_workers; NumPy's shuffle
+                                                   # takes 6.6 ms), and rank r of a sharded build first fast-forwards the RNG past the frames
+                                                   # of the ranks before it (~10 s for the last of 8 ranks of a 40 k-frame build; a line on
+                                                   # stdout says so).  "uniform" (opt-in, for speed): the same distribution -- an ordered
+                                                   # uniform sample without replacement -- from a per-frame generator seeded by ONE draw of
+                                                   # the global RNG and the frame index (0.25 ms; not the reference's pixels, but
+                                                   # reproducible under np.random.seed and independent of how the frames are sharded).
+                                                   # "auto": "reference" in a single process, "uniform" with several ranks.  The resolved
+                                                   # mode is recorded in build_times["pixel_sampling"]
         self.sampler_workers = "auto"              # "reference" sampling with prefetch_frames > 0: the serial part of a frame's
                                                    # shuffle is only its DRAWS (how far the RNG moves: avl_mt19937_skip_shuffles,
                                                    # half the cost of the sample).  The sampler thread walks the RNG frame by frame
@@ -189,7 +189,7 @@ class VLMapBuilder:
                   "start at once (same distribution, other pixels)", flush=True)
 
     def _resolve_pixel_sampling(self) -> None:
-        """pixel_sampling = "auto" (the default) becomes "reference" in a single process -- the pixels of a seeded upstream run,
+        """pixel_sampling = "auto" (opt-in; the default is "reference") becomes "reference" in a single process -- the pixels of a seeded upstream run,
         vlmap_builder.py:275-277 -- and "uniform" with several ranks, where the reference's one serial random stream would make
         the last rank fast-forward past every other rank's frames before its first one."""
         if self.pixel_sampling != "auto":
@@ -474,7 +474,8 @@ class VLMapBuilder:
         stage = bool(self.stage_frames and (self.prefetch_frames or 0) > 0)
         self._stager = None
         self.pipeline_stats = {}
-        self.build_times = dict(checkpoints_on_fusing_thread_s=0.0, checkpoints=0, frames_in_c_loop_calls=0, c_loop_calls=0)
+        self.build_times = dict(checkpoints_on_fusing_thread_s=0.0, checkpoints=0, frames_in_c_loop_calls=0, c_loop_calls=0,
+                                pixel_sampling=self.pixel_sampling)
         t_loop = time.perf_counter()
         import collections
         group = []                  # frames waiting for one avl_builder_integrate_frames call

@@ -688,8 +688,10 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     extract = make_vit_standin(torch) if feature_standin == "vit-l16" else None
 
     # frame-by-frame launches with the frames resident: the LOOP runs in C (avl_builder_integrate_frames, 64 frames per call; one
-    # launch pair -- deferred: one launch -- per frame, exactly what 64 integrate_frame calls issue).  A Python call costs 12.4 us
-    # of host time, more than the 11.9 us pipe_kernel it launches (tools/probe_frame_loop.py); --python-frame-loop keeps it in Python
+    # launch pair -- deferred: one launch -- per frame, no two frames share a launch; inside a call frame i + 1's map-independent half
+    # of K1 rides in frame i's launch (PreGather), which per-frame integrate_frame calls cannot do).  VLMapBuilder issues the same
+    # calls whenever staged frames are waiting (frame_loop_frames).  A Python call costs 12.4 us of host time, more than the
+    # pipe_kernel it launches (tools/probe_frame_loop.py); --python-frame-loop keeps the loop in Python (one integrate_frame per frame)
     c_loop = BATCH == 1 and extract is None and not getattr(args, "python_frame_loop", False)
     SEQ = 64
 
@@ -1072,6 +1074,9 @@ def make_summary(out):
     HBM peak of the bytes each kernel reads; build rates per frame; the merge path warm and cold; the product pipeline."""
     r3 = lambda v: None if v is None else round(float(v), 4)
     ex = out.get("extra", {}) or {}
+    if "single_gpu_merge_path" in ex:          # --workload build: the record itself is the build
+        ex = {"map_build_strong_deferred_fuse" if ex.get("deferred_fuse") else ("map_build_strong_batched64" if ex.get("frames_per_launch", 1) > 1
+                                                                                else "map_build_strong"): ex}
     sm = {}
     c5 = ex.get("fused_multimodal_config5") or {}
     if "ms" in c5:

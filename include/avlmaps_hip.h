@@ -72,9 +72,6 @@ AVL_API int avl_memset(void* d_ptr, int value, size_t bytes, void* stream);
 AVL_API int avl_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 AVL_API int avl_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 AVL_API int avl_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
-/* dst row i = src row d_rows[i] (rows of row_bytes bytes, int64 indices): packs the rows an incremental checkpoint has to
- * write (the changed and the new voxels, avl_builder_finalize_ex's d_row_dirty) so that only they cross PCIe -- the reference
- * rewrites the whole map file every 100 frames (vlmap_builder.py:180-183). */
 /* Stable argsort of n NON-NEGATIVE integer keys smaller than 2^bits: d_perm[i] = position of the i-th smallest key, ties in
  * position order (an LSD radix sort over the low `bits` bits only).  d_keys int32 or int64 (key_bytes 4 / 8), d_perm int64[n].
  * The multi-GPU merge plan sorts 3-bit destination ranks and 22-bit row numbers held in int64 tensors (avlmaps_amd/parallel.py:
@@ -87,6 +84,9 @@ AVL_API int avl_argsort_bits(int64_t n, const void* d_keys, int key_bytes, int b
  * the finished float32 rows it received at their final positions with it (avlmaps_amd/parallel.py). */
 AVL_API int avl_scatter_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, int64_t n_dst,
                              int32_t* d_err_flag, void* stream);
+/* dst row i = src row d_rows[i] (rows of row_bytes bytes, int64 indices): packs the rows an incremental checkpoint has to
+ * write (the changed and the new voxels, avl_builder_finalize_ex's d_row_dirty) so that only they cross PCIe -- the reference
+ * rewrites the whole map file every 100 frames (vlmap_builder.py:180-183). */
 AVL_API int avl_gather_rows(const void* d_src, int64_t row_bytes, const int64_t* d_rows, int64_t n, void* d_dst, void* stream);
 /* Read-only streaming probe over a caller buffer of `rows` x `row_floats` float32.
  * pattern bit 0: 0 = plain coalesced 16-byte grid-stride reads, 1 = the similarity kernels' row-line walk;
@@ -523,6 +523,7 @@ AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, 
  *                     summed in rank order, grid_feat / grid_pos / weight / grid_rgb / cell of the block written.  d_work: 256-aligned scratch of
  *                     avl_merge2_fold_work_bytes (which record of peer p belongs to row r, sum alpha and a to-do flag per row).  Bits of *d_err_flag: 1 = a record outside the
  *                     block, 2 = a row nobody sent, 4 = a single-rank record next to other contributors. */
+AVL_API int avl_merge2_load(void);   /* load the merge's code object now (avl_builder_create does): not inside the first merge */
 AVL_API int avl_merge2_prepare_work_bytes(int64_t n, size_t* h_bytes);
 AVL_API int avl_merge2_prepare(int64_t n, const int64_t* d_key, const int32_t* d_cell, int key_bits, int64_t flags, int64_t* d_key_sorted,
                                int32_t* d_cell_sorted, int32_t* d_perm, int64_t* d_hdr, void* d_work, size_t work_bytes, void* stream);

@@ -67,7 +67,7 @@ def main():
     if sampling == "uniform":
         b.pixel_sampling = "uniform"                          # per-frame generators: the sharding does not matter
     else:
-        b.pixel_sampling = "reference"                        # (several ranks default to "uniform"): the seeded reference run's pixels
+        b.pixel_sampling = "reference"                        # (the default): the seeded reference run's pixels
         b.shard_sampling = sampling
     np.random.seed(seed)                                      # the state the reference run started from, on EVERY rank
     b.create_mobile_base_map()
