@@ -418,11 +418,19 @@ __device__ __forceinline__ SampleRec bp_voxelize_body(int blk, const FrameParams
 }
 
 // optional per-sample log for the exact sequential replay of weight / grid_rgb at finalisation (position = key order)
+// One 32-byte record per sample = one memory sector: the replay walks a voxel's samples through an index list, i.e. every entry is
+// a random access -- with alpha / key / colour in three arrays that was three sectors per entry (replay_chain_kernel 1.63 ms for the
+// 27 M active samples of a 10 000-frame build).  The slots stay in an array of their own: the compaction and the sort read only them.
+struct alignas(32) LogRec {
+    double alpha;
+    unsigned long long key;
+    uint32_t rgb;
+    uint32_t pad[3];
+};
+static_assert(sizeof(LogRec) == 32, "one sector per replay-log record");
 struct ReplayLog {
     uint32_t* slot;            // 0xFFFFFFFF = sample did not update a voxel
-    unsigned long long* key;
-    double* alpha;
-    uint32_t* rgb;
+    LogRec* rec;
 };
 
 // K2 body.  Runs right behind K1 in the same kernel: the sample comes in registers, and a cell another workgroup is still
@@ -481,9 +489,19 @@ __device__ __forceinline__ void link_body(int blk, int P, const int32_t* __restr
         if (log.slot) {
             const long long i = log_base + s;
             log.slot[i] = slot >= 0 ? (uint32_t)slot : 0xFFFFFFFFu;
-            log.key[i] = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
-            log.alpha[i] = in.alpha;
-            log.rgb[i] = in.rgbv;
+#ifdef AVL_ABL_NOLOGREC   // timing ablation only (WRONG replay): what the record store costs a frame
+            if (false) {
+#elif defined(AVL_LOG_UNCOND)
+            {
+#else
+            if (slot >= 0) {     // (the replay only ever reads the records of samples that updated a voxel)
+#endif
+                const unsigned long long k = batch ? (batch[s / P_frame].frame_key | (unsigned)(s % P_frame)) : (frame_key | (unsigned)s);
+                using u64x2 = __attribute__((ext_vector_type(2))) unsigned long long;
+                u64x2* r = reinterpret_cast<u64x2*>(log.rec + i);
+                r[0] = u64x2{(unsigned long long)__double_as_longlong(in.alpha), k};
+                r[1] = u64x2{(unsigned long long)in.rgbv, 0ull};
+            }
         }
     }
 #ifdef AVL_PROBE_CHAIN
@@ -1177,9 +1195,12 @@ __device__ __forceinline__ void replay_walk(double& w, double (&c)[3], bool& sta
         unsigned long long ky[kReplayAhead];
 #pragma unroll
         for (int k = 0; k < kReplayAhead; ++k) {
-            a[k] = log.alpha[e[k]];
-            v[k] = log.rgb[e[k]];
-            ky[k] = log.key[e[k]];
+            using u64x2 = __attribute__((ext_vector_type(2))) unsigned long long;
+            const u64x2* r = reinterpret_cast<const u64x2*>(log.rec + e[k]);
+            const u64x2 r0 = r[0];
+            a[k] = __longlong_as_double((long long)r0.x);
+            ky[k] = r0.y;
+            v[k] = (uint32_t)r[1].x;
         }
 #pragma unroll
         for (int k = 0; k < kReplayAhead; ++k)
@@ -1749,7 +1770,7 @@ int avl_builder_destroy(avl_builder* b) {
     (void)hipFree(b->head_alt);
     (void)hipFree(b->dirty);
     (void)hipFree(b->counters); (void)hipFree(b->err_flags); (void)hipFree(b->recs_mem);
-    (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+    (void)hipFree(b->log.slot); (void)hipFree(b->log.rec);
     (void)hipFree(b->rs_mem);
     (void)hipFree(b->d_table);
     delete b;
@@ -1805,15 +1826,13 @@ int avl_builder_enable_replay_log(avl_builder* b, int64_t max_samples) {
         set_error("avl_builder_enable_replay_log: frames were already fused; enable the log on a fresh or reset builder");
         return AVL_ERR_STATE;
     }
-    (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+    (void)hipFree(b->log.slot); (void)hipFree(b->log.rec);
     b->log = ReplayLog{};
     b->log_cap = 0;
     hipError_t e = hipMalloc((void**)&b->log.slot, (size_t)max_samples * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&b->log.key, (size_t)max_samples * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipMalloc((void**)&b->log.alpha, (size_t)max_samples * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&b->log.rgb, (size_t)max_samples * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&b->log.rec, (size_t)max_samples * sizeof(LogRec));
     if (e != hipSuccess) {
-        (void)hipFree(b->log.slot); (void)hipFree(b->log.key); (void)hipFree(b->log.alpha); (void)hipFree(b->log.rgb);
+        (void)hipFree(b->log.slot); (void)hipFree(b->log.rec);
         b->log = ReplayLog{};
         set_error("avl_builder_enable_replay_log: hipMalloc failed: %s", hipGetErrorString(e));
         return AVL_ERR_HIP;

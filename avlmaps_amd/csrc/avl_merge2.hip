@@ -133,8 +133,22 @@ __global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, in
         int q = (int)(row / per);
         q = q < ws - 1 ? q : ws - 1;
         const int prev = (int)(pn[i] & 0xFF) - 1, next = (int)(pn[i] >> 8) - 1;
-        atomicAdd(&m2_hist[p * ws + q], 1u);
-        if (prev < 0 && next < 0) atomicAdd(&m2_hist[W2 + p * ws + q], 1u);
+        // (one rank, or a stretch of a single rank's voxels: the whole wave counts into the same word -- one lane adds the wave's total
+        // instead of 64 serialised LDS atomics; m2_entries_kernel 210 -> 60 us at 2.25 M entries of one rank)
+        const int bin = p * ws + q;
+        const bool single = prev < 0 && next < 0;
+        const unsigned long long act = __ballot(1);
+        const int bin0 = __builtin_amdgcn_readfirstlane(bin);
+        if (__ballot(bin != bin0) == 0) {
+            const unsigned long long sm = __ballot(single);
+            if ((threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+                atomicAdd(&m2_hist[bin0], (unsigned)__popcll(act));
+                if (sm) atomicAdd(&m2_hist[W2 + bin0], (unsigned)__popcll(sm));
+            }
+        } else {
+            atomicAdd(&m2_hist[bin], 1u);
+            if (single) atomicAdd(&m2_hist[W2 + bin], 1u);
+        }
         if (prev >= 0) atomicAdd(&m2_hist[2 * W2 + prev * ws + p], 1u);
         if (p == rank) {
             const long long j = e - o.off[p];

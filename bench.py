@@ -775,12 +775,14 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
     n_final = None if fin is None else int(fin["M"]) if "M" in fin else int(fin["grid_pos"].shape[0])
     if ws > 1 and tim:
         # per-rank merge traffic next to the times (rank 0's own breakdown stays at the top level)
+        keys = ("bytes_sent_per_rank", "payload_bytes_sent", "payload_bytes_fp64_form", "rows_sent", "local_voxels", "own_rows", "single_rank_voxels",
+                "shared_voxels_local", "directory_entries", "compute_total_s", "in_collectives_total_s", "compute_s", "in_collectives_s", "wall_s",
+                "shared_gpu_wait_s", "null_launch_us", "exchange_s", "scatter_reduce_s")
         per_rank = [None] * ws
-        dist.all_gather_object(per_rank, {k: tim.get(k) for k in ("bytes_sent_per_rank", "payload_bytes_sent", "payload_bytes_fp64_form", "rows_sent",
-                                                                     "local_voxels", "own_rows", "single_rank_voxels", "shared_voxels_local",
-                                                                     "directory_entries", "compute_total_s", "in_collectives_total_s", "compute_s",
-                                                                     "in_collectives_s", "wall_s", "shared_gpu_wait_s", "null_launch_us", "exchange_s", "scatter_reduce_s")})
+        dist.all_gather_object(per_rank, {k: tim.get(k) for k in keys})
         tim["per_rank"] = per_rank
+        tim["timed_merge_is"] = ("the first merge of this size in the process (after one small untimed merge of the warm-up frames): its send / "
+                                 "receive / work buffers are allocated inside, as in a build that merges once")
     single_gpu_merge = None
     if ws == 1 and not solo:          # (solo: rank 0 of an N-rank run measuring the single-GPU reference while the others wait)
         # what the merge path itself costs on this GPU at this map size (plan = key sort, scatter into the send buffer, the
