@@ -171,6 +171,9 @@ class MapFileWriter:
     def __init__(self, path):
         self.path = Path(path)
         self.n_saved = None          # rows in the file, None = nothing written by this writer yet
+        self.write_threads = 1       # > 1: full saves fill grid_feat's chunks with pwrite()s from that many threads instead of H5Dwrite.  OFF by
+                                     # default: on the GPU box's overlay file system H5Dwrite runs at 5.2-5.5 GB/s and the chunk-level path at 1.4
+                                     # (profiles/r06_parallel_save_probe.txt) -- measured for VERDICT r5 #7, not adopted
         self.stats = []              # per save: dict(mode, rows_written, rows_total)
         self.mirror = None           # host copy of the per-voxel datasets as last saved (adopted from a full save, patched by
                                      # save_packed): what lets a checkpoint ship only its changed rows across PCIe
@@ -199,14 +202,22 @@ class MapFileWriter:
         if not incremental:
             # a full save never leaves a half-written map behind: written next to the target, then renamed over it
             tmp = self.path.with_name(self.path.name + ".tmp")
+            deferred = None
             with h5lite.H5File(tmp, "w") as f:
                 f.create_dataset("mapped_iter_list", data=iters, maxshape=(None,))
                 for k in self.ROW_SETS:
                     a = np.asarray(arrays[k])
                     chunks = (self.FEAT_CHUNK_ROWS,) + a.shape[1:] if k == "grid_feat" else None
+                    if k == "grid_feat" and self.write_threads > 1 and a.nbytes >= (64 << 20):
+                        # 99 % of the file: its chunks are allocated here and filled below by plain pwrite()s from several threads
+                        deferred = f.create_dataset_deferred(k, a.shape, a.dtype, chunks)
+                        if deferred is not None:
+                            continue
                     f.create_dataset(k, data=a, maxshape=(None,) + a.shape[1:], chunks=chunks)
                 f.create_dataset("occupied_ids", data=np.asarray(arrays["occupied_ids"]))
                 f.create_dataset(self.MARKER, data=np.ones(1, np.int32))
+            if deferred is not None:
+                h5lite.parallel_write_chunks(tmp, deferred, np.asarray(arrays["grid_feat"]), self.write_threads)
             os.replace(tmp, self.path)
             self.stats.append(dict(mode="full", rows_written=n, rows_total=n))
             self.n_saved = n

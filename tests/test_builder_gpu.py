@@ -96,8 +96,10 @@ def test_builder_matches_reference_golden(ops, golden, name, path):
     out2 = acc2.finalize()
     assert np.array_equal(out2["grid_pos"], g["grid_pos"])
     assert np.array_equal(out2["grid_rgb"], np.floor(g["grid_rgb"]).astype(np.uint8))
-    wref = g["weight"].astype(np.float32)
-    assert np.mean(out2["weight"] == wref) > 0.999 and np.allclose(out2["weight"], wref, rtol=2e-7, atol=0)
+    # ... and the weights are the reference's, bit for bit.  The device's exp() differs from the host libm's by one ulp of float64 in 6 %
+    # of the arguments (tools/probe_exp.hip), but a 1e-16 relative change of one alpha moves a float32 running sum across a rounding
+    # boundary with probability ~1e-9 per update: 0 of 862 / 463 / 26 295 voxels differ (profiles/r06_exact_weight_counts.txt)
+    assert np.array_equal(out2["weight"], g["weight"].astype(np.float32))
 
 
 def synth_scene(rng, nfr, H, W, Hf, Wf, D):
@@ -143,7 +145,7 @@ def test_builder_vs_sequential_oracle_medium(ops):
     accr = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000, replay=True)
     outr = accr.finalize()
     assert np.array_equal(outr["grid_rgb"], ref["grid_rgb"])            # sequential uint8 colour: bit exact
-    assert np.mean(outr["weight"] == ref["weight"]) > 0.999             # exp() may differ by an ulp between libms
+    assert np.array_equal(outr["weight"], ref["weight"])                # sequential float32 weight: bit exact (see the golden test)
     # determinism: a second run gives identical indices and (to fp64 round-off) identical features
     acc2 = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=200_000)
     out2 = acc2.finalize()
