@@ -638,7 +638,7 @@ __device__ __forceinline__ void map_operands(const f32x4 (&b)[8], int m, half8& 
 // XR (with FQ): rows = 32 QT + 1..4 -- the last 1..4 query rows ("64 categories + other", clip_utils.py:213-215: 65 columns) are
 // contracted by v_mfma_f32_4x4x4_16b_f16 (16 blocks of 4 voxel-halves x the same 4 query rows: D[lane][r] = sum_k A[4 (lane / 4)
 // + r][k] * B[lane][k], tools/probe_mfma4.hip) instead of a third 32-row tile with one live row: 1/16 of its multiply-adds in
-// half of its issue cycles -- at the power cap that is time (Q = 65: see DESIGN.md)
+// half of its issue cycles -- at the power cap that is time (Q = 65: profiles/HISTORY.md 4.1)
 template <int QT, int NSTEPS, bool PRE, bool FQ, bool QM = false, bool P24 = false, bool XR = false>
 __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const float* __restrict__ feat, int64_t N, int D, int64_t ld, const _Float16* __restrict__ img,
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
     const int j = lane & 31, kg = lane >> 5;
     const int row_b = (KC + kRowPadHalves) * 2;  // bytes per query row
     // FQ: a partial last MFMA tile gets one extra all-zero row that its padding lanes read -- multiplying zeros toggles far
-    // fewer matrix-core bits than re-reading a valid row, and at the power cap that is time (Q = 65: see DESIGN.md)
+    // fewer matrix-core bits than re-reading a valid row, and at the power cap that is time (Q = 65: profiles/HISTORY.md 4.1)
     static_assert(!XR || FQ, "the extra-row path builds its query image in the kernel");
     constexpr int TQ = (QT + (XR ? 1 : 0)) * 32;   // rows of the per-query tables
     const int zrow = (FQ && rows < (XR ? 32 * QT + 4 : 32 * QT)) ? 1 : 0;
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_split_f16_kernel(
 // resident; a workgroup carries T voxel tiles through it with their accumulators in registers (16 QT VGPRs per tile), swaps the
 // image for the other chunk, finishes the T tiles, and swaps back for its next T tiles: two LDS refills of half the image per T
 // tiles, against a refill of the whole image per TB = 2 tiles in the streamed kernel, whose per-chunk staging traffic and
-// barriers were 9 % of its time.  A voxel row is read in two visits of 2 KB.
+// barriers were 9 % of its time (profiles/HISTORY.md 4.1c).  A voxel row is read in two visits of 2 KB.
 // image layout = the resident kernel's [kc][hi, lo][Qtot][KC + pad] (sim_prep_queries_kernel, interleaved = 0).
 // ------------------------------------------------------------------------------------------------
 template <int QT, int T, int NS, bool PRE, bool QM = false, bool P24 = false>
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(kSplitThreads) void sim_stream_f16_kernel(
 
 // Tile-blocked variant of the streamed kernel for QT <= 2.  TB = voxel tiles a workgroup carries through the chunk loop
 // together: a chunk's LDS residency -- its staging traffic from L2 and the s_barrier that retires it, 11 % + 7 % of the kernel
-// at one tile per chunk pass -- is paid once per TB tiles: the chunk's columns of tile 0, then of tile 1, ... are
+// at one tile per chunk pass (profiles/HISTORY.md 4.1c) -- is paid once per TB tiles: the chunk's columns of tile 0, then of tile 1, ... are
 // contracted against the same buffer into TB accumulator sets (16 * QT registers per extra tile: TB = 2 for QT = 2, 3 spills).
 // Same-box A/B (2 M voxels): D = 1536, Q = 64: 2.40 -> 2.25 ms; config 5's column-block launches 2.51 -> 2.42 ms; with a
 // power-of-two row stride (D = 1024: 4 KiB) the two-tile walk is 5 % SLOWER (HBM channel camping), and for QT >= 3 the extra

@@ -191,7 +191,7 @@ class VLMapBuilder:
     def _resolve_pixel_sampling(self) -> None:
         """pixel_sampling = "auto" (opt-in; the default is "reference") becomes "reference" in a single process -- the pixels of a seeded upstream run,
         vlmap_builder.py:275-277 -- and "uniform" with several ranks, where the reference's one serial random stream would make
-        the last rank fast-forward past every other rank's frames before its first one."""
+        the last rank fast-forward past every other rank's frames before its first one (profiles/HISTORY.md 5)."""
         if self.pixel_sampling != "auto":
             return
         rank, ws = _dist_rank_ws()

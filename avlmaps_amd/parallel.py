@@ -68,6 +68,12 @@ def init_distributed(backend: Optional[str] = None):
             local = local % torch.cuda.device_count()
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+        if backend == "nccl" and torch.cuda.is_available():
+            # RCCL builds its communicator lazily inside the FIRST collective (0.9-3.3 s on an MI355X box, profiles/r06_*): pay it
+            # here, at process start-up, not inside the first merge of a build
+            warm = torch.zeros(1, device="cuda")
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
     return rank, ws, local
 
 

@@ -52,7 +52,7 @@ def event_timer(lib):
 def sustained_ms(lib, fn, launches=100, warm=60, stream=None):
     """mean duration of `launches` back-to-back calls after `warm` untimed ones (one event pair): the rate at the package's
     settled power operating point - the first ~30 launches of an MFMA-heavy kernel after an idle gap run 10-25 % slower
-    while the power controller converges (power-management transient)"""
+    while the power controller converges (profiles/HISTORY.md 4.1, power-management transient)"""
     e0, e1 = C.c_void_p(), C.c_void_p()
     lib.avl_event_create(C.byref(e0))
     lib.avl_event_create(C.byref(e1))
@@ -1245,7 +1245,7 @@ def main():
                             frames=nst, frames_per_s=rv["frames_per_s"], single_gpu_frames_per_s=sv["frames_per_s"],
                             speedup_vs_single_gpu=rv["frames_per_s"] / sv["frames_per_s"]),
                         pixel_sampling="per-frame sample lists are inputs of the kernel boundary here (no RNG fast-forward in the timed region); "
-                                       "VLMapBuilder's pixel-faithful mode fast-forwards the global RNG first, see DESIGN.md section 5")
+                                       "VLMapBuilder's pixel-faithful mode fast-forwards the global RNG first, see INTEGRATION.md (multi-GPU)")
         except Exception as e:   # the extra must never break the benchmark line
             if rank == 0:
                 out.setdefault("extra", {})["map_build_strong"] = dict(error=repr(e))

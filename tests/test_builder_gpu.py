@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 FEAT_RTOL = 2e-5     # closed-form fp64 accumulation vs the reference's float32 running mean
 # grid_rgb: the reference stores its running mean into a uint8 array, truncating at EVERY update, which biases it
 # downwards by up to ~1 LSB per update; the GPU path truncates the exact weighted mean once.  Not part of the
-# parity contract (indices + scores); bounded here, documented in DESIGN.md.
+# parity contract (indices + scores); bounded here, documented in DESIGN.md 2.
 RGB_LSB = 3          # few updates per voxel
 
 

@@ -160,7 +160,7 @@ def builder_case(i):
         if not (np.array_equal(out["grid_pos"], ref["grid_pos"]) and np.array_equal(out["occupied_ids"], ref["occupied_ids"])):
             fails.append((c, "voxel ids differ"))
         drgb = np.abs(out["grid_rgb"].astype(int) - ref["grid_rgb"].astype(int))
-        # the reference's own knife edge: when the incoming colour equals the stored one, (c w + c a) / (w + a) is c or
+        # the reference's own knife edge (profiles/HISTORY.md 4.3): when the incoming colour equals the stored one, (c w + c a) / (w + a) is c or
         # c - 1 ulp depending on the last bit of exp(); the device and host exp differ by an ulp now and then -> at most 1 LSB, in at
         # most 1 % of the bytes -- or the three channels of ONE voxel of a map of a few dozen voxels (dense sampling into a 20-cell grid)
         if drgb.max() > 1 or (drgb != 0).sum() > max(3, 0.01 * drgb.size):      # (3: the channels of one voxel)

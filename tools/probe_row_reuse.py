@@ -1,7 +1,7 @@
 """How often does a frame of BASELINE's build revisit accumulator rows that could still sit in the eight 4 MB L2s?  (CPU, NumPy.)
 The build workload of bench.py: 720x1080 depth surfaces, 7 776 random pixels per frame, the loop trajectory.  Per frame: the
 distinct voxels hit (K3's groups), the share of them also hit in the previous frame, and the hit rate of an LRU set of 8 000 rows
-(32 MB / 4 KB) -- the best an XCD-affine, L2-resident accumulator scheme could get (DESIGN 8, VERDICT r5 #3)."""
+(32 MB / 4 KB) -- the best an XCD-affine, L2-resident accumulator scheme could get (DESIGN.md 4.2, VERDICT r5 #3)."""
 import collections
 import sys
 from pathlib import Path

@@ -1,4 +1,4 @@
-// Kill-or-build measurement for the XCD-affine persistent builder (DESIGN 8, VERDICT r5 #3).
+// Kill-or-build measurement for the XCD-affine persistent builder (DESIGN.md 4.2, VERDICT r5 #3).
 //
 // K3's memory work per frame, isolated: G voxel groups, each gathers one 2 KB float32 feature row (streamed, no reuse) and
 // read-modify-writes one 4 KB float64 accumulator row; consecutive frames touch mostly the SAME voxels (a camera moves slowly).

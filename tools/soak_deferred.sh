@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: bounded soak of the deferred-fuse build (3 000 frames per run = 3 000 pipe_kernel launches, each with samples polling
 # for cells under creation), plain and under rocprofv3; every run under its own timeout, so a stall shows up as "bad", not as a hung box.
-# SOAK_RUNS / SOAK_PROF_RUNS set the repetitions (200 / 20 were run for DESIGN.md 4.3).
+# SOAK_RUNS / SOAK_PROF_RUNS set the repetitions (200 / 20 were run for profiles/HISTORY.md 4.3).
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 ok=0; bad=0

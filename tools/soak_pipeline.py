@@ -72,7 +72,7 @@ while time.time() < t_end:
         got, b = build(Path(t1), **opts)
     cases += 1
     # one launch pair per BATCH sums a voxel's samples of several frames in one list: its features equal the frame-by-frame ones to
-    # float64 rounding, everything else and every non-batched configuration bit for bit
+    # float64 rounding (profiles/HISTORY.md 4.3), everything else and every non-batched configuration bit for bit
     feat_ok = (np.array_equal(ref[1], got[1]) if opts["batch_frames"] == 1 else
                (ref[1].shape == got[1].shape and np.allclose(ref[1], got[1], rtol=1e-6, atol=1e-30)))
     same = ref[0] == got[0] and feat_ok and all(np.array_equal(a, c) for a, c in zip(ref[2:6], got[2:6]))
