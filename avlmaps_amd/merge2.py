@@ -590,12 +590,14 @@ def merge_accumulator_v2(acc, group, exact_rgb, timings, gather_to, status, gloc
     return res
 
 
-def merge_raw_sharded_v2(raw, group=None, replay_fn=None, gs2: Optional[int] = None, gs: int = 1 << 10, vh: int = 1 << 10, ncell: Optional[int] = None):
+def merge_raw_sharded_v2(raw, group=None, replay_fn=None, gs2: Optional[int] = None, gs: int = 1 << 10, vh: int = 1 << 10, ncell: Optional[int] = None,
+                         coll=None):
     """The same merge on exported raw accumulators (CPU tensors; gloo): the NumPy twin of the kernels under the same choreography.
     Returns the rank's block as torch tensors + the twin's intermediates, or None if the keys are not ordered by rank."""
     import torch
     from . import parallel
-    coll = parallel._Coll(group) if parallel._dist_on(group) else None
+    if coll is None:                  # (tests pass an in-process stand-in with _Coll's interface)
+        coll = parallel._Coll(group) if parallel._dist_on(group) else None
     K = HostKernels(raw, replay_fn)
     ncell = int(ncell or (1 << 31) - 1)
     r = merge_sharded_v2(K, coll, K.D, _bit_length(ncell - 1), (gs2 - 1) if gs2 else -1, gs, vh, replay_fn is not None)

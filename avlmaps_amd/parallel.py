@@ -136,6 +136,11 @@ class _SharedGpuLock:
         self.held = False
 
 
+def torch_cat_rows(*parts):
+    import torch
+    return torch.cat(list(parts), dim=0)
+
+
 class _Coll:
     """the handful of collectives the merge uses; with the gloo backend (tests: several ranks on one GPU, or CPU tensors)
     device tensors are staged through the host, with nccl (= RCCL) they go as they are.  Every call is bracketed by device
@@ -254,9 +259,24 @@ class _Coll:
         """all_to_all_single along dim 0 with split sizes (rows); returns the received tensor (sum(out_splits), ...)"""
         t0 = self._tic(inp)
         h = self._h(inp).contiguous()
+        in_splits, out_splits = [int(x) for x in in_splits], [int(x) for x in out_splits]
+        # a rank that sends or receives NOTHING in this exchange (the replay hops: only one rank receives) would hand the backend an
+        # empty tensor; one dummy row travels from the rank to itself instead -- a self split is nobody else's business, so every
+        # rank decides this alone
+        pad = h.shape[0] == 0 or sum(out_splits) == 0
+        if pad:
+            o = sum(in_splits[:self.rank])
+            h = torch_cat_rows(h[:o], h.new_zeros((1,) + tuple(h.shape[1:])), h[o:])
+            in_splits[self.rank] += 1
+            out_splits[self.rank] += 1
         out = h.new_empty((int(sum(out_splits)),) + tuple(h.shape[1:]))
         with self._net():
-            self.dist.all_to_all_single(out, h, [int(x) for x in out_splits], [int(x) for x in in_splits], group=self.group)
+            self.dist.all_to_all_single(out, h, out_splits, in_splits, group=self.group)
+        if pad:
+            o = sum(out_splits[:self.rank])
+            out = torch_cat_rows(out[:o], out[o + 1:])
+            in_splits[self.rank] -= 1
+            out_splits[self.rank] -= 1
         res = out.to(inp.device)
         del out, h                              # gloo rehearsals: GBs of pageable staging are unmapped here, not on the rank's compute clock
         row_b = inp.element_size() * (int(inp.numel() // inp.shape[0]) if inp.shape[0] else 0)

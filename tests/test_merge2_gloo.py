@@ -146,3 +146,38 @@ def test_layout_is_the_same_arithmetic_on_both_sides():
             which, s_off, d_off, p_off, cnt = Ls[q].peer_lists(p)
             assert cnt == A[p, q] and which == ("send" if p == q else "recv")
             assert d_off - s_off == 8 * A[p, q] and p_off - d_off == Dn[p, q] * ((D + 1) // 2)
+
+
+@pytest.mark.parametrize("ws,seed", [(2, 1), (4, 2), (5, 3), (8, 4), (13, 5), (16, 6)])
+def test_gather_plan_merge_random_worlds_over_threads(ws, seed):
+    """the choreography + the NumPy twin for ws ranks as THREADS of this process (tests/thread_world.py: an in-process stand-in for
+    parallel._Coll that moves the same tensors), random sharing patterns: empty ranks, voxels shared by up to all ranks, a rank whose
+    voxels ALL belong to other ranks' blocks, odd feature widths -- every block against the brute-force merge of the raw lists"""
+    from thread_world import run_ranks
+    rng = np.random.default_rng(100 + seed)
+    D = int(rng.choice([3, 8, 12, 17]))
+    pool = rng.permutation(400)[: int(rng.integers(30, 200))]
+    cellsets = []
+    for k in range(ws):
+        style = rng.integers(0, 4)
+        if style == 0:
+            cs = []                                                       # a rank without voxels
+        elif style == 1:
+            cs = rng.choice(pool, int(rng.integers(1, len(pool))), replace=False).tolist()      # heavy sharing
+        else:
+            cs = rng.integers(0, 400, int(rng.integers(5, 60))).tolist()
+        cellsets.append(sorted(set(int(c) for c in cs)))
+    if not any(cellsets):
+        cellsets[0] = [7, 9]
+    raws = [make_rank_raw(300 + 17 * seed + k, D, cellsets[k], frame_lo=1000 * k) for k in range(ws)]
+
+    def rank_fn(r, coll):
+        return merge2.merge_raw_sharded_v2(raws[r], group=None, replay_fn=fake_replay(r, raws[r]["cell"].numpy()), gs2=7, gs=GS, vh=VH, ncell=400,
+                                           coll=coll)
+    outs = run_ranks(ws, rank_fn)
+    M = None
+    for r in range(ws):
+        cells, _ = check_block(outs[r], r, ws, D, cellsets, raws)
+        M = len(cells)
+    assert sum(o["rows"][1] - o["rows"][0] for o in outs) == M
+    assert [c for o in outs for c in o["cell"].tolist()] == cells

@@ -2,12 +2,14 @@
 (csrc/avl_merge2.hip, avl_builder_m2_pack) for several ranks of ONE process -- every rank a thread with its own VoxelAccumulator,
 the collectives an in-process stand-in that moves the same bytes -- against (a) the single-process map of all frames and (b) the
 NumPy twin of the kernels on the exported accumulators, bit for bit."""
-import threading
+import sys
+from pathlib import Path
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, str(Path(__file__).resolve().parent))
 
 
 @pytest.fixture(scope="module")
@@ -18,94 +20,7 @@ def ops():
     return ops
 
 
-class _NoLock:
-    wait_s, held = 0.0, False
-
-
-class ThreadWorld:
-    def __init__(self, ws):
-        self.ws, self.barrier, self.slots = ws, threading.Barrier(ws), [None] * ws
-
-
-class ThreadColl:
-    """parallel._Coll's interface over threads of one process (device or CPU tensors)"""
-
-    class _Dist:
-        class ReduceOp:
-            MAX = "max"
-
-        @staticmethod
-        def get_backend(group):
-            return "threads"
-
-    def __init__(self, world, rank):
-        self.w, self.rank, self.ws = world, rank, world.ws
-        self.comm_s, self.bytes_out, self.calls, self.gpu_lock, self.dist, self.group = 0.0, 0, 0, _NoLock(), self._Dist, None
-
-    def _sync(self, t):
-        if getattr(t, "is_cuda", False):
-            import torch
-            torch.cuda.synchronize()
-
-    def _round(self, mine, take):
-        self._sync(mine[0] if isinstance(mine, tuple) else mine)
-        self.w.slots[self.rank] = mine
-        self.w.barrier.wait()
-        res = take(self.w.slots)
-        self._sync(res[0] if isinstance(res, list) else res)
-        self.w.barrier.wait()
-        self.calls += 1
-        return res
-
-    def all_gather(self, t):
-        return self._round(t, lambda s: [x.clone() for x in s])
-
-    def all_gather_into(self, out, chunk):
-        n = chunk.numel()
-
-        def take(s):
-            for r, c in enumerate(s):
-                if r != self.rank:
-                    out[r * n:(r + 1) * n].copy_(c)
-            return out
-        return self._round(chunk, take)
-
-    def all_to_all(self, inp, in_splits, out_splits):
-        import torch
-
-        def take(s):
-            parts = []
-            for p, (t, ins) in enumerate(s):
-                o = sum(ins[:self.rank])
-                assert ins[self.rank] == out_splits[p], (p, self.rank, ins, out_splits)
-                parts.append(t[o:o + ins[self.rank]])
-            return torch.cat(parts) if parts else inp[:0]
-        self.bytes_out += 8 * (sum(in_splits) - in_splits[self.rank])
-        return self._round((inp, list(in_splits)), take)
-
-    def all_reduce(self, t, op):
-        import torch
-        return self._round(t, lambda s: torch.stack([x for x in s]).max(0).values)
-
-
-def run_ranks(ws, fn):
-    world = ThreadWorld(ws)
-    out, errs = [None] * ws, []
-
-    def body(r):
-        try:
-            import torch
-            torch.cuda.set_device(0)
-            out[r] = fn(r, ThreadColl(world, r))
-        except BaseException as e:      # noqa: BLE001 -- a failing rank must not leave the others in a barrier
-            errs.append(e)
-            world.barrier.abort()
-    th = [threading.Thread(target=body, args=(r,)) for r in range(ws)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    if errs:
-        raise errs[0]
-    return out
+from thread_world import run_ranks  # noqa: E402
 
 
 def build_shards(ops, ws, D=64, nfr=24, seed=7, rate=5, cs=0.1, gs=400, replay=True):

@@ -20,7 +20,7 @@ def main():
     import torch
     import bench
     from avlmaps_amd import merge2, ops, parallel
-    from test_merge2_gpu import run_ranks
+    from thread_world import run_ranks
     H, W, Hf, Wf, D, rate, nbuf = 720, 1080, 347, 520, 512, 100, 4
     depths, rgbs, feats = bench.make_build_inputs(torch, H, W, Hf, Wf, D, nbuf, seed=99)
     Ts = bench.pc_transforms(bench.trajectory(frames, "spiral", 4.0))
