@@ -120,6 +120,7 @@ _SIGS = {
     "avl_finalize_merged": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_builder_replay_chain": (C.c_int, [_vp, _i64, _vp, C.c_uint64, _vp, _vp]),
     "avl_builder_drop_replay_cache": (C.c_int, [_vp, _vp]),
+    "avl_builder_replay_prepare": (C.c_int, [_vp, _i64, _vp]),
     "avl_replay_state_apply": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_rows_add_f64": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
     "avl_rows_add_f64_async": (C.c_int, [_i64, C.c_int, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),

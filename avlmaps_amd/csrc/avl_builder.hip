@@ -1392,6 +1392,7 @@ struct avl_builder {
     LogSegments* ls_cache = nullptr;
     long long ls_log_used = -1;
     int64_t ls_n = -1;
+
     // next frame's stateless half of K1 in the C frame loop (PreGather): two buffers of recs_cap records, the one K1 reads and the one
     // being written
     PreRec* pre_buf[2] = {nullptr, nullptr};
@@ -2269,6 +2270,8 @@ int avl_builder_finalize(avl_builder* b, int64_t n, float* d_grid_feat, int32_t*
     return avl_builder_finalize_ex(b, n, d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, nullptr, 0, stream);
 }
 
+static int ensure_log_segments(avl_builder* b, int64_t n, hipStream_t st);
+
 int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32_t* d_grid_pos, float* d_weight,
                             uint8_t* d_grid_rgb, int32_t* d_occupied_ids, uint8_t* d_row_dirty, int clear_dirty, void* stream) {
     AVL_REQUIRE(b, "avl_builder_finalize: null handle");
@@ -2302,14 +2305,15 @@ int avl_builder_finalize_ex(avl_builder* b, int64_t n, float* d_grid_feat, int32
                          d_grid_feat, d_grid_pos, d_weight, d_grid_rgb, d_occupied_ids, st);
     if (rc == AVL_OK && b->log.slot && b->key_bias == 0 && b->log_used > 0 && (d_weight || d_grid_rgb)) {
         // exact sequential weight / grid_rgb: stable sort of the key-ordered log by slot, then replay per voxel
-        LogSegments ls;
-        rc = ls.build(b, n, st);
+        // (the builder's ONE voxel-sorted form of the log, shared with the merge's replay: it lives in the scratch allocated with the log,
+        // so a private second build here would overwrite a cached one; it stays valid until the next frame is fused)
+        rc = ensure_log_segments(b, n, st);
         if (rc == AVL_OK) {
+            const LogSegments& ls = *b->ls_cache;
             hipLaunchKernelGGL(replay_rgb_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
                                (long long)b->n0 * b->gs, perm, keys_out, ls.order, ls.seg_start, ls.seg_end, b->log, d_weight, d_grid_rgb);
             if (hipGetLastError() != hipSuccess) rc = AVL_ERR_HIP;
         }
-        ls.release(st);
     }
     if (rc == AVL_OK && d_row_dirty) {
         hipLaunchKernelGGL(row_dirty_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n, perm, b->dirty,
@@ -2328,6 +2332,34 @@ int avl_builder_drop_replay_cache(avl_builder* b, void* stream) {
     return AVL_OK;
 }
 
+// the log sorted by voxel (LogSegments), built if it is not there: a merge asks for it FIRST, so that the compaction, the sort and the one
+// host synchronisation in between run under the plan's host work and collectives instead of in front of the replay
+static int ensure_log_segments(avl_builder* b, int64_t n, hipStream_t st) {
+    if (b->ls_cache && b->ls_log_used == b->log_used && b->ls_n == n) return AVL_OK;
+    drop_log_segments(b, st);
+    b->ls_cache = new LogSegments();
+    int rc = b->ls_cache->build(b, n, st);
+    if (rc != AVL_OK) {
+        drop_log_segments(b, st);
+        return rc;
+    }
+    b->ls_log_used = b->log_used;
+    b->ls_n = n;
+    return AVL_OK;
+}
+
+int avl_builder_replay_prepare(avl_builder* b, int64_t n, void* stream) {
+    AVL_REQUIRE(b, "avl_builder_replay_prepare: null handle");
+    int64_t have = 0;
+    int rc = avl_builder_num_voxels(b, &have, stream);
+    if (rc != AVL_OK) return rc;
+    AVL_REQUIRE(n == have, "avl_builder_replay_prepare: n=%lld but the map holds %lld voxels", (long long)n, (long long)have);
+    if (!b->log.slot || b->key_bias != 0 || n == 0 || b->log_used == 0) return AVL_OK;      // (nothing to prepare: replay_chain reports a missing log)
+    // (a build on a stream of the builder's own, overlapping the merge plan's host work, was measured in round 6: nothing in the 8-rank
+    // rehearsal, +10 ms on the first merge of a process for the stream and its events -- the form is built on the caller's stream)
+    return ensure_log_segments(b, n, as_stream(stream));
+}
+
 int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_slot, uint64_t grow_key, void* d_state,
                              void* stream) {
     AVL_REQUIRE(b, "avl_builder_replay_chain: null handle");
@@ -2342,17 +2374,8 @@ int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d_row_of_
     }
     if (n == 0 || b->log_used == 0) return AVL_OK;
     AVL_REQUIRE(d_row_of_slot && d_state, "avl_builder_replay_chain: null pointer");
-    if (!b->ls_cache || b->ls_log_used != b->log_used || b->ls_n != n) {
-        drop_log_segments(b, st);
-        b->ls_cache = new LogSegments();
-        rc = b->ls_cache->build(b, n, st);
-        if (rc != AVL_OK) {
-            drop_log_segments(b, st);
-            return rc;
-        }
-        b->ls_log_used = b->log_used;
-        b->ls_n = n;
-    }
+    rc = ensure_log_segments(b, n, st);
+    if (rc != AVL_OK) return rc;
     const LogSegments& ls = *b->ls_cache;
     hipLaunchKernelGGL(replay_chain_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, st, n,
                        (unsigned long long)grow_key, d_row_of_slot, ls.order, ls.seg_start, ls.seg_end, b->log,

@@ -419,7 +419,10 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
     trace = timings is not None and os.environ.get("AVLMAPS_MERGE_TRACE") == "1"
 
     def mark(label):
-        if timings is not None:
+        # phase boundaries are HOST clocks; the device is only drained here when a trace is asked for (AVLMAPS_MERGE_TRACE=1) -- otherwise a
+        # phase's kernels run on while the host prepares the next one (pack under the replay's set-up, ...), as in a build that is not
+        # being timed; every collective drains the device before it starts its own clock, so a rank's total compute stays exact
+        if trace:
             sync()
         marks.append((label, time.perf_counter(), coll.comm_s if coll is not None else 0.0, coll.gpu_lock.wait_s if coll is not None else 0.0))
     mark("start")
@@ -500,6 +503,8 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
     if trace:
         mark("fold: flags")
     del send, recv
+    if timings is not None and not trace:
+        sync()
     mark("fold")
     if trace:
         import sys
@@ -571,7 +576,9 @@ def merge_accumulator_v2(acc, group, exact_rgb, timings, gather_to, status, gloc
         names = dict(plan="plan", pack="export", replay="replay_chain", exchange="exchange", fold="fold_finalize", gather="gather")
         wall_s = {names[k]: v for k, v in wall.items()}
         comm_s = {names[k]: v for k, v in comm.items()}
-        timings.update(mode="row-sharded all_to_all", plan="gather plan (two all_gathers, one radix-sorted union per rank; mixed float32 / float64 payload in ONE "
+        timings.update(phase_clock="host clocks at the phase boundaries; the device is drained only by the collectives and at the end (per phase with "
+                                   "AVLMAPS_MERGE_TRACE=1): a phase's kernels may finish under the next phase's host work, the total is exact",
+                       mode="row-sharded all_to_all", plan="gather plan (two all_gathers, one radix-sorted union per rank; mixed float32 / float64 payload in ONE "
                        "all_to_all; replay hops as small all_to_alls)",
                        plan_s=wall_s["plan"], scatter_s=wall_s["export"], replay_chain_s=wall_s["replay_chain"], exchange_s=wall_s["exchange"],
                        accumulate_s=wall_s["fold_finalize"], finalize_s=0.0, gather_s=wall_s["gather"], null_launch_us=None, wall_s=wall_s,

@@ -810,6 +810,9 @@ def run_build_core(args, torch, dist, lib, rank, ws, total_frames, warmup=8, bat
         single_gpu_merge["merge_cold_note"] = ("wall time of the FIRST merge of this process (no warm-up merge, no warm_up_merge; the accumulators' map of "
                                                f"{nvox} voxels; its {nvox * D * 4 / 1e9:.1f} GB block of finished rows is allocated inside)" if was_first else
                                                "an earlier build of this process had merged already: the allocator's blocks were released (empty_cache), the code was warm")
+        if exact_rgb:
+            acc.drop_replay_cache()                            # (the plain finalisation sorts the replay log itself, like the merges above)
+        torch.cuda.synchronize()
         t_fin = time.perf_counter()
         acc.finalize(as_torch=True)
         torch.cuda.synchronize()

@@ -430,6 +430,9 @@ AVL_API int avl_builder_replay_chain(avl_builder* b, int64_t n, const int64_t* d
 /* The log sorted by voxel is kept between avl_builder_replay_chain calls until the next frame is fused (a merge calls it twice);
  * this drops it, so that a caller timing a merge twice on the same map pays for the sort both times (bench.py). */
 AVL_API int avl_builder_drop_replay_cache(avl_builder* b, void* stream);
+/* build that voxel-sorted log NOW (n = avl_builder_num_voxels) instead of inside the next avl_builder_replay_chain / finalize; a no-op without
+ * a replay log */
+AVL_API int avl_builder_replay_prepare(avl_builder* b, int64_t n, void* stream);
 /* ------------------------------------------------------------------------------------------------
  * The local steps of the multi-GPU merge plan (avlmaps_amd/parallel.py, plan_merge_directory): which final row -- the reference's
  * voxel id, vlmap_builder.py:163-170 -- every voxel of every rank gets.  torch.distributed carries the collectives between them;

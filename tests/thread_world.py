@@ -8,8 +8,12 @@ class _NoLock:
 
 
 class ThreadWorld:
-    def __init__(self, ws):
+    def __init__(self, ws, exclusive=False):
         self.ws, self.barrier, self.slots = ws, threading.Barrier(ws), [None] * ws
+        # exclusive: only ONE rank computes at a time (a lock taken at start, dropped inside every collective), and the time spent
+        # inside collectives incl. waiting for the lock is booked to comm_s -- a rank's wall time minus comm_s is then what it computes
+        # on a GPU of its own (tools/probe_merge2.py)
+        self.lock = threading.Lock() if exclusive else None
 
 
 class ThreadColl:
@@ -33,12 +37,19 @@ class ThreadColl:
             torch.cuda.synchronize()
 
     def _round(self, mine, take):
+        import time
         self._sync(mine[0] if isinstance(mine, tuple) else mine)
+        t0 = time.perf_counter()
+        if self.w.lock is not None:
+            self.w.lock.release()
         self.w.slots[self.rank] = mine
         self.w.barrier.wait()
         res = take(self.w.slots)
         self._sync(res[0] if isinstance(res, list) else res)
         self.w.barrier.wait()
+        if self.w.lock is not None:
+            self.w.lock.acquire()
+        self.comm_s += time.perf_counter() - t0
         self.calls += 1
         return res
 
@@ -73,8 +84,8 @@ class ThreadColl:
         return self._round(t, lambda s: torch.stack([x for x in s]).max(0).values)
 
 
-def run_ranks(ws, fn):
-    world = ThreadWorld(ws)
+def run_ranks(ws, fn, exclusive=False):
+    world = ThreadWorld(ws, exclusive)
     out, errs = [None] * ws, []
 
     def body(r):
@@ -82,7 +93,16 @@ def run_ranks(ws, fn):
             import torch
             if torch.cuda.is_available():
                 torch.cuda.set_device(0)
-            out[r] = fn(r, ThreadColl(world, r))
+            if world.lock is not None:
+                world.lock.acquire()
+            try:
+                out[r] = fn(r, ThreadColl(world, r))
+            finally:
+                if world.lock is not None and world.lock.locked():
+                    try:
+                        world.lock.release()
+                    except RuntimeError:
+                        pass
         except BaseException as e:      # noqa: BLE001 -- a failing rank must not leave the others in a barrier
             errs.append(e)
             world.barrier.abort()
