@@ -129,6 +129,12 @@ def test_gather_plan_merge_through_the_product_entry_point(ops):
         assert np.array_equal(out[k].cpu().numpy(), want[k]), k
         assert np.array_equal(out["full"][k].cpu().numpy(), want[k]), k
     assert np.array_equal(out["full"]["occupied_ids"].cpu().numpy(), want["occupied_ids"])
+    # the merge's replay and the plain finalisation share ONE voxel-sorted form of the replay log (it lives in scratch allocated with
+    # the log): merge -> finalize -> merge without a frame in between must give the same weights and colours each time
+    again = whole.finalize()
+    third = parallel.merge_accumulator_sharded(whole, timings={})
+    for k in ("weight", "grid_rgb", "grid_feat"):
+        assert np.array_equal(again[k], want[k]) and np.array_equal(third[k].cpu().numpy(), want[k]), k
     os.environ["AVLMAPS_MERGE_PLAN"] = "directory"
     try:
         old = parallel.merge_accumulator_sharded(whole, timings={})
