@@ -58,10 +58,11 @@ _SIGS = {
     "avl_merge2_load": (C.c_int, []),
     "avl_merge2_prepare_work_bytes": (C.c_int, [_i64, C.POINTER(_sz)]),
     "avl_merge2_prepare": (C.c_int, [_i64, _vp, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "avl_merge2_work_bytes": (C.c_int, [_i64, _i64, C.c_int, C.POINTER(_sz)]),
-    "avl_merge2_plan": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _sz, _vp, _vp, _vp]),
-    "avl_builder_m2_pack": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "avl_merge2_side_state": (C.c_int, [_i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_merge2_max_chunks": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "avl_merge2_work_bytes": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.POINTER(_sz)]),
+    "avl_merge2_plan": (C.c_int, [C.c_int, C.c_int, _vp, _i64, _vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp, _sz, _vp, _vp, _vp]),
+    "avl_builder_m2_pack": (C.c_int, [_vp, _i64, C.c_int, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "avl_merge2_side_state": (C.c_int, [_i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "avl_merge2_state_gather": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_merge2_state_scatter": (C.c_int, [_i64, _vp, _vp, _vp, _vp]),
     "avl_merge2_fold": (C.c_int, [_i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -1062,12 +1062,14 @@ __global__ __launch_bounds__(256) void export_rows_f64_kernel(int64_t k, int D, 
 // feature row: export_rows_f32_kernel's expression for a voxel of this rank alone (straight into this rank's own block when it owns
 // the row), export_rows_f64_kernel's for a voxel several ranks touched.
 struct M2PackSeg {
-    long long start[65];      // own voxels [start[q], start[q + 1]) go to rank q
-    long long dstart[64];     // number of single-rank voxels before start[q]
+    long long cum[65];        // cum[q] = voxels of this call for ranks < q (cum[ws] = all of them): wave w serves rank q with cum[q] <= w < cum[q + 1]
+    long long lo[64];         // ... and is voxel lo[q] + (w - cum[q]) of the rank's final-row order
+    long long dlo[64];        // single-rank voxels of that order before lo[q]
+    long long row0[64];       // first final row this call covers at rank q (a chunk of q's block): side records carry row - row0[q]
     long long side_off[64], done_off[64], part_off[64];   // word (8 B) offsets of q's three lists in the send buffer
 };
 
-__global__ __launch_bounds__(256) void m2_pack_kernel(long long n, int ws, int rank, int D, long long per, M2PackSeg sg,
+__global__ __launch_bounds__(256) void m2_pack_kernel(long long n, int ws, int rank, int D, long long own_r0, M2PackSeg sg,
                                                       const int32_t* __restrict__ order, const int32_t* __restrict__ row_s,
                                                       const int32_t* __restrict__ prev_s, const int32_t* __restrict__ next_s,
                                                       const int32_t* __restrict__ sidx, const double* __restrict__ sum_feat,
@@ -1078,23 +1080,25 @@ __global__ __launch_bounds__(256) void m2_pack_kernel(long long n, int ws, int r
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
     const long long ldf = (D + 1) / 2 * 2;
-    for (long long i = wave0; i < n; i += nwaves) {
+    for (long long w = wave0; w < n; w += nwaves) {
         int q = 0;
-        while (q + 1 < ws && i >= sg.start[q + 1]) ++q;
-        const long long j = i - sg.start[q];
+        while (q + 1 < ws && w >= sg.cum[q + 1]) ++q;
+        const long long j = w - sg.cum[q];
+        const long long i = sg.lo[q] + j;
         const long long sl = order[i];
         const bool is_new = prev_s[sl] < 0, single = is_new && next_s[sl] < 0;
-        const long long didx = (long long)sidx[i] - sg.dstart[q], pidx = j - didx;
+        const long long didx = (long long)sidx[i] - sg.dlo[q], pidx = j - didx;
         const bool direct = single && q == rank && own_feat != nullptr;
-        const long long row_rel = (long long)row_s[sl] - (long long)q * per;
+        const long long row = row_s[sl];
+        const long long row_rel = row - sg.row0[q];
         const double a1 = first_alpha[sl];
         const double* s = sum_feat + sl * D;
         const float* f1 = first_feat + sl * D;
         if (single) {
-            const double w = sum_w4[sl * 4];
+            const double wsum = sum_w4[sl * 4];
             const double a1sq = a1 * a1;
-            float* o = direct ? own_feat + row_rel * D : reinterpret_cast<float*>(send + sg.done_off[q]) + didx * ldf;
-            for (int c = lane; c < D; c += 64) o[c] = (float)((a1sq * (double)f1[c] + s[c]) / w);     // finalize_kernel's expression
+            float* o = direct ? own_feat + (row - own_r0) * D : reinterpret_cast<float*>(send + sg.done_off[q]) + didx * ldf;
+            for (int c = lane; c < D; c += 64) o[c] = (float)((a1sq * (double)f1[c] + s[c]) / wsum);     // finalize_kernel's expression
         } else {
             const double wf = is_new ? a1 * a1 : a1;   // global first touch: a1^2 f1 (reference closed form); else the sample's plain weight
             double* o = reinterpret_cast<double*>(send + sg.part_off[q]) + pidx * D;
@@ -2221,32 +2225,34 @@ int avl_builder_export_rows_f64(avl_builder* b, int64_t k, const int32_t* d_slot
     return AVL_OK;
 }
 
-int avl_builder_m2_pack(avl_builder* b, int64_t n, int ws, int rank, int64_t per, const int64_t* h_start, const int64_t* h_dstart,
-                        const int64_t* h_side_off, const int64_t* h_done_off, const int64_t* h_part_off, const int32_t* d_order,
-                        const int32_t* d_row, const int32_t* d_prev, const int32_t* d_next, const int32_t* d_sidx, int64_t* d_send,
-                        float* d_own_feat, void* stream) {
+int avl_builder_m2_pack(avl_builder* b, int64_t n, int ws, int rank, int64_t own_r0, const int64_t* h_cum, const int64_t* h_lo,
+                        const int64_t* h_dlo, const int64_t* h_row0, const int64_t* h_side_off, const int64_t* h_done_off,
+                        const int64_t* h_part_off, const int32_t* d_order, const int32_t* d_row, const int32_t* d_prev, const int32_t* d_next,
+                        const int32_t* d_sidx, int64_t* d_send, float* d_own_feat, void* stream) {
     AVL_REQUIRE(b, "avl_builder_m2_pack: null handle");
-    AVL_REQUIRE(n >= 0 && ws >= 1 && ws <= 64 && rank >= 0 && rank < ws && per >= 1, "avl_builder_m2_pack: bad arguments");
+    AVL_REQUIRE(n >= 0 && ws >= 1 && ws <= 64 && rank >= 0 && rank < ws && own_r0 >= 0, "avl_builder_m2_pack: bad arguments");
     hipStream_t st = as_stream(stream);
     int rc = flush_pending(b, st);
     if (rc != AVL_OK) return rc;
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(n <= b->capacity, "avl_builder_m2_pack: n=%lld exceeds the capacity %lld", (long long)n, (long long)b->capacity);
-    AVL_REQUIRE(h_start && h_dstart && h_side_off && h_done_off && h_part_off && d_order && d_row && d_prev && d_next && d_sidx && d_send,
+    AVL_REQUIRE(h_cum && h_lo && h_dlo && h_row0 && h_side_off && h_done_off && h_part_off && d_order && d_row && d_prev && d_next && d_sidx && d_send,
                 "avl_builder_m2_pack: null pointer");
     M2PackSeg sg{};
-    for (int q = 0; q <= 64; ++q) sg.start[q] = h_start[q < ws ? q : ws];
+    for (int q = 0; q <= 64; ++q) sg.cum[q] = h_cum[q < ws ? q : ws];
     for (int q = 0; q < ws; ++q) {
-        sg.dstart[q] = h_dstart[q];
+        sg.lo[q] = h_lo[q];
+        sg.dlo[q] = h_dlo[q];
+        sg.row0[q] = h_row0[q];
         sg.side_off[q] = h_side_off[q];
         sg.done_off[q] = h_done_off[q];
         sg.part_off[q] = h_part_off[q];
     }
-    AVL_REQUIRE(sg.start[ws] == n, "avl_builder_m2_pack: the destination ranges cover %lld voxels, n = %lld", sg.start[ws], (long long)n);
+    AVL_REQUIRE(sg.cum[0] == 0 && sg.cum[ws] == n, "avl_builder_m2_pack: the destination ranges cover %lld voxels, n = %lld", sg.cum[ws], (long long)n);
     int64_t blocks = (n + 3) / 4;
     const int64_t maxb = (int64_t)num_cus() * 16;
     if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(m2_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n, ws, rank, b->D, (long long)per, sg, d_order, d_row,
+    hipLaunchKernelGGL(m2_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n, ws, rank, b->D, (long long)own_r0, sg, d_order, d_row,
                        d_prev, d_next, d_sidx, b->sum_feat, b->sum_w4, b->first_feat, b->first_alpha, reinterpret_cast<long long*>(d_send),
                        d_own_feat);
     AVL_HIP_CHECK(hipGetLastError());

@@ -112,12 +112,14 @@ __global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, in
                                                          const uint32_t* __restrict__ scell, const uint32_t* __restrict__ se,
                                                          const uint8_t* __restrict__ erank, const uint32_t* __restrict__ hp,
                                                          const uint16_t* __restrict__ pn, const int32_t* __restrict__ rowscan,
-                                                         const int32_t* __restrict__ perm, long long grow_row, unsigned long long* __restrict__ res,
+                                                         const int32_t* __restrict__ perm, long long grow_row, long long chunk_rows, int nchunk,
+                                                         unsigned long long* __restrict__ res,
                                                          int32_t* __restrict__ rowcell, int32_t* __restrict__ row_s, int32_t* __restrict__ prev_s,
                                                          int32_t* __restrict__ next_s, uint32_t* __restrict__ krow, uint32_t* __restrict__ vslot) {
-    extern __shared__ unsigned m2_hist[];                 // [all | done | hop] x ws x ws
+    extern __shared__ unsigned m2_hist[];                 // [all | done | hop] x ws x ws, then per chunk of a block's rows [all | done] x ws x ws
     const int W2 = ws * ws;
-    for (int t = threadIdx.x; t < 3 * W2; t += blockDim.x) m2_hist[t] = 0;
+    const int nbins = (3 + 2 * nchunk) * W2;
+    for (int t = threadIdx.x; t < nbins; t += blockDim.x) m2_hist[t] = 0;
     __syncthreads();
     const long long M = (long long)res[0];
     const long long per = M > 0 ? (M + ws - 1) / ws : 1;
@@ -150,6 +152,12 @@ __global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, in
             if (single) atomicAdd(&m2_hist[W2 + bin], 1u);
         }
         if (prev >= 0) atomicAdd(&m2_hist[2 * W2 + prev * ws + p], 1u);
+        if (nchunk > 0) {      // the exchange in chunks of chunk_rows rows of every owner's block: the same two tables per chunk
+            const int c = (int)((row - (long long)q * per) / chunk_rows);
+            const int cb = (3 + 2 * (c < nchunk ? c : nchunk - 1)) * W2 + bin;
+            atomicAdd(&m2_hist[cb], 1u);
+            if (single) atomicAdd(&m2_hist[cb + W2], 1u);
+        }
         if (p == rank) {
             const long long j = e - o.off[p];
             const int32_t s = perm[j];
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void m2_entries_kernel(long long E, int ws, in
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 3 * W2; t += blockDim.x)
+    for (int t = threadIdx.x; t < nbins; t += blockDim.x)
         if (m2_hist[t]) atomicAdd(&res[2 + t], (unsigned long long)m2_hist[t]);
 }
 
@@ -202,18 +210,20 @@ __global__ void m2_state_scatter_kernel(long long k, const int32_t* __restrict__
 }
 
 struct M2Seg {
-    long long start[kM2MaxRanks + 1];   // own voxels [start[q], start[q + 1]) of the final-row order go to rank q
+    long long cum[kM2MaxRanks + 1];     // as M2PackSeg (avl_builder.hip): record t serves rank q with cum[q] <= t < cum[q + 1]
+    long long lo[kM2MaxRanks];          // ... and is voxel lo[q] + (t - cum[q]) of the rank's final-row order
     long long side_off[kM2MaxRanks];    // word offset of destination q's side records in the send buffer
 };
 
 // words 5..7 of every side record: the replay state where this rank is the voxel's LAST contributor, zeros elsewhere
 __global__ void m2_side_state_kernel(long long n, int ws, M2Seg sg, const int32_t* __restrict__ order, const int32_t* __restrict__ next_s,
                                      const long long* __restrict__ state, long long* __restrict__ send) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         int q = 0;
-        while (q + 1 < ws && i >= sg.start[q + 1]) ++q;
-        const int32_t s = order[i];
-        long long* rec = send + sg.side_off[q] + 8 * (i - sg.start[q]);
+        while (q + 1 < ws && t >= sg.cum[q + 1]) ++q;
+        const long long j = t - sg.cum[q];
+        const int32_t s = order[sg.lo[q] + j];
+        long long* rec = send + sg.side_off[q] + 8 * j;
         const bool last = state && next_s[s] < 0;
         rec[5] = last ? state[3ll * s] : 0ll;
         rec[6] = last ? state[3ll * s + 1] : 0ll;
@@ -366,7 +376,7 @@ struct M2Layout {
     size_t tmp_bytes;
 };
 
-static int m2_layout(long long E, long long n, int ws, M2Layout& L) {
+static int m2_layout(long long E, long long n, int ws, int nchunk, M2Layout& L) {
     const size_t e = (size_t)(E > 0 ? E : 1), m = (size_t)(n > 0 ? n : 1);
     size_t t_cell = 0, t_row = 0, t_small = 0, t_scan = 0, t_scan_e = 0;
     AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_cell, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, e, 0, 32, nullptr));
@@ -382,7 +392,7 @@ static int m2_layout(long long E, long long n, int ws, M2Layout& L) {
     L.row = take(m * 4); L.prev = take(m * 4); L.next = take(m * 4); L.order = take(m * 4); L.sidx = take(m * 4);
     L.selA = take(m * 8); L.selB = take(m * 8); L.idx_prev = take(m * 4); L.idx_next = take(m * 4);
     L.rowcell = take(e * 4);
-    L.res = take((size_t)(2 + 3 * ws * ws) * 8);
+    L.res = take((size_t)(2 + (3 + 2 * nchunk) * ws * ws) * 8);
     L.ecell = take(e * 4); L.eidx = take(e * 4); L.erank = take(e); L.scell = take(e * 4); L.se = take(e * 4); L.hp = take(e * 4);
     L.pn = take(e * 2); L.headflag = take(e); L.rowscan = take(e * 4);
     L.krow = take(m * 4); L.vslot = take(m * 4); L.krow_s = take(m * 4); L.single = take(m); L.kp = take(m * 4); L.kn = take(m * 4);
@@ -451,19 +461,30 @@ int avl_merge2_fold_work_bytes(int64_t n_own, int ws, size_t* h_bytes) {
     return AVL_OK;
 }
 
-int avl_merge2_work_bytes(int64_t E, int64_t n, int ws, size_t* h_bytes) {
-    AVL_REQUIRE(h_bytes && E >= 0 && E < (1ll << 31) && n >= 0 && n <= E && ws >= 1 && ws <= kM2MaxRanks,
-                "avl_merge2_work_bytes: bad arguments (at most %d ranks, 2^31 entries)", kM2MaxRanks);
+// the per-chunk tables live in the entries kernel's LDS histogram next to the three whole-exchange ones: at most this many chunks
+static int m2_max_chunks(int ws) { return std::max(0, (12288 / (ws * ws) - 3) / 2); }
+
+int avl_merge2_max_chunks(int ws, int* h_max) {
+    AVL_REQUIRE(h_max && ws >= 1 && ws <= kM2MaxRanks, "avl_merge2_max_chunks: bad arguments");
+    *h_max = m2_max_chunks(ws);
+    return AVL_OK;
+}
+
+int avl_merge2_work_bytes(int64_t E, int64_t n, int ws, int nchunk, size_t* h_bytes) {
+    AVL_REQUIRE(h_bytes && E >= 0 && E < (1ll << 31) && n >= 0 && n <= E && ws >= 1 && ws <= kM2MaxRanks && nchunk >= 0 && nchunk <= m2_max_chunks(ws),
+                "avl_merge2_work_bytes: bad arguments (at most %d ranks, 2^31 entries, avl_merge2_max_chunks chunks)", kM2MaxRanks);
     M2Layout L;
-    int rc = m2_layout(E, n, ws, L);
+    int rc = m2_layout(E, n, ws, nchunk, L);
     if (rc != AVL_OK) return rc;
     *h_bytes = L.total;
     return AVL_OK;
 }
 
 int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, const int32_t* d_perm, int cell_bits,
-                    int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off, int64_t* h_res, void* stream) {
+                    int64_t grow_row, int want_replay_lists, int64_t chunk_rows, int nchunk, void* d_work, size_t work_bytes, int64_t* h_off,
+                    int64_t* h_res, void* stream) {
     AVL_REQUIRE(ws >= 1 && ws <= kM2MaxRanks && rank >= 0 && rank < ws && h_n_all && h_off && h_res, "avl_merge2_plan: bad arguments");
+    AVL_REQUIRE(nchunk >= 0 && nchunk <= m2_max_chunks(ws) && (nchunk == 0 || chunk_rows >= 1), "avl_merge2_plan: bad chunking (avl_merge2_max_chunks)");
     AVL_REQUIRE(cell_bits >= 1 && cell_bits <= 31, "avl_merge2_plan: cell_bits in [1, 31]");
     M2Offsets o;
     long long E = 0;
@@ -478,7 +499,7 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
     const long long n = h_n_all[rank];
     const long long stride = nmax + (nmax + 1) / 2;
     M2Layout L;
-    int rc = m2_layout(E, n, ws, L);
+    int rc = m2_layout(E, n, ws, nchunk, L);
     if (rc != AVL_OK) return rc;
     AVL_REQUIRE(d_work && work_bytes >= L.total, "avl_merge2_plan: work buffer of %zu bytes, %zu needed (avl_merge2_work_bytes)", work_bytes, L.total);
     char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(d_work) + 255) / 256 * 256);
@@ -486,7 +507,7 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
     const size_t offs[11] = {L.row, L.prev, L.next, L.order, L.sidx, L.selA, L.selB, L.idx_prev, L.idx_next, L.rowcell, L.res};
     for (int k = 0; k < 11; ++k) h_off[k] = (int64_t)offs[k] + shift;
     hipStream_t st = as_stream(stream);
-    const int nres = 2 + 3 * ws * ws;
+    const int nres = 2 + (3 + 2 * nchunk) * ws * ws;
     unsigned long long* res = reinterpret_cast<unsigned long long*>(base + L.res);
     AVL_HIP_CHECK(hipMemsetAsync(res, 0, (size_t)nres * 8, st));
     if (E > 0) {
@@ -506,9 +527,9 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
             auto it = rocprim::make_transform_iterator(reinterpret_cast<const uint8_t*>(headflag), FlagToI32{});
             AVL_HIP_CHECK(rocprim::exclusive_scan(base + L.tmp, tb, it, I32(L.rowscan), 0, (size_t)E, rocprim::plus<int32_t>(), st));
         }
-        hipLaunchKernelGGL(m2_entries_kernel, dim3(std::min(m2_grid(E), 1024u)), dim3(256), (size_t)(3 * ws * ws) * sizeof(unsigned), st, E, ws, rank, o,
-                           stride, g, U32(L.scell), U32(L.se), erank, U32(L.hp), reinterpret_cast<const uint16_t*>(base + L.pn), I32(L.rowscan), d_perm,
-                           (long long)grow_row, res, I32(L.rowcell), I32(L.row), I32(L.prev), I32(L.next), U32(L.krow), U32(L.vslot));
+        hipLaunchKernelGGL(m2_entries_kernel, dim3(std::min(m2_grid(E), 1024u)), dim3(256), (size_t)((3 + 2 * nchunk) * ws * ws) * sizeof(unsigned), st, E, ws,
+                           rank, o, stride, g, U32(L.scell), U32(L.se), erank, U32(L.hp), reinterpret_cast<const uint16_t*>(base + L.pn), I32(L.rowscan),
+                           d_perm, (long long)grow_row, (long long)(nchunk ? chunk_rows : 1), nchunk, res, I32(L.rowcell), I32(L.row), I32(L.prev), I32(L.next), U32(L.krow), U32(L.vslot));
         if (n > 0) {
             tb = L.tmp_bytes;
             AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.krow), U32(L.krow_s), U32(L.vslot), U32(L.order), (size_t)n, 0,
@@ -556,14 +577,18 @@ int avl_merge2_state_scatter(int64_t k, const int32_t* d_idx, const int64_t* d_i
     return AVL_OK;
 }
 
-int avl_merge2_side_state(int64_t n, int ws, const int64_t* h_start, const int64_t* h_side_off, const int32_t* d_order, const int32_t* d_next,
-                          const int64_t* d_state, int64_t* d_send, void* stream) {
-    AVL_REQUIRE(n >= 0 && ws >= 1 && ws <= kM2MaxRanks && h_start && h_side_off, "avl_merge2_side_state: bad arguments");
+int avl_merge2_side_state(int64_t n, int ws, const int64_t* h_cum, const int64_t* h_lo, const int64_t* h_side_off, const int32_t* d_order,
+                          const int32_t* d_next, const int64_t* d_state, int64_t* d_send, void* stream) {
+    AVL_REQUIRE(n >= 0 && ws >= 1 && ws <= kM2MaxRanks && h_cum && h_lo && h_side_off, "avl_merge2_side_state: bad arguments");
     if (n == 0) return AVL_OK;
     AVL_REQUIRE(d_order && d_next && d_send, "avl_merge2_side_state: null pointer");
     M2Seg sg;
-    for (int q = 0; q <= kM2MaxRanks; ++q) sg.start[q] = h_start[q < ws ? q : ws];
-    for (int q = 0; q < kM2MaxRanks; ++q) sg.side_off[q] = q < ws ? h_side_off[q] : 0;
+    for (int q = 0; q <= kM2MaxRanks; ++q) sg.cum[q] = h_cum[q < ws ? q : ws];
+    for (int q = 0; q < kM2MaxRanks; ++q) {
+        sg.lo[q] = q < ws ? h_lo[q] : 0;
+        sg.side_off[q] = q < ws ? h_side_off[q] : 0;
+    }
+    AVL_REQUIRE(sg.cum[ws] == n, "avl_merge2_side_state: the destination ranges cover %lld voxels, n = %lld", sg.cum[ws], (long long)n);
     hipLaunchKernelGGL(m2_side_state_kernel, dim3(m2_grid(n)), dim3(256), 0, as_stream(stream), (long long)n, ws, sg, d_order, d_next,
                        reinterpret_cast<const long long*>(d_state), reinterpret_cast<long long*>(d_send));
     AVL_HIP_CHECK(hipGetLastError());

@@ -16,7 +16,9 @@ process costs what the tenth does):
                 as float64 partial sums; rows this rank owns itself never leave (single-rank ones are written into the block directly)
     replay      exact sequential weight / colour (vlmap_builder.py:164-178 dtypes): voxels no lower rank holds replay at once on
                 every rank; for the shared ones 24 B of state hop rank -> next contributor, one small all_to_all per receiving rank
-    exchange    ONE all_to_all_single: per destination [side records 64 B | float32 rows | float64 rows]
+    exchange    ONE all_to_all_single: per destination [side records 64 B | float32 rows | float64 rows] -- or, for blocks above
+                AVLMAPS_MERGE_CHUNK_MB, one per chunk of R rows of every owner's block: pack(c + 1) / exchange(c) / fold(c - 1) overlap
+                (parallel._Coll.all_to_all_start / _finish), two send buffers of one chunk each
     fold        avl_merge2_fold: wave per row of the block, contributors summed in rank order, finished with finalize's expressions
 The same choreography runs on CPU tensors with the NumPy twin of the kernels (HostKernels: gloo tests, and what the GPU tests
 compare the HIP kernels with).  Keys that are not ordered by rank (frames not sharded contiguously) fall back to
@@ -40,28 +42,68 @@ def _bit_length(v: int) -> int:
     return max(1, int(v).bit_length())
 
 
-class Layout:
-    """where every list of the payload exchange lies, from the plan's ws x ws tables (identical arithmetic on every rank)"""
+def max_chunks(ws: int) -> int:
+    """how many chunks of an owner's block the plan can size (avl_merge2_max_chunks: its per-chunk tables sit in the LDS histogram)"""
+    return max(0, (12288 // (ws * ws) - 3) // 2)
 
-    def __init__(self, res: np.ndarray, rank: int, ws: int, D: int):
+
+class Plan:
+    """what every rank knows after avl_merge2_plan's read-back: M, the growth key, the ws x ws size tables [sender][owner] of the whole
+    exchange (A: voxels, Dn: the single-rank ones among them, H[prev][rank]: replay hops) and, when the exchange runs in chunks of
+    chunk_rows rows of every owner's block, the same two tables per chunk"""
+
+    def __init__(self, res: np.ndarray, rank: int, ws: int, D: int, chunk_rows: int = 0, nchunk: int = 0):
         W2 = ws * ws
         self.M = int(res[0])
         self.grow_key = int(res[1]) & U64_ALL_ONES
-        self.A = res[2:2 + W2].reshape(ws, ws).astype(np.int64)                # [sender][owner]: voxels
-        self.Dn = res[2 + W2:2 + 2 * W2].reshape(ws, ws).astype(np.int64)      # ... of one rank alone
-        self.H = res[2 + 2 * W2:2 + 3 * W2].reshape(ws, ws).astype(np.int64)   # [prev rank][rank]: replay hops
+        self.A = res[2:2 + W2].reshape(ws, ws).astype(np.int64)
+        self.Dn = res[2 + W2:2 + 2 * W2].reshape(ws, ws).astype(np.int64)
+        self.H = res[2 + 2 * W2:2 + 3 * W2].reshape(ws, ws).astype(np.int64)
         self.rank, self.ws, self.D = rank, ws, D
-        self.ldw = (D + 1) // 2                                                # words of a float32 row
         self.per = max(1, (self.M + ws - 1) // ws)
         self.r0 = min(self.M, rank * self.per)
         self.r1 = min(self.M, self.r0 + self.per)
+        if nchunk:
+            self.R = int(chunk_rows)
+            self.C = max(1, (self.per + self.R - 1) // self.R)
+            assert self.C <= nchunk, (self.C, nchunk)
+            t = res[2 + 3 * W2:2 + (3 + 2 * nchunk) * W2].reshape(nchunk, 2, ws, ws).astype(np.int64)
+            self.Ac, self.Dc = t[:self.C, 0], t[:self.C, 1]
+            assert np.array_equal(self.Ac.sum(0), self.A) and np.array_equal(self.Dc.sum(0), self.Dn), "merge2: the chunk tables do not add up"
+        else:
+            self.R, self.C = self.per, 1
+            self.Ac, self.Dc = self.A[None], self.Dn[None]
+        self.start = np.concatenate([[0], np.cumsum(self.A[rank])]).astype(np.int64)       # own voxels (final-row order) by destination
+        self.dstart = np.concatenate([[0], np.cumsum(self.Dn[rank])]).astype(np.int64)
+        self.n_own = self.r1 - self.r0
+
+    def layout(self, c: int) -> "Layout":
+        return Layout(self, c)
+
+
+class Layout:
+    """where every list of ONE payload exchange lies (the whole exchange, or chunk c of it): identical arithmetic on every rank"""
+
+    def __init__(self, P: Plan, c: int = 0):
+        rank, ws, D = P.rank, P.ws, P.D
+        self.P, self.c, self.rank, self.ws, self.D, self.per = P, c, rank, ws, D, P.per
+        self.A, self.Dn = P.Ac[c], P.Dc[c]
+        self.ldw = (D + 1) // 2                                                # words of a float32 row
+        self.own_r0 = P.r0
+        self.row_lo = min(P.r1, P.r0 + c * P.R)                                # this rank's rows of the chunk: [row_lo, row_lo + n_rows)
+        self.n_rows = max(0, min(P.R, P.r1 - self.row_lo))
+        before_a = P.Ac[:c, rank].sum(0) if c else np.zeros(ws, np.int64)
+        before_d = P.Dc[:c, rank].sum(0) if c else np.zeros(ws, np.int64)
+        self.lo = (P.start[:ws] + before_a).astype(np.int64)                    # first own voxel (final-row order) of the call per destination
+        self.dlo = (P.dstart[:ws] + before_d).astype(np.int64)                  # single-rank voxels before it
+        self.row0 = (np.arange(ws, dtype=np.int64) * P.per + c * P.R)           # first row of the chunk at every destination
+        self.cum = np.concatenate([[0], np.cumsum(self.A[rank])]).astype(np.int64)
+        self.n = int(self.cum[ws])
 
         def seg_words(p, q):
             a, d = int(self.A[p, q]), int(self.Dn[p, q])
             return a * 8 + d * self.ldw + (a - d) * D
         # send buffer: the remote destinations in rank order, this rank's own segment LAST (it never travels)
-        self.start = np.concatenate([[0], np.cumsum(self.A[rank])]).astype(np.int64)
-        self.dstart = np.concatenate([[0], np.cumsum(self.Dn[rank])]).astype(np.int64)[:ws]
         self.send_words = np.array([seg_words(rank, q) for q in range(ws)], dtype=np.int64)
         off, o = np.zeros(ws, np.int64), 0
         for q in list(range(rank)) + list(range(rank + 1, ws)) + [rank]:
@@ -78,7 +120,7 @@ class Layout:
         self.recv_total = int(self.recv_words.sum())
 
     def peer_lists(self, p):
-        """(buffer, side word offset, done word offset, part word offset, records) of what peer p contributes to this rank's block"""
+        """(buffer, side word offset, done word offset, part word offset, records) of what peer p contributes to this rank's rows"""
         a, d = int(self.A[p, self.rank]), int(self.Dn[p, self.rank])
         base = int(self.send_off[p]) if p == self.rank else int(self.recv_off[p])
         return ("send" if p == self.rank else "recv"), base, base + a * 8, base + a * 8 + d * self.ldw, a
@@ -119,7 +161,7 @@ class HostKernels:
         c[:self.n] = self.raw["first_key"][self.perm]
         c[nmax:].view(np.int32)[:self.n] = self.raw["cell"][self.perm]
 
-    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, grow_row, want_lists):
+    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, grow_row, want_lists, chunk_rows=0, nchunk=0):
         g = gathered.numpy()
         stride = nmax + (nmax + 1) // 2
         off = np.concatenate([[0], np.cumsum(n_all)]).astype(np.int64)
@@ -150,7 +192,7 @@ class HostKernels:
         keyrow[row[head]] = ekey[se][head]
         per = max(1, (M + ws - 1) // ws)
         q = np.minimum(row // per, ws - 1)
-        res = np.zeros(2 + 3 * ws * ws, np.int64)
+        res = np.zeros(2 + (3 + 2 * nchunk) * ws * ws, np.int64)
         res[0] = M
         res[1] = int(keyrow[grow_row]) if 0 <= grow_row < M else -1
         W2 = ws * ws
@@ -158,6 +200,10 @@ class HostKernels:
         single_e = (prev < 0) & (nxt < 0)
         np.add.at(res, 2 + W2 + (rs * ws + q)[single_e], 1)
         np.add.at(res, 2 + 2 * W2 + (prev * ws + rs)[prev >= 0], 1)
+        if nchunk:
+            c = np.minimum((row - q * per) // chunk_rows, nchunk - 1)
+            np.add.at(res, 2 + (3 + 2 * c) * W2 + rs * ws + q, 1)
+            np.add.at(res, 2 + (4 + 2 * c[single_e]) * W2 + (rs * ws + q)[single_e], 1)
         mine = rs == rank
         s = self.perm[se[mine] - off[rank]]
         n = self.n
@@ -194,15 +240,17 @@ class HostKernels:
         r, D = self.raw, self.D
         a1 = r["first_alpha"]
         for q in range(L.ws):
-            i0, i1 = int(L.start[q]), int(L.start[q + 1])
+            i0 = int(L.lo[q])
+            i1 = i0 + int(L.A[L.rank, q])
             if i1 == i0:
                 continue
             sl = self.order[i0:i1]
             is_new = self.prev[sl] < 0
             single = is_new & (self.next[sl] < 0)
-            didx = self.sidx[i0:i1].astype(np.int64) - int(L.dstart[q])
+            didx = self.sidx[i0:i1].astype(np.int64) - int(L.dlo[q])
             pidx = np.arange(i1 - i0) - didx
-            row_rel = self.row[sl].astype(np.int64) - q * L.per
+            row = self.row[sl].astype(np.int64)
+            row_rel = row - int(L.row0[q])
             direct = single & (q == L.rank) & (own_feat is not None)
             side = w[int(L.side_off[q]):int(L.side_off[q]) + 8 * (i1 - i0)].reshape(-1, 8)
             word = row_rel | (np.where(single, didx, pidx) << 32)
@@ -214,7 +262,7 @@ class HostKernels:
             nd = int(L.Dn[L.rank, q])
             done = w[int(L.done_off[q]):int(L.done_off[q]) + nd * L.ldw].view(np.float32).reshape(nd, 2 * L.ldw)
             if own_feat is not None and q == L.rank:
-                own_feat[row_rel[direct]] = fin[direct].astype(np.float32)
+                own_feat[(row - L.own_r0)[direct]] = fin[direct].astype(np.float32)
                 keep = single & ~direct
             else:
                 keep = single
@@ -228,7 +276,8 @@ class HostKernels:
     def side_state(self, send, L, state):
         w = send.numpy()
         for q in range(L.ws):
-            i0, i1 = int(L.start[q]), int(L.start[q + 1])
+            i0 = int(L.lo[q])
+            i1 = i0 + int(L.A[L.rank, q])
             if i1 == i0:
                 continue
             sl = self.order[i0:i1]
@@ -236,15 +285,23 @@ class HostKernels:
             last = (self.next[sl] < 0) if state is not None else np.zeros(i1 - i0, bool)
             side[:, 5:8] = np.where(last[:, None], state[sl] if state is not None else 0, 0)
 
-    def fold(self, send, recv, L, gs, vh, have_log, own_feat):
-        """returns the block as arrays + the twin's intermediate sums (w4, state, contributors) for the tests"""
-        n_own, D = L.r1 - L.r0, L.D
+    def new_block(self, n_own, D, own_feat):
+        return dict(grid_feat=own_feat, grid_pos=np.zeros((n_own, 3), np.int32), weight=np.zeros(n_own, np.float32),
+                    grid_rgb=np.zeros((n_own, 3), np.uint8), cell=np.zeros(n_own, np.int32),
+                    w4=np.zeros((n_own, 4)), state=np.zeros((n_own, 3), np.int64), part_rows=[], part_acc=[])       # (the twin's intermediates: tests)
+
+    def fold(self, send, recv, L, gs, vh, have_log, out):
+        """rows [L.row_lo, L.row_lo + L.n_rows) of the rank's block from one exchange; also keeps the twin's intermediate sums for the tests"""
+        n_own, D = L.n_rows, L.D
+        if n_own == 0:
+            return
+        b0 = L.row_lo - L.own_r0
         bufs = dict(send=send.numpy(), recv=recv.numpy() if recv is not None else None)
         w4 = np.zeros((n_own, 4))
         acc = np.zeros((n_own, D))
         ncontrib = np.zeros(n_own, np.int64)
         state = np.zeros((n_own, 3), np.int64)
-        feat = own_feat if own_feat is not None else np.zeros((n_own, D), np.float32)
+        feat = out["grid_feat"][b0:b0 + n_own]
         single_row = np.zeros(n_own, bool)
         seen = np.zeros(n_own, bool)
         for p in range(L.ws):                                            # rank order: reproducible float64 sums
@@ -255,7 +312,7 @@ class HostKernels:
             side = w[s_off:s_off + 8 * cnt].reshape(cnt, 8)
             word = side[:, 0].view(np.uint64)
             rows = (word & np.uint64(0xFFFFFFFF)).astype(np.int64)
-            assert (rows >= 0).all() and (rows < n_own).all() and (np.diff(rows) > 0).all(), "merge2: a peer's rows are not inside the block"
+            assert (rows >= 0).all() and (rows < n_own).all() and (np.diff(rows) > 0).all(), "merge2: a peer's rows are not inside the chunk"
             fidx = ((word >> np.uint64(32)) & np.uint64(0x3FFFFFFF)).astype(np.int64)
             sg = (word & np.uint64(SINGLE)) != 0
             dr = (word & np.uint64(DIRECT)) != 0
@@ -275,12 +332,20 @@ class HostKernels:
         assert not (single_row & (ncontrib > 1)).any()
         sh = ~single_row
         feat[sh] = (acc[sh] / w4[sh, :1]).astype(np.float32)
-        cell = self.rowcell[L.r0:L.r1]
-        pos = np.stack([cell // (gs * vh), (cell // vh) % gs, cell % vh], 1).astype(np.int32)
-        weight = w4[:, 0].astype(np.float32)
-        rgb = np.clip(w4[:, 1:4] / w4[:, :1] + 1e-9, 0, 255).astype(np.uint8)
-        return dict(grid_feat=feat, grid_pos=pos, weight=weight, grid_rgb=rgb, cell=cell.copy(), w4=w4, state=state, part_rows=np.nonzero(sh)[0],
-                    part_acc=acc[sh])
+        cell = self.rowcell[L.row_lo:L.row_lo + n_own]
+        out["cell"][b0:b0 + n_own] = cell
+        out["grid_pos"][b0:b0 + n_own] = np.stack([cell // (gs * vh), (cell // vh) % gs, cell % vh], 1).astype(np.int32)
+        out["weight"][b0:b0 + n_own] = w4[:, 0].astype(np.float32)
+        out["grid_rgb"][b0:b0 + n_own] = np.clip(w4[:, 1:4] / w4[:, :1] + 1e-9, 0, 255).astype(np.uint8)
+        out["w4"][b0:b0 + n_own] = w4
+        out["state"][b0:b0 + n_own] = state
+        out["part_rows"].append(np.nonzero(sh)[0] + b0)
+        out["part_acc"].append(acc[sh])
+
+    def finish_block(self, out):
+        out["part_rows"] = np.concatenate(out["part_rows"]) if out["part_rows"] else np.zeros(0, np.int64)
+        out["part_acc"] = np.concatenate(out["part_acc"]) if out["part_acc"] else np.zeros((0, self.D))
+        return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------------
@@ -328,19 +393,20 @@ class HipKernels:
             chunk[nmax:].view(self.torch.int32)[:self.n].copy_(self._cell[:self.n])
         del self._key, self._cell
 
-    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, grow_row, want_lists):
+    def plan(self, gathered, n_all, nmax, rank, ws, cell_bits, grow_row, want_lists, chunk_rows=0, nchunk=0):
         import ctypes as C
         t = self.torch
         E = int(sum(n_all))
         nb = C.c_size_t()
-        self.check(self.lib.avl_merge2_work_bytes(E, self.n, ws, C.byref(nb)), "avl_merge2_work_bytes")
+        self.check(self.lib.avl_merge2_work_bytes(E, self.n, ws, int(nchunk), C.byref(nb)), "avl_merge2_work_bytes")
         self.work = t.empty(int(nb.value), dtype=t.uint8, device=self.device)
         h_n = (C.c_int64 * ws)(*[int(v) for v in n_all])
         h_off = (C.c_int64 * 11)()
-        nres = 2 + 3 * ws * ws
+        nres = 2 + (3 + 2 * int(nchunk)) * ws * ws
         h_res = (C.c_int64 * nres)()
         self.check(self.lib.avl_merge2_plan(ws, rank, h_n, int(nmax), gathered.data_ptr(), self.perm.data_ptr(), int(cell_bits), int(grow_row),
-                                            1 if want_lists else 0, self.work.data_ptr(), int(nb.value), h_off, h_res, self.st), "avl_merge2_plan")
+                                            1 if want_lists else 0, int(chunk_rows), int(nchunk), self.work.data_ptr(), int(nb.value), h_off, h_res,
+                                            self.st), "avl_merge2_plan")
         base = self.work.data_ptr()
         names = ("row", "prev", "next", "order", "sidx", "selA", "selB", "idx_prev", "idx_next", "rowcell", "res")
         self.p = {k: base + int(h_off[i]) for i, k in enumerate(names)}
@@ -370,27 +436,34 @@ class HipKernels:
 
     def pack(self, send, L, own_feat):
         p = self.p
-        self.check(self.lib.avl_builder_m2_pack(self.acc._h, self.n, L.ws, L.rank, L.per, self._i64s(L.start), self._i64s(L.dstart), self._i64s(L.side_off),
-                                                self._i64s(L.done_off), self._i64s(L.part_off), p["order"], p["row"], p["prev"], p["next"], p["sidx"],
-                                                send.data_ptr(), own_feat.data_ptr() if own_feat is not None else None, self.st), "avl_builder_m2_pack")
+        self.check(self.lib.avl_builder_m2_pack(self.acc._h, L.n, L.ws, L.rank, L.own_r0, self._i64s(L.cum), self._i64s(L.lo), self._i64s(L.dlo),
+                                                self._i64s(L.row0), self._i64s(L.side_off), self._i64s(L.done_off), self._i64s(L.part_off),
+                                                p["order"], p["row"], p["prev"], p["next"], p["sidx"], send.data_ptr(),
+                                                own_feat.data_ptr() if own_feat is not None else None, self.st), "avl_builder_m2_pack")
 
     def side_state(self, send, L, state):
-        self.check(self.lib.avl_merge2_side_state(self.n, L.ws, self._i64s(L.start), self._i64s(L.side_off), self.p["order"], self.p["next"],
+        self.check(self.lib.avl_merge2_side_state(L.n, L.ws, self._i64s(L.cum), self._i64s(L.lo), self._i64s(L.side_off), self.p["order"], self.p["next"],
                                                   state.data_ptr() if state is not None else None, send.data_ptr(), self.st), "avl_merge2_side_state")
 
-    def fold(self, send, recv, L, gs, vh, have_log, own_feat):
+    def new_block(self, n_own, D, own_feat):
         import ctypes as C
         t = self.torch
-        n_own, D = L.r1 - L.r0, L.D
-        out = dict(grid_feat=own_feat if own_feat is not None else t.empty((n_own, D), dtype=t.float32, device=self.device),
-                   grid_pos=t.empty((n_own, 3), dtype=t.int32, device=self.device),
-                   weight=t.empty((n_own,), dtype=t.float32, device=self.device),
-                   grid_rgb=t.empty((n_own, 3), dtype=t.uint8, device=self.device),
-                   cell=t.empty((n_own,), dtype=t.int32, device=self.device))
         self.err = t.zeros(1, dtype=t.int32, device=self.device)
+        return dict(grid_feat=own_feat, grid_pos=t.empty((n_own, 3), dtype=t.int32, device=self.device),
+                    weight=t.empty((n_own,), dtype=t.float32, device=self.device), grid_rgb=t.empty((n_own, 3), dtype=t.uint8, device=self.device),
+                    cell=t.empty((n_own,), dtype=t.int32, device=self.device))
+
+    def fold(self, send, recv, L, gs, vh, have_log, out):
+        """rows [L.row_lo, L.row_lo + L.n_rows) of the rank's block from one exchange"""
+        import ctypes as C
+        t = self.torch
+        n, D = L.n_rows, L.D
+        if n == 0:
+            return
         nb = C.c_size_t()
-        self.check(self.lib.avl_merge2_fold_work_bytes(n_own, L.ws, C.byref(nb)), "avl_merge2_fold_work_bytes")
-        table = t.empty(int(nb.value), dtype=t.uint8, device=self.device)          # (torch's blocks are 512-byte aligned)
+        self.check(self.lib.avl_merge2_fold_work_bytes(n, L.ws, C.byref(nb)), "avl_merge2_fold_work_bytes")
+        if getattr(self, "_table", None) is None or self._table.numel() < int(nb.value):
+            self._table = t.empty(int(nb.value), dtype=t.uint8, device=self.device)          # (torch's blocks are 512-byte aligned)
         ptr = dict(send=send.data_ptr(), recv=recv.data_ptr() if recv is not None else 0)
         side, done, part, cnt = [], [], [], []
         for p in range(L.ws):
@@ -400,10 +473,14 @@ class HipKernels:
             part.append(ptr[which] + 8 * p_off)
             cnt.append(c)
         vps = lambda a: (C.c_void_p * len(a))(*a)
-        self.check(self.lib.avl_merge2_fold(n_own, L.r0, L.ws, D, gs, vh, vps(side), vps(done), vps(part), self._i64s(cnt), self.p["rowcell"],
-                                            1 if have_log else 0, out["grid_feat"].data_ptr(), out["grid_pos"].data_ptr(), out["weight"].data_ptr(),
-                                            out["grid_rgb"].data_ptr(), out["cell"].data_ptr(), table.data_ptr(), int(nb.value), self.err.data_ptr(), self.st),
-                   "avl_merge2_fold")
+        b0 = L.row_lo - L.own_r0
+        self.check(self.lib.avl_merge2_fold(n, L.row_lo, L.ws, D, gs, vh, vps(side), vps(done), vps(part), self._i64s(cnt), self.p["rowcell"],
+                                            1 if have_log else 0, out["grid_feat"].data_ptr() + 4 * D * b0, out["grid_pos"].data_ptr() + 12 * b0,
+                                            out["weight"].data_ptr() + 4 * b0, out["grid_rgb"].data_ptr() + 3 * b0, out["cell"].data_ptr() + 4 * b0,
+                                            self._table.data_ptr(), int(self._table.numel()), self.err.data_ptr(), self.st), "avl_merge2_fold")
+
+    def finish_block(self, out):
+        self._table = None
         return out
 
 
@@ -411,7 +488,7 @@ class HipKernels:
 def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0, timings: Optional[dict] = None, sync=None):
     """The choreography, shared by the device path (K = HipKernels) and its twin (K = HostKernels).  coll: parallel._Coll or None
     (one process).  Returns None when the keys are not ordered by rank (the caller falls back to the general plan), else
-    (out dict, Layout, info dict)."""
+    (out dict, Plan, info dict)."""
     import torch
     rank, ws = (coll.rank, coll.ws) if coll is not None else (0, 1)
     sync = sync or (lambda: None)
@@ -448,50 +525,93 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
         mark("plan: header + lists out")
     if coll is not None:
         coll.all_gather_into(gathered, chunk)
-    res = K.plan(gathered, n_all, nmax, rank, ws, cell_bits, grow_row, have_log and ws > 1)
+    # the payload goes in chunks of R rows of every owner's block once a block is larger than that: export -> all_to_all -> fold of
+    # neighbouring chunks overlap (nccl: the exchange runs on the backend's stream) and the buffers are O(chunk), not O(local voxels).
+    # R: AVLMAPS_MERGE_CHUNK_MB (default 1024) of float64 payload per owner and chunk -- a chunk costs a rank ~0.25 ms of launches and
+    # hand-overs (profiles/r06_merge_chunks_probe.txt: 1 / 3 / 5 / 18 chunks at the bench's 8-rank merge), ~2 % of what it spends on the wire
+    per_max = max(1, -(-sum(n_all) // ws))
+    R = int(os.environ.get("AVLMAPS_MERGE_CHUNK_ROWS", "0")) or max(1024, (int(os.environ.get("AVLMAPS_MERGE_CHUNK_MB", "1024")) << 20) // (8 * D + 64))
+    nchunk = 0
+    if coll is not None and ws > 1 and 0 < R < per_max and max_chunks(ws) >= 2:
+        nchunk = -(-per_max // R)
+        if nchunk > max_chunks(ws):
+            R = -(-per_max // max_chunks(ws))
+            nchunk = -(-per_max // R)
+    res = K.plan(gathered, n_all, nmax, rank, ws, cell_bits, grow_row, have_log and ws > 1, R, nchunk)
     if trace:
         mark("plan: kernels + read-back")
-    L = Layout(res, rank, ws, D)
+    P = Plan(res, rank, ws, D, R, nchunk)
+    Ls = [P.layout(c) for c in range(P.C)]
     del gathered, chunk
     mark("plan")
-    n_own = L.r1 - L.r0
-    own_feat = None
+    n_own = P.n_own
     if K.device != "cpu":
         own_feat = torch.empty((n_own, D), dtype=torch.float32, device=K.device)
     else:
         own_feat = np.zeros((n_own, D), np.float32)
-    send = K.new_words(L.send_total)
-    K.pack(send, L, own_feat)
+    out = K.new_block(n_own, D, own_feat)
+    words = max(L.send_total for L in Ls)
+    sends = [K.new_words(words) for _ in range(min(2, P.C))]
+    K.pack(sends[0], Ls[0], own_feat)
     mark("pack")
     # ---- exact sequential weight / colour: at once where no lower rank holds the voxel, hop by hop where ranks share it
     state = None
     chain_bytes = 0
     if have_log:
         state = K.new_state()
-        K.replay("A", state, L.grow_key)
+        K.replay("A", state, P.grow_key)
         if ws > 1:
-            po = np.concatenate([[0], np.cumsum(L.H[:, rank])]).astype(np.int64)          # my voxels grouped by prev rank
-            no = np.concatenate([[0], np.cumsum(L.H[rank, :])]).astype(np.int64)          # ... by next rank
+            po = np.concatenate([[0], np.cumsum(P.H[:, rank])]).astype(np.int64)          # my voxels grouped by prev rank
+            no = np.concatenate([[0], np.cumsum(P.H[rank, :])]).astype(np.int64)          # ... by next rank
             for q in range(1, ws):
-                if not L.H[:, q].any():
+                if not P.H[:, q].any():
                     continue                                            # nobody shares a voxel with q's predecessors: every rank skips the round
-                k_out = int(L.H[rank, q]) if rank < q else 0
-                out = K.state_gather(state, int(no[q]), int(no[q]) + k_out) if k_out else torch.zeros(0, dtype=torch.int64, device=send.device)
+                k_out = int(P.H[rank, q]) if rank < q else 0
+                hop = K.state_gather(state, int(no[q]), int(no[q]) + k_out) if k_out else torch.zeros(0, dtype=torch.int64, device=sends[0].device)
                 ins = [0] * ws
                 ins[q] = 3 * k_out
-                outs = [3 * int(L.H[p, q]) if rank == q else 0 for p in range(ws)]
-                got = coll.all_to_all(out, ins, outs)
+                outs = [3 * int(P.H[p, q]) if rank == q else 0 for p in range(ws)]
+                got = coll.all_to_all(hop, ins, outs)
                 chain_bytes += 24 * k_out
                 if rank == q and got.numel():
                     K.state_scatter(state, got, 0, int(po[ws]))
-                    K.replay("B", state, L.grow_key)
-    K.side_state(send, L, state)
+                    K.replay("B", state, P.grow_key)
+    K.side_state(sends[0], Ls[0], state)
     mark("replay")
-    recv = None
-    if coll is not None and ws > 1:
-        recv = coll.all_to_all(send[:L.remote_words], L.in_splits(), L.out_splits())
-    mark("exchange")
-    out = K.fold(send, recv, L, gs, vh, have_log, own_feat)
+    exchanging = coll is not None and ws > 1
+    if P.C == 1:
+        recv = coll.all_to_all(sends[0][:Ls[0].remote_words], Ls[0].in_splits(), Ls[0].out_splits()) if exchanging else None
+        mark("exchange")
+        K.fold(sends[0], recv, Ls[0], gs, vh, have_log, out)
+    else:
+        # chunk c + 1 is packed while chunk c travels and chunk c - 1 folds; a send buffer is reused two chunks later, after its
+        # exchange was finished and its fold issued on this stream
+        ex = [0.0, 0.0, 0.0]                                             # wall, in collectives, waiting for a shared GPU: of the exchange calls
+
+        def clocked(fn, *a):
+            t0, c0, l0 = time.perf_counter(), coll.comm_s, coll.gpu_lock.wait_s
+            r = fn(*a)
+            ex[0] += time.perf_counter() - t0
+            ex[1] += coll.comm_s - c0
+            ex[2] += coll.gpu_lock.wait_s - l0
+            return r
+
+        def start(c):
+            return coll.all_to_all_start(sends[c % 2][:Ls[c].remote_words], Ls[c].in_splits(), Ls[c].out_splits(), overlap=not trace)
+        loop0 = marks[-1]
+        h = clocked(start, 0)
+        for c in range(P.C):
+            if c + 1 < P.C:
+                K.pack(sends[(c + 1) % 2], Ls[c + 1], own_feat)
+                K.side_state(sends[(c + 1) % 2], Ls[c + 1], state)
+            recv = clocked(coll.all_to_all_finish, h)
+            if c + 1 < P.C:
+                h = clocked(start, c + 1)
+            K.fold(sends[c % 2], recv, Ls[c], gs, vh, have_log, out)
+        del h
+        # the exchange calls' share of the loop, booked as the "exchange" phase (the rest of the loop is the fold's)
+        marks.append(("exchange", loop0[1] + ex[0], loop0[2] + ex[1], loop0[3] + ex[2]))
+    out = K.finish_block(out)
     if trace:
         mark("fold: kernels")
     err = getattr(K, "err", None)
@@ -502,7 +622,7 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
             raise RuntimeError(f"multi-rank merge: the fold found an inconsistent exchange (flags {int(err.item())})")
     if trace:
         mark("fold: flags")
-    del send, recv
+    del sends, recv
     if timings is not None and not trace:
         sync()
     mark("fold")
@@ -511,8 +631,9 @@ def merge_sharded_v2(K, coll, D, cell_bits, grow_row, gs, vh, have_log, status=0
         steps = [(b[0], 1e3 * ((b[1] - a[1]) - (b[2] - a[2]) - (b[3] - a[3]))) for a, b in zip(marks[:-1], marks[1:])]
         print(f"[merge2 trace] rank {rank}: " + " | ".join(f"{k} {v:.2f}" for k, v in steps) + " (own ms)", file=sys.stderr, flush=True)
         marks[:] = [m for m in marks if ":" not in m[0]]
-    info = dict(marks=marks, n_all=n_all, have_log=have_log, chain_bytes=chain_bytes, n_own=n_own)
-    return out, L, info
+    info = dict(marks=marks, n_all=n_all, have_log=have_log, chain_bytes=chain_bytes, n_own=n_own, chunks=P.C, chunk_rows=P.R,
+                remote_words=sum(int(L.remote_words) for L in Ls), buffer_words=words * len(Ls[:2]))
+    return out, P, info
 
 
 def _phase_times(marks):
@@ -571,7 +692,7 @@ def merge_accumulator_v2(acc, group, exact_rgb, timings, gather_to, status, gloc
         A, Dn = L.A, L.Dn
         sent_all = int(A[rank].sum() - A[rank, rank])
         sent_done = int(Dn[rank].sum() - Dn[rank, rank])
-        payload = 8 * int(L.remote_words)
+        payload = 8 * int(info["remote_words"])
         plan_bytes = (12 * int(max(info["n_all"])) * (ws - 1) + 32 * (ws - 1)) if coll is not None else 0
         names = dict(plan="plan", pack="export", replay="replay_chain", exchange="exchange", fold="fold_finalize", gather="gather")
         wall_s = {names[k]: v for k, v in wall.items()}
@@ -593,7 +714,8 @@ def merge_accumulator_v2(acc, group, exact_rgb, timings, gather_to, status, gloc
                        bytes_sent_per_rank=payload + plan_bytes + info["chain_bytes"] + gather_bytes,
                        local_row_bytes=n * W * 8, dense_reduce_payload_bytes=L.M * W * 8, exact_rgb=bool(info["have_log"]),
                        collectives=(coll.calls if coll else 0), world_size=ws, backend=(coll.dist.get_backend(coll.group) if coll is not None else "none"),
-                       rows_sent_single=sent_done)
+                       rows_sent_single=sent_done, exchange_chunks=info["chunks"], exchange_chunk_rows=info["chunk_rows"],
+                       exchange_buffer_bytes=8 * info["buffer_words"])
     return res
 
 
@@ -614,6 +736,6 @@ def merge_raw_sharded_v2(raw, group=None, replay_fn=None, gs2: Optional[int] = N
     rank = L.rank
     sent_all = int(L.A[rank].sum() - L.A[rank, rank])
     res = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in out.items()}
-    res.update(M=L.M, rows=(L.r0, L.r1), grow_key=L.grow_key, bytes_sent=8 * int(L.remote_words), plan="gather",
-               payload_bytes_fp64_form=sent_all * ((K.D + 4) * 8 + 8), layout=L, chain_bytes=info["chain_bytes"])
+    res.update(M=L.M, rows=(L.r0, L.r1), grow_key=L.grow_key, bytes_sent=8 * int(info["remote_words"]), plan="gather",
+               payload_bytes_fp64_form=sent_all * ((K.D + 4) * 8 + 8), layout=L, chain_bytes=info["chain_bytes"], chunks=info["chunks"])
     return res

@@ -283,6 +283,35 @@ class _Coll:
         self._toc(inp, t0, row_b * sum(int(c) for r, c in enumerate(in_splits) if r != self.rank))
         return res
 
+    def all_to_all_start(self, inp, in_splits, out_splits, overlap=True):
+        """all_to_all that may still be in flight when this returns: with nccl (= RCCL) and device tensors the exchange is queued on the
+        backend's stream behind the work already on the current one and the caller goes on issuing kernels; all_to_all_finish makes the
+        current stream wait for it and hands out the received tensor.  Staged (gloo) and empty exchanges complete here.  Only the host
+        time of the two calls is booked to comm_s for an exchange in flight -- the transfer itself hides under the caller's kernels or
+        shows up where the caller next drains the device."""
+        in_splits, out_splits = [int(x) for x in in_splits], [int(x) for x in out_splits]
+        if (not overlap or self.stage or not inp.is_cuda or os.environ.get("AVLMAPS_MERGE_ASYNC", "1") == "0"
+                or inp.shape[0] == 0 or sum(out_splits) == 0):
+            return ("done", self.all_to_all(inp, in_splits, out_splits))
+        import time
+        t0 = time.perf_counter()
+        out = inp.new_empty((int(sum(out_splits)),) + tuple(inp.shape[1:]))
+        work = self.dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
+        self.comm_s += time.perf_counter() - t0
+        row_b = inp.element_size() * int(inp.numel() // inp.shape[0])
+        self.bytes_out += row_b * sum(c for r, c in enumerate(in_splits) if r != self.rank)
+        self.calls += 1
+        return ("flying", work, out, inp)
+
+    def all_to_all_finish(self, handle):
+        if handle[0] == "done":
+            return handle[1]
+        import time
+        t0 = time.perf_counter()
+        handle[1].wait()                            # the current stream waits for the backend's; the host does not
+        self.comm_s += time.perf_counter() - t0
+        return handle[2]
+
     def send(self, t, dst):
         t0 = self._tic(t)
         h = self._h(t).contiguous()

@@ -512,14 +512,18 @@ AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, 
  *                     h_res[2 + 3 ws^2] (host; the call synchronises once to deliver it): M, the first-touch key of row grow_row
  *                     (-1 if M <= grow_row), then three ws x ws tables [sender p][receiver q]: voxels of p whose row q owns, the
  *                     single-rank ones among them, voxels of q whose previous contributor is p.
- *   avl_builder_m2_pack   sender: own voxels in final-row order -> the send buffer of the ONE payload all_to_all (int64 words).
- *                     Destination q gets own voxels [h_start[q], h_start[q + 1]) (h_dstart[q] single-rank voxels precede them):
- *                     64-byte side records at word h_side_off[q] ([row - q * per | list index << 32 | single << 63 | direct << 62,
+ *                     With nchunk > 0 (<= avl_merge2_max_chunks; chunk_rows * nchunk must cover ceil(sum n / ws) rows) h_res continues
+ *                     with nchunk x two ws x ws tables: the first two tables restricted to rows [q per + c chunk_rows, q per + (c + 1)
+ *                     chunk_rows) of every owner q's block (per = ceil(M / ws)) -- the sizes of an exchange done chunk by chunk.
+ *   avl_builder_m2_pack   sender, ONE exchange (the whole payload or one chunk of it): the n voxels of the call in destination order --
+ *                     wave w serves rank q with h_cum[q] <= w < h_cum[q + 1] and is voxel h_lo[q] + (w - h_cum[q]) of d_order (the
+ *                     rank's final-row order; h_dlo[q] single-rank voxels precede h_lo[q] there) -> the send buffer (int64 words):
+ *                     64-byte side records at word h_side_off[q] ([row - h_row0[q] | list index << 32 | single << 63 | direct << 62,
  *                     sum_w4 (4 x f64), 3 zero words]), finished float32 rows of single-rank voxels at h_done_off[q] (row stride
  *                     (D + 1) / 2 words), float64 partial rows of shared voxels at h_part_off[q].  d_own_feat (nullable): this rank's
- *                     block of grid_feat -- single-rank voxels whose row it owns are written there directly (`direct`).
- *   avl_merge2_side_state  after the replay: words 5..7 of every side record = the replay state (d_state n x 3 i64, nullable) where
- *                     this rank is the voxel's last contributor (d_next < 0), zeros elsewhere.
+ *                     block of grid_feat (first row own_r0) -- single-rank voxels whose row it owns are written there directly (`direct`).
+ *   avl_merge2_side_state  after the replay: words 5..7 of the call's side records (same h_cum / h_lo) = the replay state (d_state n x 3
+ *                     i64, nullable) where this rank is the voxel's last contributor (d_next < 0), zeros elsewhere.
  *   avl_merge2_state_gather / _scatter   the 24-byte replay states of the listed voxels <-> a contiguous hop buffer.
  *   avl_merge2_fold   owner: the block [r0, r0 + n_own) from what the peers sent (h_side / h_done / h_part: per peer the device
  *                     addresses of its three lists, h_count[p] records; the rank's own lists stay in its send buffer): contributors
@@ -530,16 +534,17 @@ AVL_API int avl_merge2_load(void);   /* load the merge's code object now (avl_bu
 AVL_API int avl_merge2_prepare_work_bytes(int64_t n, size_t* h_bytes);
 AVL_API int avl_merge2_prepare(int64_t n, const int64_t* d_key, const int32_t* d_cell, int key_bits, int64_t flags, int64_t* d_key_sorted,
                                int32_t* d_cell_sorted, int32_t* d_perm, int64_t* d_hdr, void* d_work, size_t work_bytes, void* stream);
-AVL_API int avl_merge2_work_bytes(int64_t n_entries, int64_t n_own, int ws, size_t* h_bytes);
+AVL_API int avl_merge2_max_chunks(int ws, int* h_max);    /* how many chunks of an owner's block the plan can size (tables in LDS) */
+AVL_API int avl_merge2_work_bytes(int64_t n_entries, int64_t n_own, int ws, int nchunk, size_t* h_bytes);
 AVL_API int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, const int64_t* d_gathered, const int32_t* d_perm,
-                            int cell_bits, int64_t grow_row, int want_replay_lists, void* d_work, size_t work_bytes, int64_t* h_off,
-                            int64_t* h_res, void* stream);
-AVL_API int avl_builder_m2_pack(avl_builder* b, int64_t n, int ws, int rank, int64_t per, const int64_t* h_start, const int64_t* h_dstart,
-                                const int64_t* h_side_off, const int64_t* h_done_off, const int64_t* h_part_off, const int32_t* d_order,
-                                const int32_t* d_row, const int32_t* d_prev, const int32_t* d_next, const int32_t* d_sidx, int64_t* d_send,
-                                float* d_own_feat, void* stream);
-AVL_API int avl_merge2_side_state(int64_t n, int ws, const int64_t* h_start, const int64_t* h_side_off, const int32_t* d_order,
-                                  const int32_t* d_next, const int64_t* d_state, int64_t* d_send, void* stream);
+                            int cell_bits, int64_t grow_row, int want_replay_lists, int64_t chunk_rows, int nchunk, void* d_work,
+                            size_t work_bytes, int64_t* h_off, int64_t* h_res, void* stream);
+AVL_API int avl_builder_m2_pack(avl_builder* b, int64_t n, int ws, int rank, int64_t own_r0, const int64_t* h_cum, const int64_t* h_lo,
+                                const int64_t* h_dlo, const int64_t* h_row0, const int64_t* h_side_off, const int64_t* h_done_off,
+                                const int64_t* h_part_off, const int32_t* d_order, const int32_t* d_row, const int32_t* d_prev,
+                                const int32_t* d_next, const int32_t* d_sidx, int64_t* d_send, float* d_own_feat, void* stream);
+AVL_API int avl_merge2_side_state(int64_t n, int ws, const int64_t* h_cum, const int64_t* h_lo, const int64_t* h_side_off,
+                                  const int32_t* d_order, const int32_t* d_next, const int64_t* d_state, int64_t* d_send, void* stream);
 AVL_API int avl_merge2_state_gather(int64_t k, const int32_t* d_idx, const int64_t* d_state, int64_t* d_out, void* stream);
 AVL_API int avl_merge2_state_scatter(int64_t k, const int32_t* d_idx, const int64_t* d_in, int64_t* d_state, void* stream);
 AVL_API int avl_merge2_fold(int64_t n_own, int64_t r0, int ws, int D, int gs, int vh, const void* const* h_side, const void* const* h_done,

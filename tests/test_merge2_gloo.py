@@ -88,6 +88,8 @@ def _worker(rank, ws, port, tmpdir):
     D, cellsets, raws = make_world(ws)
     sh = merge2.merge_raw_sharded_v2(raws[rank], replay_fn=fake_replay(rank, raws[rank]["cell"].numpy()), gs2=7, gs=GS, vh=VH, ncell=400)
     cells, table = check_block(sh, rank, ws, D, cellsets, raws)
+    R = int(os.environ.get("AVLMAPS_MERGE_CHUNK_ROWS", "0"))
+    assert sh["chunks"] == (-(-max(1, -(-len(cells) // ws)) // R) if 0 < R < -(-sum(len(c) for c in cellsets) // ws) else 1)
     # the blocks, gathered, are the dense single-reduce result of parallel.merge_raw
     dense = parallel.merge_raw(raws[rank], dst=0)
     blocks = [None] * ws
@@ -111,8 +113,11 @@ def _worker(rank, ws, port, tmpdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ws", [2, 3, 8])
-def test_gather_plan_merge_gloo(tmp_path, ws):
+@pytest.mark.parametrize("ws,chunk_rows", [(2, None), (3, None), (8, None), (3, 7), (8, 3)])
+def test_gather_plan_merge_gloo(tmp_path, monkeypatch, ws, chunk_rows):
+    """chunk_rows: the payload exchange in chunks of that many rows of every owner's block (merge2.merge_sharded_v2), same blocks"""
+    if chunk_rows:
+        monkeypatch.setenv("AVLMAPS_MERGE_CHUNK_ROWS", str(chunk_rows))
     port = _free_port()
     mp.spawn(_worker, args=(ws, port, str(tmp_path)), nprocs=ws, join=True)
     assert all((tmp_path / f"m2_{r}").exists() for r in range(ws))
@@ -136,7 +141,32 @@ def test_layout_is_the_same_arithmetic_on_both_sides():
     Dn = (A * rng.random((ws, ws))).astype(np.int64)
     H = np.triu(rng.integers(0, 9, (ws, ws)), 1)
     res = np.concatenate([[int(A.sum()) // 2, -1], A.ravel(), Dn.ravel(), H.ravel()]).astype(np.int64)
-    Ls = [merge2.Layout(res, r, ws, D) for r in range(ws)]
+    Ls = [merge2.Plan(res, r, ws, D).layout(0) for r in range(ws)]
+    check_layouts(Ls, A, Dn, ws, D)
+    # the same exchange in three chunks: per-chunk tables that add up to the whole ones
+    parts = rng.random((3, ws, ws))
+    Ac = np.floor(A[None] * parts / parts.sum(0)).astype(np.int64)
+    Ac[2] = A - Ac[:2].sum(0)
+    Dc = np.minimum(Ac, np.floor(Dn[None] * parts / parts.sum(0)).astype(np.int64))
+    Dc[2] = Dn - Dc[:2].sum(0)
+    Dc[2] = np.clip(Dc[2], 0, Ac[2])
+    Dn3 = Dc.sum(0)
+    M = int(A.sum()) // 2
+    R = -(-(-(-M // ws)) // 3)
+    res3 = np.concatenate([[M, -1], A.ravel(), Dn3.ravel(), H.ravel(), np.stack([Ac, Dc], 1).ravel()]).astype(np.int64)
+    Ps = [merge2.Plan(res3, r, ws, D, R, 3) for r in range(ws)]
+    assert all(P.C == 3 for P in Ps)
+    for c in range(3):
+        Lc = [P.layout(c) for P in Ps]
+        check_layouts(Lc, Ac[c], Dc[c], ws, D)
+        for r in range(ws):
+            assert Lc[r].row_lo == min(Ps[r].r1, Ps[r].r0 + c * R) and (Lc[r].row0 == np.arange(ws) * Ps[r].per + c * R).all()
+    for r in range(ws):
+        assert sum(P.layout(c).n_rows for c in range(3) for P in [Ps[r]]) == Ps[r].n_own
+        assert (Ps[r].layout(2).lo + Ac[2][r] == Ps[r].start[1:]).all()          # the chunks of a destination are consecutive stretches of the order
+
+
+def check_layouts(Ls, A, Dn, ws, D):
     for p in range(ws):
         assert Ls[p].in_splits()[p] == 0 and Ls[p].out_splits()[p] == 0
         assert Ls[p].send_total == sum(Ls[p].send_words) and Ls[p].remote_words == sum(Ls[p].in_splits())
@@ -181,3 +211,18 @@ def test_gather_plan_merge_random_worlds_over_threads(ws, seed):
         M = len(cells)
     assert sum(o["rows"][1] - o["rows"][0] for o in outs) == M
     assert [c for o in outs for c in o["cell"].tolist()] == cells
+    assert all(o["chunks"] == 1 for o in outs)
+    # the same worlds with the exchange in chunks of a few rows: the same blocks, bit for bit, in buffers of a chunk
+    R = int(rng.integers(1, 9))
+    os.environ["AVLMAPS_MERGE_CHUNK_ROWS"] = str(R)
+    try:
+        outs_c = run_ranks(ws, rank_fn)
+    finally:
+        del os.environ["AVLMAPS_MERGE_CHUNK_ROWS"]
+    per_max = -(-sum(len(c) for c in cellsets) // ws)
+    if R < per_max and merge2.max_chunks(ws) >= 2:
+        assert all(o["chunks"] == outs_c[0]["chunks"] for o in outs_c) and outs_c[0]["chunks"] >= min(2, -(-max(1, -(-M // ws)) // R))
+    for a, b in zip(outs, outs_c):
+        for k in ("cell", "grid_feat", "grid_pos", "weight", "grid_rgb", "w4", "state", "part_rows", "part_acc"):
+            assert torch.equal(a[k], b[k]), k
+        assert a["bytes_sent"] == b["bytes_sent"] and a["rows"] == b["rows"] and a["grow_key"] == b["grow_key"]

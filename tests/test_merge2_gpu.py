@@ -56,10 +56,37 @@ def test_gather_plan_merge_on_device_equals_the_single_process_map_and_the_twin(
     check_merge_world(ops, ws, D)
 
 
-def check_merge_world(ops, ws, D, **scene):
+@pytest.mark.parametrize("ws,D,chunk_rows", [(2, 64, 500), (3, 30, 97), (8, 64, 64), (8, 5, 1000)])
+def test_gather_plan_merge_in_chunks(ops, ws, D, chunk_rows):
+    """the payload exchange in chunks of chunk_rows rows of every owner's block (double-buffered send buffers, pack of chunk c + 1
+    issued before chunk c folds): the same map"""
+    check_merge_world(ops, ws, D, chunk_rows=chunk_rows)
+
+
+def test_overlapped_all_to_all_over_rccl():
+    """parallel._Coll.all_to_all_start / _finish on RCCL with the one rank a 1-GPU box can run (tests/dist_a2a_worker.py)"""
+    import os
+    import subprocess
+    from test_parallel_gloo import _free_port
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               AVLMAPS_FORCE_COLLECTIVES="1")
+    env.pop("AVLMAPS_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve().parent / "dist_a2a_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "A2A_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def check_merge_world(ops, ws, D, chunk_rows=None, **scene):
     """(also the body of tools/fuzz_merge2.py's random worlds)"""
+    import os
     import torch
     from avlmaps_amd import merge2
+    if chunk_rows:
+        os.environ["AVLMAPS_MERGE_CHUNK_ROWS"] = str(chunk_rows)
+        try:
+            return check_merge_world(ops, ws, D, None, _chunked=chunk_rows, **scene)
+        finally:
+            del os.environ["AVLMAPS_MERGE_CHUNK_ROWS"]
+    chunked = scene.pop("_chunked", None)
     whole, shards, gs, vh = build_shards(ops, ws, D=D, **scene)
     want = whole.finalize()
     M = len(want["grid_pos"])
@@ -100,6 +127,10 @@ def check_merge_world(ops, ws, D, **scene):
         assert np.array_equal(o["grid_pos"], t["grid_pos"]) and np.array_equal(o["cell"], t["cell"])
         shared += int(L.A[r].sum() - L.Dn[r].sum())
         assert info["have_log"]
+        if chunked and ws > 1 and chunked < -(-sum(info["n_all"]) // ws) and merge2.max_chunks(ws) >= 2:
+            assert info["chunks"] == L.C == twin[r][2]["chunks"], (info["chunks"], L.C, twin[r][2]["chunks"])
+            assert L.C >= min(2, -(-max(1, -(-M // ws)) // chunked)), (L.C, M, ws, chunked)
+            assert info["buffer_words"] == min(2, L.C) * max(int(L.layout(c).send_total) for c in range(L.C))     # two chunks, not the whole payload
     if ws > 1 and not scene:
         assert shared > 50, shared                                                 # the point of the test: voxels several ranks touched
     # against the single-process build: a voxel of one rank is bit-identical, a shared one differs by the float64 summation order

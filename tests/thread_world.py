@@ -79,6 +79,12 @@ class ThreadColl:
         self.bytes_out += 8 * (sum(in_splits) - in_splits[self.rank])
         return self._round((inp, list(in_splits)), take)
 
+    def all_to_all_start(self, inp, in_splits, out_splits, overlap=True):
+        return ("done", self.all_to_all(inp, in_splits, out_splits))
+
+    def all_to_all_finish(self, handle):
+        return handle[1]
+
     def all_reduce(self, t, op):
         import torch
         return self._round(t, lambda s: torch.stack([x for x in s]).max(0).values)

@@ -19,17 +19,22 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
 _lib.load()
 _lib.require_gpu()
-t0, n, fails = time.time(), 0, 0
+t0, n, fails, nchunked = time.time(), 0, 0, 0
 while time.time() - t0 < budget:
     ws = int(rng.integers(1, 9))
     cfg = dict(D=int(rng.choice([3, 5, 16, 30, 64, 256, 512, 768])), nfr=int(rng.integers(max(2, ws), 33)), seed=int(rng.integers(0, 1 << 30)),
                rate=int(rng.choice([1, 3, 5, 11])), cs=float(rng.choice([0.05, 0.1, 0.3])), gs=int(rng.choice([120, 400, 1000])))
     D = cfg.pop("D")
+    if rng.random() < 0.5:
+        cfg["chunk_rows"] = int(rng.choice([1, 17, 100, 1000, 5000]))          # the payload exchange in chunks of that many rows per owner
+        nchunked += 1
     try:
         T.check_merge_world(ops, ws, D, **cfg)
     except Exception as e:      # noqa: BLE001
         fails += 1
-        print(f"FAIL ws={ws} D={D} {cfg}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+        import traceback
+        tb = traceback.extract_tb(e.__traceback__)[-1]
+        print(f"FAIL ws={ws} D={D} {cfg}: {type(e).__name__}: {str(e)[:300]} at {tb.filename.split('/')[-1]}:{tb.lineno} `{tb.line}`", flush=True)
     n += 1
-print(f"fuzz_merge2: {n} worlds (1-8 ranks, D 3-768), {fails} failures, seed {seed}")
+print(f"fuzz_merge2: {n} worlds (1-8 ranks, D 3-768; {nchunked} with a chunked exchange), {fails} failures, seed {seed}")
 sys.exit(1 if fails else 0)

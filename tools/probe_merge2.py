@@ -59,7 +59,7 @@ def main():
         wall, comm, _ = merge2._phase_times(info["marks"])
         return dict(n=n, M=L.M, total_ms=1e3 * (time.perf_counter() - t0), compute_ms=round(1e3 * sum(wall[k] - comm[k] for k in wall), 3),
                     phases_ms={k: round(1e3 * (wall[k] - comm[k]), 3) for k in wall},
-                    shared=int(L.A[r].sum() - L.Dn[r].sum()), sent_MB=round(8e-6 * L.remote_words, 1))
+                    shared=int(L.A[r].sum() - L.Dn[r].sum()), sent_MB=round(8e-6 * info["remote_words"], 1), chunks=info["chunks"])
 
     for rep in range(reps):
         if rep == reps - 1:
