@@ -884,40 +884,106 @@ __global__ __launch_bounds__(AVL_K3_THREADS) AVL_K3_OCC(CH) void pipe_kernel(Fra
     }
 }
 
-// generic feature width: one 256-float chunk at a time, re-walking the (short) list per chunk
+// generic feature width (D > 1536).  A voxel's samples are summed in ASCENDING SAMPLE ORDER like fuse_group_impl does, so that two runs
+// of a build give the same bits: the wave orders up to 64 members at a time (ranks from wave-wide compares, the order parked in LDS)
+// and adds them 64 columns x kGenTile column groups at a time from registers; a list of more than 64 members is taken in ROUNDS -- every
+// round re-walks it and keeps the 64 smallest sample indices above the previous round's largest -- whose partial sums are added to the
+// row one after the other (a fixed association, whatever order the atomics of K2 arrived in).
+constexpr int kGenTile = 8;
 __global__ __launch_bounds__(256) void fuse_generic_kernel(int P, int D, unsigned long long frame_key,
                                                            const BatchEntry* __restrict__ batch, int P_frame, Recs recs,
                                                            int32_t* __restrict__ head, const float* __restrict__ feat,
                                                            double* __restrict__ sum_feat, double* __restrict__ sum_w4,
                                                            float* __restrict__ first_feat, double* __restrict__ first_alpha,
                                                            unsigned long long* __restrict__ slot_key, uint8_t* __restrict__ dirty) {
+    __shared__ int ord_s[4][64];
     const int lane = threadIdx.x & 63;
+    int* ord = ord_s[(threadIdx.x >> 6) & 3];
     const int s0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (s0 >= P) return;
     if (!recs.owner[s0]) return;
     const int32_t slot = recs.slot[s0];
     const bool is_new = slot_key[slot] == kNoKey;
     const int h0 = head[slot];
-    int min_s = INT_MAX;
-    double a1 = 0.0, w4 = 0.0;
-    for (int cur = h0; cur >= 0; cur = recs.next[cur]) {
-        const double alpha = recs.alpha[cur];
-        if (cur < min_s) { min_s = cur; a1 = alpha; }
-        const uint32_t rgbv = recs.rgb[cur];
-        if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
+    auto wave_max = [&](int v) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o));
+        return v;
+    };
+    // one walk: the size of the list, its smallest sample (the first touch) and -- all a short list needs -- its first 64 members
+    int n_total = 0, min_s = INT_MAX, held = INT_MAX;
+    for (int cur = h0; cur >= 0 && (unsigned)cur < (unsigned)P && n_total < P; cur = recs.next[cur]) {
+        if (n_total < 64 && lane == n_total) held = cur;
+        min_s = min(min_s, cur);
+        ++n_total;
     }
+    if (n_total == 0) return;      // (a corrupted list: never -- the owner is on its own list)
+    const double a1 = recs.alpha[min_s];
+    const float* row1 = (batch ? batch[min_s / P_frame].feat : feat) + (size_t)recs.fpix[min_s] * D;
     double* sf = sum_feat + (size_t)slot * D;
     float* ff = first_feat + (size_t)slot * D;
-    for (int d = lane; d < D; d += 64) {
-        double acc = 0.0;
-        float f1 = 0.f;
-        for (int cur = h0; cur >= 0; cur = recs.next[cur]) {
-            const float v = (batch ? batch[cur / P_frame].feat : feat)[(size_t)recs.fpix[cur] * D + d];
-            if (cur == min_s) f1 = v;
-            if (!(is_new && cur == min_s)) acc += recs.alpha[cur] * (double)v;   // the first touch of a new voxel stays out of the sum (fuse_body)
+    if (is_new)
+        for (int d = lane; d < D; d += 64) ff[d] = row1[d];
+    double w4 = 0.0;
+    int prev = -1;
+    bool first_round = true;
+    for (int done = 0; done < n_total;) {
+        int m;
+        if (n_total <= 64) {
+            m = n_total;
+        } else {
+            // the 64 smallest sample indices above `prev`: lanes fill up, then a smaller newcomer replaces the largest one held
+            held = INT_MAX;
+            int cnt = 0, curmax = -1, steps = 0;
+            for (int cur = h0; cur >= 0 && (unsigned)cur < (unsigned)P && steps < P; cur = recs.next[cur], ++steps) {
+                if (cur <= prev) continue;
+                if (cnt < 64) {
+                    if (lane == cnt) held = cur;
+                    if (++cnt == 64) curmax = wave_max(held);
+                } else if (cur < curmax) {
+                    const unsigned long long at = __ballot(held == curmax);
+                    if (lane == __ffsll((long long)at) - 1) held = cur;
+                    curmax = wave_max(held);
+                }
+            }
+            m = cnt;
+            if (m == 0) break;     // (a corrupted list: never)
         }
-        sf[d] = is_new ? acc : sf[d] + acc;
-        if (is_new) ff[d] = f1;
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += __builtin_amdgcn_readlane(held, j) < held ? 1 : 0;
+        if (lane < m) ord[rank] = held;
+        __builtin_amdgcn_wave_barrier();
+        prev = ord[m - 1];
+        for (int k = 0; k < m; ++k) {
+            const int cur = ord[k];
+            const double alpha = recs.alpha[cur];
+            const uint32_t rgbv = recs.rgb[cur];
+            if (lane < 4) w4 += lane == 0 ? alpha : alpha * (double)((rgbv >> (8 * (lane - 1))) & 0xffu);
+        }
+        for (int d0 = 0; d0 < D; d0 += 64 * kGenTile) {
+            double acc[kGenTile];
+#pragma unroll
+            for (int t = 0; t < kGenTile; ++t) acc[t] = 0.0;
+            for (int k = 0; k < m; ++k) {
+                const int cur = ord[k];
+                if (is_new && cur == min_s) continue;            // the first touch of a new voxel stays out of the sum (fuse_group_impl)
+                const double alpha = recs.alpha[cur];
+                const float* row = (batch ? batch[cur / P_frame].feat : feat) + (size_t)recs.fpix[cur] * D;
+#pragma unroll
+                for (int t = 0; t < kGenTile; ++t) {
+                    const int d = d0 + t * 64 + lane;
+                    if (d < D) acc[t] += alpha * (double)row[d];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kGenTile; ++t) {
+                const int d = d0 + t * 64 + lane;
+                if (d < D) sf[d] = (is_new && first_round) ? acc[t] : sf[d] + acc[t];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        done += m;
+        first_round = false;
     }
     if (lane < 4) {
         double* w = sum_w4 + (size_t)slot * 4 + lane;

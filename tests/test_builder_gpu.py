@@ -204,10 +204,10 @@ def test_far_voxels_keep_their_direction(ops, mode):
     assert clear.mean() > 0.99 and np.array_equal(am[clear], np.argmax(want, axis=1)[clear])
 
 
-@pytest.mark.parametrize("D", [5, 30, 257, 768, 1024, 1536])
+@pytest.mark.parametrize("D", [5, 30, 257, 768, 1024, 1536, 1600, 2050])
 def test_builder_feature_widths(ops, D):
-    """every register-chunk variant of K3 (D <= 256 / 512 / 1024), rows that are not 16-byte multiples, and the generic kernel
-    (D > 1024: a fused visual | audio map is built at D = 1536) against the sequential oracle -- frame by frame, deferred,
+    """every register-chunk variant of K3 (D <= 256 / 512 / 768 / 1024 / 1536: a fused visual | audio map is built at D = 1536), rows that
+    are not 16-byte multiples, and the generic kernel (D > 1536) against the sequential oracle -- frame by frame, deferred,
     batched; the three GPU modes give the same ids / colour / weight and the same features to fp64 rounding"""
     from oracle import avl_oracle as O
     rng = np.random.default_rng(100 + D)
@@ -628,13 +628,15 @@ def test_finalize_rows_ships_only_changed_and_new_rows(ops, golden):
     assert 0 < changed[:n0].sum() < n0
 
 
-def test_builder_is_bitwise_reproducible(ops):
+@pytest.mark.parametrize("D,rate,cs,lo,hi", [(512, 3, 0.25, 2.5, 30), (1600, 1, 0.5, 40, 1000)])
+def test_builder_is_bitwise_reproducible(ops, D, rate, cs, lo, hi):
     """K3 sums the samples of a voxel in ascending sample order (up to 64 per voxel and launch), not in the arrival order of
-    their atomics: repeated runs, the deferred mode and the frame-by-frame mode give the same bits in every output"""
+    their atomics: repeated runs, the deferred mode and the frame-by-frame mode give the same bits in every output.  The generic-width
+    kernel (D = 1600) orders lists of ANY length (rounds of 64): every pixel into coarse cells, single frames and batched launches"""
     from oracle import avl_oracle as O
     rng = np.random.default_rng(23)
-    H, W, Hf, Wf, D, nfr, rate = 90, 120, 44, 59, 512, 6, 3
-    gs, cam_h, cs = 80, 1.6, 0.25
+    H, W, Hf, Wf, nfr = 90, 120, 44, 59, 6
+    gs, cam_h = 80, 1.6
     calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
     depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
     b2c, bt = O.setup_transforms([1, 0, 0, 0, -1, 0, 0, 0, -1], cam_h, [0, 0, -1], [-1, 0, 0], [0, 1, 0])
@@ -646,10 +648,25 @@ def test_builder_is_bitwise_reproducible(ops):
         acc = run_gpu_builder(ops, gs, cs, cam_h, calib, Ts, depths, rgbs, feats, samples, capacity=50_000, replay=True, deferred=deferred)
         runs.append(acc.finalize())
         pts, groups = acc.num_points(), acc.num_groups()
-    assert 2.5 < pts / groups < 30, pts / groups                       # the point of the test: several samples per voxel and frame
+    assert lo < pts / groups < hi, pts / groups                        # the point of the test: several samples per voxel and frame
     for r in runs[1:]:
         for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight", "grid_feat"):
             assert np.array_equal(r[k], runs[0][k]), k
+    if D > 1536:
+        # batched launches: lists of hundreds of members (three frames' samples of a voxel in one list), twice -> the same bits
+        fs = [np.ascontiguousarray(np.transpose(f, (1, 2, 0))) for f in feats]
+        both = []
+        for _ in range(2):
+            acc = ops.VoxelAccumulator(gs, cs, int(cam_h / cs), D, capacity=50_000)
+            acc.enable_replay_log(sum(len(x) for x in samples))
+            for i0 in (0, 3):
+                acc.integrate_batch(list(depths[i0:i0 + 3]), calib, Ts[i0:i0 + 3], samples[i0:i0 + 3], fs[i0:i0 + 3], list(rgbs[i0:i0 + 3]), frame_idx0=i0)
+            both.append(acc.finalize())
+        for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight", "grid_feat"):
+            assert np.array_equal(both[0][k], both[1][k]), k
+        for k in ("grid_pos", "occupied_ids", "grid_rgb", "weight"):
+            assert np.array_equal(both[0][k], runs[0][k]), k
+        np.testing.assert_allclose(both[0]["grid_feat"], runs[0]["grid_feat"], rtol=1e-6, atol=1e-6)
 
 
 def test_deferred_fuse_heavy_collisions_and_mixed_calls(ops):

@@ -99,7 +99,15 @@ def test_map_attribute_surface_and_obstacles():
     assert VLMapBuilder(Path("/tmp"), cfg, None, [], [], None, None).create_camera_map() is NotImplementedError
 
 
-def test_map_file_is_the_reference_hdf5_layout(tmp_path):
+@pytest.fixture(params=["H5Dwrite", "H5Dwrite_chunk"])
+def chunk_writes(request, monkeypatch):
+    """large chunked datasets are written chunk by chunk with H5Dwrite_chunk (h5lite.H5File._write_whole_chunks); here: every one, or none"""
+    from avlmaps_amd.utils import h5lite
+    monkeypatch.setattr(h5lite.H5File, "DIRECT_CHUNK_BYTES", 0 if request.param == "H5Dwrite_chunk" else 1 << 62)
+    return request.param
+
+
+def test_map_file_is_the_reference_hdf5_layout(tmp_path, chunk_writes):
     """save_3d_map writes a real HDF5 file with the six dataset names / dtypes / shapes of the reference writer
     (mapping_utils.py:499-505) -- through h5py, or through the HDF5 C library where h5py is missing -- and load_3d_map reads
     it back as the reference reader does (:508-541); init_height_id is a 0-d int32 dataset like upstream's"""
@@ -213,7 +221,7 @@ def test_h5lite_extendible_datasets_and_foreign_files(tmp_path):
             assert "testdouble" in f.keys() and f.read("testdouble").dtype == np.float64
 
 
-def test_map_file_writer_incremental_checkpoints(tmp_path):
+def test_map_file_writer_incremental_checkpoints(tmp_path, chunk_writes):
     """MapFileWriter: after the first full save only dirty + new rows (and the new cells of occupied_ids) are written; the
     file read back is always the complete current map in the reference's layout"""
     from avlmaps_amd.utils import h5lite
