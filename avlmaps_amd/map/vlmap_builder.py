@@ -499,12 +499,24 @@ class VLMapBuilder:
                 if g[5] is not None:
                     self._stager.release(g[5])        # depth / rgb / samples are read by these launches only (features: deferred)
             group.clear()
+        # steps of the fusing thread that took longer than 50 ms (a cold process has a few: the first frames of the stream, the
+        # accumulator's allocation, a checkpoint): build_times["slow_steps"] = [(seconds, frame, what)], what a stalled build is asked first
+        slow = self.build_times["slow_steps"] = []
+        t_lap = [time.perf_counter()]
+
+        def lap(what, frame):
+            t = time.perf_counter()
+            if t - t_lap[0] > 0.05 and len(slow) < 32:
+                slow.append((round(t - t_lap[0], 4), int(frame), what))
+            t_lap[0] = t
         for frame_i, rgb, depth, samples, staged in self._frame_stream(lo, hi, depth_sample_rate, skip_shuffles=skip, stage=stage):
+            lap("waiting for the frame stream", frame_i)
             if self.skip_mapped_frames and acc is not None and frame_i in mapped_iter_set and frame_i in self._resumed_frames:
                 continue        # the pixel shuffle of the skipped frame was still drawn, so later frames sample as upstream
             t_ext = time.perf_counter()
             feat = self._features_hwc(rgb)
             t_ext = time.perf_counter() - t_ext
+            lap("feature extractor", frame_i)
             if acc is None:
                 D = int(feat.shape[2])
                 self.clip_feat_dim = D
@@ -524,6 +536,7 @@ class VLMapBuilder:
                     # ranks: the replay state is chained through the ranks in frame order, parallel.merge_accumulator)
                     npix = depth.shape[0] * depth.shape[1]
                     acc.enable_replay_log((hi - lo) * ((npix + depth_sample_rate - 1) // depth_sample_rate))
+                lap("accumulator set-up (allocation, resume, replay log)", frame_i)
             if staged is not None:
                 # the frame's arrays are already on their way to the device (page-locked slot, copy stream): the fusing stream
                 # waits for them on the device, the host does not
@@ -578,6 +591,7 @@ class VLMapBuilder:
                         probation = None
                 pending_storage = rng_
             mapped_iter_set.add(frame_i)
+            lap("fusing (launches, group bookkeeping)", frame_i)
             if ws == 1 and self.save_every and frame_i % self.save_every == self.save_every - 1:
                 issue_group()
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
@@ -587,6 +601,7 @@ class VLMapBuilder:
                 self._checkpoint(acc, mapped_iter_set)
                 self.build_times["checkpoints_on_fusing_thread_s"] += time.perf_counter() - t_ck
                 self.build_times["checkpoints"] += 1
+                lap("checkpoint", frame_i)
             elif ws > 1 and self.save_every and (frame_i - lo) % self.save_every == self.save_every - 1 and rounds_done < rounds_total:
                 # upstream saves every 100 frames (vlmap_builder.py:181-183); with several ranks a checkpoint is a merge, i.e. a
                 # collective: every rank joins round j after its (j + 1) * save_every-th frame (or at the end of its shard)
@@ -594,7 +609,9 @@ class VLMapBuilder:
                 self._flush(acc, pending, calib_mat, calib_inv, transforms)
                 self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=False)
                 rounds_done += 1
+                lap("checkpoint round (merge)", frame_i)
         issue_group()
+        lap("last launches", hi)
         if acc is None:
             if ws == 1:
                 raise RuntimeError("no frames to map")
@@ -610,6 +627,7 @@ class VLMapBuilder:
         if self._stager is not None:
             self._stager.close()                       # waits for the launches that still read its slots
             self._stager = None
+        lap("draining the device (stager close)", hi)
         while ws > 1 and rounds_done < rounds_total:      # a short (or empty) shard: the checkpoint rounds the others still run
             self._checkpoint_ranks(acc, mapped_iter_set, rank, ws, final=False)
             rounds_done += 1
@@ -810,7 +828,10 @@ class VLMapBuilder:
         if background and self.skip_busy_checkpoints and prev is not None and prev.is_alive():
             self.checkpoints_skipped = getattr(self, "checkpoints_skipped", 0) + 1
             return
+        import time
+        t_join = time.perf_counter()
         self._join_save()
+        t_join = time.perf_counter() - t_join
         writer = getattr(self, "_map_writer", None)
         lean_ok = (self.incremental_checkpoints and h5lite.available() and writer is not None and writer.n_saved is not None
                    and writer.mirror is not None and writer.path == Path(self.map_save_path) and writer.path.exists())
@@ -852,9 +873,15 @@ class VLMapBuilder:
             self._save_thread = threading.Thread(target=write, name="avl-save", daemon=False)
             self._save_thread.start()
         else:
+            t_w = time.perf_counter()
             write()
             self._join_save()
             self.last_map = writer.current_map()
+            if hasattr(self, "build_times"):      # the final save of a build, in parts: waiting for the previous checkpoint's writer, rows to the host, file
+                st = writer.stats[-1] if writer.stats else {}
+                self.build_times["final_save_parts"] = dict(wait_for_writer_s=t_join, changed_rows_to_host_s=log[-1][1], file_s=time.perf_counter() - t_w,
+                                                            rows_written=st.get("rows_written"), rows_total=st.get("rows_total"),
+                                                            mirror_s=st.get("mirror_seconds"))
 
     def _join_save(self) -> None:
         prev = getattr(self, "_save_thread", None)

@@ -106,6 +106,7 @@ def _lib():
         "H5Tget_class": (C.c_int, [hid]), "H5Tget_size": (C.c_size_t, [hid]), "H5Tget_sign": (C.c_int, [hid]), "H5Tclose": (C.c_int, [hid]),
         "H5Pcreate": (hid, [hid]), "H5Pset_chunk": (C.c_int, [hid, C.c_int, C.POINTER(hsz)]), "H5Pclose": (C.c_int, [hid]),
         "H5Pset_alloc_time": (C.c_int, [hid, C.c_int]), "H5Pset_fill_time": (C.c_int, [hid, C.c_int]),
+        "H5Dget_create_plist": (hid, [hid]), "H5Pget_chunk": (C.c_int, [hid, C.c_int, C.POINTER(hsz)]), "H5Pget_layout": (C.c_int, [hid]),
         "H5Lexists": (C.c_int, [hid, C.c_char_p, hid]),
         "H5Gget_num_objs": (C.c_int, [hid, C.POINTER(hsz)]),
         "H5Gget_objname_by_idx": (C.c_ssize_t, [hid, hsz, C.c_char_p, C.c_size_t]),
@@ -397,9 +398,26 @@ class H5File:
         finally:
             lib.H5Dclose(dset)
 
+    def _chunk_rows(self, dset, shape) -> int:
+        """rows per chunk if the dataset is chunked in whole rows, else 0"""
+        lib = _lib()
+        pl = lib.H5Dget_create_plist(dset)
+        if pl < 0:
+            return 0
+        try:
+            if lib.H5Pget_layout(pl) != 2:                   # H5D_CHUNKED
+                return 0
+            cd = (C.c_uint64 * max(1, len(shape)))()
+            if lib.H5Pget_chunk(pl, len(shape), cd) != len(shape) or tuple(int(c) for c in cd)[1:] != tuple(shape[1:]):
+                return 0
+            return int(cd[0])
+        finally:
+            lib.H5Pclose(pl)
+
     def write_row_runs(self, name: str, runs, array: np.ndarray):
         """dset[r0:r1] = array[r0:r1] for every (r0, r1) of `runs`: the dataset is opened once and each run goes out as one
-        contiguous hyperslab straight from `array` (which holds ALL rows of the dataset's current extent)"""
+        contiguous hyperslab straight from `array` (which holds ALL rows of the dataset's current extent) -- or, when the runs are
+        made of whole chunks (MapFileWriter's are) and large, chunk by chunk with H5Dwrite_chunk like a full save"""
         lib = _lib()
         array = np.ascontiguousarray(array)
         dset = self._open(name)
@@ -407,16 +425,34 @@ class H5File:
             shape, dt = self._info(dset)
             if array.dtype != dt or tuple(array.shape[1:]) != shape[1:] or array.shape[0] > shape[0]:
                 raise H5Error(f"write_row_runs({name}): array {array.shape} {array.dtype} does not fit dataset {shape} {dt}")
+            runs = [(int(a), int(b)) for a, b in runs if int(b) > int(a)]
+            for r0, r1 in runs:
+                if r1 > array.shape[0]:
+                    raise H5Error(f"write_row_runs({name}): run [{r0}, {r1}) beyond the array")
+            row_bytes = int(np.prod(shape[1:], dtype=np.int64)) * dt.itemsize if len(shape) > 1 else dt.itemsize
+            if (lib.has_write_chunk and _LITTLE_ENDIAN and len(shape) >= 2 and array.shape[0] == shape[0]
+                    and sum(b - a for a, b in runs) * row_bytes >= self.DIRECT_CHUNK_BYTES):
+                cr = self._chunk_rows(dset, shape)
+                if cr and all(a % cr == 0 and (b % cr == 0 or b == shape[0]) for a, b in runs):
+                    off = (C.c_uint64 * len(shape))()
+                    cb = cr * row_bytes
+                    base = array.ctypes.data
+                    for r0, r1 in runs:
+                        for c0 in range(r0, r1, cr):
+                            off[0] = c0
+                            if c0 + cr <= shape[0]:
+                                rc = lib.H5Dwrite_chunk(dset, 0, 0, off, cb, base + c0 * row_bytes)
+                            else:                             # the partial last chunk of the dataset: padded with zeros
+                                tail = np.zeros((cr,) + tuple(shape[1:]), dtype=dt)
+                                tail[:shape[0] - c0] = array[c0:]
+                                rc = lib.H5Dwrite_chunk(dset, 0, 0, off, cb, tail.ctypes.data)
+                            if rc < 0:
+                                raise H5Error(f"H5Dwrite_chunk({name}, row {c0}) failed")
+                    return
             fspace = lib.H5Dget_space(dset)
             mtype = _tid(_TYPES[dt][1])
-            row_bytes = int(np.prod(shape[1:], dtype=np.int64)) * dt.itemsize if len(shape) > 1 else dt.itemsize
             try:
                 for r0, r1 in runs:
-                    r0, r1 = int(r0), int(r1)
-                    if r1 <= r0:
-                        continue
-                    if r1 > array.shape[0]:
-                        raise H5Error(f"write_row_runs({name}): run [{r0}, {r1}) beyond the array")
                     start = _dims((r0,) + (0,) * (len(shape) - 1))
                     count = _dims((r1 - r0,) + shape[1:])
                     _ok(lib.H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, None, count, None), "H5Sselect_hyperslab")

@@ -900,7 +900,10 @@ def run_pipeline_probe(torch, frames=300):
                                                      # the frame loop alone (decode queue, sampling, pinned staging, kernels, the periodic
                                                      # checkpoints' share of the fusing thread) and the final save of the whole map
                                                      frame_loop_frames_per_s=frames / bt["frame_loop_s"], final_save_s=bt["final_save_s"],
+                                                     final_save_parts={k: (round(v, 4) if isinstance(v, float) else v)
+                                                                       for k, v in (bt.get("final_save_parts") or {}).items()},
                                                      checkpoints_skipped_writer_busy=bt.get("checkpoints_skipped", 0),
+                                                     slow_steps_over_50ms=bt.get("slow_steps", []),
                                                      host_threads={k: bt.get(k) for k in ("sampler_busy_s", "sampler_workers", "sampler_workers_busy_s",
                                                                                           "stager_busy_s", "fuse_thread_wait_s",
                                                                                           "checkpoints_on_fusing_thread_s")})
