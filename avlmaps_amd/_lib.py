@@ -8,7 +8,7 @@ import threading
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = Path(os.environ.get("AVLMAPS_HIP_LIB", _PKG / "lib" / "libavlmaps_hip.so"))
+LIB_PATH = Path(os.environ.get("AVLMAPS_HIP_LIB") or _PKG / "lib" / "libavlmaps_hip.so")       # (an empty variable = the stock library)
 
 AVL_OK = 0
 SIM_AUTO, SIM_EXACT, SIM_SPLIT_F16, SIM_EXACT_VALU, SIM_PREPARED, SIM_PREPARED24 = 0, 1, 2, 3, 4, 5

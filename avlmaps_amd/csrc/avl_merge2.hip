@@ -32,6 +32,14 @@
 
 #include "avl_common.h"
 
+// rocPRIM's radix sort falls back to a merge sort below 2^20 items: ~18 block-merge launches of 5 us each for a rank's 290 k voxels, four
+// times per merge.  Onesweep from 4 096 items on (a histogram + one pass per 8 key bits): fewer, fuller launches
+// (profiles/r06_merge2_8ranks_one_process_kernel_stats.csv has the merge-sort form).
+#ifndef AVL_M2_MERGE_SORT_LIMIT
+#define AVL_M2_MERGE_SORT_LIMIT 4096
+#endif
+using M2SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, AVL_M2_MERGE_SORT_LIMIT>;
+
 namespace avl {
 
 constexpr int kM2MaxRanks = 64;
@@ -379,9 +387,9 @@ struct M2Layout {
 static int m2_layout(long long E, long long n, int ws, int nchunk, M2Layout& L) {
     const size_t e = (size_t)(E > 0 ? E : 1), m = (size_t)(n > 0 ? n : 1);
     size_t t_cell = 0, t_row = 0, t_small = 0, t_scan = 0, t_scan_e = 0;
-    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_cell, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, e, 0, 32, nullptr));
-    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_row, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, 32, nullptr));
-    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t_small, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 8, nullptr));
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(nullptr, t_cell, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, e, 0, 32, nullptr));
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(nullptr, t_row, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, m, 0, 32, nullptr));
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(nullptr, t_small, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 8, nullptr));
     {
         auto it = rocprim::make_transform_iterator((const uint8_t*)nullptr, FlagToI32{});
         AVL_HIP_CHECK(rocprim::exclusive_scan(nullptr, t_scan, it, (int32_t*)nullptr, 0, m, rocprim::plus<int32_t>(), nullptr));
@@ -424,7 +432,7 @@ int avl_merge2_prepare_work_bytes(int64_t n, size_t* h_bytes) {
     AVL_REQUIRE(h_bytes && n >= 0 && n < (1ll << 31), "avl_merge2_prepare_work_bytes: bad arguments");
     size_t t = 0;
     const size_t m = (size_t)(n > 0 ? n : 1);
-    AVL_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 64,
+    AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(nullptr, t, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, m, 0, 64,
                                             nullptr));
     *h_bytes = m2_al(m * 4) + m2_al(t ? t : 16) + 256;
     return AVL_OK;
@@ -445,7 +453,7 @@ int avl_merge2_prepare(int64_t n, const int64_t* d_key, const int32_t* d_cell, i
         void* tmp = base + m2_al((size_t)n * 4);
         size_t tb = need - 256 - m2_al((size_t)n * 4);
         hipLaunchKernelGGL(m2_iota_kernel, dim3(m2_grid(n)), dim3(256), 0, st, (long long)n, iota);
-        AVL_HIP_CHECK(rocprim::radix_sort_pairs(tmp, tb, reinterpret_cast<const unsigned long long*>(d_key), reinterpret_cast<unsigned long long*>(d_key_sorted),
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(tmp, tb, reinterpret_cast<const unsigned long long*>(d_key), reinterpret_cast<unsigned long long*>(d_key_sorted),
                                                 iota, d_perm, (size_t)n, 0, key_bits, st));
     }
     hipLaunchKernelGGL(m2_presorted_kernel, dim3(n > 0 ? m2_grid(n) : 1), dim3(256), 0, st, (long long)n, d_cell, d_perm,
@@ -519,7 +527,7 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
         uint8_t* headflag = reinterpret_cast<uint8_t*>(base + L.headflag);
         hipLaunchKernelGGL(m2_compact_kernel, dim3(m2_grid(E)), dim3(256), 0, st, E, ws, o, stride, (long long)nmax, g, U32(L.ecell), U32(L.eidx), erank);
         size_t tb = L.tmp_bytes;
-        AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.ecell), U32(L.scell), U32(L.eidx), U32(L.se), (size_t)E, 0, cell_bits, st));
+        AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(base + L.tmp, tb, U32(L.ecell), U32(L.scell), U32(L.eidx), U32(L.se), (size_t)E, 0, cell_bits, st));
         hipLaunchKernelGGL(m2_segments_kernel, dim3(m2_grid(E)), dim3(256), 0, st, E, U32(L.scell), U32(L.se), erank, U32(L.hp),
                            reinterpret_cast<uint16_t*>(base + L.pn), headflag, res);
         {
@@ -532,7 +540,7 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
                            d_perm, (long long)grow_row, (long long)(nchunk ? chunk_rows : 1), nchunk, res, I32(L.rowcell), I32(L.row), I32(L.prev), I32(L.next), U32(L.krow), U32(L.vslot));
         if (n > 0) {
             tb = L.tmp_bytes;
-            AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.krow), U32(L.krow_s), U32(L.vslot), U32(L.order), (size_t)n, 0,
+            AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(base + L.tmp, tb, U32(L.krow), U32(L.krow_s), U32(L.vslot), U32(L.order), (size_t)n, 0,
                                                     std::max(1, bit_length((unsigned long long)E)), st));
             uint8_t* single = reinterpret_cast<uint8_t*>(base + L.single);
             hipLaunchKernelGGL(m2_own_kernel, dim3(m2_grid(n)), dim3(256), 0, st, n, ws, I32(L.order), I32(L.prev), I32(L.next), single,
@@ -543,9 +551,9 @@ int avl_merge2_plan(int ws, int rank, const int64_t* h_n_all, int64_t nmax, cons
             if (want_replay_lists && ws > 1) {
                 const int rb = std::max(1, bit_length((unsigned long long)ws));
                 tb = L.tmp_bytes;
-                AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.kp), U32(L.kps), I32(L.order), I32(L.idx_prev), (size_t)n, 0, rb, st));
+                AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(base + L.tmp, tb, U32(L.kp), U32(L.kps), I32(L.order), I32(L.idx_prev), (size_t)n, 0, rb, st));
                 tb = L.tmp_bytes;
-                AVL_HIP_CHECK(rocprim::radix_sort_pairs(base + L.tmp, tb, U32(L.kn), U32(L.kps), I32(L.order), I32(L.idx_next), (size_t)n, 0, rb, st));
+                AVL_HIP_CHECK(rocprim::radix_sort_pairs<M2SortCfg>(base + L.tmp, tb, U32(L.kn), U32(L.kps), I32(L.order), I32(L.idx_next), (size_t)n, 0, rb, st));
             }
         }
         AVL_HIP_CHECK(hipGetLastError());
