@@ -685,6 +685,8 @@ def _run_ranks(nproc, args, port, timeout=900, **env_extra):
 @pytest.mark.parametrize("nproc,n_frames,name,mode", [(2, 6, "g2a_builder_small.npz", "sharded"), (3, 4, "g2a_builder_small.npz", "sharded"),
                                                       (2, 16, "g2b_builder_growth.npz", "sharded"), (3, 16, "g2b_builder_growth.npz", "sharded"),
                                                       (8, 16, "g2b_builder_growth.npz", "sharded"),
+                                                      (3, 16, "g2b_builder_growth.npz", "sharded, exchange in chunks of 40 rows"),
+                                                      (8, 16, "g2b_builder_growth.npz", "sharded, exchange in chunks of 9 rows"),
                                                       (2, 6, "g2a_builder_small.npz", "reduce"), (2, 16, "g2b_builder_growth.npz", "reduce")])
 def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, nproc, n_frames, name, mode):
     """VLMapBuilder under N ranks (one process each, frames sharded contiguously; the device merge -- row-sharded all_to_all of
@@ -699,7 +701,10 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
     one, many = tmp_path / "one", tmp_path / "many"
     seed = 1234 if name.startswith("g2a") else 99              # what tools/gen_golden.py seeded the reference run with
     _run_ranks(1, [GOLDEN_DIR / name, one, n_frames, "replay", seed], 29541)
-    _run_ranks(nproc, [GOLDEN_DIR / name, many, n_frames, "replay", seed], 29542, AVL_TEST_MERGE_MODE=mode)
+    chunk_rows = int(mode.split()[-2]) if "chunks" in mode else 0        # the payload exchange of every merge in chunks (merge2.merge_sharded_v2)
+    mode = mode.split(",")[0]
+    _run_ranks(nproc, [GOLDEN_DIR / name, many, n_frames, "replay", seed], 29542, AVL_TEST_MERGE_MODE=mode,
+               **(dict(AVLMAPS_MERGE_CHUNK_ROWS=chunk_rows) if chunk_rows else {}))
     a = load_3d_map(one / "vlmap" / "vlmaps.h5df")
     b = load_3d_map(many / "vlmap" / "vlmaps.h5df")
     assert a[0] == b[0] == list(range(n_frames))
@@ -718,6 +723,7 @@ def test_seeded_multi_rank_build_equals_the_single_rank_map(golden, tmp_path, np
             assert t["mode"].startswith("row-sharded") and t["world_size"] == nproc and t["backend"] == "gloo"
             assert tuple(t["shard_rows"]) == parallel.shard_rows(M, r, nproc) and t["shard_feat_shape"] == [t["own_rows"], D]
             assert t["plan"].startswith("gather plan")           # contiguous frame shards: two all_gathers, one payload all_to_all (merge2.py)
+            assert (t["exchange_chunks"] > 1 and t["exchange_chunk_rows"] == chunk_rows) if chunk_rows else t["exchange_chunks"] == 1
             assert t["rows_sent"] <= t["local_voxels"] and t["payload_bytes_fp64_form"] == t["rows_sent"] * ((D + 4) * 8 + 8)
             # mixed payload: 64 B of side record per row + a float32 row (voxels of this rank alone) or a float64 row (shared)
             assert t["rows_sent"] * (64 + D * 4) <= t["payload_bytes_sent"] <= t["rows_sent"] * (64 + D * 8)
