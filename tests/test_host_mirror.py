@@ -221,6 +221,43 @@ def test_h5lite_extendible_datasets_and_foreign_files(tmp_path):
             assert "testdouble" in f.keys() and f.read("testdouble").dtype == np.float64
 
 
+def test_h5lite_row_runs_whole_chunks_or_hyperslabs(tmp_path, chunk_writes):
+    """write_row_runs: runs made of whole chunks may go out with H5Dwrite_chunk (incl. the partial last chunk of the dataset and chunks
+    that did not exist before a resize), anything else as hyperslabs -- the dataset read back is the array either way"""
+    from avlmaps_amd.utils import h5lite
+    if not h5lite.available():
+        pytest.skip("libhdf5 not found")
+    rng = np.random.default_rng(12)
+    a = rng.standard_normal((203, 5)).astype(np.float32)
+    p = tmp_path / "runs.h5"
+    with h5lite.H5File(p, "w") as f:
+        f.create_dataset("g", data=a[:100], maxshape=(None, 5), chunks=(8, 5))       # 12 full chunks + a partial one
+        f.create_dataset("v", data=a[:100, 0].copy(), maxshape=(None,))              # 1-d: never chunk by chunk
+    b = a.copy()
+    b[:100] += 1
+    with h5lite.H5File(p, "r+") as f:
+        f.resize("g", 203)
+        dset = f._open("g")
+        try:
+            assert f._chunk_rows(dset, (203, 5)) == 8
+        finally:
+            h5lite._lib().H5Dclose(dset)
+        f.write_row_runs("g", [(0, 8), (16, 40), (96, 203)], b)                       # whole chunks; the last run ends in the partial chunk 200..202
+        f.resize("v", 203)
+        f.write_row_runs("v", [(0, 203)], b[:, 0].copy())
+    want = a.copy()
+    want[0:8], want[16:40], want[96:203] = b[0:8], b[16:40], b[96:203]
+    with h5lite.H5File(p) as f:
+        assert np.array_equal(f.read("g"), want) and np.array_equal(f.read("v"), b[:, 0])
+    with h5lite.H5File(p, "r+") as f:
+        f.write_row_runs("g", [(3, 11), (50, 51)], b)                                 # not chunk-aligned: hyperslabs
+        with pytest.raises(h5lite.H5Error):
+            f.write_row_runs("g", [(200, 204)], b)
+    want[3:11], want[50:51] = b[3:11], b[50:51]
+    with h5lite.H5File(p) as f:
+        assert np.array_equal(f.read("g"), want)
+
+
 def test_map_file_writer_incremental_checkpoints(tmp_path, chunk_writes):
     """MapFileWriter: after the first full save only dirty + new rows (and the new cells of occupied_ids) are written; the
     file read back is always the complete current map in the reference's layout"""
