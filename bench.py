@@ -1238,7 +1238,8 @@ def main():
                         merge_breakdown={k: mb.get(k) for k in ("plan", "wall_s", "in_collectives_s", "compute_s", "compute_total_s",
                                                                 "in_collectives_total_s", "merged_voxels", "local_voxels", "single_rank_voxels",
                                                                 "shared_voxels_local", "payload_bytes_sent", "payload_bytes_fp64_form",
-                                                                "bytes_sent_per_rank", "world_size", "backend")},
+                                                                "bytes_sent_per_rank", "world_size", "backend", "exchange_chunks", "exchange_chunk_rows",
+                                                                "exchange_buffer_bytes")},
                         other_merge_mode=dict(merge_mode=ro["merge_mode"], frames_per_s=ro["frames_per_s"], seconds=ro["seconds"],
                                               merge_finalize_seconds=ro["merge_finalize_seconds"], voxels_merged=ro["voxels_merged"],
                                               speedup_vs_single_gpu=ro["frames_per_s"] / s1["frames_per_s"],
