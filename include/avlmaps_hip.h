@@ -502,7 +502,7 @@ AVL_API int avl_merge_side_unpack(int64_t R, const int64_t* d_side, int64_t r0, 
  *                     of nmax + (nmax + 1) / 2 int64 words each -- [keys (nmax x i64) | cells (nmax x i32)], h_n_all[p] entries valid in
  *                     chunk p; keys must be ordered by rank (contiguous frame shards), so that the concatenation is in key order and a
  *                     voxel's row is the number of first contributors before it; cells below 2^cell_bits; d_perm: this rank's own
- *                     avl_merge2_prepare permutation.  Work buffer: avl_merge2_work_bytes(sum n, n of this rank, ws).  Results (byte offsets into
+ *                     avl_merge2_prepare permutation.  Work buffer: avl_merge2_work_bytes(sum n, n of this rank, ws, nchunk).  Results (byte offsets into
  *                     d_work returned in h_off[11]): 0 row (n x i32, final row of own voxel s), 1 prev, 2 next (n x i32: the
  *                     neighbouring contributors of the voxel in rank order, -1 = none), 3 order (n x i32: own voxels in final-row
  *                     order), 4 sidx (n x i32: single-rank voxels before position i of that order), 5 selA, 6 selB (n x i64:
