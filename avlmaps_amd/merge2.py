@@ -446,7 +446,6 @@ class HipKernels:
                                                   state.data_ptr() if state is not None else None, send.data_ptr(), self.st), "avl_merge2_side_state")
 
     def new_block(self, n_own, D, own_feat):
-        import ctypes as C
         t = self.torch
         self.err = t.zeros(1, dtype=t.int32, device=self.device)
         return dict(grid_feat=own_feat, grid_pos=t.empty((n_own, 3), dtype=t.int32, device=self.device),
