@@ -47,7 +47,23 @@ def main():
     torch.cuda.synchronize()
     ncell = 1000 * 1000 * 30
 
+    import os
+    prof_rank = int(os.environ.get("PROBE_CPROFILE_RANK", "-1"))      # cProfile of one rank's merges (host bookkeeping between the launches)
+    prof = None
+    if prof_rank >= 0:
+        import cProfile
+        prof = cProfile.Profile()
+
     def rank_fn(r, coll):
+        if r == prof_rank:
+            prof.enable()
+            try:
+                return rank_body(r, coll)
+            finally:
+                prof.disable()
+        return rank_body(r, coll)
+
+    def rank_body(r, coll):
         acc = accs[r]
         tim = {}
         t0 = time.perf_counter()
@@ -69,6 +85,9 @@ def main():
         print(f"--- merge {rep}" + (" (replay cache dropped)" if rep == reps - 1 else ""))
         for r, x in enumerate(res):
             print(r, x)
+    if prof is not None:
+        import pstats
+        pstats.Stats(prof).sort_stats("tottime").print_stats(28)
     print("NOTE: one rank computes at a time (a lock dropped inside every stand-in collective); phases = the rank's own time, collectives and lock waits excluded")
 
 
