@@ -247,13 +247,14 @@ def test_builder_feature_widths(ops, D):
     np.testing.assert_allclose(outs["batch"]["grid_feat"], outs["frames"]["grid_feat"], rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("seed,cs,batch", [(1, 0.4, 1), (2, 0.25, 1), (3, 0.4, 3), (4, 0.8, 6)])
-def test_builder_heavy_collisions(ops, seed, cs, batch):
+@pytest.mark.parametrize("seed,cs,batch,D", [(1, 0.4, 1, 32), (2, 0.25, 1, 32), (3, 0.4, 3, 32), (4, 0.8, 6, 32), (5, 0.4, 1, 1600), (6, 0.8, 3, 1600)])
+def test_builder_heavy_collisions(ops, seed, cs, batch, D):
     """coarse cells and every pixel sampled: tens to hundreds of samples per voxel per frame (long per-voxel lists, hot
-    CAS cells, many frames per voxel) against the sequential oracle, per-frame and batched"""
+    CAS cells, many frames per voxel) against the sequential oracle, per-frame and batched; D = 1600: the generic-width fuse
+    kernel, whose lists of more than 64 members are summed in rounds"""
     from oracle import avl_oracle as O
     rng = np.random.default_rng(seed)
-    H, W, Hf, Wf, D, nfr = 60, 80, 29, 39, 32, 6
+    H, W, Hf, Wf, nfr = 60, 80, 29, 39, 6
     gs, cam_h = 40, 1.6
     calib = np.array([W / 2, 0, W / 2, 0, W / 2, H / 2, 0, 0, 1.0])
     depths, rgbs, feats, poses = synth_scene(rng, nfr, H, W, Hf, Wf, D)
